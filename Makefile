@@ -1,0 +1,48 @@
+# Build of the MI355X-native megapath framework.
+#   make host    -> luisarender_amd/lib/liblrhost.so   (scene description, flattening, BVH, image IO)
+#   make hip     -> luisarender_amd/lib/liblrhip.so    (HIP megakernel path tracer, C ABI include/lrhip.h)
+#   make oracle  -> oracle/liboracle.so                (CPU checker; tests/bench only)
+#   make cli     -> luisarender_amd/bin/luisa-render-cli + plugin libluisa-render-integrator-megapath.so
+CXX      ?= g++
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wextra
+ORACLE_FLAGS ?= -std=c++17 -O3 -march=x86-64-v3 -ffp-contract=off -fPIC -Wall -Wextra -pthread
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall
+
+LIBDIR := luisarender_amd/lib
+BINDIR := luisarender_amd/bin
+HOSTDIR := luisarender_amd/csrc/host
+HIPDIR := luisarender_amd/csrc/hip
+
+HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/image_io.cpp \
+            $(HOSTDIR)/accel.cpp $(HOSTDIR)/host_api.cpp
+HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
+HIP_SRC := $(HIPDIR)/lrhip.hip
+HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
+
+.PHONY: all host hip oracle cli clean
+all: host oracle hip cli
+
+host: $(LIBDIR)/liblrhost.so
+$(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
+
+oracle: oracle/liboracle.so
+oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h
+	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/oracle.cpp
+
+hip: $(LIBDIR)/liblrhip.so
+$(LIBDIR)/liblrhip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+cli: $(BINDIR)/luisa-render-cli
+$(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)
+	@mkdir -p $(BINDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $(BINDIR)/libluisa-render-integrator-megapath.so $(HOSTDIR)/plugin_megapath.cpp \
+	    -L$(LIBDIR) -llrhost -ldl -Wl,-rpath,'$$ORIGIN/../lib'
+	$(CXX) $(CXXFLAGS) -o $@ $(HOSTDIR)/cli.cpp -L$(LIBDIR) -llrhost -ldl -pthread -Wl,-rpath,'$$ORIGIN/../lib'
+
+clean:
+	rm -f $(LIBDIR)/*.so $(BINDIR)/* oracle/liboracle.so

@@ -1,0 +1,92 @@
+/* lrhip.h — thin C ABI of the MI355X (gfx950) megakernel path tracer (liblrhip.so).
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no such C interface: its
+ * MegaPath integrator is a C++ plugin (`create`/`destroy`, src/base/scene_node.h:58-67) whose
+ * Instance::render JIT-compiles and launches a LuisaCompute kernel.  Each entry point below
+ * replaces one step of that path; the reference-side binding a maintainer would add lives in
+ * INTEGRATION.md and luisarender_amd/csrc/host/plugin_megapath.cpp.
+ *
+ *   lrhip_create / lrhip_destroy   Context::create_device + Stream       src/apps/cli.cpp:166-172,181
+ *   lrhip_upload_scene             Pipeline::create uploads               src/base/pipeline.cpp:44-99,
+ *                                  Geometry::build                        src/base/geometry.cpp:12-27
+ *   lrhip_film_clear               ColorFilmInstance::prepare/clear       src/films/color.cpp:132-144
+ *   lrhip_render                   _render_one_camera's spp loop of       src/base/integrator.cpp:86-107
+ *                                  render(sample_id, time, weight).dispatch(resolution), i.e.
+ *                                  Li() + film accumulate                 src/integrators/mega_path.cpp:49-156
+ *   lrhip_film_download            ColorFilmInstance::download            src/films/color.cpp:99-105
+ *   lrhip_get_counters             (no reference equivalent; roofline accounting)
+ *
+ * Conventions: 0 = OK, negative = error (text via lrhip_last_error, thread-local); nothing
+ * throws or aborts across the boundary.  One context per GPU; a context is not thread-safe;
+ * different contexts may be driven from different host threads / processes.  All buffers are
+ * POD, little-endian, laid out as in lr_scene.h.  The library copies what it needs during
+ * lrhip_upload_scene; the caller keeps ownership of the scene tables.
+ */
+#ifndef LRHIP_H
+#define LRHIP_H
+
+#include "lr_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrhip_ctx lrhip_ctx;
+
+#define LRHIP_OK 0
+#define LRHIP_ERROR_INVALID (-1)  /* bad argument / state        */
+#define LRHIP_ERROR_DEVICE (-2)   /* HIP runtime failure         */
+#define LRHIP_ERROR_UNSUPPORTED (-3)
+
+/* Work of one lrhip_render call: samples [spp_begin, spp_end) of every pixel of the screen tiles
+ * {tile_begin + k * tile_stride : tile_begin + k * tile_stride < tile_end}.  Tiles are 8x8 pixels,
+ * numbered row-major over ceil(W/8) x ceil(H/8).  (0, tile_count, 1) renders the whole frame;
+ * (rank, tile_count, world) is the round-robin screen-tile shard of one GPU.      */
+typedef struct lrhip_render_params {
+    uint32_t spp_begin, spp_end;
+    uint32_t tile_begin, tile_end, tile_stride;
+    uint32_t flags;          /* LRHIP_RENDER_* */
+    uint32_t pad[2];
+} lrhip_render_params;
+
+#define LRHIP_RENDER_COUNTERS 1u /* gather per-ray node/triangle counters (slower kernel variant) */
+
+typedef struct lrhip_counters {
+    uint64_t paths, closest_rays, shadow_rays;
+    uint64_t nodes_visited;  /* BVH4 nodes fetched (128 B each)              */
+    uint64_t tris_tested;    /* triangle tests (48 B each)                   */
+    uint64_t surface_hits, nee_samples, path_length_sum;
+} lrhip_counters;
+
+int lrhip_create(int device_ordinal, lrhip_ctx **out);
+void lrhip_destroy(lrhip_ctx *ctx);
+
+/* optional: launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream);
+
+/* scene->accel must be built (lrhost_scene_build_accel) */
+int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *scene);
+
+/* optional: accumulate into a caller-owned device buffer float4[W*H] (e.g. a torch tensor that
+ * RCCL reduces afterwards); NULL = library-owned film (default) */
+int lrhip_bind_film(lrhip_ctx *ctx, void *device_float4_film);
+int lrhip_film_clear(lrhip_ctx *ctx);
+
+/* asynchronous on the context's stream */
+int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *params);
+int lrhip_synchronize(lrhip_ctx *ctx);
+
+/* converted != 0: (sum.rgb / max(sum.w, 1)) * 2^exposure, alpha 1 (color.cpp:87-93);
+ * converted == 0: the raw (sum r, sum g, sum b, n) film.  Synchronises.              */
+int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted);
+
+int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out); /* summed since upload; synchronises */
+/* HIP-event time of the megakernel launches of the last lrhip_render call, in ms; synchronises */
+double lrhip_last_render_ms(lrhip_ctx *ctx);
+
+const char *lrhip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRHIP_H */

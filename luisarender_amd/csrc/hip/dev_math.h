@@ -1,0 +1,108 @@
+// dev_math.h — fp32 vector helpers for the gfx950 megakernel (device side) and for the host
+// code that pre-resolves constant closures at upload time (same arithmetic, LR_HD functions).
+//
+// Builtin semantics follow the LuisaCompute DSL the reference's device code is written in
+// (sign = copysign(1, x), fract = x - floor(x), lerp = a + t (b - a)); see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#define LR_HD __host__ __device__ __forceinline__
+#define LR_D __device__ __forceinline__
+
+namespace lrd {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.318309886183790671537767526745028724f;
+constexpr float kPiOverTwo = 1.57079632679489661923132169163975144f;
+constexpr float kPiOverFour = 0.785398163397448309615660845819875721f;
+constexpr float kOneMinusEpsilon = 0x1.fffffep-1f;
+constexpr float kFloatMax = 3.402823466e+38f;
+
+struct f2 {
+    float x, y;
+};
+struct f3 {
+    float x, y, z;
+};
+
+LR_HD f3 mk3(float x, float y, float z) { return {x, y, z}; }
+LR_HD f3 mk3(float s) { return {s, s, s}; }
+LR_HD f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+LR_HD f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+LR_HD f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+LR_HD f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+LR_HD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+LR_HD f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
+LR_HD f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+LR_HD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+LR_HD f3 &operator+=(f3 &a, f3 b) { a = a + b; return a; }
+LR_HD f3 &operator*=(f3 &a, f3 b) { a = a * b; return a; }
+LR_HD f3 &operator*=(f3 &a, float s) { a = a * s; return a; }
+
+LR_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+LR_HD f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+LR_HD float length(f3 a) { return sqrtf(dot(a, a)); }
+LR_HD f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+LR_HD float sqr(float x) { return x * x; }
+LR_HD float sign(float x) { return copysignf(1.0f, x); }
+LR_HD float fract(float x) { return x - floorf(x); }
+LR_HD float lerp(float a, float b, float t) { return a + t * (b - a); }
+LR_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+LR_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+LR_HD f3 saturate(f3 v) { return {saturate(v.x), saturate(v.y), saturate(v.z)}; }
+LR_HD f3 max0(f3 v) { return {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f)}; }
+LR_HD float max_component(f3 v) { return fmaxf(v.x, fmaxf(v.y, v.z)); }
+LR_HD f3 exp3(f3 v) { return {expf(v.x), expf(v.y), expf(v.z)}; }
+LR_HD f3 sqrt3(f3 v) { return {sqrtf(v.x), sqrtf(v.y), sqrtf(v.z)}; }
+LR_HD bool any_nan(f3 v) { return isnan(v.x) || isnan(v.y) || isnan(v.z); }
+LR_HD bool any_inf(f3 v) { return isinf(v.x) || isinf(v.y) || isinf(v.z); }
+LR_HD f3 reflect(f3 i, f3 n) { return i - 2.0f * dot(n, i) * n; }
+LR_HD f3 face_forward(f3 v, f3 n) { return dot(v, n) < 0.f ? -v : v; }
+LR_HD float cie_y(f3 rgb) { return dot(mk3(0.212671f, 0.715160f, 0.072169f), rgb); }
+
+// orthonormal shading frame (reference: src/util/frame.cpp:21-42)
+struct Frame {
+    f3 s, t, n;
+};
+LR_HD Frame frame_from_normal(f3 n) {
+    auto sgn = sign(n.z);
+    auto a = -1.f / (sgn + n.z);
+    auto b = n.x * n.y * a;
+    auto s = mk3(1.f + sgn * sqr(n.x) * a, sgn * b, -sgn * n.x);
+    auto t = mk3(b, sgn + sqr(n.y) * a, -n.y);
+    return {normalize(s), normalize(t), n};
+}
+LR_HD Frame frame_from_normal_tangent(f3 n, f3 s) {
+    auto ss = normalize(s - n * dot(n, s));
+    auto tt = normalize(cross(n, ss));
+    return {ss, tt, n};
+}
+LR_HD f3 to_world(const Frame &f, f3 d) { return normalize(d.x * f.s + d.y * f.t + d.z * f.n); }
+LR_HD f3 to_local(const Frame &f, f3 d) { return normalize(mk3(dot(d, f.s), dot(d, f.t), dot(d, f.n))); }
+LR_HD f3 clamp_shading_normal(f3 ns, f3 ng, f3 w) {// frame.cpp:49-54
+    auto w_refl = reflect(-w, ns);
+    auto w_refl_clip = dot(w_refl, ng) * dot(w, ng) > 0.f ? w_refl : normalize(w_refl - ng * dot(w_refl, ng));
+    return normalize(w_refl_clip + w);
+}
+
+// local-frame trigonometry (src/util/frame.h:48-71)
+LR_HD float cos_theta(f3 w) { return w.z; }
+LR_HD float cos2_theta(f3 w) { return w.z * w.z; }
+LR_HD float abs_cos_theta(f3 w) { return fabsf(w.z); }
+LR_HD float sin2_theta(f3 w) { return saturate(1.0f - cos2_theta(w)); }
+LR_HD float sin_theta(f3 w) { return sqrtf(sin2_theta(w)); }
+LR_HD float tan_theta(f3 w) { return sin_theta(w) / cos_theta(w); }
+LR_HD float tan2_theta(f3 w) { return sin2_theta(w) / cos2_theta(w); }
+LR_HD float cos_phi(f3 w) {
+    auto s = sin_theta(w);
+    return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f);
+}
+LR_HD float sin_phi(f3 w) {
+    auto s = sin_theta(w);
+    return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f);
+}
+LR_HD bool same_hemisphere(f3 w, f3 wp) { return w.z * wp.z > 0.0f; }
+LR_HD float abs_dot(f3 u, f3 v) { return fabsf(dot(u, v)); }
+
+}// namespace lrd

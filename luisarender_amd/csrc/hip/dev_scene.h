@@ -1,0 +1,114 @@
+// dev_scene.h — HBM-resident scene layout of the gfx950 megakernel.
+//
+// Built by lrhip_upload_scene from the lr_scene tables (include/lr_scene.h).  Layout rules:
+// every record a lane gathers per hit is 16-byte aligned and read with dwordx4 loads; records
+// that are always read together share one 128-byte line (instance = handle + matrix + normal
+// matrix; BVH node = 4 child boxes + refs).  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include "../../../include/lr_scene.h"
+#include "dev_math.h"
+
+namespace lrd {
+
+// One instance = one 128-byte line: handle (reference uint4, src/base/shape.cpp:46-70),
+// object->world columns, transpose(inverse(M3x3)) columns (src/base/geometry.cpp:378), and the
+// mesh slice offsets that stand in for the reference's bindless buffer ids.
+struct alignas(16) DInstance {
+    uint32_t handle[4];
+    float c0[3]; uint32_t vertex_offset;
+    float c1[3]; uint32_t triangle_offset;
+    float c2[3]; uint32_t pad0;
+    float t[3];  uint32_t pad1;
+    float n0[3]; uint32_t pad2;
+    float n1[3]; uint32_t pad3;
+    float n2[3]; uint32_t pad4;
+};
+static_assert(sizeof(DInstance) == 128, "DInstance must be one cache line");
+
+// Closure parameters with every constant texture folded in (what the reference's JIT does by
+// inlining ConstantTexture values, src/textures/constant.cpp:73-79).  64 bytes.
+//   MATTE   c0 = Kd                 s0 = sigma (degrees)
+//   MIRROR  c0 = color              alpha
+//   GLASS   c0 = Kr  c1 = Kt        s0 = eta_i  s1 = eta_t  s2 = Kr_ratio   alpha
+//   PLASTIC c0 = Kd' c1 = sigma_a   s0 = Kd_weight  s1 = eta                alpha
+//   METAL   c0 = n   c1 = k  c2 = Kd tint  s0 = eta_i                        alpha
+struct alignas(16) DClosure {
+    uint32_t kind;
+    uint32_t dynamic;   // 1: some parameter is a non-constant texture -> resolve per hit
+    float alpha_x, alpha_y;
+    float c0[3]; float s0;
+    float c1[3]; float s1;
+    float c2[3]; float s2;
+};
+static_assert(sizeof(DClosure) == 64, "DClosure is 4 x float4");
+
+struct alignas(16) DLight {
+    float L[3];          // emission * scale for constant emission
+    int32_t emission_tex;// >= 0 and dynamic: evaluate per hit
+    float scale;
+    uint32_t two_sided;
+    uint32_t dynamic;
+    uint32_t pad;
+};
+static_assert(sizeof(DLight) == 32, "DLight");
+
+struct DCamera {
+    uint32_t kind, width, height, pad;
+    float c2w[16];
+    float tan_half_fov, focus_distance, lens_radius, projected_pixel_size;
+    float ortho_scale, clip_near, clip_far, pad2;
+};
+
+struct DScene {
+    // acceleration structure
+    const lr_bvh4_node *nodes;
+    const lr_bvh_triangle *bvh_tris;
+    // geometry tables
+    const DInstance *instances;
+    const lr_vertex *vertices;
+    const lr_triangle *triangles;
+    const lr_alias_entry *tri_alias;
+    const float *tri_pdf;
+    const lr_light_handle *light_instances;
+    // shading tables
+    const DClosure *closures;
+    const lr_surface *surfaces;// raw records for dynamic closures
+    const DLight *lights;
+    const lr_texture *textures;
+    const float *texels;
+    const lr_filter *filter;
+    DCamera camera;
+    // environment (constant spherical)
+    uint32_t env_kind;
+    float env_L[3];
+    float env_to_world[9];
+    // integrator / sampler / film
+    uint32_t max_depth, rr_depth;
+    float rr_threshold, env_prob;
+    uint32_t light_count;   // distinct Light nodes (uniform.cpp:82)
+    uint32_t has_lights;
+    uint32_t sampler_kind, seed;
+    float film_clamp;
+    uint32_t pad;
+};
+
+struct DCounters {
+    unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
+        path_length_sum;
+};
+
+struct RenderArgs {
+    float4 *film;          // (sum r, sum g, sum b, n) per pixel, row-major
+    uint32_t spp_begin, spp_end;
+    uint32_t tile_begin, tile_end, tile_stride;
+    uint32_t tiles_x, tiles_y;
+    uint32_t chunk_count;  // spp range split into `chunk_count` contiguous chunks per tile
+    uint32_t item_count;   // tiles_in_range * chunk_count
+    uint32_t *work_counter;
+    float4 *partial;       // chunk_count > 1: per-chunk partial sums [chunk][pixel]
+    uint32_t *spill;       // traversal stack overflow area [kSpillEntries][total_threads]
+    uint32_t total_threads;
+    DCounters *counters;
+};
+
+}// namespace lrd

@@ -1,0 +1,395 @@
+// dev_shade.h — per-hit work of the megakernel: samplers, camera rays, hit reconstruction,
+// light sampling/evaluation, texture lookups and closure resolution.
+//
+// Reference map (device halves of the L1 plugins inlined into the reference's render kernel):
+//   xxhash32 / lcg / PCG32            src/util/rng.cpp:53-69,128-176
+//   IndependentSamplerInstance        src/samplers/independent.cpp:57-83
+//   Filter::Instance::sample          src/base/filter.cpp:49-64
+//   Camera::Instance::generate_ray    src/base/camera.cpp:212-224, src/cameras/{pinhole,thin_lens,ortho}.cpp
+//   Geometry::shading_point           src/base/geometry.cpp:345-389
+//   Interaction::spawn_ray[_to]       src/base/interaction.cpp:13-30
+//   UniformLightSamplerInstance       src/lightsamplers/uniform.cpp:50-137
+//   DiffuseLightClosure::_evaluate    src/lights/diffuse.cpp:67-88
+//   Texture evaluate_*_spectrum       src/base/texture.cpp:21-79, src/textures/{constant,image}.cpp
+#pragma once
+#include "dev_bsdf.h"
+#include "dev_trace.h"
+
+namespace lrd {
+
+// ---------------------------------------------------------------- RNG / sampler
+
+LR_HD uint32_t xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    constexpr uint32_t P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    auto rot = [](uint32_t h) { return (h << 17u) | (h >> 15u); };
+    auto h = w + P5 + x * P3;
+    h = P4 * rot(h);
+    h += y * P3;
+    h = P4 * rot(h);
+    h += z * P3;
+    h = P4 * rot(h);
+    h = P2 * (h ^ (h >> 15u));
+    h = P3 * (h ^ (h >> 13u));
+    return h ^ (h >> 16u);
+}
+
+LR_HD float uint_to_unit_float(uint32_t u) { return fminf(kOneMinusEpsilon, static_cast<float>(u) * 0x1p-32f); }
+
+// One sampler object per path.  INDEPENDENT reproduces the reference stream bit for bit;
+// PCG32 is the additional generator the north star asks for (one PCG32 sequence per path,
+// sequence index = the same xxhash32 seed).
+struct PathSampler {
+    uint32_t state;
+    uint64_t pcg_state, pcg_inc;
+    bool use_pcg;
+    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) {
+        state = xxhash32_4(px, py, scene.seed, index);
+        use_pcg = scene.sampler_kind == LR_SAMPLER_PCG32;
+        if (use_pcg) {// PCG32::set_sequence, rng.cpp:150-156
+            pcg_state = 0u;
+            pcg_inc = (static_cast<uint64_t>(state) << 1u) | 1u;
+            (void)pcg_next();
+            pcg_state += 0x853c49e6748fea9bull;
+            (void)pcg_next();
+        }
+    }
+    LR_D uint32_t pcg_next() {// rng.cpp:142-148
+        auto old = pcg_state;
+        pcg_state = old * 0x5851f42d4c957f2dull + pcg_inc;
+        auto xorshifted = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
+        auto rot = static_cast<uint32_t>(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+    }
+    LR_D float next_1d() {
+        if (use_pcg) { return uint_to_unit_float(pcg_next()); }
+        state = 1664525u * state + 1013904223u;// lcg, rng.cpp:132-140
+        return uint_to_unit_float(state);
+    }
+    LR_D f2 next_2d() {
+        f2 u;
+        u.x = next_1d();
+        u.y = next_1d();
+        return u;
+    }
+};
+
+struct AliasPick {
+    uint32_t index;
+    float u;
+};
+// sample_alias_table, src/util/sampling.h:38-66
+LR_HD AliasPick alias_pick(float prob_i, uint32_t alias_i, uint32_t i, float u_remapped) {
+    AliasPick p;
+    p.index = u_remapped < prob_i ? i : alias_i;
+    p.u = u_remapped < prob_i ? u_remapped / prob_i : (u_remapped - prob_i) / (1.0f - prob_i);
+    return p;
+}
+LR_HD uint32_t alias_slot(float u, uint32_t n, float &u_remapped) {
+    auto x = u * static_cast<float>(n);
+    u_remapped = fract(x);
+    return min(static_cast<uint32_t>(fmaxf(x, 0.f)), n - 1u);
+}
+
+// ---------------------------------------------------------------- camera
+
+struct FilterTables {// LDS-resident copy of lr_filter
+    const lr_filter *f;
+};
+
+LR_D void filter_sample(const lr_filter *f, f2 u, f2 &offset, float &weight) {// filter.cpp:49-64
+    constexpr uint32_t n = LR_FILTER_LUT_SIZE - 1u;
+    float ry, rx;
+    auto sy = alias_slot(u.x, n, ry);// x/y swap as in the reference
+    auto sx = alias_slot(u.y, n, rx);
+    auto py = alias_pick(f->alias_prob[sy], f->alias_index[sy], sy, ry);
+    auto px = alias_pick(f->alias_prob[sx], f->alias_index[sx], sx, rx);
+    auto pdf = f->pdf[py.index] * f->pdf[px.index];
+    auto fv = lerp(f->lut[px.index], f->lut[px.index + 1u], px.u) * lerp(f->lut[py.index], f->lut[py.index + 1u], py.u);
+    f2 p{static_cast<float>(px.index) + px.u, static_cast<float>(py.index) + py.u};
+    constexpr auto inv_size = 1.0f / static_cast<float>(LR_FILTER_LUT_SIZE);
+    offset = {(p.x * inv_size * 2.0f - 1.0f) * f->radius + f->shift[0], (p.y * inv_size * 2.0f - 1.0f) * f->radius + f->shift[1]};
+    weight = fv / pdf;
+}
+
+LR_D void camera_ray(const DScene &scene, const lr_filter *filter, uint32_t px, uint32_t py, f2 u_filter, f2 u_lens,
+                     Ray &ray, float &weight) {
+    auto &cam = scene.camera;
+    f2 off;
+    float fw;
+    filter_sample(filter, u_filter, off, fw);
+    f2 pixel{static_cast<float>(px) + .5f + off.x, static_cast<float>(py) + .5f + off.y};
+    f2 res{static_cast<float>(cam.width), static_cast<float>(cam.height)};
+    f3 o = mk3(0.f), d;
+    if (cam.kind == LR_CAMERA_PINHOLE) {// pinhole.cpp:60-67
+        auto k = cam.tan_half_fov / res.y;
+        d = normalize(mk3((pixel.x * 2.0f - res.x) * k, -((pixel.y * 2.0f - res.y) * k), -1.f));
+    } else if (cam.kind == LR_CAMERA_THIN_LENS) {// thin_lens.cpp:91-101
+        f2 cf{(pixel.x - .5f * res.x) * cam.projected_pixel_size, (pixel.y - .5f * res.y) * cam.projected_pixel_size};
+        auto p_focal = mk3(cf.x, -cf.y, -cam.focus_distance);
+        auto disk = sample_disk_concentric(u_lens);
+        o = mk3(disk.x * cam.lens_radius, disk.y * cam.lens_radius, 0.f);
+        d = normalize(p_focal - o);
+    } else {// ortho.cpp:52-58
+        o = mk3((pixel.x * 2.0f - res.x) / res.y * cam.ortho_scale, -((pixel.y * 2.0f - res.y) / res.y * cam.ortho_scale), 0.f);
+        d = mk3(0.f, 0.f, -1.f);
+    }
+    auto cos_axis = dot(d, mk3(0.f, 0.f, -1.f));// clip planes, camera.h:147-157
+    ray.t_min = cam.clip_near / cos_axis;
+    ray.t_max = cam.clip_far / cos_axis;
+    auto m = cam.c2w;
+    ray.o = mk3(m[0] * o.x + m[4] * o.y + m[8] * o.z + m[12], m[1] * o.x + m[5] * o.y + m[9] * o.z + m[13],
+                m[2] * o.x + m[6] * o.y + m[10] * o.z + m[14]);
+    ray.d = normalize(mk3(m[0], m[1], m[2]) * d.x + mk3(m[4], m[5], m[6]) * d.y + mk3(m[8], m[9], m[10]) * d.z);
+    weight = 1.f * fw;
+}
+
+// ---------------------------------------------------------------- textures
+
+LR_D float4 texel_fetch(const DScene &scene, const lr_texture &t, int x, int y) {
+    auto w = static_cast<int>(t.width), h = static_cast<int>(t.height);
+    auto zero = false;
+    auto wrap = [&](int v, int n) {
+        if (t.address == LR_TEX_ADDR_EDGE) { return min(max(v, 0), n - 1); }
+        if (t.address == LR_TEX_ADDR_MIRROR) {
+            auto period = 2 * n;
+            auto m = ((v % period) + period) % period;
+            return m < n ? m : period - 1 - m;
+        }
+        if (t.address == LR_TEX_ADDR_ZERO) {
+            if (v < 0 || v >= n) { zero = true; return 0; }
+            return v;
+        }
+        return ((v % n) + n) % n;
+    };
+    auto xx = wrap(x, w), yy = wrap(y, h);
+    if (zero) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    return reinterpret_cast<const float4 *>(scene.texels)[t.texel_offset + static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx)];
+}
+
+LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) {
+    auto &t = scene.textures[id];
+    if (t.kind == LR_TEX_CONSTANT) { return make_float4(t.v[0], t.v[1], t.v[2], t.v[3]); }
+    if (t.kind == LR_TEX_CHECKERBOARD) {
+        auto parity = (static_cast<int>(floorf(uv_it.x * t.checker_scale)) + static_cast<int>(floorf(uv_it.y * t.checker_scale))) & 1;
+        auto child = t.child[parity ? 1 : 0];
+        if (child < 0) { return parity ? make_float4(0.f, 0.f, 0.f, 1.f) : make_float4(1.f, 1.f, 1.f, 1.f); }
+        auto &c = scene.textures[child];// one level of nesting: children are constant or image
+        if (c.kind == LR_TEX_CONSTANT) { return make_float4(c.v[0], c.v[1], c.v[2], c.v[3]); }
+        id = child;
+    }
+    auto &ti = scene.textures[id];
+    f2 uv{uv_it.x * ti.uv_scale[0] + ti.uv_offset[0], uv_it.y * ti.uv_scale[1] + ti.uv_offset[1]};
+    float4 v;
+    if (ti.filter == LR_TEX_FILTER_POINT) {
+        v = texel_fetch(scene, ti, static_cast<int>(floorf(uv.x * static_cast<float>(ti.width))),
+                        static_cast<int>(floorf(uv.y * static_cast<float>(ti.height))));
+    } else {
+        auto fx = uv.x * static_cast<float>(ti.width) - 0.5f, fy = uv.y * static_cast<float>(ti.height) - 0.5f;
+        auto x0 = floorf(fx), y0 = floorf(fy);
+        auto tx = fx - x0, ty = fy - y0;
+        auto ix = static_cast<int>(x0), iy = static_cast<int>(y0);
+        auto c00 = texel_fetch(scene, ti, ix, iy), c10 = texel_fetch(scene, ti, ix + 1, iy);
+        auto c01 = texel_fetch(scene, ti, ix, iy + 1), c11 = texel_fetch(scene, ti, ix + 1, iy + 1);
+        auto mix = [&](float a, float b, float c, float d) {
+            return (a * (1.f - tx) + b * tx) * (1.f - ty) + (c * (1.f - tx) + d * tx) * ty;
+        };
+        v = make_float4(mix(c00.x, c10.x, c01.x, c11.x), mix(c00.y, c10.y, c01.y, c11.y),
+                        mix(c00.z, c10.z, c01.z, c11.z), mix(c00.w, c10.w, c01.w, c11.w));
+    }
+    auto decode = [&](float c, int ch) {// image.cpp:138-153
+        if (ti.encoding == LR_TEX_ENC_SRGB) {
+            c = c <= 0.04045f ? c * (1.0f / 12.92f) : powf((c + 0.055f) * (1.0f / 1.055f), 2.4f);
+        } else if (ti.encoding == LR_TEX_ENC_GAMMA) {
+            c = powf(c, ti.gamma[min(ch, 2)]);
+        }
+        return ti.scale[ch] * c;
+    };
+    return make_float4(decode(v.x, 0), decode(v.y, 1), decode(v.z, 2), decode(v.w, 3));
+}
+
+// ---------------------------------------------------------------- closure resolution
+// Texture access is abstracted so the same code folds constants on the host at upload time
+// (TexFn reads lr_texture::v) and evaluates image textures per hit on the device.
+
+LR_HD f3 extend_rgb(float4 c, uint32_t n) {// texture.cpp:14-18
+    if (n == 1u) { return mk3(c.x, c.x, c.x); }
+    if (n == 2u) { return mk3(c.x, c.y, 1.f); }
+    return mk3(c.x, c.y, c.z);
+}
+
+template<typename TexFn, typename ChannelsFn>
+LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&channels, float eta_i) {
+    DClosure c{};
+    c.kind = s.kind;
+    auto albedo = [&](int32_t id, float dv, f3 &value, float &strength) {// evaluate_albedo_spectrum + srgb decode
+        if (id < 0) { value = mk3(dv), strength = dv; return; }
+        value = saturate(extend_rgb(tex(id), channels(id)));
+        strength = cie_y(value);
+    };
+    auto alpha = [&](int32_t id, float dv) {// e.g. mirror.cpp:145-154
+        if (id < 0) { c.alpha_x = c.alpha_y = dv; return; }
+        auto r = tex(id);
+        auto remap = (s.flags & LR_SURFACE_FLAG_REMAP_ROUGHNESS) != 0u;
+        if (channels(id) == 1u) { c.alpha_x = c.alpha_y = remap ? roughness_to_alpha(r.x) : r.x; }
+        else { c.alpha_x = remap ? roughness_to_alpha(r.x) : r.x, c.alpha_y = remap ? roughness_to_alpha(r.y) : r.y; }
+    };
+    auto store = [](float *dst, f3 v) { dst[0] = v.x, dst[1] = v.y, dst[2] = v.z; };
+    f3 v;
+    float strength;
+    switch (s.kind) {
+        case LR_SURFACE_MATTE: {// matte.cpp:119-134
+            albedo(s.tex[0], 1.f, v, strength);
+            store(c.c0, v);
+            // the host drops a black sigma texture (`_sigma && !_sigma->node()->is_black()`, matte.cpp:125)
+            c.s0 = s.tex[1] >= 0 ? saturate(tex(s.tex[1]).x) * 90.f : 0.f;
+            break;
+        }
+        case LR_SURFACE_MIRROR: {// mirror.cpp:141-163
+            alpha(s.tex[1], 0.f);
+            albedo(s.tex[0], 1.f, v, strength);
+            store(c.c0, v);
+            break;
+        }
+        case LR_SURFACE_GLASS: {// glass.cpp:232-285 (fixed spectrum: eta = first channel)
+            alpha(s.tex[2], 0.f);
+            float kr_lum, kt_lum;
+            albedo(s.tex[0], 1.f, v, kr_lum);
+            store(c.c0, v);
+            albedo(s.tex[1], 1.f, v, kt_lum);
+            store(c.c1, v);
+            c.s2 = kr_lum == 0.f ? 0.f : kr_lum / (kr_lum + kt_lum);
+            c.s0 = eta_i;
+            c.s1 = s.tex[3] >= 0 ? tex(s.tex[3]).x : 1.5f;
+            break;
+        }
+        case LR_SURFACE_PLASTIC: {// plastic.cpp:256-291
+            alpha(s.tex[1], 0.f);
+            auto eta = (s.tex[3] >= 0 ? tex(s.tex[3]).x : 1.5f) / eta_i;
+            f3 kd, sigma_a;
+            float kd_lum, sigma_lum;
+            albedo(s.tex[0], 1.f, kd, kd_lum);
+            albedo(s.tex[2], 0.f, sigma_a, sigma_lum);
+            auto thickness = s.tex[4] >= 0 ? tex(s.tex[4]).x : 1.f;
+            auto average_transmittance = expf(-2.f * sigma_lum * thickness);
+            auto diffuse_fresnel = fresnel_dielectric_integral(eta);
+            store(c.c0, kd / (mk3(1.f) - kd * diffuse_fresnel));
+            c.s0 = kd_lum * average_transmittance;
+            store(c.c1, sigma_a);
+            c.s1 = eta;
+            break;
+        }
+        case LR_SURFACE_METAL: {// metal.cpp:273-308
+            alpha(s.tex[1], .5f);
+            store(c.c0, mk3(s.f[0], s.f[1], s.f[2]));
+            store(c.c1, mk3(s.f[3], s.f[4], s.f[5]));
+            if (s.tex[0] >= 0) { albedo(s.tex[0], 1.f, v, strength); } else { v = mk3(1.f); }
+            store(c.c2, v);
+            c.s0 = eta_i;
+            break;
+        }
+        default: c.kind = LR_SURFACE_NULL; break;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------- hit reconstruction
+
+struct SurfacePoint {// the subset of the reference's Interaction the hot path reads
+    f3 p, ng;
+    Frame shading;
+    f2 uv;
+    float area;
+    uint32_t flags;       // Shape property flags
+    uint32_t tags;        // handle.y
+    uint32_t offset_bits; // handle.w
+    uint32_t tri_offset;  // mesh triangle slice (pdf / alias tables)
+    bool back_facing;
+};
+
+LR_D float intersection_offset_factor(uint32_t handle_w) {// shape.cpp:88-93
+    auto x = static_cast<float>(handle_w & 0xffffu) * (1.0f / 65536.f);
+    return clampf(x * 255.f + 1.f, 1.f, 256.f);
+}
+
+// Geometry::shading_point, geometry.cpp:345-389.  FULL = false computes only what a sampled light
+// point needs (p, ng, area, uv) with the same arithmetic.
+template<bool FULL>
+LR_D void reconstruct(const DScene &scene, uint32_t inst_id, uint32_t prim, f3 bary, SurfacePoint &sp) {
+    auto ip = reinterpret_cast<const float4 *>(scene.instances + inst_id);
+    auto h = reinterpret_cast<const uint4 *>(ip)[0];
+    auto q0 = ip[1], q1 = ip[2], q2 = ip[3], q3 = ip[4];
+    auto vertex_offset = __float_as_uint(q0.w), tri_offset = __float_as_uint(q1.w);
+    auto tri = scene.triangles[tri_offset + prim];
+    auto vp = reinterpret_cast<const float4 *>(scene.vertices + vertex_offset);
+    auto a0 = vp[tri.i0 * 2u], a1 = vp[tri.i0 * 2u + 1u];
+    auto b0 = vp[tri.i1 * 2u], b1 = vp[tri.i1 * 2u + 1u];
+    auto c0 = vp[tri.i2 * 2u], c1 = vp[tri.i2 * 2u + 1u];
+    f3 m0 = mk3(q0.x, q0.y, q0.z), m1 = mk3(q1.x, q1.y, q1.z), m2 = mk3(q2.x, q2.y, q2.z), mt = mk3(q3.x, q3.y, q3.z);
+    auto mul = [&](f3 v) { return m0 * v.x + m1 * v.y + m2 * v.z; };
+    f3 p0 = mk3(a0.x, a0.y, a0.z), p1 = mk3(b0.x, b0.y, b0.z), p2 = mk3(c0.x, c0.y, c0.z);
+    f2 uv0{a1.z, a1.w}, uv1{b1.z, b1.w}, uv2{c1.z, c1.w};
+    auto dp0 = p1 - p0, dp1 = p2 - p0;
+    sp.p = mul(bary.x * p0 + bary.y * p1 + bary.z * p2) + mt;
+    auto c = cross(mul(dp0), mul(dp1));
+    sp.area = length(c) * .5f;
+    sp.ng = normalize(c);
+    sp.flags = h.x & 1023u;
+    sp.tags = h.y;
+    sp.offset_bits = h.w;
+    sp.tri_offset = tri_offset;
+    sp.uv = (sp.flags & LR_SHAPE_HAS_VERTEX_UV) ?
+                f2{bary.x * uv0.x + bary.y * uv1.x + bary.z * uv2.x, bary.x * uv0.y + bary.y * uv1.y + bary.z * uv2.y} :
+                f2{bary.y, bary.z};
+    if (FULL) {
+        auto r0 = ip[5], r1 = ip[6], r2 = ip[7];
+        f3 n0 = mk3(a0.w, a1.x, a1.y), n1 = mk3(b0.w, b1.x, b1.y), n2 = mk3(c0.w, c1.x, c1.y);
+        auto ns_local = bary.x * n0 + bary.y * n1 + bary.z * n2;
+        f2 duv0{uv1.x - uv0.x, uv1.y - uv0.y}, duv1{uv2.x - uv0.x, uv2.y - uv0.y};
+        auto det = duv0.x * duv1.y - duv0.y * duv1.x;
+        auto inv_det = 1.f / det;
+        auto dpdu_local = (dp0 * duv1.y - dp1 * duv0.y) * inv_det;
+        auto fallback = frame_from_normal(sp.ng);
+        auto dpdu = det == 0.f ? fallback.s : mul(dpdu_local);
+        auto ns = (sp.flags & LR_SHAPE_HAS_VERTEX_NORMAL) ?
+                      normalize(mk3(r0.x, r0.y, r0.z) * ns_local.x + mk3(r1.x, r1.y, r1.z) * ns_local.y + mk3(r2.x, r2.y, r2.z) * ns_local.z) :
+                      sp.ng;
+        sp.shading = frame_from_normal_tangent(face_forward(ns, sp.ng), dpdu);
+    }
+}
+
+// LuisaCompute `offset_ray_origin` (Ray Tracing Gems ch. 6), restated from the published algorithm
+LR_D f3 offset_ray_origin(f3 p, f3 n) {
+    constexpr auto origin = 1.0f / 32.0f;
+    constexpr auto float_scale = 1.0f / 65536.0f;
+    constexpr auto int_scale = 256.0f;
+    auto one = [&](float pc, float nc) {
+        auto of_i = static_cast<int>(int_scale * nc);
+        auto p_i = __int_as_float(__float_as_int(pc) + (pc < 0.f ? -of_i : of_i));
+        return fabsf(pc) < origin ? pc + float_scale * nc : p_i;
+    };
+    return mk3(one(p.x, n.x), one(p.y, n.y), one(p.z, n.z));
+}
+LR_D f3 robust_origin(const SurfacePoint &sp, f3 w) {// Interaction::p_robust, interaction.cpp:13-19
+    auto front = dot(sp.shading.n, w) > 0.f;
+    auto n = front ? sp.ng : -sp.ng;
+    return offset_ray_origin(sp.p, intersection_offset_factor(sp.offset_bits) * n);
+}
+
+// DiffuseLightClosure::_evaluate, diffuse.cpp:67-88
+LR_D void light_evaluate(const DScene &scene, const SurfacePoint &lp, uint32_t prim, f3 p_from, f3 &L, float &pdf) {
+    auto &light = scene.lights[lp.tags & 4095u];
+    auto pdf_area = scene.tri_pdf[lp.tri_offset + prim] / lp.area;
+    auto cos_wo = abs_dot(normalize(p_from - lp.p), lp.ng);
+    f3 Le = mk3(light.L[0], light.L[1], light.L[2]);
+    if (light.dynamic) {// evaluate_illuminant_spectrum of a non-constant texture: xyz as-is, clamp >= 0
+        auto v = texture_eval(scene, light.emission_tex, lp.uv);
+        Le = max0(mk3(v.x, v.y, v.z)) * light.scale;
+    }
+    auto diff = lp.p - p_from;
+    auto p = dot(diff, diff) * pdf_area * (1.0f / cos_wo);
+    auto invalid = fabsf(cos_wo) < 1e-6f || (!light.two_sided && lp.back_facing);
+    L = invalid ? mk3(0.f) : Le;
+    pdf = invalid ? 0.f : p;
+}
+
+}// namespace lrd

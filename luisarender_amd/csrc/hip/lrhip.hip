@@ -1,0 +1,442 @@
+// lrhip.hip — C ABI (include/lrhip.h) of the gfx950 megakernel path tracer: context, scene
+// upload into HBM, launches, film read-back.  Device code lives in the dev_*.h headers and
+// megapath_kernel.h.  Written for gfx950 only; no host fallback exists — without a HIP device
+// every entry point fails with LRHIP_ERROR_DEVICE.
+#include "../../../include/lrhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "megapath_kernel.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define LR_HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                     \
+        auto err_ = (expr);                                                                                  \
+        if (err_ != hipSuccess) {                                                                            \
+            return fail(LRHIP_ERROR_DEVICE, std::string{#expr} + ": " + hipGetErrorString(err_));            \
+        }                                                                                                    \
+    } while (0)
+
+struct DeviceBuffer {
+    void *ptr{nullptr};
+    size_t bytes{0};
+    void release() {
+        if (ptr != nullptr) { (void)hipFree(ptr); }
+        ptr = nullptr, bytes = 0;
+    }
+};
+
+// persistent-grid sizing inputs that must not depend on the device actually present, so that the
+// chunking (and therefore the fp32 summation order of the film) is identical on every GPU
+constexpr uint32_t kChunkTargetItems = 4u * 256u * 8u;
+
+}// namespace
+
+struct lrhip_ctx {
+    int device{0};
+    hipStream_t stream{nullptr};
+    bool own_stream{true};
+    hipEvent_t ev_begin{nullptr}, ev_end{nullptr};
+    bool timed{false};
+    std::vector<DeviceBuffer> scene_buffers;
+    lrd::DScene scene{};
+    bool scene_ready{false};
+    uint32_t width{0}, height{0};
+    float film_scale[3]{1.f, 1.f, 1.f};
+    DeviceBuffer film_own, converted, partial, spill, counters, work_counter;
+    float4 *film{nullptr};// bound film (own or external)
+    uint32_t grid_blocks{0};
+    uint32_t cu_count{0};
+    uint32_t bvh_depth{0};
+};
+
+namespace {
+
+template<typename T>
+int upload(lrhip_ctx *ctx, const T *host, size_t count, const T **device) {
+    DeviceBuffer b;
+    b.bytes = std::max<size_t>(count * sizeof(T), 16u);
+    LR_HIP_CHECK(hipMalloc(&b.ptr, b.bytes));
+    ctx->scene_buffers.emplace_back(b);
+    if (count != 0u) { LR_HIP_CHECK(hipMemcpy(b.ptr, host, count * sizeof(T), hipMemcpyHostToDevice)); }
+    *device = static_cast<const T *>(b.ptr);
+    return LRHIP_OK;
+}
+
+int ensure(DeviceBuffer &b, size_t bytes) {
+    if (b.bytes >= bytes) { return LRHIP_OK; }
+    b.release();
+    LR_HIP_CHECK(hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return LRHIP_OK;
+}
+
+void release_scene(lrhip_ctx *ctx) {
+    for (auto &b : ctx->scene_buffers) { b.release(); }
+    ctx->scene_buffers.clear();
+    ctx->scene_ready = false;
+}
+
+// 3x3 inverse-transpose, same arithmetic as luisa::inverse(float3x3) + transpose (geometry.cpp:378)
+void normal_matrix(const float *m, float out[9]) {
+    float a[3][3];// a[c][r]
+    for (auto c = 0; c < 3; c++) {
+        for (auto r = 0; r < 3; r++) { a[c][r] = m[c * 4 + r]; }
+    }
+    auto one_over_det = 1.0f / (a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) -
+                                a[1][0] * (a[0][1] * a[2][2] - a[2][1] * a[0][2]) +
+                                a[2][0] * (a[0][1] * a[1][2] - a[1][1] * a[0][2]));
+    float inv[3][3];// inv[c][r]
+    inv[0][0] = (a[1][1] * a[2][2] - a[2][1] * a[1][2]) * one_over_det;
+    inv[0][1] = (a[2][1] * a[0][2] - a[0][1] * a[2][2]) * one_over_det;
+    inv[0][2] = (a[0][1] * a[1][2] - a[1][1] * a[0][2]) * one_over_det;
+    inv[1][0] = (a[2][0] * a[1][2] - a[1][0] * a[2][2]) * one_over_det;
+    inv[1][1] = (a[0][0] * a[2][2] - a[2][0] * a[0][2]) * one_over_det;
+    inv[1][2] = (a[1][0] * a[0][2] - a[0][0] * a[1][2]) * one_over_det;
+    inv[2][0] = (a[1][0] * a[2][1] - a[2][0] * a[1][1]) * one_over_det;
+    inv[2][1] = (a[2][0] * a[0][1] - a[0][0] * a[2][1]) * one_over_det;
+    inv[2][2] = (a[0][0] * a[1][1] - a[1][0] * a[0][1]) * one_over_det;
+    for (auto c = 0; c < 3; c++) {// transpose: column c of the result = row c of inv
+        for (auto r = 0; r < 3; r++) { out[c * 3 + r] = inv[r][c]; }
+    }
+}
+
+uint32_t bvh_depth(const lr_accel &accel) {
+    std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
+    auto depth = 0u;
+    while (!stack.empty()) {
+        auto [node, d] = stack.back();
+        stack.pop_back();
+        depth = std::max(depth, d);
+        for (auto c : accel.nodes[node].child) {
+            if (c != LR_INVALID_ID && !(c & 0x80000000u)) { stack.emplace_back(c, d + 1u); }
+        }
+    }
+    return depth;
+}
+
+}// namespace
+
+extern "C" {
+
+const char *lrhip_last_error(void) { return g_last_error.c_str(); }
+
+int lrhip_create(int device_ordinal, lrhip_ctx **out) {
+    if (out == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_create: out is NULL"); }
+    int count = 0;
+    LR_HIP_CHECK(hipGetDeviceCount(&count));
+    if (device_ordinal < 0 || device_ordinal >= count) {
+        return fail(LRHIP_ERROR_INVALID, "lrhip_create: device ordinal " + std::to_string(device_ordinal) +
+                                             " out of range (" + std::to_string(count) + " HIP devices)");
+    }
+    LR_HIP_CHECK(hipSetDevice(device_ordinal));
+    auto ctx = new lrhip_ctx{};
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop{};
+    if (auto e = hipGetDeviceProperties(&prop, device_ordinal); e != hipSuccess) {
+        delete ctx;
+        return fail(LRHIP_ERROR_DEVICE, std::string{"hipGetDeviceProperties: "} + hipGetErrorString(e));
+    }
+    ctx->cu_count = static_cast<uint32_t>(prop.multiProcessorCount);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) {
+        delete ctx;
+        return fail(LRHIP_ERROR_DEVICE, "lrhip_create: failed to create stream/events");
+    }
+    *out = ctx;
+    return LRHIP_OK;
+}
+
+void lrhip_destroy(lrhip_ctx *ctx) {
+    if (ctx == nullptr) { return; }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    release_scene(ctx);
+    ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
+    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release();
+    if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
+    if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream) {
+    if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_stream: ctx is NULL"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
+    if (hip_stream == nullptr) {
+        LR_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    }
+    return LRHIP_OK;
+}
+
+int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
+    if (ctx == nullptr || s == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: NULL argument"); }
+    if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
+        return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
+    }
+    if (s->environment.kind != LR_ENV_NONE && s->environment.kind != LR_ENV_SPHERICAL) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
+    }
+    if (s->any_non_opaque) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: alpha-tested surfaces are not supported yet");
+    }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    release_scene(ctx);
+    ctx->bvh_depth = bvh_depth(s->accel);
+    if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
+                                                 " exceeds the traversal stack capacity");
+    }
+    auto &d = ctx->scene;
+    d = lrd::DScene{};
+    int rc;
+#define LR_UP(call)                                   \
+    if ((rc = (call)) != LRHIP_OK) {                  \
+        release_scene(ctx);                           \
+        return rc;                                    \
+    }
+    LR_UP(upload(ctx, s->accel.nodes, s->accel.node_count, &d.nodes));
+    LR_UP(upload(ctx, s->accel.triangles, s->accel.triangle_count, &d.bvh_tris));
+    LR_UP(upload(ctx, s->vertices, s->vertex_count, &d.vertices));
+    LR_UP(upload(ctx, s->triangles, s->triangle_count, &d.triangles));
+    LR_UP(upload(ctx, s->tri_alias, s->triangle_count, &d.tri_alias));
+    LR_UP(upload(ctx, s->tri_pdf, s->triangle_count, &d.tri_pdf));
+    LR_UP(upload(ctx, s->light_instances, s->light_instance_count, &d.light_instances));
+    LR_UP(upload(ctx, s->surfaces, s->surface_count, &d.surfaces));
+    LR_UP(upload(ctx, s->textures, s->texture_count, &d.textures));
+    LR_UP(upload(ctx, s->texels, s->texel_count * 4u, &d.texels));
+    LR_UP(upload(ctx, &s->filter, 1u, &d.filter));
+    // instances: one 128-byte line each
+    std::vector<lrd::DInstance> instances(s->instance_count);
+    for (uint32_t i = 0; i < s->instance_count; i++) {
+        auto &src = s->instances[i];
+        auto &dst = instances[i];
+        std::memset(&dst, 0, sizeof(dst));
+        dst.handle[0] = src.handle.x, dst.handle[1] = src.handle.y, dst.handle[2] = src.handle.z, dst.handle[3] = src.handle.w;
+        auto m = src.object_to_world;
+        for (auto r = 0; r < 3; r++) { dst.c0[r] = m[r], dst.c1[r] = m[4 + r], dst.c2[r] = m[8 + r], dst.t[r] = m[12 + r]; }
+        float nm[9];
+        normal_matrix(m, nm);
+        for (auto r = 0; r < 3; r++) { dst.n0[r] = nm[r], dst.n1[r] = nm[3 + r], dst.n2[r] = nm[6 + r]; }
+        auto &mesh = s->meshes[src.handle.x >> 10u];
+        dst.vertex_offset = mesh.vertex_offset;
+        dst.triangle_offset = mesh.triangle_offset;
+    }
+    LR_UP(upload(ctx, instances.data(), instances.size(), &d.instances));
+    // closures: fold constant textures on the host (same arithmetic as the per-hit device path)
+    auto is_constant = [&](int32_t id) { return id < 0 || s->textures[id].kind == LR_TEX_CONSTANT; };
+    std::vector<lrd::DClosure> closures(s->surface_count);
+    for (uint32_t i = 0; i < s->surface_count; i++) {
+        auto &surf = s->surfaces[i];
+        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX) {
+            release_scene(ctx);
+            return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Disney/Mix closures are not built yet (SURVEY §8 f2)");
+        }
+        auto dynamic = surf.normal_tex >= 0;
+        for (auto t : surf.tex) { dynamic = dynamic || !is_constant(t); }
+        lrd::DClosure c{};
+        if (!dynamic) {
+            c = lrd::resolve_closure(
+                surf,
+                [&](int32_t id) {
+                    auto &t = s->textures[id];
+                    return make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
+                },
+                [&](int32_t id) { return s->textures[id].channels; }, 1.f);
+        } else {
+            c.kind = surf.kind;
+        }
+        c.dynamic = dynamic ? 1u : 0u;
+        closures[i] = c;
+    }
+    LR_UP(upload(ctx, closures.data(), closures.size(), &d.closures));
+    std::vector<lrd::DLight> lights(s->light_count);
+    for (uint32_t i = 0; i < s->light_count; i++) {
+        auto &src = s->lights[i];
+        lrd::DLight l{};
+        l.emission_tex = src.emission_tex, l.scale = src.scale, l.two_sided = src.two_sided;
+        auto &t = s->textures[src.emission_tex];
+        l.dynamic = t.kind == LR_TEX_CONSTANT ? 0u : 1u;
+        if (!l.dynamic) {// evaluate_illuminant_spectrum of a static texture, texture.cpp:49-53,77-79
+            auto rgb = lrd::extend_rgb(make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), t.channels);
+            auto sv = lrd::max0(rgb) * src.scale;
+            l.L[0] = sv.x, l.L[1] = sv.y, l.L[2] = sv.z;
+        }
+        lights[i] = l;
+    }
+    LR_UP(upload(ctx, lights.data(), lights.size(), &d.lights));
+#undef LR_UP
+    auto &cam = d.camera;
+    cam.kind = s->camera.kind, cam.width = s->camera.width, cam.height = s->camera.height;
+    std::memcpy(cam.c2w, s->camera.camera_to_world, sizeof(cam.c2w));
+    cam.tan_half_fov = s->camera.tan_half_fov, cam.focus_distance = s->camera.focus_distance;
+    cam.lens_radius = s->camera.lens_radius, cam.projected_pixel_size = s->camera.projected_pixel_size;
+    cam.ortho_scale = s->camera.ortho_scale, cam.clip_near = s->camera.clip_near, cam.clip_far = s->camera.clip_far;
+    d.env_kind = s->environment.kind;
+    if (d.env_kind == LR_ENV_SPHERICAL) {
+        auto &t = s->textures[s->environment.emission_tex];
+        if (t.kind != LR_TEX_CONSTANT) {
+            release_scene(ctx);
+            return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: image-based environments are SURVEY §8 f1 (next)");
+        }
+        auto sv = lrd::max0(lrd::extend_rgb(make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), t.channels)) * s->environment.scale;
+        d.env_L[0] = sv.x, d.env_L[1] = sv.y, d.env_L[2] = sv.z;
+        std::memcpy(d.env_to_world, s->environment.env_to_world, sizeof(d.env_to_world));
+    }
+    d.max_depth = s->integrator.max_depth, d.rr_depth = s->integrator.rr_depth;
+    d.rr_threshold = s->integrator.rr_threshold, d.env_prob = s->integrator.env_prob;
+    d.light_count = s->integrator.light_count;
+    d.has_lights = s->light_count != 0u ? 1u : 0u;
+    d.sampler_kind = s->sampler.kind, d.seed = s->sampler.seed;
+    if (d.sampler_kind != LR_SAMPLER_INDEPENDENT && d.sampler_kind != LR_SAMPLER_PCG32) {
+        release_scene(ctx);
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Sobol samplers are SURVEY §8 f2 (next)");
+    }
+    d.film_clamp = s->film.clamp;
+    for (auto i = 0; i < 3; i++) { ctx->film_scale[i] = s->film.scale[i]; }
+    ctx->width = s->camera.width, ctx->height = s->camera.height;
+    auto film_bytes = static_cast<size_t>(ctx->width) * ctx->height * sizeof(float4);
+    if (auto r = ensure(ctx->film_own, film_bytes); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->converted, film_bytes); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->counters, sizeof(lrd::DCounters)); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->work_counter, 256u); r != LRHIP_OK) { return r; }
+    LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
+    ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
+    LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
+    // persistent grid: as many blocks as are resident
+    int blocks_per_cu = 0;
+    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false>, lrd::kBlockThreads, 0));
+    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+    ctx->grid_blocks = ctx->cu_count * static_cast<uint32_t>(blocks_per_cu);
+    auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
+    if (auto r = ensure(ctx->spill, total_threads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    ctx->scene_ready = true;
+    return LRHIP_OK;
+}
+
+int lrhip_bind_film(lrhip_ctx *ctx, void *device_float4_film) {
+    if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_bind_film: no scene uploaded"); }
+    ctx->film = device_float4_film != nullptr ? static_cast<float4 *>(device_float4_film) : static_cast<float4 *>(ctx->film_own.ptr);
+    return LRHIP_OK;
+}
+
+int lrhip_film_clear(lrhip_ctx *ctx) {
+    if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_clear: no scene uploaded"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    LR_HIP_CHECK(hipMemsetAsync(ctx->film, 0, static_cast<size_t>(ctx->width) * ctx->height * sizeof(float4), ctx->stream));
+    return LRHIP_OK;
+}
+
+int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
+    if (ctx == nullptr || p == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_render: no scene uploaded"); }
+    auto tiles_x = (ctx->width + 7u) / 8u, tiles_y = (ctx->height + 7u) / 8u;
+    auto tile_count = tiles_x * tiles_y;
+    if (p->spp_end < p->spp_begin || p->tile_stride == 0u || p->tile_end > tile_count || p->tile_begin > p->tile_end) {
+        return fail(LRHIP_ERROR_INVALID, "lrhip_render: invalid spp/tile range");
+    }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->timed = false;
+    if (p->spp_end == p->spp_begin || p->tile_begin == p->tile_end) { return LRHIP_OK; }
+    // MegakernelPathTracingInstance::_render_one_camera (mega_path.cpp:40-47): no lights -> nothing rendered
+    if (!ctx->scene.has_lights && ctx->scene.env_kind == LR_ENV_NONE) { return LRHIP_OK; }
+    auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
+    auto spp = p->spp_end - p->spp_begin;
+    // chunking is a function of the frame only (tile_count, spp), never of the device or the shard
+    auto chunk_count = std::max(1u, std::min(spp, (kChunkTargetItems + tile_count - 1u) / tile_count));
+    lrd::RenderArgs args{};
+    args.film = ctx->film;
+    args.spp_begin = p->spp_begin, args.spp_end = p->spp_end;
+    args.tile_begin = p->tile_begin, args.tile_end = p->tile_end, args.tile_stride = p->tile_stride;
+    args.tiles_x = tiles_x, args.tiles_y = tiles_y;
+    args.chunk_count = chunk_count;
+    args.item_count = tiles_in_range * chunk_count;
+    args.work_counter = static_cast<uint32_t *>(ctx->work_counter.ptr);
+    args.spill = static_cast<uint32_t *>(ctx->spill.ptr);
+    args.total_threads = ctx->grid_blocks * lrd::kBlockThreads;
+    args.counters = static_cast<lrd::DCounters *>(ctx->counters.ptr);
+    auto pixel_count = ctx->width * ctx->height;
+    if (chunk_count > 1u) {
+        if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
+        args.partial = static_cast<float4 *>(ctx->partial.ptr);
+    }
+    LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 4u, ctx->stream));
+    auto blocks = std::min(ctx->grid_blocks, (args.item_count + 3u) / 4u);
+    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    if (p->flags & LRHIP_RENDER_COUNTERS) {
+        hipLaunchKernelGGL(lrd::megapath_kernel<true>, dim3(blocks), dim3(lrd::kBlockThreads), 0, ctx->stream, ctx->scene, args);
+    } else {
+        hipLaunchKernelGGL(lrd::megapath_kernel<false>, dim3(blocks), dim3(lrd::kBlockThreads), 0, ctx->stream, ctx->scene, args);
+    }
+    LR_HIP_CHECK(hipGetLastError());
+    LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
+    ctx->timed = true;
+    if (chunk_count > 1u) {
+        hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
+                           args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
+        LR_HIP_CHECK(hipGetLastError());
+    }
+    return LRHIP_OK;
+}
+
+int lrhip_synchronize(lrhip_ctx *ctx) {
+    if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_synchronize: ctx is NULL"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LRHIP_OK;
+}
+
+int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted) {
+    if (ctx == nullptr || rgba == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_download: invalid argument"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    auto pixel_count = ctx->width * ctx->height;
+    auto bytes = static_cast<size_t>(pixel_count) * sizeof(float4);
+    const void *src = ctx->film;
+    if (converted) {
+        hipLaunchKernelGGL(lrd::film_convert_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
+                           static_cast<float4 *>(ctx->converted.ptr), pixel_count, ctx->film_scale[0], ctx->film_scale[1], ctx->film_scale[2]);
+        LR_HIP_CHECK(hipGetLastError());
+        src = ctx->converted.ptr;
+    }
+    LR_HIP_CHECK(hipMemcpyAsync(rgba, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LRHIP_OK;
+}
+
+int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out) {
+    if (ctx == nullptr || out == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_get_counters: invalid argument"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    static_assert(sizeof(lrhip_counters) == sizeof(lrd::DCounters), "counter layouts must match");
+    LR_HIP_CHECK(hipMemcpy(out, ctx->counters.ptr, sizeof(lrhip_counters), hipMemcpyDeviceToHost));
+    return LRHIP_OK;
+}
+
+double lrhip_last_render_ms(lrhip_ctx *ctx) {
+    if (ctx == nullptr || !ctx->timed) { return 0.0; }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess) { return -1.0; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) { return -1.0; }
+    return static_cast<double>(ms);
+}
+
+}// extern "C"

@@ -1,0 +1,318 @@
+// megapath_kernel.h — the persistent-threads megakernel path tracer for gfx950.
+//
+// One launch renders (tiles x sample-chunks) work items pulled from an atomic queue.  A
+// wavefront owns one 8x8-pixel tile at a time, lane <-> pixel, and each lane walks its pixel's
+// samples back to back ("path regeneration"): the moment a path dies the lane starts the next
+// sample, so the wave's 64 lanes stay occupied until the tile's samples run out.  Pixel sums live
+// in registers for the whole item and are written once — no film atomics (the reference does four
+// float atomics per sample, src/films/color.cpp:116-121).
+//
+// Per loop iteration every live lane traces at most two rays in ONE traversal loop
+// (dev_trace.h trace_pair): the shadow ray of the bounce just shaded and the continuation ray.
+// A path whose only pending work is a shadow ray is retired into (Li_prev, nee) so the lane can
+// already start the next sample's camera ray in the same traversal.
+//
+// The estimator is the reference's MegakernelPathTracingInstance::Li
+// (src/integrators/mega_path.cpp:49-156) and film accumulation ColorFilmInstance::_accumulate
+// (src/films/color.cpp:107-130); sample order per pixel is the reference's (spp launches in
+// sequence, src/base/integrator.cpp:92-94), so sums are reproduced in the same order.
+#pragma once
+#include "dev_shade.h"
+
+namespace lrd {
+
+struct FilmAcc {
+    float r, g, b, n;
+};
+
+LR_D void film_accumulate(FilmAcc &acc, f3 rgb, float clamp) {// color.cpp:107-130, effective_spp = 1
+    if (!(any_nan(rgb) || any_inf(rgb))) {
+        auto threshold = clamp * fmaxf(1.f, 1.f);
+        auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
+        auto c = rgb * (threshold / fmaxf(strength, threshold));
+        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) { acc.r += c.x, acc.g += c.y, acc.b += c.z; }
+        acc.n += 1.f;
+    }
+}
+
+LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp:133-140
+    auto sum = f_pdf + g_pdf;
+    return sum == 0.0f ? 0.0f : f_pdf / sum;
+}
+
+template<bool COUNT>
+__global__ __launch_bounds__(kBlockThreads) void megapath_kernel(DScene scene, RenderArgs args) {
+    __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
+    __shared__ lr_filter s_filter;
+    const auto tid = threadIdx.x;
+    const auto lane = tid & 63u;
+    const auto gtid = blockIdx.x * kBlockThreads + tid;
+    {// stage the filter tables (1 KiB) in LDS
+        auto src = reinterpret_cast<const uint32_t *>(scene.filter);
+        auto dst = reinterpret_cast<uint32_t *>(&s_filter);
+        for (auto i = tid; i < sizeof(lr_filter) / 4u; i += kBlockThreads) { dst[i] = src[i]; }
+    }
+    __syncthreads();
+    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads};
+    DCounters local{};
+
+    for (;;) {
+        // ---- next work item of this wavefront
+        uint32_t item = 0u;
+        if (lane == 0u) { item = atomicAdd(args.work_counter, 1u); }
+        item = __shfl(item, 0);
+        if (item >= args.item_count) { break; }
+        const auto tile_index = item / args.chunk_count;
+        const auto chunk = item - tile_index * args.chunk_count;
+        const auto tile = args.tile_begin + tile_index * args.tile_stride;
+        const auto tx = tile % args.tiles_x, ty = tile / args.tiles_x;
+        const auto px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3u);
+        const auto in_bounds = px < scene.camera.width && py < scene.camera.height;
+        const auto pixel_index = py * scene.camera.width + px;
+        const auto spp_total = args.spp_end - args.spp_begin;
+        const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
+        auto s_next = args.spp_begin + chunk * per_chunk;
+        const auto s_end = min(s_next + per_chunk, args.spp_end);
+        FilmAcc acc{0.f, 0.f, 0.f, 0.f};
+        if (in_bounds && args.chunk_count == 1u) {
+            auto v = args.film[pixel_index];
+            acc = {v.x, v.y, v.z, v.w};
+        }
+
+        // ---- per-lane path state
+        PathSampler sampler{};
+        Ray ray{}, shadow{};
+        f3 beta = mk3(0.f), Li = mk3(0.f), Li_prev = mk3(0.f), nee = mk3(0.f);
+        auto pdf_bsdf = 1e16f;
+        auto depth = 0u;
+        auto path_open = false, has_closest = false, has_shadow = false, shadow_is_prev = false;
+
+        for (;;) {
+            if (!has_closest) {
+                if (path_open) {
+                    if (has_shadow) {// finished except for its last shadow ray: retire, keep the lane busy
+                        Li_prev = Li;
+                        shadow_is_prev = true;
+                    } else {
+                        film_accumulate(acc, Li, scene.film_clamp);
+                    }
+                    path_open = false;
+                }
+                if (in_bounds && s_next < s_end) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
+                    sampler.start(scene, px, py, s_next);
+                    s_next++;
+                    auto u_filter = sampler.next_2d();
+                    auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
+                    float weight;
+                    camera_ray(scene, &s_filter, px, py, u_filter, u_lens, ray, weight);
+                    beta = mk3(weight);
+                    Li = mk3(0.f);
+                    pdf_bsdf = 1e16f;
+                    depth = 0u;
+                    path_open = true, has_closest = true;
+                    if (COUNT) { local.paths++; }
+                }
+            }
+            if (!__any(has_closest || has_shadow)) { break; }
+
+            bool occluded;
+            HitRecord hit;
+            TraceStats ts{0u, 0u};
+            if (COUNT) {
+                local.closest_rays += has_closest ? 1u : 0u;
+                local.shadow_rays += has_shadow ? 1u : 0u;
+            }
+            trace_pair<COUNT>(scene, stack, has_shadow, shadow, has_closest, ray, occluded, hit, ts);
+            if (COUNT) { local.nodes_visited += ts.nodes, local.tris_tested += ts.tris; }
+
+            if (has_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
+                auto c = occluded ? mk3(0.f) : nee;
+                if (shadow_is_prev) {
+                    film_accumulate(acc, Li_prev + c, scene.film_clamp);
+                    shadow_is_prev = false;
+                } else {
+                    Li += c;
+                }
+                has_shadow = false;
+            }
+            if (!has_closest) { continue; }
+
+            // ---- shade the closest hit of `ray` (one iteration of the reference's depth loop)
+            has_closest = false;
+            auto wo = -ray.d;
+            if (hit.inst == kInvalid) {// miss, mega_path.cpp:70-76
+                if (scene.env_kind != LR_ENV_NONE) {
+                    auto pdf = (kInvPi * 0.25f) * scene.env_prob;
+                    Li += beta * mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]) * balance(pdf_bsdf, pdf);
+                }
+                continue;
+            }
+            SurfacePoint it;
+            reconstruct<true>(scene, hit.inst, hit.prim, mk3(1.f - hit.u - hit.v, hit.u, hit.v), it);
+            it.back_facing = dot(wo, it.ng) < 0.0f;
+            if (COUNT) { local.surface_hits++; }
+            if (scene.has_lights && (it.flags & LR_SHAPE_HAS_LIGHT)) {// hit light, mega_path.cpp:79-86
+                f3 L;
+                float pdf;
+                light_evaluate(scene, it, hit.prim, ray.o, L, pdf);
+                pdf *= (1.f - scene.env_prob) / static_cast<float>(scene.light_count);
+                Li += beta * L * balance(pdf_bsdf, pdf);
+            }
+            if (!(it.flags & LR_SHAPE_HAS_SURFACE)) { continue; }
+            if (COUNT) { local.path_length_sum++, local.nee_samples++; }
+
+            auto u_light_selection = sampler.next_1d();
+            auto u_light_surface = sampler.next_2d();
+            auto u_lobe = sampler.next_1d();
+            auto u_bsdf = sampler.next_2d();
+            auto u_rr = 0.f;
+            if (depth + 1u >= scene.rr_depth) { u_rr = sampler.next_1d(); }
+
+            // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63
+            f3 light_L = mk3(0.f);
+            auto light_pdf = 0.f;
+            {
+                auto n = static_cast<float>(scene.light_count);
+                auto is_env = false;
+                auto tag = 0u;
+                auto prob = 0.f;
+                if (scene.env_prob == 1.f) {
+                    is_env = true, prob = 1.f;
+                } else if (scene.env_prob == 0.f) {
+                    tag = static_cast<uint32_t>(clampf(u_light_selection * n, 0.f, n - 1.f)), prob = 1.f / n;
+                } else {
+                    auto uu = (u_light_selection - scene.env_prob) / (1.f - scene.env_prob);
+                    tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
+                    is_env = u_light_selection < scene.env_prob;
+                    prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
+                }
+                if (is_env) {// constant spherical environment: uniform sphere, spherical.cpp:114-118,138
+                    auto z = 1.0f - 2.0f * u_light_surface.x;
+                    auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+                    auto phi = 2.0f * kPi * u_light_surface.y;
+                    auto w = mk3(r * cosf(phi), r * sinf(phi), z);
+                    auto e = scene.env_to_world;
+                    auto wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
+                    light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
+                    light_pdf = (kInvPi * 0.25f) * prob;
+                    shadow.o = robust_origin(it, wi);
+                    shadow.d = wi;
+                    shadow.t_min = 0.f, shadow.t_max = kFloatMax;
+                } else {// _sample_area, uniform.cpp:107-123
+                    auto handle = scene.light_instances[tag];
+                    auto lh = reinterpret_cast<const uint4 *>(scene.instances + handle.instance_id)[0];
+                    auto l_tri_offset = scene.instances[handle.instance_id].triangle_offset;
+                    float u_remapped;
+                    auto slot = alias_slot(u_light_surface.x, lh.z, u_remapped);
+                    auto entry = scene.tri_alias[l_tri_offset + slot];
+                    auto pick = alias_pick(entry.prob, entry.alias, slot, u_remapped);
+                    f2 ut{pick.u, u_light_surface.y};// sample_uniform_triangle, sampling.cpp:89-98
+                    f2 uvt = ut.x < ut.y ? f2{0.5f * ut.x, -0.5f * ut.x + ut.y} : f2{-0.5f * ut.y + ut.x, 0.5f * ut.y};
+                    SurfacePoint lp;
+                    reconstruct<false>(scene, handle.instance_id, pick.index, mk3(uvt.x, uvt.y, 1.0f - uvt.x - uvt.y), lp);
+                    lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
+                    light_evaluate(scene, lp, pick.index, it.p, light_L, light_pdf);
+                    light_pdf *= prob;
+                    auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
+                    auto Lv = lp.p - p_from;
+                    auto dist = length(Lv);
+                    shadow.o = p_from;
+                    shadow.d = Lv * (1.f / dist);
+                    shadow.t_min = 0.f, shadow.t_max = dist * .9999f;
+                }
+            }
+
+            // ---- material, mega_path.cpp:111-143
+            auto closure = scene.closures[(it.tags >> 12u) & 4095u];
+            if (closure.dynamic) {
+                auto &raw = scene.surfaces[(it.tags >> 12u) & 4095u];
+                if (raw.normal_tex >= 0) {// NormalMapWrapper, surface.h:236-254
+                    auto v = texture_eval(scene, raw.normal_tex, it.uv);
+                    auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
+                    if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
+                    auto normal = to_world(it.shading, n_local);
+                    it.shading = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), it.shading.s);
+                }
+                closure = resolve_closure(
+                    raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
+                    [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
+            }
+            if (light_pdf > 0.0f) {
+                auto eval = closure_evaluate(closure, it.shading, it.ng, wo, shadow.d);
+                auto w = balance(light_pdf, eval.pdf) / light_pdf;
+                nee = w * beta * eval.f * light_L;
+                // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
+                has_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
+            }
+            auto bs = closure_sample(closure, it.shading, it.ng, wo, u_lobe, u_bsdf);
+            ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
+            ray.d = bs.wi;
+            ray.t_min = 0.f, ray.t_max = kFloatMax;
+            pdf_bsdf = bs.pdf;
+            beta *= (bs.pdf > 0.f ? 1.f / bs.pdf : 0.f) * bs.f;
+            auto eta_scale = 1.f;
+            if (closure.kind == LR_SURFACE_GLASS) {
+                if (bs.event == kEventEnter) { eta_scale = sqr(closure.s1); }
+                else if (bs.event == kEventExit) { eta_scale = sqr(1.f / closure.s1); }
+            }
+            if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
+            if (beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f) { continue; }
+            auto q = fmaxf(max_component(beta) * eta_scale, .05f);// Russian roulette, mega_path.cpp:148-153
+            if (depth + 1u >= scene.rr_depth) {
+                if (q < scene.rr_threshold && u_rr >= q) { continue; }
+                beta *= q < scene.rr_threshold ? 1.0f / q : 1.f;
+            }
+            depth++;
+            has_closest = depth < scene.max_depth;
+        }
+
+        if (in_bounds) {
+            auto out = make_float4(acc.r, acc.g, acc.b, acc.n);
+            if (args.chunk_count == 1u) { args.film[pixel_index] = out; }
+            else { args.partial[static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + pixel_index] = out; }
+        }
+    }
+
+    if (COUNT) {// one atomic per counter per wave
+        auto reduce = [&](unsigned long long v, unsigned long long *dst) {
+            for (auto off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off); }
+            if (lane == 0u) { atomicAdd(dst, v); }
+        };
+        reduce(local.paths, &args.counters->paths);
+        reduce(local.closest_rays, &args.counters->closest_rays);
+        reduce(local.shadow_rays, &args.counters->shadow_rays);
+        reduce(local.nodes_visited, &args.counters->nodes_visited);
+        reduce(local.tris_tested, &args.counters->tris_tested);
+        reduce(local.surface_hits, &args.counters->surface_hits);
+        reduce(local.nee_samples, &args.counters->nee_samples);
+        reduce(local.path_length_sum, &args.counters->path_length_sum);
+    }
+}
+
+// film += sum over chunks of the per-chunk partial sums, in chunk order (deterministic)
+__global__ void resolve_partial_kernel(float4 *film, const float4 *partial, uint32_t pixel_count, uint32_t chunk_count,
+                                       uint32_t width, uint32_t tiles_x, uint32_t tile_begin, uint32_t tile_end,
+                                       uint32_t tile_stride) {
+    auto i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixel_count) { return; }
+    auto px = i % width, py = i / width;
+    auto tile = (py / 8u) * tiles_x + px / 8u;
+    if (tile < tile_begin || tile >= tile_end || (tile - tile_begin) % tile_stride != 0u) { return; }
+    auto v = film[i];
+    for (auto c = 0u; c < chunk_count; c++) {
+        auto p = partial[static_cast<size_t>(c) * pixel_count + i];
+        v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+    }
+    film[i] = v;
+}
+
+// convert kernel of the Color film, color.cpp:87-93
+__global__ void film_convert_kernel(const float4 *film, float4 *out, uint32_t pixel_count, float sx, float sy, float sz) {
+    auto i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixel_count) { return; }
+    auto c = film[i];
+    auto inv = 1.f / fmaxf(c.w, 1.f);
+    out[i] = make_float4((inv * sx) * c.x, (inv * sy) * c.y, (inv * sz) * c.z, 1.f);
+}
+
+}// namespace lrd

@@ -1,0 +1,358 @@
+// image_io.cpp — float image output/input without tinyexr / stb (absent submodules).
+// save_image mirrors src/util/imageio.cpp:694-726: float RGBA -> ".exr" (fp32 channels) or
+// ".hdr" (Radiance RGBE); any other extension falls back to ".exr".  The EXR writer emits
+// uncompressed scanlines (tinyexr would ZIP them; every OpenEXR reader accepts both).
+// Readers: PFM, Radiance HDR, uncompressed scanline EXR (float/half), binary PPM/PGM.
+#include "scene.h"
+
+#include <cmath>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+
+namespace lr {
+
+namespace fs = std::filesystem;
+
+namespace {
+
+std::string lower_ext(const fs::path &p) {
+    auto ext = p.extension().string();
+    for (auto &c : ext) { c = static_cast<char>(std::tolower(c)); }
+    return ext;
+}
+
+template<typename T>
+void put(std::string &buf, T v) { buf.append(reinterpret_cast<const char *>(&v), sizeof(T)); }
+void put_str(std::string &buf, const char *s) { buf.append(s, std::strlen(s) + 1u); }
+
+void write_exr(const fs::path &path, const float *rgba, uint32_t w, uint32_t h) {
+    std::string head;
+    put<uint32_t>(head, 20000630u);// magic
+    put<uint32_t>(head, 2u);       // version 2, scanline, single part
+    // channels (alphabetical): A B G R, all FLOAT (pixel type 2)
+    put_str(head, "channels"), put_str(head, "chlist");
+    put<uint32_t>(head, 4u * 18u + 1u);
+    for (auto name : {"A", "B", "G", "R"}) {
+        put_str(head, name);
+        put<uint32_t>(head, 2u);// FLOAT
+        put<uint8_t>(head, 0u); // pLinear
+        head.append(3u, '\0');
+        put<uint32_t>(head, 1u), put<uint32_t>(head, 1u);
+    }
+    put<uint8_t>(head, 0u);
+    put_str(head, "compression"), put_str(head, "compression"), put<uint32_t>(head, 1u), put<uint8_t>(head, 0u);
+    auto box = [&](const char *name) {
+        put_str(head, name), put_str(head, "box2i"), put<uint32_t>(head, 16u);
+        put<int32_t>(head, 0), put<int32_t>(head, 0);
+        put<int32_t>(head, static_cast<int32_t>(w) - 1), put<int32_t>(head, static_cast<int32_t>(h) - 1);
+    };
+    box("dataWindow"), box("displayWindow");
+    put_str(head, "lineOrder"), put_str(head, "lineOrder"), put<uint32_t>(head, 1u), put<uint8_t>(head, 0u);
+    put_str(head, "pixelAspectRatio"), put_str(head, "float"), put<uint32_t>(head, 4u), put<float>(head, 1.f);
+    put_str(head, "screenWindowCenter"), put_str(head, "v2f"), put<uint32_t>(head, 8u), put<float>(head, 0.f), put<float>(head, 0.f);
+    put_str(head, "screenWindowWidth"), put_str(head, "float"), put<uint32_t>(head, 4u), put<float>(head, 1.f);
+    put<uint8_t>(head, 0u);// end of header
+
+    auto line_bytes = static_cast<uint64_t>(w) * 16u;
+    auto table_offset = head.size();
+    auto data_offset = table_offset + static_cast<uint64_t>(h) * 8u;
+    std::ofstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to save film to '" + path.string() + "'."}; }
+    f.write(head.data(), static_cast<std::streamsize>(head.size()));
+    for (uint32_t y = 0; y < h; y++) {
+        auto off = data_offset + static_cast<uint64_t>(y) * (8u + line_bytes);
+        f.write(reinterpret_cast<const char *>(&off), 8);
+    }
+    std::vector<float> line(static_cast<size_t>(w) * 4u);
+    for (uint32_t y = 0; y < h; y++) {
+        auto yy = static_cast<int32_t>(y);
+        auto size = static_cast<uint32_t>(line_bytes);
+        f.write(reinterpret_cast<const char *>(&yy), 4);
+        f.write(reinterpret_cast<const char *>(&size), 4);
+        static constexpr int order[4] = {3, 2, 1, 0};// A B G R
+        for (auto c = 0; c < 4; c++) {
+            for (uint32_t x = 0; x < w; x++) {
+                line[static_cast<size_t>(c) * w + x] = rgba[(static_cast<size_t>(y) * w + x) * 4u + static_cast<size_t>(order[c])];
+            }
+        }
+        f.write(reinterpret_cast<const char *>(line.data()), static_cast<std::streamsize>(line_bytes));
+    }
+}
+
+void float_to_rgbe(const float *rgb, uint8_t *out) {
+    auto m = std::max(rgb[0], std::max(rgb[1], rgb[2]));
+    if (m < 1e-32f) {
+        out[0] = out[1] = out[2] = out[3] = 0u;
+        return;
+    }
+    int e;
+    auto scale = std::frexp(m, &e) * 256.f / m;
+    out[0] = static_cast<uint8_t>(rgb[0] * scale);
+    out[1] = static_cast<uint8_t>(rgb[1] * scale);
+    out[2] = static_cast<uint8_t>(rgb[2] * scale);
+    out[3] = static_cast<uint8_t>(e + 128);
+}
+
+void write_hdr(const fs::path &path, const float *rgba, uint32_t w, uint32_t h) {
+    std::ofstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to save film to '" + path.string() + "'."}; }
+    f << "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " << h << " +X " << w << "\n";
+    std::vector<uint8_t> line(static_cast<size_t>(w) * 4u);
+    for (uint32_t y = 0; y < h; y++) {
+        for (uint32_t x = 0; x < w; x++) { float_to_rgbe(rgba + (static_cast<size_t>(y) * w + x) * 4u, &line[x * 4u]); }
+        f.write(reinterpret_cast<const char *>(line.data()), static_cast<std::streamsize>(line.size()));
+    }
+}
+
+float half_to_float(uint16_t hbits) {
+    uint32_t sign = (hbits >> 15u) & 1u, exp = (hbits >> 10u) & 31u, man = hbits & 1023u;
+    uint32_t f;
+    if (exp == 0u) {
+        if (man == 0u) { f = sign << 31u; }
+        else {
+            exp = 127u - 15u + 1u;
+            while ((man & 1024u) == 0u) { man <<= 1u, exp--; }
+            f = (sign << 31u) | (exp << 23u) | ((man & 1023u) << 13u);
+        }
+    } else if (exp == 31u) {
+        f = (sign << 31u) | 0x7f800000u | (man << 13u);
+    } else {
+        f = (sign << 31u) | ((exp + 112u) << 23u) | (man << 13u);
+    }
+    float out;
+    std::memcpy(&out, &f, 4);
+    return out;
+}
+
+LoadedImage read_pfm(const fs::path &path) {
+    std::ifstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
+    std::string magic;
+    int w, h;
+    float scale;
+    f >> magic >> w >> h >> scale;
+    f.get();
+    auto channels = magic == "PF" ? 3 : (magic == "Pf" ? 1 : (magic == "PF4" ? 4 : 0));
+    if (channels == 0 || w <= 0 || h <= 0) { throw Error{"Invalid PFM image '" + path.string() + "'."}; }
+    std::vector<float> raw(static_cast<size_t>(w) * static_cast<size_t>(h) * static_cast<size_t>(channels));
+    f.read(reinterpret_cast<char *>(raw.data()), static_cast<std::streamsize>(raw.size() * 4u));
+    if (scale > 0.f) {// big endian
+        for (auto &v : raw) {
+            uint32_t b;
+            std::memcpy(&b, &v, 4);
+            b = __builtin_bswap32(b);
+            std::memcpy(&v, &b, 4);
+        }
+    }
+    LoadedImage img;
+    img.width = static_cast<uint32_t>(w), img.height = static_cast<uint32_t>(h);
+    img.channels = static_cast<uint32_t>(channels), img.is_hdr = true;
+    img.pixels.resize(static_cast<size_t>(w) * static_cast<size_t>(h) * 4u);
+    for (auto y = 0; y < h; y++) {// PFM rows are bottom-to-top
+        for (auto x = 0; x < w; x++) {
+            auto src = &raw[(static_cast<size_t>(h - 1 - y) * static_cast<size_t>(w) + static_cast<size_t>(x)) * static_cast<size_t>(channels)];
+            auto dst = &img.pixels[(static_cast<size_t>(y) * static_cast<size_t>(w) + static_cast<size_t>(x)) * 4u];
+            dst[0] = src[0], dst[1] = channels >= 3 ? src[1] : 0.f, dst[2] = channels >= 3 ? src[2] : 0.f;
+            dst[3] = channels == 4 ? src[3] : (channels == 1 ? 0.f : 1.f);
+        }
+    }
+    return img;
+}
+
+LoadedImage read_hdr(const fs::path &path) {
+    std::ifstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
+    std::string line;
+    std::getline(f, line);
+    if (line.rfind("#?", 0) != 0) { throw Error{"Invalid Radiance HDR image '" + path.string() + "'."}; }
+    while (std::getline(f, line) && !line.empty() && line != "\r") {}
+    std::getline(f, line);
+    int w = 0, h = 0;
+    if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) { throw Error{"Unsupported HDR orientation in '" + path.string() + "'."}; }
+    LoadedImage img;
+    img.width = static_cast<uint32_t>(w), img.height = static_cast<uint32_t>(h), img.channels = 3u, img.is_hdr = true;
+    img.pixels.resize(static_cast<size_t>(w) * static_cast<size_t>(h) * 4u);
+    std::vector<uint8_t> scan(static_cast<size_t>(w) * 4u);
+    for (auto y = 0; y < h; y++) {
+        uint8_t head[4];
+        f.read(reinterpret_cast<char *>(head), 4);
+        if (head[0] == 2u && head[1] == 2u && (head[2] & 0x80u) == 0u && w >= 8 && w < 32768) {// new RLE
+            for (auto c = 0; c < 4; c++) {
+                auto x = 0;
+                while (x < w) {
+                    auto count = f.get();
+                    if (count > 128) {
+                        auto value = static_cast<uint8_t>(f.get());
+                        count -= 128;
+                        while (count-- > 0 && x < w) { scan[static_cast<size_t>(x++) * 4u + static_cast<size_t>(c)] = value; }
+                    } else {
+                        while (count-- > 0 && x < w) { scan[static_cast<size_t>(x++) * 4u + static_cast<size_t>(c)] = static_cast<uint8_t>(f.get()); }
+                    }
+                }
+            }
+        } else {// flat
+            std::memcpy(scan.data(), head, 4);
+            f.read(reinterpret_cast<char *>(scan.data() + 4), static_cast<std::streamsize>(scan.size() - 4u));
+        }
+        for (auto x = 0; x < w; x++) {
+            auto p = &scan[static_cast<size_t>(x) * 4u];
+            auto dst = &img.pixels[(static_cast<size_t>(y) * static_cast<size_t>(w) + static_cast<size_t>(x)) * 4u];
+            if (p[3] == 0u) { dst[0] = dst[1] = dst[2] = 0.f; }
+            else {
+                auto s = std::ldexp(1.f, static_cast<int>(p[3]) - (128 + 8));
+                dst[0] = static_cast<float>(p[0]) * s, dst[1] = static_cast<float>(p[1]) * s, dst[2] = static_cast<float>(p[2]) * s;
+            }
+            dst[3] = 1.f;
+        }
+    }
+    return img;
+}
+
+LoadedImage read_exr(const fs::path &path) {
+    std::ifstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
+    std::string data{std::istreambuf_iterator<char>{f}, std::istreambuf_iterator<char>{}};
+    size_t p = 0;
+    auto rd32 = [&](size_t at) { uint32_t v; std::memcpy(&v, data.data() + at, 4); return v; };
+    if (data.size() < 8u || rd32(0) != 20000630u) { throw Error{"Invalid EXR image '" + path.string() + "'."}; }
+    if ((rd32(4) & 0x1e00u) != 0u) { throw Error{"Only single-part scanline EXR is supported: '" + path.string() + "'."}; }
+    p = 8;
+    struct Channel { std::string name; uint32_t type; };
+    std::vector<Channel> channels;
+    int32_t xmin = 0, ymin = 0, xmax = -1, ymax = -1;
+    uint8_t compression = 0;
+    while (p < data.size() && data[p] != '\0') {
+        std::string name{data.c_str() + p};
+        p += name.size() + 1u;
+        std::string type{data.c_str() + p};
+        p += type.size() + 1u;
+        auto size = rd32(p);
+        p += 4;
+        if (name == "channels") {
+            auto q = p;
+            while (data[q] != '\0') {
+                Channel c;
+                c.name = data.c_str() + q;
+                q += c.name.size() + 1u;
+                c.type = rd32(q);
+                q += 16u;
+                channels.emplace_back(c);
+            }
+        } else if (name == "dataWindow") {
+            std::memcpy(&xmin, data.data() + p, 4), std::memcpy(&ymin, data.data() + p + 4, 4);
+            std::memcpy(&xmax, data.data() + p + 8, 4), std::memcpy(&ymax, data.data() + p + 12, 4);
+        } else if (name == "compression") {
+            compression = static_cast<uint8_t>(data[p]);
+        }
+        p += size;
+    }
+    p++;
+    if (compression != 0u) { throw Error{"Compressed EXR input is not supported without zlib bindings: '" + path.string() + "'."}; }
+    auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
+    LoadedImage img;
+    img.width = w, img.height = h, img.is_hdr = true;
+    img.pixels.assign(static_cast<size_t>(w) * h * 4u, 0.f);
+    auto has_alpha = false;
+    uint32_t color_channels = 0u;
+    for (auto &c : channels) {
+        if (c.name == "A") { has_alpha = true; } else { color_channels++; }
+    }
+    img.channels = has_alpha ? 4u : std::min(color_channels, 3u);
+    if (!has_alpha) {
+        for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) { img.pixels[i * 4u + 3u] = 1.f; }
+    }
+    auto table = p;
+    for (uint32_t y = 0; y < h; y++) {
+        uint64_t off;
+        std::memcpy(&off, data.data() + table + static_cast<size_t>(y) * 8u, 8);
+        int32_t yy;
+        std::memcpy(&yy, data.data() + off, 4);
+        auto q = static_cast<size_t>(off) + 8u;
+        auto row = static_cast<uint32_t>(yy - ymin);
+        for (auto &c : channels) {
+            auto slot = c.name == "R" ? 0 : c.name == "G" ? 1 : c.name == "B" ? 2 : c.name == "A" ? 3 : (c.name == "Y" ? 0 : -1);
+            auto bytes = c.type == 1u ? 2u : 4u;
+            for (uint32_t x = 0; x < w; x++) {
+                float v;
+                if (c.type == 1u) {
+                    uint16_t hb;
+                    std::memcpy(&hb, data.data() + q + static_cast<size_t>(x) * 2u, 2);
+                    v = half_to_float(hb);
+                } else if (c.type == 2u) {
+                    std::memcpy(&v, data.data() + q + static_cast<size_t>(x) * 4u, 4);
+                } else {
+                    uint32_t u;
+                    std::memcpy(&u, data.data() + q + static_cast<size_t>(x) * 4u, 4);
+                    v = static_cast<float>(u);
+                }
+                if (slot >= 0) { img.pixels[(static_cast<size_t>(row) * w + x) * 4u + static_cast<size_t>(slot)] = v; }
+                if (c.name == "Y") {
+                    img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 1u] = v;
+                    img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 2u] = v;
+                }
+            }
+            q += static_cast<size_t>(w) * bytes;
+        }
+    }
+    return img;
+}
+
+LoadedImage read_pnm(const fs::path &path) {
+    std::ifstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
+    std::string magic;
+    f >> magic;
+    auto next_int = [&] {
+        for (;;) {
+            f >> std::ws;
+            if (f.peek() == '#') { std::string c; std::getline(f, c); } else { break; }
+        }
+        int v;
+        f >> v;
+        return v;
+    };
+    auto w = next_int(), h = next_int(), maxv = next_int();
+    f.get();
+    auto channels = magic == "P6" ? 3 : (magic == "P5" ? 1 : 0);
+    if (channels == 0 || maxv != 255) { throw Error{"Unsupported PNM image '" + path.string() + "'."}; }
+    std::vector<uint8_t> raw(static_cast<size_t>(w) * static_cast<size_t>(h) * static_cast<size_t>(channels));
+    f.read(reinterpret_cast<char *>(raw.data()), static_cast<std::streamsize>(raw.size()));
+    LoadedImage img;
+    img.width = static_cast<uint32_t>(w), img.height = static_cast<uint32_t>(h), img.channels = static_cast<uint32_t>(channels);
+    img.pixels.resize(static_cast<size_t>(w) * static_cast<size_t>(h) * 4u);
+    for (size_t i = 0; i < static_cast<size_t>(w) * static_cast<size_t>(h); i++) {
+        for (auto c = 0; c < 3; c++) {
+            img.pixels[i * 4u + static_cast<size_t>(c)] = static_cast<float>(raw[i * static_cast<size_t>(channels) + static_cast<size_t>(channels == 3 ? c : 0)]) / 255.f;
+        }
+        img.pixels[i * 4u + 3u] = 1.f;
+    }
+    return img;
+}
+
+}// namespace
+
+void save_image(const std::string &path_in, const float *rgba, uint32_t width, uint32_t height) {
+    fs::path path{path_in};
+    auto ext = lower_ext(path);
+    if (ext != ".exr" && ext != ".hdr") {
+        log_warning("Unsupported image extension '" + ext + "' in path '" + path.string() + "'. Falling back to '.exr'.");
+        path.replace_extension(".exr");
+        ext = ".exr";
+    }
+    if (auto folder = path.parent_path(); !folder.empty() && !fs::exists(folder)) { fs::create_directories(folder); }
+    if (ext == ".exr") { write_exr(path, rgba, width, height); } else { write_hdr(path, rgba, width, height); }
+}
+
+LoadedImage load_image(const std::string &path_in) {
+    fs::path path{path_in};
+    auto ext = lower_ext(path);
+    if (ext == ".pfm") { return read_pfm(path); }
+    if (ext == ".hdr") { return read_hdr(path); }
+    if (ext == ".exr") { return read_exr(path); }
+    if (ext == ".ppm" || ext == ".pgm") { return read_pnm(path); }
+    throw Error{"Image format '" + ext + "' needs stb/tinyexr (absent); supported: .pfm .hdr .exr(uncompressed) .ppm .pgm — '" +
+                path.string() + "'."};
+}
+
+}// namespace lr

@@ -1,0 +1,957 @@
+// scene.cpp — scene graph -> flattened tables.  See scene.h for the reference map.
+#include "scene.h"
+
+#include <array>
+#include <cstring>
+#include <filesystem>
+#include <functional>
+#include <unordered_map>
+
+namespace lr {
+
+namespace fs = std::filesystem;
+
+// ------------------------------------------------------------------ helpers
+
+void create_alias_table(const float *values, size_t n, std::vector<lr_alias_entry> &table, std::vector<float> &pdf) {
+    // src/util/sampling.cpp:38-87 — double-precision sum, float table, pairing from the back
+    auto sum = 0.0;
+    for (size_t i = 0; i < n; i++) { sum += std::abs(values[i]); }
+    pdf.assign(n, 0.f);
+    if (sum == 0.) {
+        std::fill(pdf.begin(), pdf.end(), static_cast<float>(1.0 / static_cast<double>(n)));
+    } else {
+        auto inv_sum = 1.0 / sum;
+        for (size_t i = 0; i < n; i++) { pdf[i] = static_cast<float>(std::abs(values[i]) * inv_sum); }
+    }
+    auto ratio = static_cast<double>(n) / sum;
+    std::vector<uint32_t> over, under;
+    over.reserve(n), under.reserve(n);
+    table.assign(n, lr_alias_entry{});
+    for (size_t i = 0; i < n; i++) {
+        auto p = static_cast<float>(values[i] * ratio);
+        table[i] = {p, static_cast<uint32_t>(i)};
+        (p > 1.0f ? over : under).emplace_back(static_cast<uint32_t>(i));
+    }
+    while (!over.empty() && !under.empty()) {
+        auto o = over.back();
+        auto u = under.back();
+        over.pop_back();
+        under.pop_back();
+        table[o].prob -= 1.0f - table[u].prob;
+        table[u].alias = o;
+        if (table[o].prob > 1.0f) {
+            over.push_back(o);
+        } else if (table[o].prob < 1.0f) {
+            under.push_back(o);
+        }
+    }
+    for (auto i : over) { table[i] = {1.0f, i}; }
+    for (auto i : under) { table[i] = {1.0f, i}; }
+}
+
+lr_uint4 encode_instance_handle(uint32_t buffer_base, uint32_t flags, uint32_t surface_tag, uint32_t light_tag,
+                                uint32_t medium_tag, uint32_t tri_count, float shadow_terminator,
+                                float intersection_offset) {
+    // src/base/shape.cpp:46-70, limits src/base/shape.h:124-137
+    if (buffer_base > (1u << 22u) - 1u) { throw Error{"Invalid geometry buffer base."}; }
+    if (flags > 1023u) { throw Error{"Invalid property flags."}; }
+    if (surface_tag > 4095u) { throw Error{"Invalid surface tag (more than 4095 surfaces)."}; }
+    if (light_tag > 4095u) { throw Error{"Invalid light tag (more than 4095 lights)."}; }
+    if (medium_tag > 255u) { throw Error{"Invalid medium tag."}; }
+    auto fixed = [](float x) {
+        x = std::clamp(x, 0.f, 1.f);
+        constexpr auto scale = 1.f / 65536.f;
+        return static_cast<uint32_t>(std::clamp(std::round(x / scale), 0.f, 65535.f));
+    };
+    lr_uint4 h{};
+    h.x = (buffer_base << 10u) | flags;
+    h.y = (surface_tag << 12u) | light_tag | (medium_tag << 24u);
+    h.z = tri_count;
+    h.w = (fixed(shadow_terminator) << 16u) | fixed(intersection_offset);
+    return h;
+}
+
+lr_scene SceneData::view(size_t camera_index) const {
+    lr_scene s{};
+    s.vertices = vertices.data(), s.vertex_count = vertices.size();
+    s.triangles = triangles.data(), s.triangle_count = triangles.size();
+    s.tri_alias = tri_alias.data();
+    s.tri_pdf = tri_pdf.data();
+    s.meshes = meshes.data(), s.mesh_count = static_cast<uint32_t>(meshes.size());
+    s.instances = instances.data(), s.instance_count = static_cast<uint32_t>(instances.size());
+    s.light_instances = light_instances.data(), s.light_instance_count = static_cast<uint32_t>(light_instances.size());
+    s.surfaces = surfaces.data(), s.surface_count = static_cast<uint32_t>(surfaces.size());
+    s.lights = lights.data(), s.light_count = static_cast<uint32_t>(lights.size());
+    s.textures = textures.data(), s.texture_count = static_cast<uint32_t>(textures.size());
+    s.texels = texels.data(), s.texel_count = texels.size() / 4u;
+    s.environment = environment;
+    s.environment.alias = env_alias.empty() ? nullptr : env_alias.data();
+    s.environment.pdf = env_pdf.empty() ? nullptr : env_pdf.data();
+    if (camera_index >= cameras.size()) { throw Error{"Camera index out of range."}; }
+    s.camera = cameras[camera_index].camera;
+    s.filter = cameras[camera_index].filter;
+    s.film = cameras[camera_index].film;
+    s.sampler = sampler;
+    s.integrator = integrator;
+    s.accel.nodes = bvh_nodes.empty() ? nullptr : bvh_nodes.data();
+    s.accel.node_count = static_cast<uint32_t>(bvh_nodes.size());
+    s.accel.triangles = bvh_triangles.empty() ? nullptr : bvh_triangles.data();
+    s.accel.triangle_count = static_cast<uint32_t>(bvh_triangles.size());
+    for (auto i = 0; i < 3; i++) { s.accel.world_min[i] = world_min[i], s.accel.world_max[i] = world_max[i]; }
+    s.any_non_opaque = any_non_opaque ? 1u : 0u;
+    return s;
+}
+
+namespace {
+
+float3 to_float3(const std::vector<double> &v) {
+    return {static_cast<float>(v[0]), static_cast<float>(v[1]), static_cast<float>(v[2])};
+}
+
+float3 float3_or(const NodeDesc *d, const std::string &name, float3 dv) {
+    auto v = d->vector_opt(name, 3u);
+    return v ? to_float3(*v) : dv;
+}
+
+void store_matrix(float *dst, const float4x4 &m) {
+    for (auto c = 0; c < 4; c++) {
+        for (auto r = 0; r < 4; r++) { dst[c * 4 + r] = m[c][r]; }
+    }
+}
+
+uint64_t fnv1a(const void *data, size_t size, uint64_t h = 0xcbf29ce484222325ull) {
+    auto p = static_cast<const uint8_t *>(data);
+    for (size_t i = 0; i < size; i++) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+// 602.785 / 539.285 / 445.772 nm samples of the reference's built-in conductor tables
+// (src/surfaces/metal_ior.inl.h through SPD::sample, src/base/spd.cpp:91-99: 5 nm LUT,
+// linear interpolation); generated by tools/extract_metal_ior.py.
+struct MetalIOR {
+    const char *name;
+    float n[3], k[3];
+};
+#include "metal_ior_rgb.inl.h"
+
+const MetalIOR *find_metal(std::string name) {
+    for (auto &c : name) { c = static_cast<char>(std::tolower(c)); }
+    static const std::unordered_map<std::string, const char *> aliases{
+        {"ag", "Ag"}, {"silver", "Ag"}, {"al", "Al"}, {"aluminium", "Al"}, {"au", "Au"}, {"gold", "Au"},
+        {"cu", "Cu"}, {"copper", "Cu"}, {"cuzn", "CuZn"}, {"cu-zn", "CuZn"}, {"brass", "CuZn"},
+        {"fe", "Fe"}, {"iron", "Fe"}, {"ti", "Ti"}, {"titanium", "Ti"}, {"v", "V"}, {"vanadium", "V"},
+        {"vn", "VN"}, {"li", "Li"}, {"lithium", "Li"}, {"cr", "Cr"}, {"chromium", "Cr"}};
+    auto it = aliases.find(name);
+    if (it == aliases.end()) { return nullptr; }
+    for (auto &m : metal_ior_rgb) {
+        if (std::strcmp(m.name, it->second) == 0) { return &m; }
+    }
+    return nullptr;
+}
+
+// ------------------------------------------------------------------ builder
+
+class Builder {
+    const SceneDesc &_desc;
+    SceneData &_out;
+    std::unordered_map<const NodeDesc *, int32_t> _texture_ids;
+    std::unordered_map<const NodeDesc *, uint32_t> _surface_tags;
+    std::unordered_map<const NodeDesc *, uint32_t> _light_tags;
+    std::unordered_map<const NodeDesc *, uint32_t> _shape_meshes;// shape node -> mesh index
+    std::unordered_map<const NodeDesc *, uint32_t> _shape_props;
+    std::unordered_map<uint64_t, uint32_t> _mesh_cache;          // content hash -> mesh index
+    std::unordered_map<const NodeDesc *, bool> _light_null, _surface_null;
+    float _scene_shadow_terminator{0.f};
+    float _scene_intersection_offset{0.f};
+    std::vector<float4x4> _transform_stack;// TransformTree (src/base/transform.cpp:25-59)
+
+    static void _check_tag(const NodeDesc *d, Tag tag) {
+        if (d->tag() != tag && d->tag() != Tag::INTERNAL) {
+            throw Error{std::string{"Invalid tag of scene description node '"} + d->identifier() + "' (expected " +
+                        tag_description(tag) + ", got " + tag_description(d->tag()) + "). [" + d->location() + "]"};
+        }
+        if (!d->is_defined() && d->tag() != Tag::INTERNAL) {
+            throw Error{"Undefined scene description node '" + d->identifier() + "'."};
+        }
+    }
+
+public:
+    Builder(const SceneDesc &desc, SceneData &out) : _desc{desc}, _out{out} {}
+
+    // ---------------- transforms (src/transforms/*.cpp)
+    float4x4 transform_matrix(const NodeDesc *d) {
+        if (d == nullptr) { return float4x4::identity(); }
+        _check_tag(d, Tag::TRANSFORM);
+        auto &impl = d->impl_type();
+        if (impl == "identity") { return float4x4::identity(); }
+        if (impl == "matrix") {// matrix.cpp:15-42 (row-major text, transposed on load)
+            auto m = d->float_list_or_empty("m");
+            auto out = float4x4::identity();
+            if (m.size() == 16u) {
+                if (!(m[12] == 0.f && m[13] == 0.f && m[14] == 0.f && m[15] == 1.f)) {
+                    log_warning("Expected affine transform matrices; the last row is fixed. [" + d->location() + "]");
+                    m[12] = 0.f, m[13] = 0.f, m[14] = 0.f, m[15] = 1.f;
+                }
+                for (auto row = 0; row < 4; row++) {
+                    for (auto col = 0; col < 4; col++) { out[col][row] = m[static_cast<size_t>(row * 4 + col)]; }
+                }
+            } else if (!m.empty()) {
+                throw Error{"Invalid matrix entries. [" + d->location() + "]"};
+            }
+            return out;
+        }
+        if (impl == "srt") {// srt.cpp:14-24
+            auto s3 = d->vector_opt("scale", 3u);
+            auto scale = s3 ? to_float3(*s3) : make_float3(d->float_or("scale", 1.f));
+            auto r = d->vector_opt("rotate", 4u);
+            float4 rot = r ? float4{static_cast<float>((*r)[0]), static_cast<float>((*r)[1]),
+                                    static_cast<float>((*r)[2]), static_cast<float>((*r)[3])} :
+                             float4{0.f, 0.f, 1.f, 0.f};
+            auto t = float3_or(d, "translate", make_float3(0.f));
+            return translation(t) * rotation(normalize(float3{rot.x, rot.y, rot.z}), radians(rot.w)) * scaling(scale);
+        }
+        if (impl == "view") {// view.cpp:18-42
+            auto origin = d->vector_opt("origin", 3u);
+            auto o = origin ? to_float3(*origin) : float3_or(d, "position", make_float3(0.f));
+            auto front = float3_or(d, "front", {0.f, 0.f, -1.f});
+            auto up = float3_or(d, "up", {0.f, 1.f, 0.f});
+            auto w = normalize(-front);
+            auto u = normalize(cross(up, w));
+            auto v = normalize(cross(w, u));
+            return {{make_float4(u, 0.f), make_float4(v, 0.f), make_float4(w, 0.f), make_float4(o, 1.f)}};
+        }
+        if (impl == "stack") {// stack.cpp:22-36: m = t_i * m
+            auto m = float4x4::identity();
+            for (auto c : d->node_list_or_empty("transforms")) { m = transform_matrix(c) * m; }
+            return m;
+        }
+        if (impl == "lerp") {
+            throw Error{"Animated 'Lerp' transforms are out of scope of the megapath hot path (SURVEY §2 row 16). [" +
+                        d->location() + "]"};
+        }
+        throw Error{"Unknown transform implementation '" + impl + "'. [" + d->location() + "]"};
+    }
+
+    // ---------------- textures
+    int32_t load_texture(const NodeDesc *d) {
+        if (d == nullptr) { return -1; }
+        _check_tag(d, Tag::TEXTURE);
+        if (auto it = _texture_ids.find(d); it != _texture_ids.end()) { return it->second; }
+        lr_texture t{};
+        t.child[0] = t.child[1] = -1;
+        auto &impl = d->impl_type();
+        if (impl == "constant") {// constant.cpp:21-42
+            auto scale = d->float_or("scale", 1.f);
+            auto v = d->float_list_or_empty("v");
+            if (v.empty()) {
+                log_warning("No value for ConstantTexture. Fallback to single-channel zero. [" + d->location() + "]");
+                v.emplace_back(0.f);
+            } else if (v.size() > 4u) {
+                log_warning("Too many values for ConstantTexture; extra values are discarded. [" + d->location() + "]");
+                v.resize(4u);
+            }
+            t.kind = LR_TEX_CONSTANT;
+            t.channels = static_cast<uint32_t>(v.size());
+            for (size_t i = 0; i < v.size(); i++) { t.v[i] = scale * v[i]; }
+        } else if (impl == "image") {// image.cpp:47-112
+            t.kind = LR_TEX_IMAGE;
+            auto filter = d->string_or("filter", "bilinear");
+            auto address = d->string_or("address", "repeat");
+            for (auto &c : filter) { c = static_cast<char>(std::tolower(c)); }
+            for (auto &c : address) { c = static_cast<char>(std::tolower(c)); }
+            if (address == "zero") { t.address = LR_TEX_ADDR_ZERO; }
+            else if (address == "edge") { t.address = LR_TEX_ADDR_EDGE; }
+            else if (address == "mirror") { t.address = LR_TEX_ADDR_MIRROR; }
+            else if (address == "repeat") { t.address = LR_TEX_ADDR_REPEAT; }
+            else { throw Error{"Invalid texture address mode '" + address + "'. [" + d->location() + "]"}; }
+            if (filter == "point") { t.filter = LR_TEX_FILTER_POINT; }
+            else if (filter == "bilinear" || filter == "trilinear" || filter == "anisotropic" || filter == "aniso") {
+                t.filter = LR_TEX_FILTER_BILINEAR;// the reference samples LOD 0 only (image.cpp:166 "TODO: LOD")
+            } else { throw Error{"Invalid texture filter mode '" + filter + "'. [" + d->location() + "]"}; }
+            auto s2 = d->vector_opt("uv_scale", 2u);
+            auto o2 = d->vector_opt("uv_offset", 2u);
+            auto s1 = s2 ? 1.f : d->float_or("uv_scale", 1.f), o1 = o2 ? 0.f : d->float_or("uv_offset", 0.f);
+            t.uv_scale[0] = s2 ? static_cast<float>((*s2)[0]) : s1, t.uv_scale[1] = s2 ? static_cast<float>((*s2)[1]) : s1;
+            t.uv_offset[0] = o2 ? static_cast<float>((*o2)[0]) : o1, t.uv_offset[1] = o2 ? static_cast<float>((*o2)[1]) : o1;
+            auto path = d->path_or("file");
+            if (path.empty()) { throw Error{"No valid values given for property 'file'. [" + d->location() + "]"}; }
+            auto ext = fs::path{path}.extension().string();
+            for (auto &c : ext) { c = static_cast<char>(std::tolower(c)); }
+            auto encoding = d->string_or("encoding", (ext == ".exr" || ext == ".hdr" || ext == ".pfm") ? "linear" : "sRGB");
+            for (auto &c : encoding) { c = static_cast<char>(std::tolower(c)); }
+            t.gamma[0] = t.gamma[1] = t.gamma[2] = 1.f;
+            if (encoding == "srgb") { t.encoding = LR_TEX_ENC_SRGB; }
+            else if (encoding == "gamma") {
+                t.encoding = LR_TEX_ENC_GAMMA;
+                t.gamma[0] = t.gamma[1] = t.gamma[2] = d->float_or("gamma", 1.f);
+            } else {
+                if (encoding != "linear") { log_warning("Unknown texture encoding '" + encoding + "'; using linear."); }
+                t.encoding = LR_TEX_ENC_LINEAR;
+            }
+            auto scale = d->float_or("scale", 1.f);
+            for (auto &s : t.scale) { s = scale; }
+            auto image = load_image(path);
+            t.width = image.width, t.height = image.height, t.channels = image.channels;
+            t.texel_offset = _out.texels.size() / 4u;
+            _out.texels.insert(_out.texels.end(), image.pixels.begin(), image.pixels.end());
+        } else if (impl == "checkerboard") {
+            t.kind = LR_TEX_CHECKERBOARD;
+            t.child[0] = load_texture(d->node_or_null("on"));
+            t.child[1] = load_texture(d->node_or_null("off"));
+            t.checker_scale = d->float_or("scale", 1.f);
+            t.channels = 4u;
+        } else {
+            throw Error{"Unsupported texture implementation '" + impl + "'. [" + d->location() + "]"};
+        }
+        auto id = static_cast<int32_t>(_out.textures.size());
+        _out.textures.emplace_back(t);
+        _texture_ids.emplace(d, id);
+        return id;
+    }
+
+    bool texture_is_black(int32_t id) const {// Texture::is_black
+        if (id < 0) { return false; }
+        auto &t = _out.textures[static_cast<size_t>(id)];
+        if (t.kind == LR_TEX_CONSTANT) { return t.v[0] == 0.f && t.v[1] == 0.f && t.v[2] == 0.f && t.v[3] == 0.f; }
+        if (t.kind == LR_TEX_IMAGE) { return t.scale[0] == 0.f; }
+        return false;
+    }
+
+    // ---------------- surfaces
+    static bool surface_is_null(const NodeDesc *d) { return d == nullptr || d->impl_type() == "null"; }
+
+    uint32_t register_surface(const NodeDesc *d) {// Pipeline::register_surface, pipeline.cpp:20-26
+        _check_tag(d, Tag::SURFACE);
+        if (auto it = _surface_tags.find(d); it != _surface_tags.end()) { return it->second; }
+        lr_surface s{};
+        for (auto &t : s.tex) { t = -1; }
+        s.alpha_tex = s.normal_tex = -1;
+        s.normal_strength = 1.f;
+        auto &impl = d->impl_type();
+        auto tex = [&](const char *name) { return load_texture(d->node_or_null(name)); };
+        auto remap = d->bool_or("remap_roughness", true);
+        if (remap) { s.flags |= LR_SURFACE_FLAG_REMAP_ROUGHNESS; }
+        auto wrappers = true;
+        auto children = std::array<uint32_t, 2>{0u, 0u};
+        if (impl == "matte") {// matte.cpp:25-26
+            s.kind = LR_SURFACE_MATTE;
+            s.tex[0] = tex("Kd"), s.tex[1] = tex("sigma");
+            if (texture_is_black(s.tex[1])) { s.tex[1] = -1; }// `_sigma && !_sigma->node()->is_black()`, matte.cpp:125
+        } else if (impl == "mirror") {// mirror.cpp:23-28
+            s.kind = LR_SURFACE_MIRROR;
+            auto color = d->node_or_null("color");
+            if (color == nullptr) { color = d->node_or_null("Kd"); }
+            s.tex[0] = load_texture(color), s.tex[1] = tex("roughness");
+        } else if (impl == "glass") {// glass.cpp:57-81
+            s.kind = LR_SURFACE_GLASS;
+            s.tex[0] = tex("Kr"), s.tex[1] = tex("Kt"), s.tex[2] = tex("roughness");
+            if (auto name = d->string_or("eta"); !name.empty()) {
+                static const std::unordered_map<std::string, std::array<float, 3>> builtin{
+                    {"bk7", {1.5140814565098806f, 1.5165571794092296f, 1.5223224896834853f}},
+                    {"baf10", {1.665552211440938f, 1.6698355055693541f, 1.680044942398477f}},
+                    {"fk51a", {1.4846524304153899f, 1.486399794903804f, 1.4904761200647965f}},
+                    {"lasf9", {1.8422161861952726f, 1.8499302872507852f, 1.8690214187351977f}},
+                    {"sf5", {1.6663001504164476f, 1.6723956342450994f, 1.6875677127863755f}},
+                    {"sf10", {1.720557014155419f, 1.7279815121138318f, 1.7465722778961204f}},
+                    {"sf11", {1.7754589288508518f, 1.7842240428294434f, 1.8065917880168352f}},
+                    {"diamond", {2.410486117067883f, 2.4164392529553234f, 2.431466411471524f}},
+                    {"ice", {1.3077084260466776f, 1.3095827995357034f, 1.3137441348487024f}},
+                    {"quartz", {1.4562471554155727f, 1.4582990183632742f, 1.4630571022260817f}},
+                    {"salt", {1.5404463273409252f, 1.5441711411436845f, 1.5531314007749342f}},
+                    {"sapphire", {1.764706495252994f, 1.7680107911479397f, 1.7755615929437936f}}};
+                for (auto &c : name) { c = static_cast<char>(std::tolower(c)); }
+                if (auto it = builtin.find(name); it != builtin.end()) {
+                    lr_texture t{};
+                    t.kind = LR_TEX_CONSTANT, t.channels = 3u;
+                    t.v[0] = it->second[0], t.v[1] = it->second[1], t.v[2] = it->second[2];
+                    t.child[0] = t.child[1] = -1;
+                    s.tex[3] = static_cast<int32_t>(_out.textures.size());
+                    _out.textures.emplace_back(t);
+                } else {
+                    log_warning("Unknown built-in glass '" + name + "'. Fallback to constant IOR = 1.5.");
+                }
+            } else {
+                s.tex[3] = tex("eta");
+                if (s.tex[3] >= 0) {
+                    auto ch = _out.textures[static_cast<size_t>(s.tex[3])].channels;
+                    if (ch == 2u || ch == 4u) { throw Error{"Invalid channel count for GlassSurface::eta. [" + d->location() + "]"}; }
+                }
+            }
+            wrappers = false;// glass has only the normal-map wrapper (glass.cpp:281-282)
+            s.normal_tex = tex("normal_map");
+            s.normal_strength = d->float_or("normal_map_strength", 1.f);
+        } else if (impl == "plastic" || impl == "substrate") {// plastic.cpp:53-60
+            s.kind = LR_SURFACE_PLASTIC;
+            s.tex[0] = tex("Kd"), s.tex[1] = tex("roughness"), s.tex[2] = tex("sigma_a");
+            s.tex[3] = tex("eta"), s.tex[4] = tex("thickness");
+        } else if (impl == "metal") {// metal.cpp:54-152
+            s.kind = LR_SURFACE_METAL;
+            s.tex[0] = tex("Kd"), s.tex[1] = tex("roughness");
+            const MetalIOR *ior = nullptr;
+            if (auto name = d->string_or("eta"); !name.empty()) {
+                ior = find_metal(name);
+                if (ior == nullptr) {
+                    log_warning("Unknown metal '" + name + "'. Fallback to Aluminium. [" + d->location() + "]");
+                    ior = find_metal("al");
+                }
+                for (auto i = 0; i < 3; i++) { s.f[i] = ior->n[i], s.f[3 + i] = ior->k[i]; }
+            } else {
+                auto eta = d->float_list("eta");
+                if (eta.size() % 3u != 0u || eta.size() < 6u) { throw Error{"Invalid eta list size. [" + d->location() + "]"}; }
+                auto count = eta.size() / 3u;
+                std::vector<float> lambda(count), n(count), k(count);
+                for (size_t i = 0; i < count; i++) { lambda[i] = eta[i * 3u], n[i] = eta[i * 3u + 1u], k[i] = eta[i * 3u + 2u]; }
+                if (!std::is_sorted(lambda.begin(), lambda.end())) { throw Error{"Unsorted wavelengths in eta list. [" + d->location() + "]"}; }
+                if (lambda.front() > 360.f || lambda.back() < 830.f) { throw Error{"Invalid wavelength range in eta list. [" + d->location() + "]"}; }
+                // 5 nm LUT (metal.cpp:131-147) then SPD::sample at the RGB peak wavelengths
+                auto lut = [&](uint32_t i, const std::vector<float> &y) {
+                    auto wavelength = static_cast<float>(i * 5u + 360u);
+                    auto lb = std::lower_bound(lambda.begin(), lambda.end(), wavelength);
+                    auto index = std::clamp(static_cast<size_t>(std::distance(lambda.begin(), lb)), size_t{1}, lambda.size() - 1u);
+                    auto t = (wavelength - lambda[index - 1u]) / (lambda[index] - lambda[index - 1u]);
+                    return y[index - 1u] + t * (y[index] - y[index - 1u]);
+                };
+                constexpr std::array<float, 3> peaks{602.785f, 539.285f, 445.772f};
+                for (auto c = 0; c < 3; c++) {
+                    auto t = (std::clamp(peaks[static_cast<size_t>(c)], 360.f, 830.f) - 360.f) / 5.f;
+                    auto i = static_cast<uint32_t>(std::min(t, 93.f));
+                    auto fr = t - std::floor(t);
+                    s.f[c] = lut(i, n) + fr * (lut(i + 1u, n) - lut(i, n));
+                    s.f[3 + c] = lut(i, k) + fr * (lut(i + 1u, k) - lut(i, k));
+                }
+            }
+        } else if (impl == "disney") {// disney.cpp:36-58
+            s.kind = LR_SURFACE_DISNEY;
+            auto color = d->node_or_null("color");
+            if (color == nullptr) { color = d->node_or_null("Kd"); }
+            s.tex[0] = load_texture(color);
+            static constexpr std::array<const char *, 12> names{
+                "metallic", "eta", "roughness", "specular_tint", "anisotropic", "sheen", "sheen_tint",
+                "clearcoat", "clearcoat_gloss", "specular_trans", "flatness", "diffuse_trans"};
+            for (size_t i = 0; i < names.size(); i++) { s.tex[i + 1u] = tex(names[i]); }
+            if (d->bool_or("thin", false)) { s.flags |= LR_SURFACE_FLAG_THIN; }
+        } else if (impl == "mix") {// mix.cpp:23-32
+            s.kind = LR_SURFACE_MIX;
+            auto a = d->node("a"), b = d->node("b");
+            if (surface_is_null(a) || surface_is_null(b)) {
+                throw Error{"Mix surface with a null child is not supported. [" + d->location() + "]"};
+            }
+            children = {register_surface(a), register_surface(b)};
+            s.u[0] = children[0], s.u[1] = children[1];
+            s.tex[0] = tex("ratio");
+            wrappers = false;
+        } else if (impl == "layered") {
+            throw Error{"Layered surface is scheduled after the closure bar (SURVEY §8f f2). [" + d->location() + "]"};
+        } else {
+            throw Error{"Unknown surface implementation '" + impl + "'. [" + d->location() + "]"};
+        }
+        if (wrappers) {// NormalMapWrapper<OpacitySurfaceWrapper<...>>, surface.h:196-203,262-267
+            auto alpha = d->node_or_null("alpha");
+            if (alpha == nullptr) { alpha = d->node_or_null("opacity"); }
+            s.alpha_tex = load_texture(alpha);
+            s.normal_tex = tex("normal_map");
+            s.normal_strength = d->float_or("normal_map_strength", 1.f);
+        }
+        auto tag = static_cast<uint32_t>(_out.surfaces.size());
+        _out.surfaces.emplace_back(s);
+        _surface_tags.emplace(d, tag);
+        return tag;
+    }
+
+    bool surface_maybe_non_opaque(uint32_t tag) const {// OpacitySurfaceWrapper::maybe_non_opaque
+        auto &s = _out.surfaces[tag];
+        if (s.alpha_tex < 0) { return false; }
+        auto &t = _out.textures[static_cast<size_t>(s.alpha_tex)];
+        // constant alpha >= 1 is treated as opaque (surface.h:204-216)
+        if (t.kind == LR_TEX_CONSTANT && t.v[0] >= 1.f) { return false; }
+        return true;
+    }
+
+    // ---------------- lights
+    bool light_is_null(const NodeDesc *d) {
+        if (d == nullptr || d->impl_type() == "null") { return true; }
+        _check_tag(d, Tag::LIGHT);
+        if (auto it = _light_null.find(d); it != _light_null.end()) { return it->second; }
+        auto null = false;
+        if (d->impl_type() == "diffuse") {// diffuse.cpp:20-30
+            auto scale = std::max(d->float_or("scale", 1.f), 0.f);
+            auto emission = d->node_or_null("emission");
+            auto id = load_texture(emission ? emission : NodeDesc::shared_default(Tag::TEXTURE, "Constant"));
+            null = scale == 0.f || texture_is_black(id);
+        } else {
+            throw Error{"Unknown light implementation '" + d->impl_type() + "'. [" + d->location() + "]"};
+        }
+        _light_null.emplace(d, null);
+        return null;
+    }
+
+    uint32_t register_light(const NodeDesc *d) {// Pipeline::register_light, pipeline.cpp:28-34
+        if (auto it = _light_tags.find(d); it != _light_tags.end()) { return it->second; }
+        lr_light l{};
+        l.kind = LR_LIGHT_DIFFUSE;
+        auto emission = d->node_or_null("emission");
+        l.emission_tex = load_texture(emission ? emission : NodeDesc::shared_default(Tag::TEXTURE, "Constant"));
+        l.scale = std::max(d->float_or("scale", 1.f), 0.f);
+        l.two_sided = d->bool_or("two_sided", false) ? 1u : 0u;
+        auto tag = static_cast<uint32_t>(_out.lights.size());
+        _out.lights.emplace_back(l);
+        _light_tags.emplace(d, tag);
+        return tag;
+    }
+
+    // ---------------- shapes
+    struct ShapeInfo {
+        bool is_mesh;
+        bool visible;
+        float shadow_terminator;
+        float intersection_offset;
+    };
+
+    ShapeInfo shape_info(const NodeDesc *d) const {
+        auto &impl = d->impl_type();
+        ShapeInfo info{};
+        info.is_mesh = impl == "mesh" || impl == "inlinemesh" || impl == "sphere";
+        if (!info.is_mesh && impl != "group" && impl != "instance") {
+            throw Error{"Unsupported shape implementation '" + impl + "'. [" + d->location() + "]"};
+        }
+        info.visible = d->bool_or("visible", true);// VisibilityShapeWrapper, shape.h:104-115
+        if (info.is_mesh) {                         // shape.h:66-102
+            info.shadow_terminator = std::clamp(d->float_or("shadow_terminator", _scene_shadow_terminator), 0.f, 1.f);
+            info.intersection_offset = std::clamp(d->float_or("intersection_offset", _scene_intersection_offset), 0.f, 1.f);
+        }
+        return info;
+    }
+
+    uint32_t load_mesh(const NodeDesc *d, uint32_t &properties) {
+        if (auto it = _shape_meshes.find(d); it != _shape_meshes.end()) {
+            properties = _shape_props.at(d);
+            return it->second;
+        }
+        LoadedMesh mesh;
+        auto &impl = d->impl_type();
+        if (impl == "inlinemesh") {// inline_mesh.cpp:21-58
+            auto indices = d->uint_list("indices");
+            auto positions = d->float_list("positions");
+            auto normals = d->float_list_or_empty("normals");
+            auto uvs = d->float_list_or_empty("uvs");
+            if (indices.size() % 3u != 0u || positions.size() % 3u != 0u || normals.size() % 3u != 0u ||
+                uvs.size() % 2u != 0u || (!normals.empty() && normals.size() != positions.size()) ||
+                (!uvs.empty() && uvs.size() / 2u != positions.size() / 3u)) {
+                throw Error{"Invalid vertex or triangle count. [" + d->location() + "]"};
+            }
+            mesh.properties = (!uvs.empty() ? uint32_t{LR_SHAPE_HAS_VERTEX_UV} : 0u) | (!normals.empty() ? uint32_t{LR_SHAPE_HAS_VERTEX_NORMAL} : 0u);
+            auto vertex_count = positions.size() / 3u;
+            mesh.triangles.resize(indices.size() / 3u);
+            for (size_t i = 0; i < mesh.triangles.size(); i++) {
+                mesh.triangles[i] = {indices[i * 3u], indices[i * 3u + 1u], indices[i * 3u + 2u]};
+                if (indices[i * 3u] >= vertex_count || indices[i * 3u + 1u] >= vertex_count || indices[i * 3u + 2u] >= vertex_count) {
+                    throw Error{"Triangle index out of range. [" + d->location() + "]"};
+                }
+            }
+            mesh.vertices.resize(vertex_count);
+            for (size_t i = 0; i < vertex_count; i++) {
+                lr_vertex v{};
+                v.px = positions[i * 3u], v.py = positions[i * 3u + 1u], v.pz = positions[i * 3u + 2u];
+                if (normals.empty()) { v.nx = 0.f, v.ny = 0.f, v.nz = 1.f; }
+                else { v.nx = normals[i * 3u], v.ny = normals[i * 3u + 1u], v.nz = normals[i * 3u + 2u]; }
+                if (!uvs.empty()) { v.u = uvs[i * 2u], v.v = uvs[i * 2u + 1u]; }
+                mesh.vertices[i] = v;
+            }
+        } else if (impl == "mesh") {// mesh.cpp:151-157
+            auto path = d->path_or("file");
+            if (path.empty()) { throw Error{"No valid values given for property 'file'. [" + d->location() + "]"}; }
+            if (d->uint_or("subdivision", 0u) != 0u) {
+                throw Error{"Mesh subdivision is not supported (SURVEY §2 row 17). [" + d->location() + "]"};
+            }
+            mesh = load_obj_mesh(path, d->bool_or("flip_uv", false), d->bool_or("drop_normal", false), d->bool_or("drop_uv", false));
+        } else {
+            throw Error{"Shape '" + impl + "' is scheduled after the bar (SURVEY §2 row 17). [" + d->location() + "]"};
+        }
+        if (mesh.vertices.empty() || mesh.triangles.empty()) { throw Error{"Empty mesh. [" + d->location() + "]"}; }
+        // dedup by content (geometry.cpp:53-57)
+        auto hash = fnv1a(mesh.vertices.data(), mesh.vertices.size() * sizeof(lr_vertex));
+        hash = fnv1a(mesh.triangles.data(), mesh.triangles.size() * sizeof(lr_triangle), hash);
+        uint32_t index;
+        if (auto it = _mesh_cache.find(hash); it != _mesh_cache.end()) {
+            index = it->second;
+        } else {
+            index = static_cast<uint32_t>(_out.meshes.size());
+            lr_mesh m{};
+            m.vertex_offset = static_cast<uint32_t>(_out.vertices.size());
+            m.vertex_count = static_cast<uint32_t>(mesh.vertices.size());
+            m.triangle_offset = static_cast<uint32_t>(_out.triangles.size());
+            m.triangle_count = static_cast<uint32_t>(mesh.triangles.size());
+            _out.vertices.insert(_out.vertices.end(), mesh.vertices.begin(), mesh.vertices.end());
+            _out.triangles.insert(_out.triangles.end(), mesh.triangles.begin(), mesh.triangles.end());
+            // per-mesh area alias table (geometry.cpp:69-79)
+            std::vector<float> areas(mesh.triangles.size());
+            for (size_t i = 0; i < mesh.triangles.size(); i++) {
+                auto t = mesh.triangles[i];
+                auto &a = mesh.vertices[t.i0], &b = mesh.vertices[t.i1], &c = mesh.vertices[t.i2];
+                float3 p0{a.px, a.py, a.pz}, p1{b.px, b.py, b.pz}, p2{c.px, c.py, c.pz};
+                areas[i] = std::abs(length(cross(p1 - p0, p2 - p0)));
+            }
+            std::vector<lr_alias_entry> table;
+            std::vector<float> pdf;
+            create_alias_table(areas.data(), areas.size(), table, pdf);
+            _out.tri_alias.insert(_out.tri_alias.end(), table.begin(), table.end());
+            _out.tri_pdf.insert(_out.tri_pdf.end(), pdf.begin(), pdf.end());
+            _out.meshes.emplace_back(m);
+            _mesh_cache.emplace(hash, index);
+        }
+        _shape_meshes.emplace(d, index);
+        _shape_props.emplace(d, mesh.properties);
+        properties = mesh.properties;
+        return index;
+    }
+
+    // Geometry::_process_shape, geometry.cpp:29-163
+    void process_shape(const NodeDesc *d, const NodeDesc *overridden_surface, const NodeDesc *overridden_light,
+                       bool overridden_visible) {
+        _check_tag(d, Tag::SHAPE);
+        auto info = shape_info(d);
+        auto own_surface = d->node_or_null("surface");
+        auto own_light = d->node_or_null("light");
+        auto surface = overridden_surface == nullptr ? own_surface : overridden_surface;
+        auto light = overridden_light == nullptr ? own_light : overridden_light;
+        auto visible = overridden_visible && info.visible;
+        if (d->node_or_null("medium") != nullptr) {
+            log_warning("Shape medium ignored: megapath never enters media (SURVEY §2 row 22). [" + d->location() + "]");
+        }
+        auto local = transform_matrix(d->node_or_null("transform"));
+        if (info.is_mesh) {
+            uint32_t vertex_props = 0u;
+            auto mesh_index = load_mesh(d, vertex_props);
+            auto &mesh = _out.meshes[mesh_index];
+            auto instance_id = static_cast<uint32_t>(_out.instances.size());
+            // TransformTree::leaf + Node::matrix: M = M_root * ... * M_leaf
+            auto object_to_world = is_identity(local) ? _transform_stack.back() : _transform_stack.back() * local;
+            for (uint32_t i = 0; i < mesh.vertex_count; i++) {
+                auto &v = _out.vertices[mesh.vertex_offset + i];
+                auto p = transform_point(object_to_world, {v.px, v.py, v.pz});
+                for (auto a = 0; a < 3; a++) {
+                    _out.world_min[a] = std::min(_out.world_min[a], p[a]);
+                    _out.world_max[a] = std::max(_out.world_max[a], p[a]);
+                }
+            }
+            auto properties = vertex_props;
+            auto surface_tag = 0u, light_tag = 0u;
+            if (!surface_is_null(surface)) {
+                surface_tag = register_surface(surface);
+                properties |= LR_SHAPE_HAS_SURFACE;
+                if (surface_maybe_non_opaque(surface_tag)) {
+                    properties |= LR_SHAPE_MAYBE_NON_OPAQUE;
+                    _out.any_non_opaque = true;
+                }
+            }
+            if (!light_is_null(light)) {
+                light_tag = register_light(light);
+                properties |= LR_SHAPE_HAS_LIGHT;
+            }
+            // u16 round trip of the wrapper factors (geometry.cpp:92-101,143-148)
+            auto fixed16 = [](float x) { return static_cast<uint16_t>(std::clamp(std::round(x * 65535.f), 0.f, 65535.f)); };
+            auto has_normal = (vertex_props & LR_SHAPE_HAS_VERTEX_NORMAL) != 0u;
+            auto shadow_term = fixed16(has_normal ? info.shadow_terminator : 0.f);
+            auto isect_offset = fixed16(info.intersection_offset);
+            lr_instance inst{};
+            inst.handle = encode_instance_handle(mesh_index, properties, surface_tag, light_tag, 0u, mesh.triangle_count,
+                                                 static_cast<float>(shadow_term) / 65535.f,
+                                                 static_cast<float>(isect_offset) / 65535.f);
+            store_matrix(inst.object_to_world, object_to_world);
+            inst.visible = visible ? 1u : 0u;
+            _out.instances.emplace_back(inst);
+            if (properties & LR_SHAPE_HAS_LIGHT) { _out.light_instances.push_back({instance_id, light_tag}); }
+        } else {
+            auto pushed = !is_identity(local);
+            if (pushed) { _transform_stack.emplace_back(_transform_stack.back() * local); }
+            auto children = d->impl_type() == "group" ? d->node_list_required("shapes") :
+                                                        NodeDesc::node_list{d->node("shape")};
+            for (auto child : children) { process_shape(child, surface, light, visible); }
+            if (pushed) { _transform_stack.pop_back(); }
+        }
+    }
+
+    // ---------------- camera, film, filter
+    static float filter_evaluate(const NodeDesc *d, const std::string &impl, float radius, float x) {
+        constexpr auto pi = 3.14159265358979323846f;
+        if (impl == "box") { return 1.f; }
+        if (impl == "triangle") { return std::max(1.f - std::abs(x / radius), 0.f); }
+        if (impl == "gaussian") {// gaussian.cpp:16-40
+            auto sigma = d->float_or("sigma", 0.f);
+            if (sigma <= 0.f) { sigma = radius / 3.f; }
+            auto s = 2.f * sigma * sigma;
+            auto G = [s, pi](float v) { return 1.f / std::sqrt(pi * s) * std::exp(-v * v / s); };
+            return G(x) - G(radius);
+        }
+        if (impl == "mitchell") {// mitchell.cpp:21-38
+            auto b = d->float_or("b", 1.f / 3.f), c = d->float_or("c", 1.f / 3.f);
+            x = 2.f * std::abs(x / radius);
+            if (x <= 1.f) {
+                return ((12.f - 9.f * b - 6.f * c) * x * x * x + (-18.f + 12.f * b + 6.f * c) * x * x + (6.f - 2.f * b)) * (1.f / 6.f);
+            }
+            if (x <= 2.f) {
+                return ((-b - 6.f * c) * x * x * x + (6.f * b + 30.f * c) * x * x + (-12.f * b - 48.f * c) * x + (8.f * b + 24.f * c)) * (1.f / 6.f);
+            }
+            return 0.f;
+        }
+        if (impl == "lanczossinc") {// lanczos_sinc.cpp:18-28
+            auto tau = d->float_or("tau", 3.f);
+            x = x / radius;
+            auto sin_x_over_x = [](float v) { return 1.f + v * v == 1.f ? 1.f : std::sin(v) / v; };
+            auto sinc = [&](float v) { return sin_x_over_x(pi * v); };
+            if (std::abs(x) > 1.f) { return 0.f; }
+            return sinc(x) * sinc(x / tau);
+        }
+        throw Error{"Unknown filter implementation '" + impl + "'."};
+    }
+
+    lr_filter build_filter(const NodeDesc *d) {// Filter::Instance::Instance, filter.cpp:24-47
+        _check_tag(d, Tag::FILTER);
+        lr_filter f{};
+        f.radius = std::max(d->float_or("radius", 0.5f), 1e-3f);
+        auto shift2 = d->vector_opt("shift", 2u);
+        auto shift1 = shift2 ? 0.f : d->float_or("shift", 0.f);
+        f.shift[0] = shift2 ? static_cast<float>((*shift2)[0]) : shift1;
+        f.shift[1] = shift2 ? static_cast<float>((*shift2)[1]) : shift1;
+        constexpr auto n = LR_FILTER_LUT_SIZE - 1;
+        constexpr auto inv_n = 1.0f / static_cast<float>(n);
+        std::array<float, n> abs_f{};
+        auto &impl = d->impl_type();
+        f.lut[0] = filter_evaluate(d, impl, f.radius, -f.radius);
+        auto integral = 0.f;
+        for (auto i = 0; i < n; i++) {
+            auto x = static_cast<float>(i + 1) * inv_n * 2.f - 1.f;
+            f.lut[i + 1] = filter_evaluate(d, impl, f.radius, x * f.radius);
+            auto f_mid = 0.5f * (f.lut[i] + f.lut[i + 1]);
+            integral += f_mid;
+            abs_f[static_cast<size_t>(i)] = std::abs(f_mid);
+        }
+        auto inv_integral = 1.f / integral;
+        for (auto &v : f.lut) { v *= inv_integral; }
+        std::vector<lr_alias_entry> table;
+        std::vector<float> pdf;
+        create_alias_table(abs_f.data(), abs_f.size(), table, pdf);
+        for (auto i = 0; i < n; i++) {
+            f.pdf[i] = pdf[static_cast<size_t>(i)];
+            f.alias_prob[i] = table[static_cast<size_t>(i)].prob;
+            f.alias_index[i] = table[static_cast<size_t>(i)].alias;
+        }
+        return f;
+    }
+
+    CameraRecord build_camera(const NodeDesc *d) {
+        _check_tag(d, Tag::CAMERA);
+        CameraRecord rec{};
+        auto &cam = rec.camera;
+        // film (color.cpp:25-42)
+        auto film = d->node("film");
+        _check_tag(film, Tag::FILM);
+        if (film->impl_type() != "color") {
+            throw Error{"Film '" + film->impl_type() + "' is out of scope (only Color). [" + film->location() + "]"};
+        }
+        auto res2 = film->vector_opt("resolution", 2u);
+        auto res1 = res2 ? 0u : film->uint_or("resolution", 1024u);
+        cam.width = res2 ? static_cast<uint32_t>((*res2)[0]) : res1;
+        cam.height = res2 ? static_cast<uint32_t>((*res2)[1]) : res1;
+        auto exp3 = film->vector_opt("exposure", 3u);
+        auto exp1 = exp3 ? 0.f : film->float_or("exposure", 0.f);
+        for (auto i = 0; i < 3; i++) {
+            rec.film.scale[i] = std::pow(2.f, exp3 ? static_cast<float>((*exp3)[static_cast<size_t>(i)]) : exp1);
+        }
+        rec.film.clamp = std::max(1.f, film->float_or("clamp", 256.f));
+        // filter
+        auto filter = d->node_or_null("filter");
+        rec.filter = build_filter(filter ? filter : NodeDesc::shared_default(Tag::FILTER, "Box"));
+        // transform (camera.cpp:16-50)
+        auto xform = d->node_or_null("transform");
+        auto c2w = float4x4::identity();
+        if (xform != nullptr) {
+            c2w = transform_matrix(xform);
+        } else {
+            auto position = float3_or(d, "position", {0.f, 0.f, 0.f});
+            auto front_opt = d->vector_opt("front", 3u);
+            float3 front;
+            if (front_opt) {
+                front = to_float3(*front_opt);
+            } else {
+                auto look_at = float3_or(d, "look_at", position + float3{0.f, 0.f, -1.f});
+                front = normalize(look_at - position);
+            }
+            auto up = float3_or(d, "up", {0.f, 1.f, 0.f});
+            if (!(position == float3{0.f, 0.f, 0.f} && front == float3{0.f, 0.f, -1.f} && up == float3{0.f, 1.f, 0.f})) {
+                auto w = normalize(-front);
+                auto u = normalize(cross(up, w));
+                auto v = normalize(cross(w, u));
+                c2w = {{make_float4(u, 0.f), make_float4(v, 0.f), make_float4(w, 0.f), make_float4(position, 1.f)}};
+            }
+        }
+        store_matrix(cam.camera_to_world, c2w);
+        cam.spp = d->uint_or("spp", 1024u);
+        auto span2 = d->vector_opt("shutter_span", 2u);
+        if (span2 ? (*span2)[0] != (*span2)[1] : false) {
+            throw Error{"Motion blur (shutter_span) is out of scope (SURVEY §2 row 16). [" + d->location() + "]"};
+        }
+        // clip planes (camera.h:116-157)
+        auto clip2 = d->vector_opt("clip", 2u);
+        if (!clip2) { clip2 = d->vector_opt("clip_plane", 2u); }
+        if (clip2) {
+            cam.clip_near = static_cast<float>((*clip2)[0]), cam.clip_far = static_cast<float>((*clip2)[1]);
+        } else {
+            auto near_plane = d->number_opt("clip");
+            if (!near_plane) { near_plane = d->number_opt("clip_plane"); }
+            cam.clip_near = near_plane ? static_cast<float>(*near_plane) : 0.f;
+            cam.clip_far = 1e10f;
+        }
+        cam.clip_near = std::clamp(cam.clip_near, 0.f, 1e10f);
+        cam.clip_far = std::clamp(cam.clip_far, 0.f, 1e10f);
+        if (cam.clip_near > cam.clip_far) { std::swap(cam.clip_near, cam.clip_far); }
+        auto &impl = d->impl_type();
+        if (impl == "pinhole") {// pinhole.cpp:35-46
+            cam.kind = LR_CAMERA_PINHOLE;
+            auto fov = radians(std::clamp(d->float_or("fov", 35.f), 1e-3f, 180.f - 1e-3f));
+            cam.tan_half_fov = std::tan(fov * 0.5f);
+        } else if (impl == "thinlens") {// thin_lens.cpp:23-34,71-87
+            cam.kind = LR_CAMERA_THIN_LENS;
+            auto aperture = d->float_or("aperture", 2.f);
+            auto focal_length = d->float_or("focal_length", 35.f);
+            float focus_distance;
+            if (auto fd = d->number_opt("focus_distance")) {
+                focus_distance = static_cast<float>(*fd);
+            } else {
+                auto target = d->vector_opt("look_at", 3u), position = d->vector_opt("position", 3u);
+                if (!target || !position) { throw Error{"ThinLens camera needs focus_distance or look_at/position. [" + d->location() + "]"}; }
+                focus_distance = length(to_float3(*target) - to_float3(*position));
+            }
+            focus_distance = std::max(std::abs(focus_distance), 1e-4f);
+            auto v = static_cast<double>(focus_distance);
+            auto f = static_cast<double>(focal_length) * 1e-3;
+            auto u = 1. / (1. / f - 1. / v);
+            auto ratio = static_cast<float>(v / u);
+            cam.focus_distance = focus_distance;
+            cam.lens_radius = static_cast<float>(.5 * f / static_cast<double>(aperture));
+            auto rx = static_cast<float>(cam.width), ry = static_cast<float>(cam.height);
+            cam.projected_pixel_size = rx > ry ?
+                std::min(static_cast<float>(ratio * .036 / rx), static_cast<float>(ratio * .024 / ry)) :
+                std::min(static_cast<float>(ratio * .024 / rx), static_cast<float>(ratio * .036 / ry));
+        } else if (impl == "ortho") {// ortho.cpp
+            cam.kind = LR_CAMERA_ORTHO;
+            cam.ortho_scale = std::pow(2.f, d->float_or("zoom", 0.f));
+        } else {
+            throw Error{"Unknown camera implementation '" + impl + "'. [" + d->location() + "]"};
+        }
+        // output file (camera.cpp:138-147)
+        auto src = d->source_file();
+        auto default_dir = src.empty() ? fs::current_path() : fs::path{src}.parent_path();
+        rec.file = d->path_or("file", (default_dir / "render.exr").string());
+        return rec;
+    }
+
+    void build_environment(const NodeDesc *d);
+
+    void build() {
+        auto root = _desc.root();
+        if (!root->is_defined()) { throw Error{"Root node is not defined in the scene description."}; }
+        for (auto i = 0; i < 3; i++) {
+            _out.world_min[i] = std::numeric_limits<float>::max();
+            _out.world_max[i] = -std::numeric_limits<float>::max();
+        }
+        _scene_shadow_terminator = root->float_or("shadow_terminator", 0.f);
+        _scene_intersection_offset = root->float_or("intersection_offset", 0.f);
+        if (auto spectrum = root->node_or_null("spectrum"); spectrum != nullptr && spectrum->impl_type() != "srgb") {
+            throw Error{"Spectrum '" + spectrum->impl_type() + "' cannot be reproduced (srgb2spec table blob is missing "
+                        "from the reference snapshot, SURVEY §0); use sRGB."};
+        }
+        // integrator (integrator.cpp:13-18, mega_path.cpp:21-25)
+        auto integrator = root->node("integrator");
+        _check_tag(integrator, Tag::INTEGRATOR);
+        _out.integrator_impl = integrator->impl_type();
+        if (integrator->impl_type() != "megapath") {
+            throw Error{"Integrator '" + integrator->impl_type() + "' is out of scope: this framework implements the "
+                        "MegaPath hot path only (SURVEY §2 row 21)."};
+        }
+        _out.integrator.max_depth = std::max(integrator->uint_or("depth", 10u), 1u);
+        _out.integrator.rr_depth = integrator->uint_or("rr_depth", 0u);
+        _out.integrator.rr_threshold = std::max(integrator->float_or("rr_threshold", 0.95f), 0.05f);
+        auto sampler = integrator->node_or_null("sampler");
+        if (sampler == nullptr) { sampler = NodeDesc::shared_default(Tag::SAMPLER, "independent"); }
+        _check_tag(sampler, Tag::SAMPLER);
+        _out.sampler.seed = sampler->uint_or("seed", 19980810u);
+        if (sampler->impl_type() == "independent") { _out.sampler.kind = LR_SAMPLER_INDEPENDENT; }
+        else if (sampler->impl_type() == "sobol") { _out.sampler.kind = LR_SAMPLER_SOBOL; }
+        else if (sampler->impl_type() == "paddedsobol") { _out.sampler.kind = LR_SAMPLER_PADDED_SOBOL; }
+        else if (sampler->impl_type() == "pcg32") { _out.sampler.kind = LR_SAMPLER_PCG32; }
+        else {
+            throw Error{"Sampler '" + sampler->impl_type() + "' is not reproducible here (PMJ02BN tables missing, ZSobol "
+                        "hash unpinned; SURVEY §2 row 8)."};
+        }
+        auto light_sampler = integrator->node_or_null("light_sampler");
+        auto env_weight = 0.5f;
+        if (light_sampler != nullptr) {
+            _check_tag(light_sampler, Tag::LIGHT_SAMPLER);
+            if (light_sampler->impl_type() != "uniform") { throw Error{"Unknown light sampler '" + light_sampler->impl_type() + "'."}; }
+            env_weight = light_sampler->float_or("environment_weight", 0.5f);
+        }
+        // environment (scene.cpp:216-217)
+        build_environment(root->node_or_null("environment"));
+        // cameras and shapes
+        for (auto c : root->node_list_required("cameras")) { _out.cameras.emplace_back(build_camera(c)); }
+        _transform_stack.assign(1u, float4x4::identity());
+        for (auto s : root->node_list_required("shapes")) { process_shape(s, nullptr, nullptr, true); }
+        if (_out.instances.empty()) { throw Error{"No shapes in the scene."}; }
+        log_info("Geometry built with " + std::to_string([&] {
+                     uint64_t n = 0;
+                     for (auto &i : _out.instances) { n += i.handle.z; }
+                     return n;
+                 }()) + " triangles.");
+        // UniformLightSamplerInstance (uniform.cpp:31-48)
+        _out.integrator.light_count = static_cast<uint32_t>(_out.lights.size());
+        if (_out.environment.kind != LR_ENV_NONE) {
+            _out.integrator.env_prob = _out.lights.empty() ? 1.f : std::clamp(env_weight, 0.01f, 0.99f);
+        } else {
+            _out.integrator.env_prob = 0.f;
+        }
+    }
+};
+
+void Builder::build_environment(const NodeDesc *d) {
+    auto &env = _out.environment;
+    env = lr_environment{};
+    env.emission_tex = -1;
+    if (d == nullptr || d->impl_type() == "null") { return; }
+    _check_tag(d, Tag::ENVIRONMENT);
+    auto m = transform_matrix(d->node_or_null("transform"));
+    // Environment::Instance::transform_to_world: 3x3 of the env transform (environment.cpp:17-19)
+    for (auto c = 0; c < 3; c++) {
+        for (auto r = 0; r < 3; r++) {
+            env.env_to_world[c * 3 + r] = m[c][r];
+            env.world_to_env[c * 3 + r] = m[r][c];// transpose (rotation)
+        }
+    }
+    if (d->impl_type() == "spherical") {// spherical.cpp:17-40
+        env.kind = LR_ENV_SPHERICAL;
+        env.emission_tex = load_texture(d->node("emission"));
+        env.scale = std::max(d->float_or("scale", 1.f), 0.f);
+        env.compensate_mis = d->bool_or("compensate_mis", true) ? 1u : 0u;
+        if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
+        auto &t = _out.textures[static_cast<size_t>(env.emission_tex)];
+        if (env.kind != LR_ENV_NONE && t.kind != LR_TEX_CONSTANT) {
+            throw Error{"Image-based Spherical environments are row f1 of SURVEY §8 (next); only constant emission is built."};
+        }
+    } else {
+        throw Error{"Environment '" + d->impl_type() + "' is row f1 of SURVEY §8 (next). [" + d->location() + "]"};
+    }
+}
+
+}// namespace
+
+std::unique_ptr<SceneData> build_scene(const SceneDesc &desc) {
+    auto out = std::make_unique<SceneData>();
+    Builder{desc, *out}.build();
+    return out;
+}
+
+}// namespace lr

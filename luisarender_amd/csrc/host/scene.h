@@ -1,0 +1,89 @@
+// scene.h — scene graph loading and flattening into the POD tables of include/lr_scene.h.
+//
+// Replaces, for the megapath hot path, the reference's L4/L3 host build:
+//   Scene::create                    src/base/scene.cpp:201-233
+//   Pipeline::create                 src/base/pipeline.cpp:44-99
+//   Geometry::build/_process_shape   src/base/geometry.cpp:12-163
+// The reference JIT-compiles each scene's materials into code; here every node becomes a
+// record in a table that one hand-written kernel interprets.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/lr_scene.h"
+#include "sdl.h"
+#include "lr_math.h"
+
+namespace lr {
+
+struct CameraRecord {
+    lr_camera camera{};
+    lr_filter filter{};
+    lr_film film{};
+    std::string file;// output image path (src/base/camera.cpp:138-147)
+};
+
+struct SceneData {
+    std::vector<lr_vertex> vertices;
+    std::vector<lr_triangle> triangles;
+    std::vector<lr_alias_entry> tri_alias;
+    std::vector<float> tri_pdf;
+    std::vector<lr_mesh> meshes;
+    std::vector<lr_instance> instances;
+    std::vector<lr_light_handle> light_instances;
+    std::vector<lr_surface> surfaces;
+    std::vector<lr_light> lights;
+    std::vector<lr_texture> textures;
+    std::vector<float> texels;// float4 units
+    lr_environment environment{};
+    std::vector<lr_alias_entry> env_alias;
+    std::vector<float> env_pdf;
+    std::vector<CameraRecord> cameras;
+    lr_sampler sampler{};
+    lr_integrator integrator{};
+    std::string integrator_impl;
+    bool any_non_opaque{false};
+    // wide BVH (accel.cpp)
+    std::vector<lr_bvh4_node> bvh_nodes;
+    std::vector<lr_bvh_triangle> bvh_triangles;
+    float world_min[3]{}, world_max[3]{};
+
+    [[nodiscard]] bool has_lighting() const {
+        return !lights.empty() || environment.kind != LR_ENV_NONE;
+    }
+    // POD view for camera `index`; valid while *this is alive and unmodified
+    [[nodiscard]] lr_scene view(size_t camera_index = 0u) const;
+};
+
+// std::pair<alias table, pdf>, restating create_alias_table (src/util/sampling.cpp:38-87)
+void create_alias_table(const float *values, size_t n, std::vector<lr_alias_entry> &table, std::vector<float> &pdf);
+
+// Shape::Handle::encode (src/base/shape.cpp:46-70)
+lr_uint4 encode_instance_handle(uint32_t buffer_base, uint32_t flags, uint32_t surface_tag, uint32_t light_tag,
+                                uint32_t medium_tag, uint32_t tri_count, float shadow_terminator,
+                                float intersection_offset);
+
+std::unique_ptr<SceneData> build_scene(const SceneDesc &desc);
+
+// accel.cpp: flatten instances to world space and build the 4-wide BVH for the HIP kernel
+void build_accel(SceneData &scene);
+
+// mesh_io.cpp: OBJ loader standing in for assimp (src/shapes/mesh.cpp:46-69 flag semantics)
+struct LoadedMesh {
+    std::vector<lr_vertex> vertices;
+    std::vector<lr_triangle> triangles;
+    uint32_t properties{0u};
+};
+LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv);
+
+// image_io.cpp
+void save_image(const std::string &path, const float *rgba, uint32_t width, uint32_t height);// src/util/imageio.cpp:694-726
+struct LoadedImage {
+    uint32_t width{0}, height{0}, channels{0};
+    bool is_hdr{false};
+    std::vector<float> pixels;// float4 per pixel, row 0 = top
+};
+LoadedImage load_image(const std::string &path);
+
+}// namespace lr

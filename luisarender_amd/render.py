@@ -1,0 +1,87 @@
+"""Thin Python driver over the device C ABI (include/lrhip.h).  No torch types cross the ABI;
+torch is only used by callers that want the film in a tensor (bench.py, multi-GPU reduce)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .scene import Scene
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def tile_count(width: int, height: int) -> int:
+    return ((width + 7) // 8) * ((height + 7) // 8)
+
+
+class MegaPathRenderer:
+    """One lrhip_ctx on one GPU.  Mirrors the reference's ProgressiveIntegrator::Instance::render
+    (src/base/integrator.cpp:34-49): prepare film -> render spp -> download (convert) -> save."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _ffi.hip_lib()  # raises if liblrhip.so is missing: there is no CPU fallback
+        self._ctx = C.c_void_p()
+        self._check(self._lib.lrhip_create(device, C.byref(self._ctx)))
+        self._scene = None
+        self.width = self.height = 0
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise DeviceError(f"lrhip error {rc}: {self._lib.lrhip_last_error().decode()}")
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._check(self._lib.lrhip_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))
+
+    def upload(self, scene: Scene, camera: int = 0) -> None:
+        view = scene.view(camera)
+        self._check(self._lib.lrhip_upload_scene(self._ctx, C.byref(view)))
+        self._scene = scene
+        self.width, self.height = int(view.camera.width), int(view.camera.height)
+
+    def bind_film(self, device_ptr: int | None) -> None:
+        self._check(self._lib.lrhip_bind_film(self._ctx, C.c_void_p(device_ptr or 0)))
+
+    def clear(self) -> None:
+        self._check(self._lib.lrhip_film_clear(self._ctx))
+
+    def render(self, spp_begin: int, spp_end: int, rank: int = 0, world: int = 1, counters: bool = False,
+               sync: bool = False) -> None:
+        """Render samples [spp_begin, spp_end) of the round-robin tile shard `rank` of `world`."""
+        p = _ffi.RenderParams()
+        p.spp_begin, p.spp_end = spp_begin, spp_end
+        p.tile_begin, p.tile_end, p.tile_stride = rank, tile_count(self.width, self.height), world
+        p.flags = 1 if counters else 0
+        self._check(self._lib.lrhip_render(self._ctx, C.byref(p)))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self) -> None:
+        self._check(self._lib.lrhip_synchronize(self._ctx))
+
+    def download(self, converted: bool = True) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.lrhip_film_download(self._ctx, out.ctypes.data, 1 if converted else 0))
+        return out
+
+    def counters(self) -> dict:
+        c = _ffi.HipCounters()
+        self._check(self._lib.lrhip_get_counters(self._ctx, C.byref(c)))
+        return c.as_dict()
+
+    def last_render_ms(self) -> float:
+        return float(self._lib.lrhip_last_render_ms(self._ctx))
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.lrhip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,104 @@
+"""Scene loading through liblrhost.so (host C ABI, include/lrhost.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class Scene:
+    """A parsed + flattened scene (lrhost_scene) and its POD view (lr_scene)."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._lib = _ffi.host_lib()
+        self._handle = handle
+        self._views: dict[int, _ffi.Scene] = {}
+
+    @staticmethod
+    def _macros(macros):
+        macros = macros or {}
+        keys = (C.c_char_p * len(macros))(*[k.encode() for k in macros])
+        vals = (C.c_char_p * len(macros))(*[str(v).encode() for v in macros.values()])
+        return keys, vals, len(macros)
+
+    @classmethod
+    def load(cls, path: str, macros: dict | None = None, build_accel: bool = True) -> "Scene":
+        lib = _ffi.host_lib()
+        keys, vals, n = cls._macros(macros)
+        handle = C.c_void_p()
+        if lib.lrhost_scene_load_file(path.encode(), keys, vals, n, C.byref(handle)) != 0:
+            raise HostError(lib.lrhost_last_error().decode())
+        scene = cls(handle)
+        if build_accel:
+            scene.build_accel()
+        return scene
+
+    @classmethod
+    def from_string(cls, source: str, virtual_path: str = "", macros: dict | None = None, json: bool = False,
+                    build_accel: bool = True) -> "Scene":
+        lib = _ffi.host_lib()
+        keys, vals, n = cls._macros(macros)
+        handle = C.c_void_p()
+        rc = lib.lrhost_scene_load_string(source.encode(), virtual_path.encode(), 1 if json else 0, keys, vals, n,
+                                          C.byref(handle))
+        if rc != 0:
+            raise HostError(lib.lrhost_last_error().decode())
+        scene = cls(handle)
+        if build_accel:
+            scene.build_accel()
+        return scene
+
+    def build_accel(self) -> None:
+        if self._lib.lrhost_scene_build_accel(self._handle) != 0:
+            raise HostError(self._lib.lrhost_last_error().decode())
+        self._views.clear()
+
+    @property
+    def camera_count(self) -> int:
+        return self._lib.lrhost_scene_camera_count(self._handle)
+
+    def view(self, camera: int = 0) -> _ffi.Scene:
+        if camera not in self._views:
+            v = _ffi.Scene()
+            if self._lib.lrhost_scene_view(self._handle, camera, C.byref(v)) != 0:
+                raise HostError(self._lib.lrhost_last_error().decode())
+            self._views[camera] = v
+        return self._views[camera]
+
+    def camera_file(self, camera: int = 0) -> str:
+        return self._lib.lrhost_scene_camera_file(self._handle, camera).decode()
+
+    @property
+    def has_lighting(self) -> bool:
+        return bool(self._lib.lrhost_scene_has_lighting(self._handle))
+
+    def resolution(self, camera: int = 0) -> tuple[int, int]:
+        v = self.view(camera)
+        return int(v.camera.width), int(v.camera.height)
+
+    def close(self) -> None:
+        if self._handle:
+            self._lib.lrhost_scene_destroy(self._handle)
+            self._handle = None
+            self._views.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def save_image(path: str, rgba: np.ndarray) -> None:
+    """save_image of the reference (src/util/imageio.cpp:694-726): float RGBA -> .exr / .hdr"""
+    lib = _ffi.host_lib()
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w = rgba.shape[:2]
+    if lib.lrhost_save_image(path.encode(), rgba.ctypes.data, w, h) != 0:
+        raise HostError(lib.lrhost_last_error().decode())

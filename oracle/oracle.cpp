@@ -1,0 +1,524 @@
+// oracle.cpp — CPU restatement of the reference's megakernel path tracer.
+// TEST INFRASTRUCTURE ONLY (see oracle.h): the parity checker and the CPU baseline, never
+// linked into or called by the product path.
+//
+// Restated call stack (reference file:line):
+//   ProgressiveIntegrator::Instance::_render_one_camera   src/base/integrator.cpp:51-113
+//   MegakernelPathTracingInstance::Li                      src/integrators/mega_path.cpp:49-156
+//   IndependentSamplerInstance                             src/samplers/independent.cpp:57-83
+//   Camera::Instance::generate_ray / Pinhole / ThinLens    src/base/camera.cpp:212-224, src/cameras/*.cpp
+//   Filter::Instance::sample                               src/base/filter.cpp:49-64
+//   Geometry::interaction / shading_point                  src/base/geometry.cpp:281-389
+//   Interaction::p_robust / spawn_ray / spawn_ray_to       src/base/interaction.cpp:13-30
+//   UniformLightSamplerInstance                            src/lightsamplers/uniform.cpp:25-163
+//   DiffuseLightClosure::_evaluate                         src/lights/diffuse.cpp:67-88
+//   ColorFilmInstance::_accumulate / convert               src/films/color.cpp:87-130
+#include "oracle.h"
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "oracle_bsdf.h"
+#include "oracle_bvh.h"
+
+namespace oracle {
+
+// LuisaCompute `offset_ray_origin` (absent submodule): the integer-ULP offset of Ray Tracing
+// Gems ch. 6, restated from the published algorithm.  `n` is already scaled by the caller.
+inline float3 offset_ray_origin(float3 p, float3 n) {
+    constexpr auto origin = 1.0f / 32.0f;
+    constexpr auto float_scale = 1.0f / 65536.0f;
+    constexpr auto int_scale = 256.0f;
+    int32_t of_i[3] = {static_cast<int32_t>(int_scale * n.x), static_cast<int32_t>(int_scale * n.y),
+                       static_cast<int32_t>(int_scale * n.z)};
+    float3 out;
+    for (auto i = 0; i < 3; i++) {
+        auto pi_bits = static_cast<int32_t>(float_bits(p[i]));
+        auto p_i = bits_float(static_cast<uint32_t>(pi_bits + (p[i] < 0.f ? -of_i[i] : of_i[i])));
+        out[i] = std::abs(p[i]) < origin ? p[i] + float_scale * n[i] : p_i;
+    }
+    return out;
+}
+
+struct Sampler {// independent.cpp:57-83 (+ PCG32 option of the north star: one PCG32 stream per path)
+    uint32_t kind{LR_SAMPLER_INDEPENDENT};
+    uint32_t state{0u};
+    PCG32 pcg;
+    void start(const lr_sampler &s, uint32_t px, uint32_t py, uint32_t index) {
+        kind = s.kind;
+        state = xxhash32(px, py, s.seed, index);
+        if (kind == LR_SAMPLER_PCG32) { pcg = PCG32{static_cast<uint64_t>(state)}; }
+    }
+    float generate_1d() { return kind == LR_SAMPLER_PCG32 ? pcg.uniform_float() : lcg(state); }
+    float2 generate_2d() {
+        float2 u;
+        u.x = generate_1d();
+        u.y = generate_1d();
+        return u;
+    }
+    float2 generate_pixel_2d() { return generate_2d(); }// sampler.h:48
+};
+
+struct FilterSample {
+    float2 offset;
+    float weight;
+};
+inline FilterSample filter_sample(const lr_filter &f, float2 u) {// filter.cpp:49-64
+    constexpr auto n = static_cast<uint32_t>(LR_FILTER_LUT_SIZE) - 1u;
+    auto prob = [&](uint32_t i) { return f.alias_prob[i]; };
+    auto alias = [&](uint32_t i) { return f.alias_index[i]; };
+    auto sy = sample_alias_table(prob, alias, n, u.x);// note the x/y swap of the reference
+    auto sx = sample_alias_table(prob, alias, n, u.y);
+    auto pdf = f.pdf[sy.index] * f.pdf[sx.index];
+    auto fv = lerp(f.lut[sx.index], f.lut[sx.index + 1u], sx.u) * lerp(f.lut[sy.index], f.lut[sy.index + 1u], sy.u);
+    float2 p{static_cast<float>(sx.index) + sx.u, static_cast<float>(sy.index) + sy.u};
+    auto inv_size = 1.0f / static_cast<float>(LR_FILTER_LUT_SIZE);
+    float2 pixel{(p.x * inv_size * 2.0f - 1.0f) * f.radius, (p.y * inv_size * 2.0f - 1.0f) * f.radius};
+    return {{pixel.x + f.shift[0], pixel.y + f.shift[1]}, fv / pdf};
+}
+
+struct CameraSample {
+    Ray ray;
+    float weight;
+};
+inline CameraSample generate_camera_ray(const lr_scene &scene, uint32_t px, uint32_t py, float2 u_filter, float2 u_lens) {
+    auto &cam = scene.camera;
+    auto fs = filter_sample(scene.filter, u_filter);
+    float2 pixel{static_cast<float>(px) + .5f + fs.offset.x, static_cast<float>(py) + .5f + fs.offset.y};// camera.cpp:215
+    float2 res{static_cast<float>(cam.width), static_cast<float>(cam.height)};
+    float3 o{0.f, 0.f, 0.f}, d;
+    if (cam.kind == LR_CAMERA_PINHOLE) {// pinhole.cpp:60-67
+        float2 p{(pixel.x * 2.0f - res.x) * (cam.tan_half_fov / res.y), (pixel.y * 2.0f - res.y) * (cam.tan_half_fov / res.y)};
+        d = normalize(f3(p.x, -p.y, -1.f));
+    } else if (cam.kind == LR_CAMERA_THIN_LENS) {// thin_lens.cpp:91-101
+        float2 pixel_offset{.5f * res.x, .5f * res.y};
+        float2 coord_focal{(pixel.x - pixel_offset.x) * cam.projected_pixel_size, (pixel.y - pixel_offset.y) * cam.projected_pixel_size};
+        auto p_focal = f3(coord_focal.x, -coord_focal.y, -cam.focus_distance);
+        auto disk = sample_uniform_disk_concentric(u_lens);
+        auto p_lens = f3(disk.x * cam.lens_radius, disk.y * cam.lens_radius, 0.f);
+        o = p_lens;
+        d = normalize(p_focal - p_lens);
+    } else {// ortho.cpp:52-58
+        float2 p{(pixel.x * 2.0f - res.x) / res.y * cam.ortho_scale, (pixel.y * 2.0f - res.y) / res.y * cam.ortho_scale};
+        o = f3(p.x, -p.y, 0.f);
+        d = f3(0.f, 0.f, -1.f);
+    }
+    // ClipPlaneCameraWrapper, camera.h:147-157
+    auto cos_axis = dot(d, f3(0.f, 0.f, -1.f));
+    auto t_min = cam.clip_near / cos_axis, t_max = cam.clip_far / cos_axis;
+    auto m = cam.camera_to_world;// camera.cpp:218-222
+    auto ow = f3(m[0] * o.x + m[4] * o.y + m[8] * o.z + m[12], m[1] * o.x + m[5] * o.y + m[9] * o.z + m[13],
+                 m[2] * o.x + m[6] * o.y + m[10] * o.z + m[14]);
+    auto dw = normalize(f3(m[0], m[1], m[2]) * d.x + f3(m[4], m[5], m[6]) * d.y + f3(m[8], m[9], m[10]) * d.z);
+    return {{ow, t_min, dw, t_max}, 1.f * fs.weight};
+}
+
+}// namespace oracle
+
+using namespace oracle;
+
+struct oracle_ctx {
+    const lr_scene *scene;
+    Accel accel;
+    explicit oracle_ctx(const lr_scene *s) : scene{s}, accel{*s} {}
+
+    // Geometry::shading_point + Interaction ctor, geometry.cpp:345-389, interaction.h:94-99
+    Interaction make_interaction(uint32_t inst_id, uint32_t prim_id, float3 bary, bool use_wo, float3 wo_or_pfrom) const {
+        auto &s = *scene;
+        auto &inst = s.instances[inst_id];
+        Interaction it;
+        it.handle = inst.handle;
+        it.inst = inst_id, it.prim = prim_id;
+        auto &mesh = s.meshes[it.mesh_index()];
+        auto tri = s.triangles[mesh.triangle_offset + prim_id];
+        auto &v0 = s.vertices[mesh.vertex_offset + tri.i0];
+        auto &v1 = s.vertices[mesh.vertex_offset + tri.i1];
+        auto &v2 = s.vertices[mesh.vertex_offset + tri.i2];
+        auto interp3 = [&](float3 a, float3 b, float3 c) { return bary.x * a + bary.y * b + bary.z * c; };
+        auto p0 = f3(v0.px, v0.py, v0.pz), p1 = f3(v1.px, v1.py, v1.pz), p2 = f3(v2.px, v2.py, v2.pz);
+        auto ns_local = interp3(f3(v0.nx, v0.ny, v0.nz), f3(v1.nx, v1.ny, v1.nz), f3(v2.nx, v2.ny, v2.nz));
+        float2 uv0{v0.u, v0.v}, uv1{v1.u, v1.v}, uv2{v2.u, v2.v};
+        auto duv0 = uv1 - uv0, duv1 = uv2 - uv0;
+        auto det = duv0.x * duv1.y - duv0.y * duv1.x;
+        auto inv_det = 1.f / det;
+        auto dp0 = p1 - p0, dp1 = p2 - p0;
+        auto dpdu_local = (dp0 * duv1.y - dp1 * duv0.y) * inv_det;
+        auto o2w = inst.object_to_world;
+        mat3 m{{f3(o2w[0], o2w[1], o2w[2]), f3(o2w[4], o2w[5], o2w[6]), f3(o2w[8], o2w[9], o2w[10])}};
+        auto t = f3(o2w[12], o2w[13], o2w[14]);
+        auto p = m * interp3(p0, p1, p2) + t;
+        auto c = cross(m * dp0, m * dp1);
+        it.area = length(c) * .5f;
+        auto ng = normalize(c);
+        auto fallback = Frame::make(ng);
+        auto dpdu = det == 0.f ? fallback.s : m * dpdu_local;
+        auto mn = transpose(inverse(m));
+        auto has_normal = (it.flags() & LR_SHAPE_HAS_VERTEX_NORMAL) != 0u;
+        auto has_uv = (it.flags() & LR_SHAPE_HAS_VERTEX_UV) != 0u;
+        auto ns = has_normal ? normalize(mn * ns_local) : ng;
+        it.uv = has_uv ? float2{bary.x * uv0.x + bary.y * uv1.x + bary.z * uv2.x, bary.x * uv0.y + bary.y * uv1.y + bary.z * uv2.y} :
+                         float2{bary.y, bary.z};
+        it.pg = p, it.ps = p, it.ng = ng;
+        it.shading = Frame::make(face_forward(ns, ng), dpdu);
+        it.back_facing = use_wo ? dot(wo_or_pfrom, ng) < 0.0f :          // geometry.cpp:290
+                                  dot(ng, wo_or_pfrom - p) < 0.f;          // uniform.cpp:122
+        return it;
+    }
+
+    // Interaction::p_robust / spawn_ray / spawn_ray_to, interaction.cpp:13-30
+    static float3 p_robust(const Interaction &it, float3 w) {
+        auto front = dot(it.shading.n, w) > 0.f;
+        auto n = front ? it.ng : -it.ng;
+        return offset_ray_origin(it.pg, it.intersection_offset_factor() * n);
+    }
+    static Ray spawn_ray(const Interaction &it, float3 wi) {
+        return {p_robust(it, wi), 0.f, wi, std::numeric_limits<float>::max()};
+    }
+    static Ray spawn_ray_to(const Interaction &it, float3 p) {
+        auto p_from = p_robust(it, p - it.pg);
+        auto L = p - p_from;
+        auto d = length(L);
+        return {p_from, 0.f, L * (1.f / d), d * .9999f};
+    }
+
+    struct LightEval {
+        Spectrum3 L{0.f, 0.f, 0.f};
+        float pdf{0.f};
+    };
+    // DiffuseLightClosure::_evaluate, diffuse.cpp:67-88
+    LightEval light_evaluate(const Interaction &it_light, float3 p_from) const {
+        auto &s = *scene;
+        auto &light = s.lights[it_light.light_tag()];
+        auto &mesh = s.meshes[it_light.mesh_index()];
+        auto pdf_triangle = s.tri_pdf[mesh.triangle_offset + it_light.prim];
+        auto pdf_area = pdf_triangle / it_light.area;
+        auto cos_wo = abs_dot(normalize(p_from - it_light.pg), it_light.ng);
+        auto L = illuminant(s, light.emission_tex, it_light.uv).value * light.scale;
+        auto diff = it_light.pg - p_from;
+        auto pdf = dot(diff, diff) * pdf_area * (1.0f / cos_wo);
+        auto invalid = std::abs(cos_wo) < 1e-6f || (!light.two_sided && it_light.back_facing);
+        return {invalid ? f3(0.f) : L, invalid ? 0.f : pdf};
+    }
+
+    struct LightSample {
+        LightEval eval;
+        Ray shadow_ray{{0.f, 0.f, 0.f}, 0.f, {0.f, 0.f, 0.f}, 0.f};
+    };
+    // LightSampler::Instance::sample, light_sampler.cpp:57-63 with UniformLightSamplerInstance::select / _sample_*
+    LightSample light_sample(const Interaction &it, float u_sel, float2 u_light) const {
+        auto &s = *scene;
+        auto env_prob = s.integrator.env_prob;
+        auto n = static_cast<float>(s.integrator.light_count);
+        auto is_env = false;
+        auto tag = 0u;
+        auto prob = 0.f;
+        if (env_prob == 1.f) {
+            is_env = true, prob = 1.f;
+        } else if (env_prob == 0.f) {
+            tag = static_cast<uint32_t>(clampf(u_sel * n, 0.f, n - 1.f)), prob = 1.f / n;
+        } else {
+            auto uu = (u_sel - env_prob) / (1.f - env_prob);
+            tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
+            is_env = u_sel < env_prob;
+            prob = is_env ? env_prob : (1.f - env_prob) / n;
+        }
+        LightSample out;
+        if (is_env) {// spherical.cpp:110-141 (constant emission: uniform sphere)
+            auto &env = s.environment;
+            auto w = sample_uniform_sphere(u_light);
+            auto L = illuminant(s, env.emission_tex, {0.f, 0.f}).value * env.scale;
+            auto e2w = env.env_to_world;
+            auto wi = normalize(f3(e2w[0], e2w[1], e2w[2]) * w.x + f3(e2w[3], e2w[4], e2w[5]) * w.y + f3(e2w[6], e2w[7], e2w[8]) * w.z);
+            out.eval = {L, uniform_sphere_pdf * prob};
+            out.shadow_ray = spawn_ray(it, wi);
+            return out;
+        }
+        // _sample_area, uniform.cpp:107-123
+        auto handle = s.light_instances[tag];
+        auto &light_inst = s.instances[handle.instance_id];
+        auto &mesh = s.meshes[light_inst.handle.x >> 10u];
+        auto table = s.tri_alias + mesh.triangle_offset;
+        auto as = sample_alias_table([&](uint32_t i) { return table[i].prob; }, [&](uint32_t i) { return table[i].alias; },
+                                     light_inst.handle.z, u_light.x);
+        auto uvw = sample_uniform_triangle({as.u, u_light.y});
+        auto it_light = make_interaction(handle.instance_id, as.index, uvw, false, it.pg);
+        auto eval = light_evaluate(it_light, it.ps);// uniform.cpp:131-134
+        eval.pdf *= prob;                            // light_sampler.cpp:83
+        out.eval = eval;
+        out.shadow_ray = spawn_ray_to(it, it_light.pg);
+        return out;
+    }
+
+    struct PathStats {
+        TraceCounters trace;
+        uint64_t closest{0}, shadow{0}, hits{0}, nee{0}, bounces{0};
+    };
+
+    // MegakernelPathTracingInstance::Li, mega_path.cpp:49-156
+    float3 Li(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
+        auto &s = *scene;
+        Sampler sampler;
+        sampler.start(s.sampler, px, py, sample_index);
+        auto u_filter = sampler.generate_pixel_2d();
+        auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
+        auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
+        Spectrum3 beta = f3(cs.weight);
+        Spectrum3 Li = f3(0.f);
+        auto ray = cs.ray;
+        auto pdf_bsdf = 1e16f;
+        auto has_env = s.environment.kind != LR_ENV_NONE;
+        for (auto depth = 0u; depth < s.integrator.max_depth; depth++) {
+            auto wo = -ray.d;
+            stats.closest++;
+            auto hit = accel.trace(ray, false, stats.trace);
+            if (hit.miss()) {
+                if (has_env) {// evaluate_miss, uniform.cpp:67-76
+                    auto L = illuminant(s, s.environment.emission_tex, {0.f, 0.f}).value * s.environment.scale;
+                    auto pdf = uniform_sphere_pdf * s.integrator.env_prob;
+                    Li += beta * L * balance_heuristic(pdf_bsdf, pdf);
+                }
+                break;
+            }
+            stats.hits++;
+            auto it = make_interaction(hit.inst, hit.prim, f3(1.f - hit.bary.x - hit.bary.y, hit.bary.x, hit.bary.y), true, wo);
+            if (s.light_count != 0u && it.has_light()) {// evaluate_hit, uniform.cpp:50-65
+                auto eval = light_evaluate(it, ray.o);
+                eval.pdf *= (1.f - s.integrator.env_prob) / static_cast<float>(s.integrator.light_count);
+                Li += beta * eval.L * balance_heuristic(pdf_bsdf, eval.pdf);
+            }
+            if (!it.has_surface()) { break; }
+            stats.bounces++;
+            auto u_light_selection = sampler.generate_1d();
+            auto u_light_surface = sampler.generate_2d();
+            auto u_lobe = sampler.generate_1d();
+            auto u_bsdf = sampler.generate_2d();
+            auto u_rr = 0.f;
+            auto rr_depth = s.integrator.rr_depth;
+            if (depth + 1u >= rr_depth) { u_rr = sampler.generate_1d(); }
+            stats.nee++;
+            auto light_sample = this->light_sample(it, u_light_selection, u_light_surface);
+            stats.shadow++;
+            auto occluded = !accel.trace(light_sample.shadow_ray, true, stats.trace).miss();
+            auto eta_scale = 1.f;
+            auto closure = Closure::populate(s, it, wo, 1.f);
+            if (light_sample.eval.pdf > 0.0f && !occluded) {
+                auto wi = light_sample.shadow_ray.d;
+                auto eval = closure.evaluate(wo, wi);
+                auto w = balance_heuristic(light_sample.eval.pdf, eval.pdf) / light_sample.eval.pdf;
+                Li += w * beta * eval.f * light_sample.eval.L;
+            }
+            auto surface_sample = closure.sample(wo, u_lobe, u_bsdf);
+            ray = spawn_ray(it, surface_sample.wi);
+            pdf_bsdf = surface_sample.eval.pdf;
+            auto w = surface_sample.eval.pdf > 0.f ? 1.f / surface_sample.eval.pdf : 0.f;
+            beta *= w * surface_sample.eval.f;
+            auto eta = closure.has_eta ? closure.eta_value : 1.f;
+            if (surface_sample.event == EVENT_ENTER) { eta_scale = sqr(eta); }
+            else if (surface_sample.event == EVENT_EXIT) { eta_scale = sqr(1.f / eta); }
+            if (any_nan(beta)) { beta = f3(0.f); }// zero_if_any_nan, spec.cpp:404-407
+            if (beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f) { break; }
+            auto rr_threshold = s.integrator.rr_threshold;
+            auto q = std::max(max_component(beta) * eta_scale, .05f);
+            if (depth + 1u >= rr_depth) {
+                if (q < rr_threshold && u_rr >= q) { break; }
+                beta *= q < rr_threshold ? 1.0f / q : 1.f;
+            }
+        }
+        return Li;
+    }
+};
+
+// ColorFilmInstance::_accumulate (effective_spp = 1), color.cpp:107-130
+static inline void film_accumulate(const lr_scene &scene, float *film, uint32_t px, uint32_t py, float3 rgb) {
+    auto p = film + (static_cast<size_t>(py) * scene.camera.width + px) * 4u;
+    if (!(any_nan(rgb) || any_inf(rgb))) {
+        auto threshold = scene.film.clamp * std::max(1.f, 1.f);
+        auto a = abs3(rgb);
+        auto strength = std::max(std::max(std::max(a.x, a.y), a.z), 0.f);
+        auto c = rgb * (threshold / std::max(strength, threshold));
+        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) { p[0] += c.x, p[1] += c.y, p[2] += c.z; }
+        p[3] += 1.f;
+    }
+}
+
+extern "C" {
+
+oracle_ctx *oracle_create(const lr_scene *scene) { return new oracle_ctx{scene}; }
+void oracle_destroy(oracle_ctx *ctx) { delete ctx; }
+
+int oracle_render(oracle_ctx *ctx, uint32_t spp_begin, uint32_t spp_end, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                  int threads, float *film, oracle_counters *counters) {
+    auto &scene = *ctx->scene;
+    if (x1 > scene.camera.width || y1 > scene.camera.height || x0 > x1 || y0 > y1) { return -1; }
+    if (scene.light_count == 0u && scene.environment.kind == LR_ENV_NONE) { return 0; }// mega_path.cpp:40-46: no lights -> black
+    threads = std::max(threads, 1);
+    std::atomic<uint32_t> next_row{y0};
+    std::vector<oracle_ctx::PathStats> stats(static_cast<size_t>(threads));
+    auto work = [&](int tid) {
+        auto &st = stats[static_cast<size_t>(tid)];
+        for (;;) {
+            auto y = next_row.fetch_add(1u);
+            if (y >= y1) { break; }
+            for (auto x = x0; x < x1; x++) {
+                for (auto sidx = spp_begin; sidx < spp_end; sidx++) {
+                    auto L = ctx->Li(x, y, sidx, st);
+                    film_accumulate(scene, film, x, y, 1.f * L);// shutter weight 1 (static camera)
+                }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (auto t = 1; t < threads; t++) { pool.emplace_back(work, t); }
+    work(0);
+    for (auto &t : pool) { t.join(); }
+    if (counters != nullptr) {
+        counters->paths += static_cast<uint64_t>(x1 - x0) * (y1 - y0) * (spp_end - spp_begin);
+        for (auto &st : stats) {
+            counters->closest_rays += st.closest, counters->shadow_rays += st.shadow;
+            counters->nodes_visited += st.trace.nodes, counters->tris_tested += st.trace.tris;
+            counters->surface_hits += st.hits, counters->nee_samples += st.nee;
+            counters->path_length_sum += st.bounces;
+        }
+    }
+    return 0;
+}
+
+void oracle_film_convert(const lr_scene *scene, const float *film, float *out) {// color.cpp:87-93
+    auto n = static_cast<size_t>(scene->camera.width) * scene->camera.height;
+    for (size_t i = 0; i < n; i++) {
+        auto c = film + i * 4u;
+        auto cnt = std::max(c[3], 1.f);
+        for (auto k = 0; k < 3; k++) { out[i * 4u + static_cast<size_t>(k)] = ((1.f / cnt) * scene->film.scale[k]) * c[k]; }
+        out[i * 4u + 3u] = 1.f;
+    }
+}
+
+void oracle_li(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sample_index, float rgb_out[3]) {
+    oracle_ctx::PathStats st;
+    auto L = ctx->Li(px, py, sample_index, st);
+    rgb_out[0] = L.x, rgb_out[1] = L.y, rgb_out[2] = L.z;
+}
+
+void oracle_trace_closest(oracle_ctx *ctx, const float o[3], const float d[3], float t_min, float t_max,
+                          uint32_t out_ids[2], float out_bary_t[3]) {
+    TraceCounters tc;
+    auto hit = ctx->accel.trace({f3(o[0], o[1], o[2]), t_min, f3(d[0], d[1], d[2]), t_max}, false, tc);
+    out_ids[0] = hit.inst, out_ids[1] = hit.prim;
+    out_bary_t[0] = hit.bary.x, out_bary_t[1] = hit.bary.y, out_bary_t[2] = hit.t;
+}
+
+void oracle_camera_ray(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sample_index, float out[7]) {
+    auto &s = *ctx->scene;
+    Sampler sampler;
+    sampler.start(s.sampler, px, py, sample_index);
+    auto u_filter = sampler.generate_pixel_2d();
+    auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
+    auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
+    out[0] = cs.ray.o.x, out[1] = cs.ray.o.y, out[2] = cs.ray.o.z;
+    out[3] = cs.ray.d.x, out[4] = cs.ray.d.y, out[5] = cs.ray.d.z;
+    out[6] = cs.weight;
+}
+
+uint32_t oracle_xxhash32_1(uint32_t x) { return xxhash32(x); }
+uint32_t oracle_xxhash32_2(uint32_t x, uint32_t y) { return xxhash32(x, y); }
+uint32_t oracle_xxhash32_3(uint32_t x, uint32_t y, uint32_t z) { return xxhash32(x, y, z); }
+uint32_t oracle_xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return xxhash32(x, y, z, w); }
+float oracle_lcg(uint32_t *state) { return lcg(*state); }
+uint32_t oracle_pcg32_next(uint64_t *state, uint64_t *inc) {
+    PCG32 g;
+    g.state = *state, g.inc = *inc;
+    auto v = g.uniform_uint();
+    *state = g.state;
+    return v;
+}
+void oracle_pcg32_seed(uint64_t seq_index, uint64_t *state, uint64_t *inc) {
+    PCG32 g{seq_index};
+    *state = g.state, *inc = g.inc;
+}
+
+void oracle_create_alias_table(const float *values, uint32_t n, lr_alias_entry *table, float *pdf) {// sampling.cpp:38-87
+    auto sum = 0.0;
+    for (uint32_t i = 0; i < n; i++) { sum += std::abs(values[i]); }
+    if (sum == 0.) {
+        for (uint32_t i = 0; i < n; i++) { pdf[i] = static_cast<float>(1.0 / static_cast<double>(n)); }
+    } else {
+        auto inv_sum = 1.0 / sum;
+        for (uint32_t i = 0; i < n; i++) { pdf[i] = static_cast<float>(std::abs(values[i]) * inv_sum); }
+    }
+    auto ratio = static_cast<double>(n) / sum;
+    std::vector<uint32_t> over, under;
+    for (uint32_t i = 0; i < n; i++) {
+        auto p = static_cast<float>(values[i] * ratio);
+        table[i] = {p, i};
+        (p > 1.0f ? over : under).push_back(i);
+    }
+    while (!over.empty() && !under.empty()) {
+        auto o = over.back(), u = under.back();
+        over.pop_back(), under.pop_back();
+        table[o].prob -= 1.0f - table[u].prob;
+        table[u].alias = o;
+        if (table[o].prob > 1.0f) { over.push_back(o); }
+        else if (table[o].prob < 1.0f) { under.push_back(o); }
+    }
+    for (auto i : over) { table[i] = {1.0f, i}; }
+    for (auto i : under) { table[i] = {1.0f, i}; }
+}
+
+void oracle_sample_alias_table(const lr_alias_entry *table, uint32_t n, float u, uint32_t *index, float *u_remapped) {
+    auto s = sample_alias_table([&](uint32_t i) { return table[i].prob; }, [&](uint32_t i) { return table[i].alias; }, n, u);
+    *index = s.index, *u_remapped = s.u;
+}
+
+void oracle_filter_sample(const lr_filter *filter, float ux, float uy, float out[3]) {
+    auto s = filter_sample(*filter, {ux, uy});
+    out[0] = s.offset.x, out[1] = s.offset.y, out[2] = s.weight;
+}
+
+void oracle_encode_handle(uint32_t buffer_base, uint32_t flags, uint32_t surface_tag, uint32_t light_tag, uint32_t medium_tag,
+                          uint32_t tri_count, float shadow_term, float isect_offset, uint32_t out[4]) {// shape.cpp:46-70
+    auto fixed = [](float x) {
+        x = clampf(x, 0.f, 1.f);
+        return static_cast<uint32_t>(clampf(std::round(x / (1.f / 65536.f)), 0.f, 65535.f));
+    };
+    out[0] = (buffer_base << 10u) | flags;
+    out[1] = (surface_tag << 12u) | (light_tag << 0u) | (medium_tag << 24u);
+    out[2] = tri_count;
+    out[3] = (fixed(shadow_term) << 16u) | fixed(isect_offset);
+}
+
+void oracle_offset_ray_origin(const float p[3], const float n[3], float out[3]) {
+    auto r = offset_ray_origin(f3(p[0], p[1], p[2]), f3(n[0], n[1], n[2]));
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+
+static Interaction flat_patch(uint32_t surface_tag, const float ns_in[3]) {
+    Interaction it;
+    it.handle.x = LR_SHAPE_HAS_SURFACE;
+    it.handle.y = surface_tag << 12u;
+    it.inst = 0u, it.prim = 0u;
+    it.ng = f3(0.f, 0.f, 1.f);
+    auto ns = normalize(f3(ns_in[0], ns_in[1], ns_in[2]));
+    it.shading = Frame::make(face_forward(ns, it.ng), Frame::make(it.ng).s);
+    it.uv = {0.25f, 0.75f};
+    return it;
+}
+
+void oracle_surface_evaluate(const lr_scene *scene, uint32_t surface_tag, const float ns[3], const float wo_in[3],
+                             const float wi_in[3], float out[4]) {
+    auto it = flat_patch(surface_tag, ns);
+    auto wo = f3(wo_in[0], wo_in[1], wo_in[2]), wi = f3(wi_in[0], wi_in[1], wi_in[2]);
+    auto e = Closure::populate(*scene, it, wo, 1.f).evaluate(wo, wi);
+    out[0] = e.f.x, out[1] = e.f.y, out[2] = e.f.z, out[3] = e.pdf;
+}
+
+void oracle_surface_sample(const lr_scene *scene, uint32_t surface_tag, const float ns[3], const float wo_in[3],
+                           float u_lobe, float ux, float uy, float out[8]) {
+    auto it = flat_patch(surface_tag, ns);
+    auto wo = f3(wo_in[0], wo_in[1], wo_in[2]);
+    auto s = Closure::populate(*scene, it, wo, 1.f).sample(wo, u_lobe, {ux, uy});
+    out[0] = s.eval.f.x, out[1] = s.eval.f.y, out[2] = s.eval.f.z, out[3] = s.eval.pdf;
+    out[4] = s.wi.x, out[5] = s.wi.y, out[6] = s.wi.z, out[7] = static_cast<float>(s.event);
+}
+
+}// extern "C"
