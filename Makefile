@@ -15,7 +15,7 @@ HOSTDIR := luisarender_amd/csrc/host
 HIPDIR := luisarender_amd/csrc/hip
 
 HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/image_io.cpp \
-            $(HOSTDIR)/accel.cpp $(HOSTDIR)/host_api.cpp
+            $(HOSTDIR)/accel.cpp $(HOSTDIR)/host_api.cpp $(HOSTDIR)/luisa_render_shim.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
@@ -26,7 +26,7 @@ all: host oracle hip cli
 host: $(LIBDIR)/liblrhost.so
 $(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl
 
 oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the MI355X megakernel path tracer on BASELINE.json's configs.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one full pass of the hot path over one frame: every pixel of the workload's
+resolution x its spp through the megakernel (film accumulate included), scene already resident
+in HBM.  N = 1 runs configs[1] ("Contemporary Bathroom"-class: 1024 x 1024, 1024 spp, depth 16;
+the real asset is an external download, so the seeded procedural stand-in of SURVEY §8(d) is
+used).  For N > 1 the same frame is sharded by screen tile over the ranks (strong scaling) and
+the float4 film is sum-reduced to rank 0 over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line with the driver's contract plus
+  "roofline":     algorithmic bytes per launch (oracle's canonical-BVH2 counters) divided
+                  by the megakernel's HIP-event duration, against the 8 TB/s HBM3E peak;
+  "cpu_baseline": the CPU oracle ("port": reference-faithful restatement, not the reference binary)
+                  timed on the host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (description, resolution, spp, depth)
+    "c2": ("Contemporary Bathroom-class (procedural stand-in, ~600k tris), 1024x1024, 1024spp, depth 16", (1024, 1024), 1024, 16),
+    "c1": ("Cornell Box, 512x512, 64spp, depth 8", (512, 512), 64, 8),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_scene(workload: str, tmpdir: str, spp_override: int | None):
+    from luisarender_amd import Scene
+    from luisarender_amd.scenes import cornell_box, generate_room_scene
+    desc, res, spp, depth = WORKLOADS[workload]
+    spp = spp_override or spp
+    if workload == "c1":
+        scene = Scene.from_string(cornell_box(resolution=res[0], spp=spp, depth=depth))
+    else:
+        scene = Scene.load(generate_room_scene(tmpdir, resolution=res, spp=spp, depth=depth))
+    return scene, desc, res, spp
+
+
+def cpu_baseline(scene, res, budget_s: float):
+    """Oracle on all host cores over a bounded sample: whole frame at 1..n spp until ~budget_s."""
+    from luisarender_amd.oracle_check import Oracle, algorithmic_bytes
+    cores = os.cpu_count() or 1
+    oracle = Oracle(scene)
+    # calibrate on a strip, then size the sample
+    t0 = time.perf_counter()
+    _, c0 = oracle.render(0, 1, rect=(0, res[1] // 2 - 16, res[0], res[1] // 2 + 16), threads=cores)
+    rate = c0["paths"] / max(time.perf_counter() - t0, 1e-6)
+    spp = int(max(1, min(16, budget_s * rate / (res[0] * res[1]))))
+    t0 = time.perf_counter()
+    _, counters = oracle.render(0, spp, threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": counters["paths"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"CPU oracle (reference-faithful restatement, not the reference binary), full frame {res[0]}x{res[1]} at {spp} spp "
+                  f"= {counters['paths']} paths in {dt:.1f} s",
+    }, algorithmic_bytes(counters) / counters["paths"], counters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=None, help="override the workload's spp (invalidates the headline number)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from luisarender_amd.parallel import reduce_film
+    from luisarender_amd.render import MegaPathRenderer
+
+    with tempfile.TemporaryDirectory(prefix="lr_bench_") as tmp:
+        scene, desc, res, spp = build_scene(args.workload, tmp, args.spp)
+        renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
+        renderer.upload(scene)
+        film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        renderer.bind_film(film.data_ptr())
+        torch.cuda.synchronize()
+
+        def step():
+            film.zero_()
+            torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
+            renderer.render(0, spp, rank=rank, world=world)
+            renderer.synchronize()
+            if world > 1:
+                reduce_film(film, dst=0)
+                torch.cuda.synchronize()
+            return renderer.last_render_ms()
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms = [step() for _ in range(args.steps)]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, mean_kernel_ms = float(t[0]), float(t[1])
+        else:
+            mean_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+
+        if rank == 0:
+            samples_per_step = res[0] * res[1] * spp
+            value = samples_per_step * args.steps / elapsed / 1e6
+            out = {
+                "metric": "Msamples/s (+ fraction of HBM roofline) at fixed SPP", "value": value, "unit": "Msamples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)",
+                           "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU"},
+            }
+            if args.spp is not None:
+                out["config"]["note"] = "spp overridden: not the headline configuration"
+            if not args.no_cpu_baseline:
+                cpu, bytes_per_sample, _ = cpu_baseline(scene, res, args.cpu_seconds)
+                out["cpu_baseline"] = cpu
+                # one launch renders this rank's shard: samples_per_step / world samples
+                launch_bytes = bytes_per_sample * samples_per_step / world
+                achieved = launch_bytes / (mean_kernel_ms * 1e-3) / 1e9
+                traffic = None
+                prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+                if os.path.exists(prof):
+                    try:
+                        traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                out["roofline"] = {
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": traffic, "kernel": "lrd::megapath_kernel<false>", "kernel_ms": mean_kernel_ms,
+                    "algorithmic_bytes_per_sample": bytes_per_sample,
+                }
+            print(json.dumps(out), flush=True)
+        renderer.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

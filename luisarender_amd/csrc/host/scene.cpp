@@ -349,7 +349,7 @@ public:
         } else if (impl == "glass") {// glass.cpp:57-81
             s.kind = LR_SURFACE_GLASS;
             s.tex[0] = tex("Kr"), s.tex[1] = tex("Kt"), s.tex[2] = tex("roughness");
-            if (auto name = d->string_or("eta"); !name.empty()) {
+            if (auto name = d->is_string_property("eta") ? d->string_or("eta") : std::string{}; !name.empty()) {
                 static const std::unordered_map<std::string, std::array<float, 3>> builtin{
                     {"bk7", {1.5140814565098806f, 1.5165571794092296f, 1.5223224896834853f}},
                     {"baf10", {1.665552211440938f, 1.6698355055693541f, 1.680044942398477f}},
@@ -392,7 +392,7 @@ public:
             s.kind = LR_SURFACE_METAL;
             s.tex[0] = tex("Kd"), s.tex[1] = tex("roughness");
             const MetalIOR *ior = nullptr;
-            if (auto name = d->string_or("eta"); !name.empty()) {
+            if (auto name = d->is_string_property("eta") ? d->string_or("eta") : std::string{}; !name.empty()) {
                 ior = find_metal(name);
                 if (ior == nullptr) {
                     log_warning("Unknown metal '" + name + "'. Fallback to Aluminium. [" + d->location() + "]");

@@ -108,6 +108,10 @@ const NodeDesc::value_list *NodeDesc::_find(const std::string &name) const {
 }
 
 bool NodeDesc::has_property(const std::string &name) const { return _find(name) != nullptr; }
+bool NodeDesc::is_string_property(const std::string &name) const {
+    auto v = _find(name);
+    return v != nullptr && std::holds_alternative<string_list>(*v);
+}
 
 template<typename L>
 const L *NodeDesc::_raw(const std::string &name) const {

@@ -70,6 +70,7 @@ public:
                               const NodeDesc *base = nullptr);
     void add_property(const std::string &name, value_list v);
     bool has_property(const std::string &name) const;
+    bool is_string_property(const std::string &name) const;// defined (here or in the base) as a string list
     const std::map<std::string, value_list> &properties() const { return _props; }
 
     // getters; *_opt return nullopt when absent / wrong list type / too few values

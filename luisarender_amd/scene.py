@@ -68,6 +68,7 @@ class Scene:
             v = _ffi.Scene()
             if self._lib.lrhost_scene_view(self._handle, camera, C.byref(v)) != 0:
                 raise HostError(self._lib.lrhost_last_error().decode())
+            v._owner = self  # keep the host tables alive as long as the view is referenced
             self._views[camera] = v
         return self._views[camera]
 

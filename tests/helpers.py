@@ -1,0 +1,52 @@
+import ctypes as C
+
+import numpy as np
+
+from luisarender_amd import Scene, _ffi
+
+MATERIALS = {
+    "matte": "Surface m : Matte { Kd : Constant { v { 0.6, 0.5, 0.4 } } }",
+    "oren": "Surface m : Matte { Kd : Constant { v { 0.6, 0.5, 0.4 } } sigma : Constant { v { 0.4 } } }",
+    "mirror": "Surface m : Mirror { color : Constant { v { 0.9, 0.8, 0.7 } } roughness : Constant { v { 0.3 } } }",
+    "glass": "Surface m : Glass { Kr : Constant { v { 0.9, 0.9, 0.9 } } Kt : Constant { v { 0.95, 0.9, 0.85 } } roughness : Constant { v { 0.25 } } eta : Constant { v { 1.5 } } }",
+    "plastic": "Surface m : Plastic { Kd : Constant { v { 0.5, 0.3, 0.2 } } roughness : Constant { v { 0.2 } } sigma_a : Constant { v { 0.1, 0.2, 0.3 } } eta : Constant { v { 1.5 } } thickness : Constant { v { 0.5 } } }",
+    "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
+}
+
+_PATCH = """
+{surface}
+Shape quad : InlineMesh {{ positions {{ -1,0,-1, 1,0,-1, 1,0,1, -1,0,1 }} indices {{ 0,1,2, 0,2,3 }} surface {{ @m }}
+  light : Diffuse {{ emission : Constant {{ v {{ 1 }} }} }} }}
+Camera cam : Pinhole {{ film : Color {{ resolution {{ 8, 8 }} }} spp {{ 1 }} position {{ 0, 3, 0 }} look_at {{ 0, 0, 0 }} up {{ 0, 0, -1 }} }}
+render {{ cameras {{ @cam }} shapes {{ @quad }} integrator : MegaPath {{ }} }}
+"""
+
+
+def material_scene(name):
+    return Scene.from_string(_PATCH.format(surface=MATERIALS[name]), build_accel=False)
+
+
+def sph(theta, phi):
+    return np.array([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], np.float32)
+
+
+class SurfaceProbe:
+    """evaluate/sample of surface tag 0 on a flat patch (ng = +z) through the oracle hooks"""
+
+    def __init__(self, scene, ns=(0.0, 0.0, 1.0)):
+        self.o = _ffi.oracle_lib()
+        self.scene = scene
+        self.view = scene.view()
+        self.ns = np.array(ns, np.float32)
+
+    def evaluate(self, wo, wi):
+        wo, wi = np.ascontiguousarray(wo, np.float32), np.ascontiguousarray(wi, np.float32)
+        out = np.zeros(4, np.float32)
+        self.o.oracle_surface_evaluate(C.byref(self.view), 0, self.ns.ctypes.data, wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
+        return out[:3].copy(), float(out[3])
+
+    def sample(self, wo, u_lobe, ux, uy):
+        wo = np.ascontiguousarray(wo, np.float32)
+        out = np.zeros(8, np.float32)
+        self.o.oracle_surface_sample(C.byref(self.view), 0, self.ns.ctypes.data, wo.ctypes.data, u_lobe, ux, uy, out.ctypes.data)
+        return out[:3].copy(), float(out[3]), out[4:7].copy(), int(out[7])

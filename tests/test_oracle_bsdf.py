@@ -1,0 +1,103 @@
+"""Pins for the oracle's closures (src/util/scattering.cpp, src/surfaces/*.cpp restated in
+oracle/oracle_bsdf.h): sampled directions agree with evaluate(), pdfs integrate to <= 1, energy is
+conserved, symmetric lobes are reciprocal, Lambert has its closed form."""
+import numpy as np
+import pytest
+
+from helpers import MATERIALS, SurfaceProbe, material_scene, sph
+
+RNG = np.random.default_rng(11)
+
+
+@pytest.mark.parametrize("name", list(MATERIALS))
+def test_sample_is_consistent_with_evaluate(name):
+    probe = SurfaceProbe(material_scene(name))
+    checked = 0
+    for _ in range(300):
+        wo = sph(RNG.uniform(0.05, 1.45), RNG.uniform(0, 2 * np.pi))
+        if name == "glass" and RNG.random() < 0.5:
+            wo[2] = -wo[2]  # from inside
+        f, pdf, wi, event = probe.sample(wo, *RNG.random(3))
+        if pdf <= 0:
+            continue
+        assert abs(np.linalg.norm(wi) - 1.0) < 1e-4
+        f2, pdf2 = probe.evaluate(wo, wi)
+        assert np.allclose(f, f2, rtol=2e-3, atol=1e-6), (name, f, f2)
+        assert abs(pdf - pdf2) <= 2e-3 * max(pdf, 1e-3), (name, pdf, pdf2)
+        if name == "glass":
+            assert event == (0 if wi[2] * wo[2] > 0 else (1 if wo[2] > 0 else 2))
+        else:
+            assert event == 0 and wi[2] * wo[2] > 0
+        checked += 1
+    assert checked > 150
+
+
+@pytest.mark.parametrize("name", list(MATERIALS))
+def test_pdf_normalisation_and_energy(name):
+    """Monte Carlo over sample(): E[1] = int pdf <= 1 and E[f / pdf] = albedo <= 1 (f includes |cos|)."""
+    probe = SurfaceProbe(material_scene(name))
+    for theta in (0.2, 0.9, 1.3):
+        wo = sph(theta, 0.7)
+        n, albedo, alive = 4000, np.zeros(3), 0
+        # integrate pdf over the sphere by uniform sampling
+        us = RNG.random((n, 2))
+        z = 1 - 2 * us[:, 0]
+        r = np.sqrt(np.maximum(0, 1 - z * z))
+        dirs = np.stack([r * np.cos(2 * np.pi * us[:, 1]), r * np.sin(2 * np.pi * us[:, 1]), z], -1).astype(np.float32)
+        pdfs = np.array([probe.evaluate(wo, d)[1] for d in dirs]) * 4 * np.pi
+        pdf_int, stderr = pdfs.mean(), pdfs.std() / np.sqrt(n)
+        assert pdf_int - 3 * stderr < 1.02, (name, theta, pdf_int, stderr)  # peaky GGX lobes: wide error bars
+        if name in ("matte", "oren"):
+            assert abs(pdf_int - 1.0) < 0.08
+        for _ in range(n):
+            f, pdf, wi, _ = probe.sample(wo, *RNG.random(3))
+            if pdf > 0:
+                albedo += f / pdf
+                alive += 1
+        albedo /= n
+        assert (albedo < 1.05).all(), (name, theta, albedo)
+        assert alive > 0.5 * n
+
+
+def test_lambert_closed_form():
+    probe = SurfaceProbe(material_scene("matte"))
+    wo, wi = sph(0.4, 0.3), sph(1.0, 2.0)
+    f, pdf = probe.evaluate(wo, wi)
+    kd = np.array([0.6, 0.5, 0.4])
+    assert np.allclose(f, kd / np.pi * wi[2], rtol=1e-5)  # f * |cos| (matte.cpp:95)
+    assert abs(pdf - wi[2] / np.pi) < 1e-6
+    f, pdf = probe.evaluate(wo, -wi)  # below the surface
+    assert (f == 0).all() and pdf == 0
+
+
+@pytest.mark.parametrize("name", ["matte", "oren", "mirror", "metal"])
+def test_reciprocity(name):
+    probe = SurfaceProbe(material_scene(name))
+    for _ in range(50):
+        a, b = sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28)), sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28))
+        fab, _ = probe.evaluate(a, b)
+        fba, _ = probe.evaluate(b, a)
+        # f(a,b) |cos b| vs f(b,a) |cos a|; the Schlick/conductor Fresnel is evaluated on dot(wi, wh) = dot(wo, wh)
+        assert np.allclose(fab / b[2], fba / a[2], rtol=5e-3, atol=1e-6), name
+
+
+def test_side_validation_with_bent_shading_normal():
+    """validate_surface_sides (surface.cpp:35-43): light leaking through the geometric surface is cut."""
+    probe = SurfaceProbe(material_scene("matte"), ns=(0.6, 0.0, 0.8))
+    wo = sph(0.3, 0.0)
+    wi_below = np.array([-0.98, 0.0, -0.05], np.float32)  # below the geometric surface, above the shading plane
+    wi_below /= np.linalg.norm(wi_below)
+    f, pdf = probe.evaluate(wo, wi_below)
+    assert (f == 0).all() and pdf == 0
+    f, pdf = probe.evaluate(wo, sph(0.5, 1.0))
+    assert (f > 0).all() and pdf > 0
+
+
+def test_plastic_and_metal_parameters():
+    sc = material_scene("metal")
+    s = sc.view().surfaces[0]
+    # copper n, k at 602.785 / 539.285 / 445.772 nm (generated constants, tools/extract_metal_ior.py)
+    assert abs(s.f[0] - 0.3679) < 1e-3 and abs(s.f[3] - 2.9826) < 1e-3 and s.kind == 5
+    probe = SurfaceProbe(sc)
+    f, _ = probe.evaluate(sph(0.3, 0.0), sph(0.3, np.pi))
+    assert f[0] > f[2]  # copper reflects red more than blue
