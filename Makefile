@@ -20,7 +20,7 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean
+.PHONY: all host hip oracle cli clean hip-variant
 all: host oracle hip cli
 
 host: $(LIBDIR)/liblrhost.so
@@ -36,6 +36,11 @@ hip: $(LIBDIR)/liblrhip.so
 $(LIBDIR)/liblrhip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+# experimental kernel variants for A/B runs on the GPU box: make hip-variant NAME=w4 DEFS="-DLR_MIN_WAVES=4"
+hip-variant:
+	@mkdir -p $(LIBDIR)/variants
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o $(LIBDIR)/variants/liblrhip_$(NAME).so $(HIP_SRC)
 
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)

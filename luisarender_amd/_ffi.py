@@ -213,7 +213,8 @@ def oracle_lib() -> C.CDLL:
 
 def hip_lib() -> C.CDLL:
     """The product's device library.  Fails loudly when the HIP extension is missing."""
-    lib = _load(os.path.join(LIB_DIR, "liblrhip.so"))
+    # LRHIP_LIB selects an experimental build variant (tools/ only); the default is the shipped library
+    lib = _load(os.environ.get("LRHIP_LIB") or os.path.join(LIB_DIR, "liblrhip.so"))
     if not getattr(lib, "_lr_ready", False):
         lib.lrhip_last_error.restype = C.c_char_p
         lib.lrhip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -40,8 +40,12 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
     return sum == 0.0f ? 0.0f : f_pdf / sum;
 }
 
+#ifndef LR_MIN_WAVES
+#define LR_MIN_WAVES 6
+#endif
+
 template<bool COUNT>
-__global__ __launch_bounds__(kBlockThreads) void megapath_kernel(DScene scene, RenderArgs args) {
+__global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(DScene scene, RenderArgs args) {
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ lr_filter s_filter;
     const auto tid = threadIdx.x;
