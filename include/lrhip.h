@@ -56,6 +56,9 @@ typedef struct lrhip_counters {
     uint64_t nodes_visited;  /* BVH4 nodes fetched (128 B each)              */
     uint64_t tris_tested;    /* triangle tests (48 B each)                   */
     uint64_t surface_hits, nee_samples, path_length_sum;
+    /* SIMD-occupancy diagnostics: lane-iterations of the traversal loop (all lanes of every wave) and the
+     * ones in which the lane had a ray in flight; shading blocks executed per lane / with a hit to shade */
+    uint64_t trace_steps, trace_steps_busy, shade_calls, shade_busy;
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);

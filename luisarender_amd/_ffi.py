@@ -137,7 +137,8 @@ class OracleCounters(C.Structure):
 
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
-                                   "surface_hits", "nee_samples", "path_length_sum")]
+                                   "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
+                                   "shade_calls", "shade_busy")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

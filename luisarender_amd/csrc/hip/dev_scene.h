@@ -59,9 +59,19 @@ struct DCamera {
     float ortho_scale, clip_near, clip_far, pad2;
 };
 
+// Quantised BVH4 packet, 64 bytes = 4 x dwordx4 (dev_trace.h).  Child planes are 8-bit offsets from the
+// packet's box origin in units of `scale` per axis; byte i of each plane word belongs to child i.
+struct alignas(16) DNodeQ {
+    float origin[3]; float scale_x;
+    uint32_t lo_x, lo_y, lo_z, hi_x;
+    uint32_t hi_y, hi_z; float scale_y, scale_z;
+    uint32_t child[4];
+};
+static_assert(sizeof(DNodeQ) == 64, "DNodeQ is half a cache line");
+
 struct DScene {
     // acceleration structure
-    const lr_bvh4_node *nodes;
+    const DNodeQ *nodes;
     const lr_bvh_triangle *bvh_tris;
     // geometry tables
     const DInstance *instances;
@@ -94,7 +104,7 @@ struct DScene {
 
 struct DCounters {
     unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
-        path_length_sum;
+        path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy;
 };
 
 struct RenderArgs {

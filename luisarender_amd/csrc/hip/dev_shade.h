@@ -35,24 +35,31 @@ LR_HD uint32_t xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 
 LR_HD float uint_to_unit_float(uint32_t u) { return fminf(kOneMinusEpsilon, static_cast<float>(u) * 0x1p-32f); }
 
-// One sampler object per path.  INDEPENDENT reproduces the reference stream bit for bit;
-// PCG32 is the additional generator the north star asks for (one PCG32 sequence per path,
-// sequence index = the same xxhash32 seed).
-struct PathSampler {
+// One sampler object per path.  PCG = false reproduces the reference stream bit for bit
+// (IndependentSampler: xxhash32 seed + LCG); PCG = true is the additional generator the north star
+// asks for (one PCG32 sequence per path, sequence index = the same xxhash32 seed).
+template<bool PCG>
+struct PathSampler;
+
+template<>
+struct PathSampler<false> {
     uint32_t state;
-    uint64_t pcg_state, pcg_inc;
-    bool use_pcg;
-    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) {
-        state = xxhash32_4(px, py, scene.seed, index);
-        use_pcg = scene.sampler_kind == LR_SAMPLER_PCG32;
-        if (use_pcg) {// PCG32::set_sequence, rng.cpp:150-156
-            pcg_state = 0u;
-            pcg_inc = (static_cast<uint64_t>(state) << 1u) | 1u;
-            (void)pcg_next();
-            pcg_state += 0x853c49e6748fea9bull;
-            (void)pcg_next();
-        }
+    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) { state = xxhash32_4(px, py, scene.seed, index); }
+    LR_D float next_1d() {
+        state = 1664525u * state + 1013904223u;// lcg, rng.cpp:132-140
+        return uint_to_unit_float(state);
     }
+    LR_D f2 next_2d() {
+        f2 u;
+        u.x = next_1d();
+        u.y = next_1d();
+        return u;
+    }
+};
+
+template<>
+struct PathSampler<true> {
+    uint64_t pcg_state, pcg_inc;
     LR_D uint32_t pcg_next() {// rng.cpp:142-148
         auto old = pcg_state;
         pcg_state = old * 0x5851f42d4c957f2dull + pcg_inc;
@@ -60,11 +67,14 @@ struct PathSampler {
         auto rot = static_cast<uint32_t>(old >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
     }
-    LR_D float next_1d() {
-        if (use_pcg) { return uint_to_unit_float(pcg_next()); }
-        state = 1664525u * state + 1013904223u;// lcg, rng.cpp:132-140
-        return uint_to_unit_float(state);
+    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) {// PCG32::set_sequence, rng.cpp:150-156
+        pcg_state = 0u;
+        pcg_inc = (static_cast<uint64_t>(xxhash32_4(px, py, scene.seed, index)) << 1u) | 1u;
+        (void)pcg_next();
+        pcg_state += 0x853c49e6748fea9bull;
+        (void)pcg_next();
     }
+    LR_D float next_1d() { return uint_to_unit_float(pcg_next()); }
     LR_D f2 next_2d() {
         f2 u;
         u.x = next_1d();

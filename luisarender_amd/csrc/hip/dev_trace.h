@@ -1,28 +1,44 @@
 // dev_trace.h — BVH4 traversal + triangle intersection for gfx950 (no ray-tracing hardware:
-// this is VALU + memory, one ray per lane, 64 rays per wavefront).
+// this is VALU + LDS + memory, one ray per lane, 64 rays per wavefront).
 //
 // Replaces the reference's Accel::intersect / intersect_any (LuisaCompute, absent submodule;
 // call sites src/base/geometry.cpp:218-279) with the published semantics: closest hit returns
 // {inst, prim, bary} (src/base/geometry.h:16-28), any-hit returns a bool.
 //
-// Shape of the loop:
-//   * one 128-byte node per step, read as eight dwordx4 loads (node = one cache line);
-//   * four slab tests, hits ordered near->far with a 5-comparator network on packed
-//     (t | slot) integer keys (t >= 0, so float order == unsigned order);
-//   * traversal stack in LDS, [entry][lane] interleaved so a wave's push/pop is conflict-free
-//     (ds_write_b32 / ds_read_b32 at consecutive banks); entries beyond kStackLds spill to a
-//     per-thread HBM area;
-//   * `trace_pair` runs the shadow ray and the next closest-hit ray of a path back-to-back in
-//     ONE loop, so a wavefront pays max_lane(steps_shadow + steps_closest) instead of
-//     max_lane(steps_shadow) + max_lane(steps_closest).
+// What bounds this loop on CDNA4 is not HBM bytes but the per-CU vector L1 (TCP): a gather where
+// every lane touches its own cache line costs one tag lookup per lane per instruction (measured:
+// ~1 lane-request/clk/CU, profiles/r01).  So the node fetch is organised around cache lines, not
+// lanes:
+//   * nodes are 64-byte quantised BVH4 packets (DNodeQ: box origin + per-axis scale + 8-bit child
+//     planes + 4 child references) — half the bytes of fp32 child boxes, conservative by
+//     construction (lo rounded down, hi rounded up);
+//   * each wave fetches the 64 packets its lanes need with FOUR fully coalesced dwordx4 loads
+//     (4 consecutive lanes read one packet = 16 lines per instruction instead of 64), parks them in
+//     a 4 KiB per-wave LDS staging area with an XOR swizzle, and every lane reads its own packet
+//     back with four conflict-free ds_read_b128;
+//   * slab tests run directly on the quantised planes: t = fma(q, scale * inv_d, (origin - o) * inv_d),
+//     24 v_cvt_f32_ubyteN + 24 v_fma per packet;
+//   * hits are ordered near->far with a 5-comparator network on packed (t | slot) integer keys;
+//   * the traversal stack lives in LDS, [entry][lane] interleaved (conflict-free push/pop); entries
+//     beyond kStackLds spill to a per-thread HBM area (lane-coalesced);
+//   * leaves are 1..4 pre-transformed 48-byte triangles (Moeller-Trumbore, 3 x dwordx4 each);
+//   * the traversal is RESUMABLE (TravState): the wave leaves the loop as soon as `refill` lanes have
+//     finished their rays, those lanes shade and spawn new rays, and everybody re-enters — measured
+//     lane occupancy of the loop was 28 % when every lane had to wait for the slowest ray;
+//   * a lane traces the shadow ray of a bounce and then the continuation ray back-to-back without
+//     leaving the loop.
 #pragma once
 #include "dev_scene.h"
 
 namespace lrd {
 
 constexpr uint32_t kBlockThreads = 256u;
-constexpr uint32_t kStackLds = 24u;      // entries per lane kept in LDS (24 KB per block)
-constexpr uint32_t kSpillEntries = 72u;  // HBM overflow entries per lane
+constexpr uint32_t kWavesPerBlock = kBlockThreads / 64u;
+#ifndef LR_STACK_LDS
+#define LR_STACK_LDS 8
+#endif
+constexpr uint32_t kStackLds = LR_STACK_LDS; // entries per lane kept in LDS
+constexpr uint32_t kSpillEntries = 88u;      // HBM overflow entries per lane
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kInvalid = 0xffffffffu;
 
@@ -40,12 +56,14 @@ struct HitRecord {
 
 struct TraceStats {
     uint32_t nodes, tris;
+    uint32_t steps, steps_busy;// loop iterations of the wave / iterations in which this lane did work
 };
 
 struct TraversalStack {
     uint32_t *lds;      // &stack[0][tid]; stride kBlockThreads
     uint32_t *spill;    // &spill[0][gtid]; stride total_threads
     uint32_t spill_stride;
+    float4 *stage;      // this wave's 4 KiB staging area (256 x float4)
     LR_D void push(uint32_t sp, uint32_t v) const {
         if (sp < kStackLds) { lds[sp * kBlockThreads] = v; }
         else { spill[static_cast<size_t>(sp - kStackLds) * spill_stride] = v; }
@@ -60,69 +78,127 @@ LR_D void cswap(uint32_t &a, uint32_t &b) {
     a = lo, b = hi;
 }
 
-// Traces `shadow` (any-hit, if has_shadow) and then `closest` (closest-hit, if has_closest) for this
-// lane.  Returns occlusion of the shadow ray in `occluded`, the closest hit in `hit` (inst == kInvalid
-// on miss).  COUNT enables the per-ray node/triangle counters.
+// 1 / d with |result| capped at 1e30: the quantised slab test multiplies plane indices by
+// scale * inv_d, and 0 * inf would poison axis-parallel rays with NaNs
+LR_D f3 safe_inverse(f3 d) {
+    auto one = [](float x) {
+        auto r = 1.0f / x;
+        return fabsf(r) < 1e30f ? r : copysignf(1e30f, x);
+    };
+    return mk3(one(d.x), one(d.y), one(d.z));
+}
+
+LR_D float ubyte_to_float(uint32_t v, int byte) {// v_cvt_f32_ubyteN
+    return static_cast<float>((v >> (8 * byte)) & 0xffu);
+}
+
+// Resumable per-lane traversal state.  It survives the shading block of OTHER lanes: a wave leaves the
+// traversal loop as soon as enough lanes have finished their rays (they go and shade / spawn new
+// rays) while the remaining lanes keep cur/sp/stack and continue afterwards — the persistent-threads
+// "dynamic fetch" scheme, inside one megakernel.
+enum : uint32_t { kPhaseIdle = 0u, kPhaseShadow = 1u, kPhaseClosest = 2u };
+struct TravState {
+    f3 o, d, inv;
+    float t_min, t_max;
+    uint32_t cur, sp;
+    uint32_t phase;
+    HitRecord hit;
+    bool occluded;
+};
+
+LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
+    tr.o = r.o, tr.d = r.d, tr.inv = safe_inverse(r.d);
+    tr.t_min = r.t_min, tr.t_max = r.t_max;
+    tr.cur = 0u, tr.sp = 0u;// root
+    tr.phase = phase;
+}
+
+// Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`
+// lanes have finished theirs.  A lane in kPhaseShadow that finishes switches to `next_closest`
+// (if has_next) without leaving the loop.  Must be called by all 64 lanes.
 template<bool COUNT>
-LR_D void trace_pair(const DScene &scene, const TraversalStack &stack, bool has_shadow, const Ray &shadow,
-                     bool has_closest, const Ray &closest, bool &occluded, HitRecord &hit, TraceStats &stats) {
-    occluded = false;
-    hit.inst = kInvalid, hit.prim = kInvalid, hit.u = 0.f, hit.v = 0.f;
-    auto phase_shadow = has_shadow;
-    if (!has_shadow && !has_closest) { return; }
-    f3 o = phase_shadow ? shadow.o : closest.o;
-    f3 d = phase_shadow ? shadow.d : closest.d;
-    auto t_min = phase_shadow ? shadow.t_min : closest.t_min;
-    auto t_max = phase_shadow ? shadow.t_max : closest.t_max;
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
-    auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
-    uint32_t sp = 0u;
-    uint32_t cur = 0u;// root
+LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next,
+                      const Ray &next_closest, int refill, TraceStats &stats) {
+    const auto lane = threadIdx.x & 63u;
+    const auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
+    const auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
+    // staging geometry: lane l loads part (l & 3) of the packets of owners (l >> 2) + 16 k, k = 0..3
+    const auto part = lane & 3u;
+    const auto owner0 = lane >> 2u;
+    const auto my_swz = (lane >> 2u) & 3u;
+    auto idle_at_entry = tr.phase == kPhaseIdle;
     for (;;) {
-        if (cur != kInvalid && !(cur & kLeafFlag)) {
-            // ---- inner node: 8 x dwordx4
-            auto base = nodes + static_cast<size_t>(cur) * 8u;
-            auto lox = base[0], loy = base[1], loz = base[2];
-            auto hix = base[3], hiy = base[4], hiz = base[5];
-            auto ch = reinterpret_cast<const uint4 *>(base)[6];
-            if (COUNT) { stats.nodes++; }
-            uint32_t key[4];
-#define LR_SLAB(i, LX, LY, LZ, HX, HY, HZ, C)                                                        \
-    {                                                                                                \
-        auto t0x = (LX - o.x) * inv.x, t1x = (HX - o.x) * inv.x;                                     \
-        auto t0y = (LY - o.y) * inv.y, t1y = (HY - o.y) * inv.y;                                     \
-        auto t0z = (LZ - o.z) * inv.z, t1z = (HZ - o.z) * inv.z;                                     \
-        auto tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), t_min));     \
-        auto tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), t_max));     \
-        auto h = (tn <= tf * 1.0000004f) && (C != kInvalid);                                         \
-        key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | i##u) : kInvalid;                        \
-    }
-            LR_SLAB(0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x)
-            LR_SLAB(1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y)
-            LR_SLAB(2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z)
-            LR_SLAB(3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w)
-#undef LR_SLAB
-            // sort ascending: 5-comparator network
-            cswap(key[0], key[1]);
-            cswap(key[2], key[3]);
-            cswap(key[0], key[2]);
-            cswap(key[1], key[3]);
-            cswap(key[1], key[2]);
-            auto ref_of = [&](uint32_t k) {
-                auto slot = k & 3u;
-                return slot == 0u ? ch.x : (slot == 1u ? ch.y : (slot == 2u ? ch.z : ch.w));
-            };
-            // push far -> near so that the nearest is popped first; keep the nearest in `cur`
-            if (key[3] != kInvalid) { stack.push(sp++, ref_of(key[3])); }
-            if (key[2] != kInvalid) { stack.push(sp++, ref_of(key[2])); }
-            if (key[1] != kInvalid) { stack.push(sp++, ref_of(key[1])); }
-            cur = key[0] != kInvalid ? ref_of(key[0]) : kInvalid;
-            if (cur != kInvalid) { continue; }
-        } else if (cur != kInvalid) {
-            // ---- leaf: Moeller-Trumbore on pre-transformed triangles (3 x dwordx4 each)
-            auto first = cur & ((1u << 27u) - 1u);
-            auto count = ((cur >> 27u) & 15u) + 1u;
+        if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u; }
+        auto live = tr.phase != kPhaseIdle;
+        auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
+        if (__any(is_inner)) {
+            // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS -> 4 ds_read_b128 per lane
+            auto want = is_inner ? tr.cur : 0u;
+            auto n0 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0)));
+            auto n1 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 16u)));
+            auto n2 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 32u)));
+            auto n3 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 48u)));
+            auto v0 = nodes[static_cast<size_t>(n0) * 4u + part];
+            auto v1 = nodes[static_cast<size_t>(n1) * 4u + part];
+            auto v2 = nodes[static_cast<size_t>(n2) * 4u + part];
+            auto v3 = nodes[static_cast<size_t>(n3) * 4u + part];
+            auto slot = owner0 * 4u + (part ^ ((owner0 >> 2u) & 3u));// ((owner0 + 16 k) >> 2) & 3 == (owner0 >> 2) & 3
+            stack.stage[slot] = v0;
+            stack.stage[slot + 64u] = v1;
+            stack.stage[slot + 128u] = v2;
+            stack.stage[slot + 192u] = v3;
+            // the packets were written by other lanes of this wave: order LDS writes before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            auto q0 = stack.stage[lane * 4u + (0u ^ my_swz)];
+            auto q1 = stack.stage[lane * 4u + (1u ^ my_swz)];
+            auto q2 = stack.stage[lane * 4u + (2u ^ my_swz)];
+            auto q3 = stack.stage[lane * 4u + (3u ^ my_swz)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (is_inner) {
+                if (COUNT) { stats.nodes++; }
+                // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
+                //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
+                auto ax = q0.w * tr.inv.x, ay = q2.z * tr.inv.y, az = q2.w * tr.inv.z;
+                auto bx = (q0.x - tr.o.x) * tr.inv.x, by = (q0.y - tr.o.y) * tr.inv.y, bz = (q0.z - tr.o.z) * tr.inv.z;
+                auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+                auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+                uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
+                uint32_t key[4];
+#pragma unroll
+                for (auto i = 0; i < 4; i++) {
+                    auto t0x = fmaf(ubyte_to_float(lox, i), ax, bx), t1x = fmaf(ubyte_to_float(hix, i), ax, bx);
+                    auto t0y = fmaf(ubyte_to_float(loy, i), ay, by), t1y = fmaf(ubyte_to_float(hiy, i), ay, by);
+                    auto t0z = fmaf(ubyte_to_float(loz, i), az, bz), t1z = fmaf(ubyte_to_float(hiz, i), az, bz);
+                    auto tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tr.t_min));
+                    auto tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tr.t_max));
+                    auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
+                    key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
+                }
+                cswap(key[0], key[1]);
+                cswap(key[2], key[3]);
+                cswap(key[0], key[2]);
+                cswap(key[1], key[3]);
+                cswap(key[1], key[2]);
+                auto ref_of = [&](uint32_t k) {
+                    auto sl = k & 3u;
+                    return sl == 0u ? ch[0] : (sl == 1u ? ch[1] : (sl == 2u ? ch[2] : ch[3]));
+                };
+                // push far -> near so that the nearest is popped first; keep the nearest in `cur`
+                if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
+                if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
+                if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
+                if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
+                else if (tr.sp > 0u) { tr.cur = stack.pop(--tr.sp); }
+                else { tr.cur = kInvalid; }
+            }
+        }
+        // ---- leaf: Moeller-Trumbore on 1..4 pre-transformed triangles (3 x dwordx4 each)
+        if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
+            auto first = tr.cur & ((1u << 27u) - 1u);
+            auto count = ((tr.cur >> 27u) & 15u) + 1u;
             auto found = false;
             for (auto k = 0u; k < count; k++) {
                 auto tb = tris + static_cast<size_t>(first + k) * 3u;
@@ -130,43 +206,42 @@ LR_D void trace_pair(const DScene &scene, const TraversalStack &stack, bool has_
                 if (COUNT) { stats.tris++; }
                 auto flags = __float_as_uint(c.w);
                 f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-                auto pvec = cross(d, e2);
+                auto pvec = cross(tr.d, e2);
                 auto det = dot(e1, pvec);
                 auto inv_det = 1.0f / det;
-                auto tvec = o - p0;
+                auto tvec = tr.o - p0;
                 auto u = dot(tvec, pvec) * inv_det;
                 auto qvec = cross(tvec, e1);
-                auto v = dot(d, qvec) * inv_det;
+                auto v = dot(tr.d, qvec) * inv_det;
                 auto t = dot(e2, qvec) * inv_det;
-                auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > t_min && t < t_max && (flags & 1u);
+                auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
                 if (ok) {
-                    t_max = t;
+                    tr.t_max = t;
                     found = true;
-                    if (!phase_shadow) {
-                        hit.inst = __float_as_uint(a.w), hit.prim = __float_as_uint(b.w);
-                        hit.u = u, hit.v = v;
+                    if (tr.phase == kPhaseClosest) {
+                        tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
+                        tr.hit.u = u, tr.hit.v = v;
                     }
                 }
             }
-            if (phase_shadow && found) {
-                occluded = true;
-                sp = 0u;// any-hit: drop the rest of the stack
+            if (tr.phase == kPhaseShadow && found) {
+                tr.occluded = true;
+                tr.sp = 0u;// any-hit: drop the rest of the stack
+            }
+            tr.cur = tr.sp > 0u ? stack.pop(--tr.sp) : kInvalid;
+        }
+        // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
+        if (live && tr.cur == kInvalid) {
+            if (tr.phase == kPhaseShadow && has_next) {
+                trav_begin(tr, next_closest, kPhaseClosest);
+            } else {
+                tr.phase = kPhaseIdle;
             }
         }
-        // ---- pop, or switch from the shadow ray to the closest-hit ray
-        if (sp > 0u) {
-            cur = stack.pop(--sp);
-            continue;
-        }
-        if (phase_shadow && has_closest) {
-            phase_shadow = false;
-            o = closest.o, d = closest.d;
-            t_min = closest.t_min, t_max = closest.t_max;
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            cur = 0u;
-            continue;
-        }
-        break;
+        auto in_flight = __ballot(tr.phase != kPhaseIdle);
+        if (in_flight == 0ull) { break; }
+        auto finished = __ballot(tr.phase == kPhaseIdle && !idle_at_entry);
+        if (__popcll(finished) >= refill) { break; }
     }
 }
 

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -114,6 +116,49 @@ void normal_matrix(const float *m, float out[9]) {
     }
 }
 
+// fp32 child boxes -> 64-byte quantised packet; conservative: decoded lo <= lo, decoded hi >= hi in the
+// same fp32 fma the kernel uses (dev_trace.h)
+lrd::DNodeQ quantise_node(const lr_bvh4_node &n) {
+    lrd::DNodeQ q{};
+    const float *lo[3] = {n.lo_x, n.lo_y, n.lo_z};
+    const float *hi[3] = {n.hi_x, n.hi_y, n.hi_z};
+    float origin[3], scale[3];
+    uint32_t plo[3] = {0u, 0u, 0u}, phi[3] = {0u, 0u, 0u};
+    for (auto a = 0; a < 3; a++) {
+        auto mn = std::numeric_limits<float>::max(), mx = -std::numeric_limits<float>::max();
+        for (auto c = 0; c < 4; c++) {
+            if (n.child[c] == LR_INVALID_ID) { continue; }
+            mn = std::min(mn, lo[a][c]), mx = std::max(mx, hi[a][c]);
+        }
+        if (mn > mx) { mn = mx = 0.f; }
+        origin[a] = mn;
+        auto sc = (mx - mn) / 255.f;
+        while (sc > 0.f && std::fmaf(255.f, sc, mn) < mx) { sc = std::nextafter(sc, std::numeric_limits<float>::max()); }
+        scale[a] = sc;
+        for (auto c = 0; c < 4; c++) {
+            uint32_t ql = 255u, qh = 0u;// empty slot: inverted
+            if (n.child[c] != LR_INVALID_ID) {
+                if (sc > 0.f) {
+                    auto fl = std::floor((static_cast<double>(lo[a][c]) - mn) / sc), fh = std::ceil((static_cast<double>(hi[a][c]) - mn) / sc);
+                    ql = static_cast<uint32_t>(std::clamp(fl, 0.0, 255.0)), qh = static_cast<uint32_t>(std::clamp(fh, 0.0, 255.0));
+                    while (ql > 0u && std::fmaf(static_cast<float>(ql), sc, mn) > lo[a][c]) { ql--; }
+                    while (qh < 255u && std::fmaf(static_cast<float>(qh), sc, mn) < hi[a][c]) { qh++; }
+                } else {
+                    ql = qh = 0u;
+                }
+            }
+            plo[a] |= ql << (8u * static_cast<uint32_t>(c));
+            phi[a] |= qh << (8u * static_cast<uint32_t>(c));
+        }
+    }
+    q.origin[0] = origin[0], q.origin[1] = origin[1], q.origin[2] = origin[2];
+    q.scale_x = scale[0], q.scale_y = scale[1], q.scale_z = scale[2];
+    q.lo_x = plo[0], q.lo_y = plo[1], q.lo_z = plo[2];
+    q.hi_x = phi[0], q.hi_y = phi[1], q.hi_z = phi[2];
+    for (auto c = 0; c < 4; c++) { q.child[c] = n.child[c]; }
+    return q;
+}
+
 uint32_t bvh_depth(const lr_accel &accel) {
     std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
     auto depth = 0u;
@@ -215,7 +260,11 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         release_scene(ctx);                           \
         return rc;                                    \
     }
-    LR_UP(upload(ctx, s->accel.nodes, s->accel.node_count, &d.nodes));
+    {
+        std::vector<lrd::DNodeQ> packed(s->accel.node_count);
+        for (uint32_t i = 0; i < s->accel.node_count; i++) { packed[i] = quantise_node(s->accel.nodes[i]); }
+        LR_UP(upload(ctx, packed.data(), packed.size(), &d.nodes));
+    }
     LR_UP(upload(ctx, s->accel.triangles, s->accel.triangle_count, &d.bvh_tris));
     LR_UP(upload(ctx, s->vertices, s->vertex_count, &d.vertices));
     LR_UP(upload(ctx, s->triangles, s->triangle_count, &d.triangles));
@@ -325,7 +374,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
     // persistent grid: as many blocks as are resident
     int blocks_per_cu = 0;
-    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false>, lrd::kBlockThreads, 0));
+    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false, false>, lrd::kBlockThreads, 0));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
     ctx->grid_blocks = ctx->cu_count * static_cast<uint32_t>(blocks_per_cu);
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
@@ -382,11 +431,13 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 4u, ctx->stream));
     auto blocks = std::min(ctx->grid_blocks, (args.item_count + 3u) / 4u);
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
-    if (p->flags & LRHIP_RENDER_COUNTERS) {
-        hipLaunchKernelGGL(lrd::megapath_kernel<true>, dim3(blocks), dim3(lrd::kBlockThreads), 0, ctx->stream, ctx->scene, args);
-    } else {
-        hipLaunchKernelGGL(lrd::megapath_kernel<false>, dim3(blocks), dim3(lrd::kBlockThreads), 0, ctx->stream, ctx->scene, args);
-    }
+    auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
+    auto pcg = ctx->scene.sampler_kind == LR_SAMPLER_PCG32;
+    auto grid = dim3(blocks), block = dim3(lrd::kBlockThreads);
+    if (count && pcg) { hipLaunchKernelGGL((lrd::megapath_kernel<true, true>), grid, block, 0, ctx->stream, ctx->scene, args); }
+    else if (count) { hipLaunchKernelGGL((lrd::megapath_kernel<true, false>), grid, block, 0, ctx->stream, ctx->scene, args); }
+    else if (pcg) { hipLaunchKernelGGL((lrd::megapath_kernel<false, true>), grid, block, 0, ctx->stream, ctx->scene, args); }
+    else { hipLaunchKernelGGL((lrd::megapath_kernel<false, false>), grid, block, 0, ctx->stream, ctx->scene, args); }
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;

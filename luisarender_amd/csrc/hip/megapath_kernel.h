@@ -21,17 +21,18 @@
 
 namespace lrd {
 
-struct FilmAcc {
-    float r, g, b, n;
-};
-
-LR_D void film_accumulate(FilmAcc &acc, f3 rgb, float clamp) {// color.cpp:107-130, effective_spp = 1
+// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) on a pixel this lane owns
+// exclusively: plain read-modify-write of the float4, no atomics.  The 32 B/sample of film traffic are
+// lane-coalesced (8 pixels of a tile row = 128 B) and stay hot in L2.
+LR_D void film_accumulate(float4 *pixel, f3 rgb, float clamp) {
     if (!(any_nan(rgb) || any_inf(rgb))) {
         auto threshold = clamp * fmaxf(1.f, 1.f);
         auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
         auto c = rgb * (threshold / fmaxf(strength, threshold));
-        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) { acc.r += c.x, acc.g += c.y, acc.b += c.z; }
-        acc.n += 1.f;
+        auto acc = *pixel;
+        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) { acc.x += c.x, acc.y += c.y, acc.z += c.z; }
+        acc.w += 1.f;
+        *pixel = acc;
     }
 }
 
@@ -41,23 +42,21 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 }
 
 #ifndef LR_MIN_WAVES
-#define LR_MIN_WAVES 6
+#define LR_MIN_WAVES 4
+#endif
+#ifndef LR_REFILL
+#define LR_REFILL 36
 #endif
 
-template<bool COUNT>
+// COUNT: gather diagnostics counters.  PCG: PCG32 streams instead of the reference's xxhash32 + LCG.
+template<bool COUNT, bool PCG>
 __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(DScene scene, RenderArgs args) {
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
-    __shared__ lr_filter s_filter;
+    __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
-    {// stage the filter tables (1 KiB) in LDS
-        auto src = reinterpret_cast<const uint32_t *>(scene.filter);
-        auto dst = reinterpret_cast<uint32_t *>(&s_filter);
-        for (auto i = tid; i < sizeof(lr_filter) / 4u; i += kBlockThreads) { dst[i] = src[i]; }
-    }
-    __syncthreads();
-    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads};
+    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + (tid >> 6u) * 256u};
     DCounters local{};
 
     for (;;) {
@@ -77,203 +76,202 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
         auto s_next = args.spp_begin + chunk * per_chunk;
         const auto s_end = min(s_next + per_chunk, args.spp_end);
-        FilmAcc acc{0.f, 0.f, 0.f, 0.f};
-        if (in_bounds && args.chunk_count == 1u) {
-            auto v = args.film[pixel_index];
-            acc = {v.x, v.y, v.z, v.w};
-        }
+        // chunk_count == 1: accumulate into the film itself; otherwise into this chunk's partial plane
+        auto pixel = args.chunk_count == 1u ? args.film + pixel_index :
+                                               args.partial + static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + pixel_index;
+        if (in_bounds && args.chunk_count != 1u) { *pixel = make_float4(0.f, 0.f, 0.f, 0.f); }
 
         // ---- per-lane path state
-        PathSampler sampler{};
-        Ray ray{}, shadow{};
-        f3 beta = mk3(0.f), Li = mk3(0.f), Li_prev = mk3(0.f), nee = mk3(0.f);
+        PathSampler<PCG> sampler{};
+        TravState tr{};
+        tr.phase = kPhaseIdle;
+        Ray ray{};// continuation ray waiting behind a shadow ray in flight
+        f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
         auto pdf_bsdf = 1e16f;
         auto depth = 0u;
-        auto path_open = false, has_closest = false, has_shadow = false, shadow_is_prev = false;
+        auto path_open = false, traced_shadow = false, traced_closest = false;
 
         for (;;) {
-            if (!has_closest) {
-                if (path_open) {
-                    if (has_shadow) {// finished except for its last shadow ray: retire, keep the lane busy
-                        Li_prev = Li;
-                        shadow_is_prev = true;
-                    } else {
-                        film_accumulate(acc, Li, scene.film_clamp);
+            // ==== (A) lanes without a ray in flight: consume results, shade, regenerate, launch rays
+            if (tr.phase == kPhaseIdle) {
+                auto want_shadow = false, want_closest = false;
+                Ray shadow{};
+                if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
+                    if (!tr.occluded) { Li += nee; }
+                    traced_shadow = false;
+                }
+                if (traced_closest) {// one iteration of the reference's depth loop, mega_path.cpp:63-154
+                    traced_closest = false;
+                    if (COUNT) { local.shade_busy++; }
+                    auto wo = -tr.d;
+                    auto hit = tr.hit;
+                    auto hit_valid = hit.inst != kInvalid;
+                    if (!hit_valid && scene.env_kind != LR_ENV_NONE) {// miss, mega_path.cpp:70-76
+                        auto pdf = (kInvPi * 0.25f) * scene.env_prob;
+                        Li += beta * mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]) * balance(pdf_bsdf, pdf);
                     }
+                    SurfacePoint it;
+                    auto has_surface = false;
+                    if (hit_valid) {
+                        reconstruct<true>(scene, hit.inst, hit.prim, mk3(1.f - hit.u - hit.v, hit.u, hit.v), it);
+                        it.back_facing = dot(wo, it.ng) < 0.0f;
+                        if (COUNT) { local.surface_hits++; }
+                        if (scene.has_lights && (it.flags & LR_SHAPE_HAS_LIGHT)) {// hit light, mega_path.cpp:79-86
+                            f3 L;
+                            float pdf;
+                            light_evaluate(scene, it, hit.prim, tr.o, L, pdf);
+                            pdf *= (1.f - scene.env_prob) / static_cast<float>(scene.light_count);
+                            Li += beta * L * balance(pdf_bsdf, pdf);
+                        }
+                        has_surface = (it.flags & LR_SHAPE_HAS_SURFACE) != 0u;
+                    }
+                    if (has_surface) {
+                        if (COUNT) { local.path_length_sum++, local.nee_samples++; }
+                        // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
+                        // light selection, light surface (2), lobe, bsdf (2), [rr]
+                        auto u_light_selection = sampler.next_1d();
+                        auto u_light_surface = sampler.next_2d();
+                        // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63
+                        f3 light_L = mk3(0.f);
+                        auto light_pdf = 0.f;
+                        {
+                            auto n = static_cast<float>(scene.light_count);
+                            auto is_env = false;
+                            auto tag = 0u;
+                            auto prob = 0.f;
+                            if (scene.env_prob == 1.f) {
+                                is_env = true, prob = 1.f;
+                            } else if (scene.env_prob == 0.f) {
+                                tag = static_cast<uint32_t>(clampf(u_light_selection * n, 0.f, n - 1.f)), prob = 1.f / n;
+                            } else {
+                                auto uu = (u_light_selection - scene.env_prob) / (1.f - scene.env_prob);
+                                tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
+                                is_env = u_light_selection < scene.env_prob;
+                                prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
+                            }
+                            if (is_env) {// constant spherical environment: uniform sphere, spherical.cpp:114-118,138
+                                auto z = 1.0f - 2.0f * u_light_surface.x;
+                                auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+                                auto phi = 2.0f * kPi * u_light_surface.y;
+                                auto w = mk3(r * cosf(phi), r * sinf(phi), z);
+                                auto e = scene.env_to_world;
+                                auto wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
+                                light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
+                                light_pdf = (kInvPi * 0.25f) * prob;
+                                shadow.o = robust_origin(it, wi);
+                                shadow.d = wi;
+                                shadow.t_min = 0.f, shadow.t_max = kFloatMax;
+                            } else {// _sample_area, uniform.cpp:107-123
+                                auto handle = scene.light_instances[tag];
+                                auto lh = reinterpret_cast<const uint4 *>(scene.instances + handle.instance_id)[0];
+                                auto l_tri_offset = scene.instances[handle.instance_id].triangle_offset;
+                                float u_remapped;
+                                auto slot = alias_slot(u_light_surface.x, lh.z, u_remapped);
+                                auto entry = scene.tri_alias[l_tri_offset + slot];
+                                auto pick = alias_pick(entry.prob, entry.alias, slot, u_remapped);
+                                f2 ut{pick.u, u_light_surface.y};// sample_uniform_triangle, sampling.cpp:89-98
+                                f2 uvt = ut.x < ut.y ? f2{0.5f * ut.x, -0.5f * ut.x + ut.y} : f2{-0.5f * ut.y + ut.x, 0.5f * ut.y};
+                                SurfacePoint lp;
+                                reconstruct<false>(scene, handle.instance_id, pick.index, mk3(uvt.x, uvt.y, 1.0f - uvt.x - uvt.y), lp);
+                                lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
+                                light_evaluate(scene, lp, pick.index, it.p, light_L, light_pdf);
+                                light_pdf *= prob;
+                                auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
+                                auto Lv = lp.p - p_from;
+                                auto dist = length(Lv);
+                                shadow.o = p_from;
+                                shadow.d = Lv * (1.f / dist);
+                                shadow.t_min = 0.f, shadow.t_max = dist * .9999f;
+                            }
+                        }
+                        // ---- material, mega_path.cpp:111-143
+                        auto closure = scene.closures[(it.tags >> 12u) & 4095u];
+                        if (closure.dynamic) {
+                            auto &raw = scene.surfaces[(it.tags >> 12u) & 4095u];
+                            if (raw.normal_tex >= 0) {// NormalMapWrapper, surface.h:236-254
+                                auto v = texture_eval(scene, raw.normal_tex, it.uv);
+                                auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
+                                if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
+                                auto normal = to_world(it.shading, n_local);
+                                it.shading = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), it.shading.s);
+                            }
+                            closure = resolve_closure(
+                                raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
+                                [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
+                        }
+                        if (light_pdf > 0.0f) {
+                            auto eval = closure_evaluate(closure, it.shading, it.ng, wo, shadow.d);
+                            auto w = balance(light_pdf, eval.pdf) / light_pdf;
+                            nee = w * beta * eval.f * light_L;
+                            // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
+                            want_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
+                        }
+                        auto u_lobe = sampler.next_1d();
+                        auto u_bsdf = sampler.next_2d();
+                        auto bs = closure_sample(closure, it.shading, it.ng, wo, u_lobe, u_bsdf);
+                        ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
+                        ray.d = bs.wi;
+                        ray.t_min = 0.f, ray.t_max = kFloatMax;
+                        pdf_bsdf = bs.pdf;
+                        beta *= (bs.pdf > 0.f ? 1.f / bs.pdf : 0.f) * bs.f;
+                        auto eta_scale = 1.f;
+                        if (closure.kind == LR_SURFACE_GLASS) {
+                            if (bs.event == kEventEnter) { eta_scale = sqr(closure.s1); }
+                            else if (bs.event == kEventExit) { eta_scale = sqr(1.f / closure.s1); }
+                        }
+                        if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
+                        auto alive = !(beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f);
+                        auto rr = depth + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
+                        auto u_rr = 0.f;
+                        if (rr) { u_rr = sampler.next_1d(); }// (drawn before the closure in the reference: same stream position)
+                        if (alive) {
+                            auto q = fmaxf(max_component(beta) * eta_scale, .05f);
+                            if (rr) {
+                                if (q < scene.rr_threshold && u_rr >= q) { alive = false; }
+                                else { beta *= q < scene.rr_threshold ? 1.0f / q : 1.f; }
+                            }
+                        }
+                        depth++;
+                        want_closest = alive && depth < scene.max_depth;
+                    }
+                }
+                if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
+                    film_accumulate(pixel, Li, scene.film_clamp);
                     path_open = false;
                 }
-                if (in_bounds && s_next < s_end) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
+                if (!path_open && in_bounds && s_next < s_end) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
                     sampler.start(scene, px, py, s_next);
                     s_next++;
                     auto u_filter = sampler.next_2d();
                     auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
                     float weight;
-                    camera_ray(scene, &s_filter, px, py, u_filter, u_lens, ray, weight);
+                    camera_ray(scene, scene.filter, px, py, u_filter, u_lens, ray, weight);
                     beta = mk3(weight);
                     Li = mk3(0.f);
                     pdf_bsdf = 1e16f;
                     depth = 0u;
-                    path_open = true, has_closest = true;
+                    path_open = true, want_closest = true;
                     if (COUNT) { local.paths++; }
                 }
+                // ---- launch: shadow ray first, the continuation ray follows inside the traversal loop
+                if (want_shadow || want_closest) {
+                    tr.hit.inst = kInvalid, tr.hit.prim = kInvalid, tr.hit.u = 0.f, tr.hit.v = 0.f;
+                    tr.occluded = false;
+                    traced_shadow = want_shadow, traced_closest = want_closest;
+                    if (want_shadow) { trav_begin(tr, shadow, kPhaseShadow); }
+                    else { trav_begin(tr, ray, kPhaseClosest); }
+                    if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
+                }
             }
-            if (!__any(has_closest || has_shadow)) { break; }
-
-            bool occluded;
-            HitRecord hit;
-            TraceStats ts{0u, 0u};
+            if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
+            // ==== (B) traverse until `refill` lanes have results to shade
+            TraceStats ts{0u, 0u, 0u, 0u};
+            trace_steps<COUNT>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
-                local.closest_rays += has_closest ? 1u : 0u;
-                local.shadow_rays += has_shadow ? 1u : 0u;
+                local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
+                local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy;
+                local.shade_calls++;
             }
-            trace_pair<COUNT>(scene, stack, has_shadow, shadow, has_closest, ray, occluded, hit, ts);
-            if (COUNT) { local.nodes_visited += ts.nodes, local.tris_tested += ts.tris; }
-
-            if (has_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
-                auto c = occluded ? mk3(0.f) : nee;
-                if (shadow_is_prev) {
-                    film_accumulate(acc, Li_prev + c, scene.film_clamp);
-                    shadow_is_prev = false;
-                } else {
-                    Li += c;
-                }
-                has_shadow = false;
-            }
-            if (!has_closest) { continue; }
-
-            // ---- shade the closest hit of `ray` (one iteration of the reference's depth loop)
-            has_closest = false;
-            auto wo = -ray.d;
-            if (hit.inst == kInvalid) {// miss, mega_path.cpp:70-76
-                if (scene.env_kind != LR_ENV_NONE) {
-                    auto pdf = (kInvPi * 0.25f) * scene.env_prob;
-                    Li += beta * mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]) * balance(pdf_bsdf, pdf);
-                }
-                continue;
-            }
-            SurfacePoint it;
-            reconstruct<true>(scene, hit.inst, hit.prim, mk3(1.f - hit.u - hit.v, hit.u, hit.v), it);
-            it.back_facing = dot(wo, it.ng) < 0.0f;
-            if (COUNT) { local.surface_hits++; }
-            if (scene.has_lights && (it.flags & LR_SHAPE_HAS_LIGHT)) {// hit light, mega_path.cpp:79-86
-                f3 L;
-                float pdf;
-                light_evaluate(scene, it, hit.prim, ray.o, L, pdf);
-                pdf *= (1.f - scene.env_prob) / static_cast<float>(scene.light_count);
-                Li += beta * L * balance(pdf_bsdf, pdf);
-            }
-            if (!(it.flags & LR_SHAPE_HAS_SURFACE)) { continue; }
-            if (COUNT) { local.path_length_sum++, local.nee_samples++; }
-
-            auto u_light_selection = sampler.next_1d();
-            auto u_light_surface = sampler.next_2d();
-            auto u_lobe = sampler.next_1d();
-            auto u_bsdf = sampler.next_2d();
-            auto u_rr = 0.f;
-            if (depth + 1u >= scene.rr_depth) { u_rr = sampler.next_1d(); }
-
-            // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63
-            f3 light_L = mk3(0.f);
-            auto light_pdf = 0.f;
-            {
-                auto n = static_cast<float>(scene.light_count);
-                auto is_env = false;
-                auto tag = 0u;
-                auto prob = 0.f;
-                if (scene.env_prob == 1.f) {
-                    is_env = true, prob = 1.f;
-                } else if (scene.env_prob == 0.f) {
-                    tag = static_cast<uint32_t>(clampf(u_light_selection * n, 0.f, n - 1.f)), prob = 1.f / n;
-                } else {
-                    auto uu = (u_light_selection - scene.env_prob) / (1.f - scene.env_prob);
-                    tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
-                    is_env = u_light_selection < scene.env_prob;
-                    prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
-                }
-                if (is_env) {// constant spherical environment: uniform sphere, spherical.cpp:114-118,138
-                    auto z = 1.0f - 2.0f * u_light_surface.x;
-                    auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
-                    auto phi = 2.0f * kPi * u_light_surface.y;
-                    auto w = mk3(r * cosf(phi), r * sinf(phi), z);
-                    auto e = scene.env_to_world;
-                    auto wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
-                    light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
-                    light_pdf = (kInvPi * 0.25f) * prob;
-                    shadow.o = robust_origin(it, wi);
-                    shadow.d = wi;
-                    shadow.t_min = 0.f, shadow.t_max = kFloatMax;
-                } else {// _sample_area, uniform.cpp:107-123
-                    auto handle = scene.light_instances[tag];
-                    auto lh = reinterpret_cast<const uint4 *>(scene.instances + handle.instance_id)[0];
-                    auto l_tri_offset = scene.instances[handle.instance_id].triangle_offset;
-                    float u_remapped;
-                    auto slot = alias_slot(u_light_surface.x, lh.z, u_remapped);
-                    auto entry = scene.tri_alias[l_tri_offset + slot];
-                    auto pick = alias_pick(entry.prob, entry.alias, slot, u_remapped);
-                    f2 ut{pick.u, u_light_surface.y};// sample_uniform_triangle, sampling.cpp:89-98
-                    f2 uvt = ut.x < ut.y ? f2{0.5f * ut.x, -0.5f * ut.x + ut.y} : f2{-0.5f * ut.y + ut.x, 0.5f * ut.y};
-                    SurfacePoint lp;
-                    reconstruct<false>(scene, handle.instance_id, pick.index, mk3(uvt.x, uvt.y, 1.0f - uvt.x - uvt.y), lp);
-                    lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
-                    light_evaluate(scene, lp, pick.index, it.p, light_L, light_pdf);
-                    light_pdf *= prob;
-                    auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
-                    auto Lv = lp.p - p_from;
-                    auto dist = length(Lv);
-                    shadow.o = p_from;
-                    shadow.d = Lv * (1.f / dist);
-                    shadow.t_min = 0.f, shadow.t_max = dist * .9999f;
-                }
-            }
-
-            // ---- material, mega_path.cpp:111-143
-            auto closure = scene.closures[(it.tags >> 12u) & 4095u];
-            if (closure.dynamic) {
-                auto &raw = scene.surfaces[(it.tags >> 12u) & 4095u];
-                if (raw.normal_tex >= 0) {// NormalMapWrapper, surface.h:236-254
-                    auto v = texture_eval(scene, raw.normal_tex, it.uv);
-                    auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
-                    if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
-                    auto normal = to_world(it.shading, n_local);
-                    it.shading = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), it.shading.s);
-                }
-                closure = resolve_closure(
-                    raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
-                    [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
-            }
-            if (light_pdf > 0.0f) {
-                auto eval = closure_evaluate(closure, it.shading, it.ng, wo, shadow.d);
-                auto w = balance(light_pdf, eval.pdf) / light_pdf;
-                nee = w * beta * eval.f * light_L;
-                // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
-                has_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
-            }
-            auto bs = closure_sample(closure, it.shading, it.ng, wo, u_lobe, u_bsdf);
-            ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
-            ray.d = bs.wi;
-            ray.t_min = 0.f, ray.t_max = kFloatMax;
-            pdf_bsdf = bs.pdf;
-            beta *= (bs.pdf > 0.f ? 1.f / bs.pdf : 0.f) * bs.f;
-            auto eta_scale = 1.f;
-            if (closure.kind == LR_SURFACE_GLASS) {
-                if (bs.event == kEventEnter) { eta_scale = sqr(closure.s1); }
-                else if (bs.event == kEventExit) { eta_scale = sqr(1.f / closure.s1); }
-            }
-            if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
-            if (beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f) { continue; }
-            auto q = fmaxf(max_component(beta) * eta_scale, .05f);// Russian roulette, mega_path.cpp:148-153
-            if (depth + 1u >= scene.rr_depth) {
-                if (q < scene.rr_threshold && u_rr >= q) { continue; }
-                beta *= q < scene.rr_threshold ? 1.0f / q : 1.f;
-            }
-            depth++;
-            has_closest = depth < scene.max_depth;
-        }
-
-        if (in_bounds) {
-            auto out = make_float4(acc.r, acc.g, acc.b, acc.n);
-            if (args.chunk_count == 1u) { args.film[pixel_index] = out; }
-            else { args.partial[static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + pixel_index] = out; }
         }
     }
 
@@ -290,6 +288,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         reduce(local.surface_hits, &args.counters->surface_hits);
         reduce(local.nee_samples, &args.counters->nee_samples);
         reduce(local.path_length_sum, &args.counters->path_length_sum);
+        reduce(local.trace_steps, &args.counters->trace_steps);
+        reduce(local.trace_steps_busy, &args.counters->trace_steps_busy);
+        reduce(local.shade_calls, &args.counters->shade_calls);
+        reduce(local.shade_busy, &args.counters->shade_busy);
     }
 }
 

@@ -1,0 +1,18 @@
+"""SIMD-occupancy diagnostics of the megakernel on the bench workload (GPU box)."""
+import sys, tempfile
+sys.path.insert(0, '.')
+from luisarender_amd import Scene
+from luisarender_amd.render import MegaPathRenderer
+from luisarender_amd.scenes import generate_room_scene
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+with tempfile.TemporaryDirectory() as tmp:
+    sc = Scene.load(generate_room_scene(tmp, resolution=(1024, 1024), spp=spp))
+    r = MegaPathRenderer(0)
+    r.upload(sc)
+    r.render(0, spp, counters=True, sync=True)
+    c = r.counters()
+    rays = c['closest_rays'] + c['shadow_rays']
+    print(c)
+    print('ms', r.last_render_ms(), 'rays/sample', rays / c['paths'], 'nodes/ray', c['nodes_visited'] / rays, 'tris/ray', c['tris_tested'] / rays)
+    print('trace lane utilisation', c['trace_steps_busy'] / max(c['trace_steps'], 1), 'steps per ray-lane', c['trace_steps_busy'] / rays)
+    print('shade lane utilisation', c['shade_busy'] / max(c['shade_calls'], 1))
