@@ -35,7 +35,7 @@ namespace lrd {
 constexpr uint32_t kBlockThreads = 256u;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / 64u;
 #ifndef LR_STACK_LDS
-#define LR_STACK_LDS 8
+#define LR_STACK_LDS 12
 #endif
 constexpr uint32_t kStackLds = LR_STACK_LDS; // entries per lane kept in LDS
 constexpr uint32_t kSpillEntries = 88u;      // HBM overflow entries per lane
@@ -182,9 +182,10 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 cswap(key[0], key[2]);
                 cswap(key[1], key[3]);
                 cswap(key[1], key[2]);
-                auto ref_of = [&](uint32_t k) {
-                    auto sl = k & 3u;
-                    return sl == 0u ? ch[0] : (sl == 1u ? ch[1] : (sl == 2u ? ch[2] : ch[3]));
+                auto ref_of = [&](uint32_t k) {// two-level v_cndmask select on the slot bits (no branches)
+                    auto lo = (k & 1u) ? ch[1] : ch[0];
+                    auto hi = (k & 1u) ? ch[3] : ch[2];
+                    return (k & 2u) ? hi : lo;
                 };
                 // push far -> near so that the nearest is popped first; keep the nearest in `cur`
                 if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
