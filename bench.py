@@ -160,7 +160,7 @@ def main():
                         traffic = None
                 out["roofline"] = {
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": traffic, "kernel": "lrd::megapath_kernel<false>", "kernel_ms": mean_kernel_ms,
+                    "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false>", "kernel_ms": mean_kernel_ms,
                     "algorithmic_bytes_per_sample": bytes_per_sample,
                 }
             print(json.dumps(out), flush=True)
