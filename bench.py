@@ -34,6 +34,11 @@ WORKLOADS = {
     "c1": ("Cornell Box, 512x512, 64spp, depth 8", (512, 512), 64, 8),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Algorithmic bytes per sample (SURVEY §8d formula on the oracle's canonical-BVH2 counters).  Measured live by
+# the cpu_baseline leg at N = 1 (and reported from that measurement); at N > 1 no oracle runs, so the N = 1
+# value of the same seeded workload is used (profiles/r01_bench_c2_1gpu.json).
+ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 2500.0}
+METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
 def build_scene(workload: str, tmpdir: str, spp_override: int | None):
@@ -137,7 +142,7 @@ def main():
             samples_per_step = res[0] * res[1] * spp
             value = samples_per_step * args.steps / elapsed / 1e6
             out = {
-                "metric": "Msamples/s (+ fraction of HBM roofline) at fixed SPP", "value": value, "unit": "Msamples/s",
+                "metric": METRIC, "value": value, "unit": "Msamples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)",
@@ -145,24 +150,25 @@ def main():
             }
             if args.spp is not None:
                 out["config"]["note"] = "spp overridden: not the headline configuration"
-            if not args.no_cpu_baseline:
+            bytes_per_sample = ALGORITHMIC_BYTES_PER_SAMPLE[args.workload]
+            if world == 1 and not args.no_cpu_baseline:  # the CPU leg runs on rank 0 at N = 1 only
                 cpu, bytes_per_sample, _ = cpu_baseline(scene, res, args.cpu_seconds)
                 out["cpu_baseline"] = cpu
-                # one launch renders this rank's shard: samples_per_step / world samples
-                launch_bytes = bytes_per_sample * samples_per_step / world
-                achieved = launch_bytes / (mean_kernel_ms * 1e-3) / 1e9
-                traffic = None
-                prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-                if os.path.exists(prof):
-                    try:
-                        traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-                    except Exception:
-                        traffic = None
-                out["roofline"] = {
-                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false>", "kernel_ms": mean_kernel_ms,
-                    "algorithmic_bytes_per_sample": bytes_per_sample,
-                }
+            # one launch renders this rank's shard: samples_per_step / world samples
+            launch_bytes = bytes_per_sample * samples_per_step / world
+            achieved = launch_bytes / (mean_kernel_ms * 1e-3) / 1e9
+            traffic = None
+            prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+            if world == 1 and args.spp is None and os.path.exists(prof):
+                try:
+                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false>", "kernel_ms": mean_kernel_ms,
+                "algorithmic_bytes_per_sample": bytes_per_sample,
+            }
             print(json.dumps(out), flush=True)
         renderer.close()
     if world > 1:
