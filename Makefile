@@ -7,9 +7,10 @@ CXX      ?= g++
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wextra
 ORACLE_FLAGS ?= -std=c++17 -O3 -march=x86-64-v3 -ffp-contract=off -fPIC -Wall -Wextra -pthread
-# fp32 division/sqrt use the 1-ulp hardware approximations and denormals flush to zero: the estimator is a
-# Monte-Carlo sum compared with the oracle under a stated tolerance, not a bit-exact integer pipeline
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero
+# fp32 division/sqrt use the hardware approximations (+6 %): the estimator is a Monte-Carlo sum compared with the
+# oracle under a stated tolerance, not a bit-exact integer pipeline.  Denormal flushing (+2.5 %) was measured and
+# REJECTED: it moved the C2 image mean by 0.8 % against the oracle (tools/dbg_c2.py), the other flags do not.
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -fno-hip-fp32-correctly-rounded-divide-sqrt
 
 LIBDIR := luisarender_amd/lib
 BINDIR := luisarender_amd/bin
@@ -26,16 +27,16 @@ HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 all: host oracle hip cli
 
 host: $(LIBDIR)/liblrhost.so
-$(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR)
+$(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl
 
 oracle: oracle/liboracle.so
-oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h
+oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h Makefile
 	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/oracle.cpp
 
 hip: $(LIBDIR)/liblrhip.so
-$(LIBDIR)/liblrhip.so: $(HIP_SRC) $(HIP_HDR)
+$(LIBDIR)/liblrhip.so: $(HIP_SRC) $(HIP_HDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
 

@@ -183,9 +183,17 @@ typedef struct lr_film {
 } lr_film;
 
 enum { LR_SAMPLER_INDEPENDENT = 0, LR_SAMPLER_SOBOL = 1, LR_SAMPLER_PADDED_SOBOL = 2, LR_SAMPLER_PCG32 = 3 };
+enum { LR_SOBOL_DIMENSIONS = 1024, LR_SOBOL_MATRIX_SIZE = 52 }; /* src/util/sobolmatrices.h:13-14 */
 typedef struct lr_sampler {
     uint32_t kind;
     uint32_t seed;    /* src/base/sampler.cpp:9-11, default 19980810 */
+    uint32_t spp;     /* Sampler::Instance::reset(.., spp): PaddedSobol permutation length (padded_sobol.cpp:112) */
+    uint32_t scale;   /* next_pow2(max(W, H)): global Sobol pixel grid (sobol.cpp:119-120) */
+    /* tables of the Sobol samplers (NULL for the others): generator matrices [1024][52] and the two
+     * van-der-Corput rows [52] for m = log2(scale) (sobol.cpp:121-129); derived by tools/gen_sobol_tables.py */
+    const uint32_t *sobol_matrices;
+    const uint64_t *vdc_sobol;
+    const uint64_t *vdc_sobol_inv;
 } lr_sampler;
 
 typedef struct lr_integrator {

@@ -82,7 +82,8 @@ class Film(C.Structure):
 
 
 class Sampler(C.Structure):
-    _fields_ = [("kind", u32), ("seed", u32)]
+    _fields_ = [("kind", u32), ("seed", u32), ("spp", u32), ("scale", u32), ("sobol_matrices", C.c_void_p),
+                ("vdc_sobol", C.c_void_p), ("vdc_sobol_inv", C.c_void_p)]
 
 
 class Integrator(C.Structure):
@@ -196,6 +197,7 @@ def oracle_lib() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = u32
             fn.argtypes = [u32] * n
+        lib.oracle_sampler_stream.argtypes = [C.POINTER(Scene), u32, u32, u32, u32, C.c_void_p]
         lib.oracle_lcg.restype = f32
         lib.oracle_lcg.argtypes = [C.POINTER(u32)]
         lib.oracle_pcg32_next.restype = u32

@@ -99,7 +99,10 @@ struct DScene {
     uint32_t has_lights;
     uint32_t sampler_kind, seed;
     float film_clamp;
-    uint32_t pad;
+    uint32_t sampler_spp;          // PaddedSobol permutation length
+    uint32_t sobol_scale, pad[3];  // global Sobol pixel grid
+    const uint32_t *sobol_matrices;// [1024][52]
+    const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
 };
 
 struct DCounters {

@@ -35,10 +35,9 @@ LR_HD uint32_t xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 
 LR_HD float uint_to_unit_float(uint32_t u) { return fminf(kOneMinusEpsilon, static_cast<float>(u) * 0x1p-32f); }
 
-// One sampler object per path.  PCG = false reproduces the reference stream bit for bit
-// (IndependentSampler: xxhash32 seed + LCG); PCG = true is the additional generator the north star
-// asks for (one PCG32 sequence per path, sequence index = the same xxhash32 seed).
-template<bool PCG>
+// One sampler object per path.  GENERIC = false reproduces the reference's default stream bit for bit
+// (IndependentSampler: xxhash32 seed + LCG); GENERIC = true: PCG32 / Sobol / PaddedSobol chosen at run time.
+template<bool GENERIC>
 struct PathSampler;
 
 template<>
@@ -55,31 +54,153 @@ struct PathSampler<false> {
         u.y = next_1d();
         return u;
     }
+    LR_D f2 next_pixel_2d() { return next_2d(); }// Sampler::Instance::generate_pixel_2d default, sampler.h:48
 };
 
+LR_HD uint32_t xxhash32_2(uint32_t x, uint32_t y) {// rng.cpp:25-36
+    constexpr uint32_t P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    auto h = y + P5 + x * P3;
+    h = P4 * ((h << 17u) | (h >> 15u));
+    h = P2 * (h ^ (h >> 15u));
+    h = P3 * (h ^ (h >> 13u));
+    return h ^ (h >> 16u);
+}
+
+// Generic sampler (runtime kind): PCG32 streams, the global Owen-scrambled Sobol sampler
+// (src/samplers/sobol.cpp:40-169) and PaddedSobol (src/samplers/padded_sobol.cpp:23-150).  Lives in its own
+// kernel instantiation so the default Independent path keeps a 1-register sampler.
 template<>
 struct PathSampler<true> {
-    uint64_t pcg_state, pcg_inc;
+    uint64_t a, b;            // PCG32: state, inc.  Sobol: a = sequence index.
+    uint32_t px, py, sample_index, dimension;
+    const DScene *scene;
+
     LR_D uint32_t pcg_next() {// rng.cpp:142-148
-        auto old = pcg_state;
-        pcg_state = old * 0x5851f42d4c957f2dull + pcg_inc;
+        auto old = a;
+        a = old * 0x5851f42d4c957f2dull + b;
         auto xorshifted = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
         auto rot = static_cast<uint32_t>(old >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
     }
-    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) {// PCG32::set_sequence, rng.cpp:150-156
-        pcg_state = 0u;
-        pcg_inc = (static_cast<uint64_t>(xxhash32_4(px, py, scene.seed, index)) << 1u) | 1u;
-        (void)pcg_next();
-        pcg_state += 0x853c49e6748fea9bull;
-        (void)pcg_next();
+    static LR_D uint32_t owen(uint32_t seed, uint32_t v) {// _fast_owen_scramble, sobol.cpp:40-48
+        v = __brev(v);
+        v ^= v * 0x3d20adeau;
+        v += seed;
+        v *= (seed >> 16u) | 1u;
+        v ^= v * 0x05526c56u;
+        v ^= v * 0x53a22864u;
+        return __brev(v);
     }
-    LR_D float next_1d() { return uint_to_unit_float(pcg_next()); }
+    LR_D uint32_t sobol_bits(uint64_t idx, uint32_t dim) const {// sobol.cpp:52-60
+        auto v = 0u;
+        auto m = scene->sobol_matrices + dim * static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE);
+        for (; idx != 0u; idx >>= 1u, m++) {
+            if (idx & 1u) { v ^= *m; }
+        }
+        return v;
+    }
+    static LR_D uint32_t permutation_element(uint32_t i, uint32_t l, uint32_t p) {// padded_sobol.cpp:59-91
+        auto w = l - 1u;
+        w |= w >> 1u, w |= w >> 2u, w |= w >> 4u, w |= w >> 8u, w |= w >> 16u;
+        do {
+            i ^= p;
+            i *= 0xe170893du;
+            i ^= p >> 16u;
+            i ^= (i & w) >> 4u;
+            i ^= p >> 8u;
+            i *= 0x0929eb3fu;
+            i ^= p >> 23u;
+            i ^= (i & w) >> 1u;
+            i *= 1u | p >> 27u;
+            i *= 0x6935fa69u;
+            i ^= (i & w) >> 11u;
+            i *= 0x74dcb303u;
+            i ^= (i & w) >> 2u;
+            i *= 0x9e501cc3u;
+            i ^= (i & w) >> 2u;
+            i *= 0xc860a3dfu;
+            i &= w;
+            i ^= i >> 5u;
+        } while (i >= l);
+        return (i + p) % l;
+    }
+    LR_D void start(const DScene &s, uint32_t x, uint32_t y, uint32_t index) {
+        scene = &s;
+        px = x, py = y, sample_index = index;
+        if (s.sampler_kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
+            dimension = 2u;
+            auto m = 31u - static_cast<uint32_t>(__clz(static_cast<int>(s.sobol_scale)));
+            if (m == 0u) {
+                a = index;
+            } else {
+                auto frame = index;
+                auto idx = static_cast<uint64_t>(frame) << (m << 1u);
+                uint64_t delta = 0u;
+                for (auto c = 0u; frame != 0u; frame >>= 1u, c++) {
+                    if (frame & 1u) { delta ^= s.vdc_sobol[c]; }
+                }
+                auto bb = delta ^ ((static_cast<uint64_t>(x) << m) | y);
+                for (auto d = 0u; bb != 0u; bb >>= 1u, d++) {
+                    if (bb & 1u) { idx ^= s.vdc_sobol_inv[d]; }
+                }
+                a = idx;
+            }
+        } else if (s.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
+            dimension = 0u;
+        } else {// PCG32::set_sequence(xxhash32 seed), rng.cpp:150-156
+            a = 0u;
+            b = (static_cast<uint64_t>(xxhash32_4(x, y, s.seed, index)) << 1u) | 1u;
+            (void)pcg_next();
+            a += 0x853c49e6748fea9bull;
+            (void)pcg_next();
+        }
+    }
+    LR_D float next_1d() {
+        auto kind = scene->sampler_kind;
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:147-153
+            dimension = dimension >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
+            auto u = static_cast<float>(owen(xxhash32_2(dimension, scene->seed), sobol_bits(a, dimension))) * 0x1p-32f;
+            dimension += 1u;
+            return clampf(u, 0.f, kOneMinusEpsilon);
+        }
+        if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:127-136
+            auto hash = xxhash32_4(px, py, sample_index ^ scene->seed, dimension);
+            auto index = permutation_element(sample_index, scene->sampler_spp, hash);
+            dimension += 1u;
+            return fminf(static_cast<float>(owen(hash, sobol_bits(index, 0u))) * 0x1p-32f, kOneMinusEpsilon);
+        }
+        return uint_to_unit_float(pcg_next());
+    }
     LR_D f2 next_2d() {
+        auto kind = scene->sampler_kind;
         f2 u;
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:154-162
+            dimension = dimension + 1u >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
+            u.x = clampf(static_cast<float>(owen(xxhash32_2(dimension, scene->seed), sobol_bits(a, dimension))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
+            u.y = clampf(static_cast<float>(owen(xxhash32_2(dimension + 1u, scene->seed), sobol_bits(a, dimension + 1u))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
+            dimension += 2u;
+            return u;
+        }
+        if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:137-149
+            auto hx = xxhash32_4(px, py, sample_index ^ scene->seed, dimension);
+            auto hy = xxhash32_4(px, py, sample_index ^ scene->seed, dimension + 1u);
+            auto index = permutation_element(sample_index, scene->sampler_spp, hx);
+            u.x = fminf(static_cast<float>(owen(hx, sobol_bits(index, 0u))) * 0x1p-32f, kOneMinusEpsilon);
+            u.y = fminf(static_cast<float>(owen(hy, sobol_bits(index, 1u))) * 0x1p-32f, kOneMinusEpsilon);
+            dimension += 2u;
+            return u;
+        }
         u.x = next_1d();
         u.y = next_1d();
         return u;
+    }
+    LR_D f2 next_pixel_2d() {// generate_pixel_2d: sobol.cpp:163-169, default sampler.h:48
+        if (scene->sampler_kind == LR_SAMPLER_SOBOL) {
+            auto s = static_cast<float>(scene->sobol_scale);
+            return {clampf(static_cast<float>(sobol_bits(a, 0u)) * 0x1p-32f * s - static_cast<float>(px), 0.f, kOneMinusEpsilon),
+                    clampf(static_cast<float>(sobol_bits(a, 1u)) * 0x1p-32f * s - static_cast<float>(py), 0.f, kOneMinusEpsilon)};
+        }
+        return next_2d();
     }
 };
 

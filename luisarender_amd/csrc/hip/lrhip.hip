@@ -357,9 +357,20 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     d.light_count = s->integrator.light_count;
     d.has_lights = s->light_count != 0u ? 1u : 0u;
     d.sampler_kind = s->sampler.kind, d.seed = s->sampler.seed;
-    if (d.sampler_kind != LR_SAMPLER_INDEPENDENT && d.sampler_kind != LR_SAMPLER_PCG32) {
-        release_scene(ctx);
-        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Sobol samplers are SURVEY §8 f2 (next)");
+    d.sampler_spp = s->sampler.spp, d.sobol_scale = s->sampler.scale;
+    if (d.sampler_kind == LR_SAMPLER_SOBOL || d.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
+        if (s->sampler.sobol_matrices == nullptr || (d.sampler_kind == LR_SAMPLER_SOBOL && d.sobol_scale > 1u && (s->sampler.vdc_sobol == nullptr || s->sampler.vdc_sobol_inv == nullptr))) {
+            release_scene(ctx);
+            return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: Sobol sampler without its tables");
+        }
+        int rc2;
+        if ((rc2 = upload(ctx, s->sampler.sobol_matrices, static_cast<size_t>(LR_SOBOL_DIMENSIONS) * LR_SOBOL_MATRIX_SIZE, &d.sobol_matrices)) != LRHIP_OK ||
+            (s->sampler.vdc_sobol != nullptr &&
+             ((rc2 = upload(ctx, s->sampler.vdc_sobol, static_cast<size_t>(LR_SOBOL_MATRIX_SIZE), &d.vdc_sobol)) != LRHIP_OK ||
+              (rc2 = upload(ctx, s->sampler.vdc_sobol_inv, static_cast<size_t>(LR_SOBOL_MATRIX_SIZE), &d.vdc_sobol_inv)) != LRHIP_OK))) {
+            release_scene(ctx);
+            return rc2;
+        }
     }
     d.film_clamp = s->film.clamp;
     for (auto i = 0; i < 3; i++) { ctx->film_scale[i] = s->film.scale[i]; }
@@ -432,7 +443,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     auto blocks = std::min(ctx->grid_blocks, (args.item_count + 3u) / 4u);
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
-    auto pcg = ctx->scene.sampler_kind == LR_SAMPLER_PCG32;
+    auto pcg = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
     auto grid = dim3(blocks), block = dim3(lrd::kBlockThreads);
     if (count && pcg) { hipLaunchKernelGGL((lrd::megapath_kernel<true, true>), grid, block, 0, ctx->stream, ctx->scene, args); }
     else if (count) { hipLaunchKernelGGL((lrd::megapath_kernel<true, false>), grid, block, 0, ctx->stream, ctx->scene, args); }

@@ -48,7 +48,8 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 #define LR_REFILL 36
 #endif
 
-// COUNT: gather diagnostics counters.  PCG: PCG32 streams instead of the reference's xxhash32 + LCG.
+// COUNT: gather diagnostics counters.  PCG ("generic sampler"): PCG32 / Sobol / PaddedSobol instead of the
+// default xxhash32 + LCG Independent stream.
 template<bool COUNT, bool PCG>
 __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(DScene scene, RenderArgs args) {
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                 if (!path_open && in_bounds && s_next < s_end) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
                     sampler.start(scene, px, py, s_next);
                     s_next++;
-                    auto u_filter = sampler.next_2d();
+                    auto u_filter = sampler.next_pixel_2d();
                     auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
                     float weight;
                     camera_ray(scene, scene.filter, px, py, u_filter, u_lens, ray, weight);

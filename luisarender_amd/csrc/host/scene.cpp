@@ -1,9 +1,12 @@
 // scene.cpp — scene graph -> flattened tables.  See scene.h for the reference map.
 #include "scene.h"
 
+#include <dlfcn.h>
+
 #include <array>
 #include <cstring>
 #include <filesystem>
+#include <fstream>
 #include <functional>
 #include <unordered_map>
 
@@ -93,6 +96,20 @@ lr_scene SceneData::view(size_t camera_index) const {
     s.filter = cameras[camera_index].filter;
     s.film = cameras[camera_index].film;
     s.sampler = sampler;
+    s.sampler.spp = s.camera.spp;// sampler()->reset(.., resolution, pixel_count, spp), integrator.cpp:59
+    s.sampler.scale = next_pow2(std::max(s.camera.width, s.camera.height));
+    if (sampler.kind == LR_SAMPLER_SOBOL || sampler.kind == LR_SAMPLER_PADDED_SOBOL) {
+        s.sampler.sobol_matrices = sobol_matrices.data();
+        if (sampler.kind == LR_SAMPLER_SOBOL) {
+            if (s.sampler.scale > 0xffffu) { throw Error{"Sobol sampler scale is too large."}; }// sobol.cpp:120
+            auto m = 0u;
+            while ((1u << m) < s.sampler.scale) { m++; }
+            if (m >= 1u) {// m == 0 (1x1 film) never reads the tables (sobol.cpp:68)
+                s.sampler.vdc_sobol = vdc_sobol.data() + static_cast<size_t>(m - 1u) * LR_SOBOL_MATRIX_SIZE;
+                s.sampler.vdc_sobol_inv = vdc_sobol_inv.data() + static_cast<size_t>(m - 1u) * LR_SOBOL_MATRIX_SIZE;
+            }
+        }
+    }
     s.integrator = integrator;
     s.accel.nodes = bvh_nodes.empty() ? nullptr : bvh_nodes.data();
     s.accel.node_count = static_cast<uint32_t>(bvh_nodes.size());
@@ -852,6 +869,35 @@ public:
 
     void build_environment(const NodeDesc *d);
 
+    // tables of src/util/sobolmatrices.cpp, re-derived by tools/gen_sobol_tables.py into data/sobol_tables.bin
+    void load_sobol_tables() {
+        Dl_info info{};
+        std::string dir = ".";
+        if (dladdr(reinterpret_cast<const void *>(&create_alias_table), &info) != 0 && info.dli_fname != nullptr) {
+            dir = fs::path{info.dli_fname}.parent_path().string();
+        }
+        std::string path;
+        if (auto env = std::getenv("LR_DATA_DIR")) { path = (fs::path{env} / "sobol_tables.bin").string(); }
+        else { path = (fs::path{dir} / ".." / "data" / "sobol_tables.bin").string(); }
+        std::ifstream f{path, std::ios::binary};
+        if (!f) { throw Error{"Sobol sampler tables not found at '" + path + "' (run tools/gen_sobol_tables.py)."}; }
+        char magic[4];
+        uint32_t dims = 0, cols = 0, nvdc = 0, ninv = 0;
+        f.read(magic, 4);
+        f.read(reinterpret_cast<char *>(&dims), 4), f.read(reinterpret_cast<char *>(&cols), 4);
+        f.read(reinterpret_cast<char *>(&nvdc), 4), f.read(reinterpret_cast<char *>(&ninv), 4);
+        if (std::memcmp(magic, "LRSB", 4) != 0 || dims != LR_SOBOL_DIMENSIONS || cols != LR_SOBOL_MATRIX_SIZE || nvdc != 25u || ninv != 26u) {
+            throw Error{"Invalid Sobol table file '" + path + "'."};
+        }
+        _out.sobol_matrices.resize(static_cast<size_t>(dims) * cols);
+        _out.vdc_sobol.resize(static_cast<size_t>(nvdc) * cols);
+        _out.vdc_sobol_inv.resize(static_cast<size_t>(ninv) * cols);
+        f.read(reinterpret_cast<char *>(_out.sobol_matrices.data()), static_cast<std::streamsize>(_out.sobol_matrices.size() * 4u));
+        f.read(reinterpret_cast<char *>(_out.vdc_sobol.data()), static_cast<std::streamsize>(_out.vdc_sobol.size() * 8u));
+        f.read(reinterpret_cast<char *>(_out.vdc_sobol_inv.data()), static_cast<std::streamsize>(_out.vdc_sobol_inv.size() * 8u));
+        if (!f) { throw Error{"Truncated Sobol table file '" + path + "'."}; }
+    }
+
     void build() {
         auto root = _desc.root();
         if (!root->is_defined()) { throw Error{"Root node is not defined in the scene description."}; }
@@ -888,6 +934,7 @@ public:
             throw Error{"Sampler '" + sampler->impl_type() + "' is not reproducible here (PMJ02BN tables missing, ZSobol "
                         "hash unpinned; SURVEY §2 row 8)."};
         }
+        if (_out.sampler.kind == LR_SAMPLER_SOBOL || _out.sampler.kind == LR_SAMPLER_PADDED_SOBOL) { load_sobol_tables(); }
         auto light_sampler = integrator->node_or_null("light_sampler");
         auto env_weight = 0.5f;
         if (light_sampler != nullptr) {

@@ -41,6 +41,8 @@ struct SceneData {
     std::vector<float> env_pdf;
     std::vector<CameraRecord> cameras;
     lr_sampler sampler{};
+    std::vector<uint32_t> sobol_matrices;      // [1024][52] (Sobol samplers only)
+    std::vector<uint64_t> vdc_sobol, vdc_sobol_inv;// all rows [25|26][52]; view() points at the row of the camera's scale
     lr_integrator integrator{};
     std::string integrator_impl;
     bool any_non_opaque{false};

@@ -41,23 +41,149 @@ inline float3 offset_ray_origin(float3 p, float3 n) {
     return out;
 }
 
-struct Sampler {// independent.cpp:57-83 (+ PCG32 option of the north star: one PCG32 stream per path)
+// Samplers: Independent (independent.cpp:57-83), global Sobol (sobol.cpp:40-169), PaddedSobol
+// (padded_sobol.cpp:23-150), and the PCG32 option of the north star (one PCG32 stream per path).
+struct Sampler {
+    const lr_sampler *cfg{nullptr};
     uint32_t kind{LR_SAMPLER_INDEPENDENT};
     uint32_t state{0u};
     PCG32 pcg;
-    void start(const lr_sampler &s, uint32_t px, uint32_t py, uint32_t index) {
-        kind = s.kind;
-        state = xxhash32(px, py, s.seed, index);
-        if (kind == LR_SAMPLER_PCG32) { pcg = PCG32{static_cast<uint64_t>(state)}; }
+    uint32_t px{0u}, py{0u}, sample_index{0u}, dimension{0u};
+    uint64_t sobol_index{0u};
+
+    static uint32_t reverse_bits(uint32_t v) {
+        v = ((v >> 1u) & 0x55555555u) | ((v & 0x55555555u) << 1u);
+        v = ((v >> 2u) & 0x33333333u) | ((v & 0x33333333u) << 2u);
+        v = ((v >> 4u) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4u);
+        v = ((v >> 8u) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8u);
+        return (v >> 16u) | (v << 16u);
     }
-    float generate_1d() { return kind == LR_SAMPLER_PCG32 ? pcg.uniform_float() : lcg(state); }
+    static uint32_t fast_owen_scramble(uint32_t seed, uint32_t v) {// sobol.cpp:40-48
+        v = reverse_bits(v);
+        v ^= v * 0x3d20adeau;
+        v += seed;
+        v *= (seed >> 16u) | 1u;
+        v ^= v * 0x05526c56u;
+        v ^= v * 0x53a22864u;
+        return reverse_bits(v);
+    }
+    uint32_t sobol_bits(uint64_t a, uint32_t dim) const {// sobol.cpp:52-60
+        auto v = 0u;
+        auto i = dim * static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE);
+        while (a != 0u) {
+            if (a & 1u) { v ^= cfg->sobol_matrices[i]; }
+            a >>= 1u;
+            i++;
+        }
+        return v;
+    }
+    static uint32_t permutation_element(uint32_t i, uint32_t l, uint32_t p) {// padded_sobol.cpp:59-91
+        auto w = l - 1u;
+        w |= w >> 1u, w |= w >> 2u, w |= w >> 4u, w |= w >> 8u, w |= w >> 16u;
+        do {
+            i ^= p;
+            i *= 0xe170893du;
+            i ^= p >> 16u;
+            i ^= (i & w) >> 4u;
+            i ^= p >> 8u;
+            i *= 0x0929eb3fu;
+            i ^= p >> 23u;
+            i ^= (i & w) >> 1u;
+            i *= 1u | p >> 27u;
+            i *= 0x6935fa69u;
+            i ^= (i & w) >> 11u;
+            i *= 0x74dcb303u;
+            i ^= (i & w) >> 2u;
+            i *= 0x9e501cc3u;
+            i ^= (i & w) >> 2u;
+            i *= 0xc860a3dfu;
+            i &= w;
+            i ^= i >> 5u;
+        } while (i >= l);
+        return (i + p) % l;
+    }
+
+    void start(const lr_sampler &s, uint32_t x, uint32_t y, uint32_t index) {
+        cfg = &s;
+        kind = s.kind;
+        px = x, py = y, sample_index = index;
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
+            dimension = 2u;
+            auto m = 0u;
+            while ((1u << m) < s.scale) { m++; }
+            if (m == 0u) {
+                sobol_index = index;
+            } else {
+                auto frame = index;
+                auto idx = static_cast<uint64_t>(frame) << (m << 1u);
+                uint64_t delta = 0u;
+                for (auto c = 0u; frame != 0u; frame >>= 1u, c++) {
+                    if (frame & 1u) { delta ^= s.vdc_sobol[c]; }
+                }
+                auto b = delta ^ ((static_cast<uint64_t>(x) << m) | y);
+                for (auto d = 0u; b != 0u; b >>= 1u, d++) {
+                    if (b & 1u) { idx ^= s.vdc_sobol_inv[d]; }
+                }
+                sobol_index = idx;
+            }
+        } else if (kind == LR_SAMPLER_PADDED_SOBOL) {
+            dimension = 0u;
+        } else {
+            state = xxhash32(x, y, s.seed, index);
+            if (kind == LR_SAMPLER_PCG32) { pcg = PCG32{static_cast<uint64_t>(state)}; }
+        }
+    }
+    float generate_1d() {
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:147-153
+            dimension = dimension >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
+            auto hash = xxhash32(dimension, cfg->seed);
+            auto u = static_cast<float>(fast_owen_scramble(hash, sobol_bits(sobol_index, dimension))) * 0x1p-32f;
+            dimension += 1u;
+            return clampf(u, 0.f, one_minus_epsilon);
+        }
+        if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:127-136
+            auto hash = xxhash32(px, py, sample_index ^ cfg->seed, dimension);
+            auto index = permutation_element(sample_index, cfg->spp, hash);
+            auto u = std::min(static_cast<float>(fast_owen_scramble(hash, sobol_bits(index, 0u))) * 0x1p-32f, one_minus_epsilon);
+            dimension += 1u;
+            return u;
+        }
+        return kind == LR_SAMPLER_PCG32 ? pcg.uniform_float() : lcg(state);
+    }
     float2 generate_2d() {
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:154-162
+            dimension = dimension + 1u >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
+            auto hx = xxhash32(dimension, cfg->seed), hy = xxhash32(dimension + 1u, cfg->seed);
+            auto ux = static_cast<float>(fast_owen_scramble(hx, sobol_bits(sobol_index, dimension))) * 0x1p-32f;
+            auto uy = static_cast<float>(fast_owen_scramble(hy, sobol_bits(sobol_index, dimension + 1u))) * 0x1p-32f;
+            dimension += 2u;
+            return {clampf(ux, 0.f, one_minus_epsilon), clampf(uy, 0.f, one_minus_epsilon)};
+        }
+        if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:137-149
+            auto hx = xxhash32(px, py, sample_index ^ cfg->seed, dimension);
+            auto hy = xxhash32(px, py, sample_index ^ cfg->seed, dimension + 1u);
+            auto index = permutation_element(sample_index, cfg->spp, hx);
+            float2 u;
+            u.x = std::min(static_cast<float>(fast_owen_scramble(hx, sobol_bits(index, 0u))) * 0x1p-32f, one_minus_epsilon);
+            u.y = std::min(static_cast<float>(fast_owen_scramble(hy, sobol_bits(index, 1u))) * 0x1p-32f, one_minus_epsilon);
+            dimension += 2u;
+            return u;
+        }
         float2 u;
         u.x = generate_1d();
         u.y = generate_1d();
         return u;
     }
-    float2 generate_pixel_2d() { return generate_2d(); }// sampler.h:48
+    float2 generate_pixel_2d() {
+        if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:163-169: unscrambled dimensions 0 / 1 of the global sequence
+            auto ux = static_cast<float>(sobol_bits(sobol_index, 0u)) * 0x1p-32f;
+            auto uy = static_cast<float>(sobol_bits(sobol_index, 1u)) * 0x1p-32f;
+            auto s = static_cast<float>(cfg->scale);
+            return {clampf(ux * s - static_cast<float>(px), 0.f, one_minus_epsilon),
+                    clampf(uy * s - static_cast<float>(py), 0.f, one_minus_epsilon)};
+        }
+        return generate_2d();// sampler.h:48
+    }
 };
 
 struct FilterSample {
@@ -418,6 +544,14 @@ void oracle_camera_ray(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sampl
     out[0] = cs.ray.o.x, out[1] = cs.ray.o.y, out[2] = cs.ray.o.z;
     out[3] = cs.ray.d.x, out[4] = cs.ray.d.y, out[5] = cs.ray.d.z;
     out[6] = cs.weight;
+}
+
+void oracle_sampler_stream(const lr_scene *scene, uint32_t px, uint32_t py, uint32_t sample_index, uint32_t n, float *out) {
+    Sampler sampler;
+    sampler.start(scene->sampler, px, py, sample_index);
+    auto p = sampler.generate_pixel_2d();
+    out[0] = p.x, out[1] = p.y;
+    for (uint32_t i = 0; i < n; i++) { out[2u + i] = sampler.generate_1d(); }
 }
 
 uint32_t oracle_xxhash32_1(uint32_t x) { return xxhash32(x); }

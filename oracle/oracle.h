@@ -58,6 +58,10 @@ void oracle_trace_closest(oracle_ctx *ctx, const float origin[3], const float di
 /* primary camera ray of (pixel, sample): origin[3], direction[3], weight */
 void oracle_camera_ray(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sample_index, float out[7]);
 
+/* first `n` generate_1d() draws of the scene's sampler for (pixel, sample): out[0..1] = generate_pixel_2d(),
+ * out[2 .. 2+n) = the following generate_1d() values */
+void oracle_sampler_stream(const lr_scene *scene, uint32_t px, uint32_t py, uint32_t sample_index, uint32_t n, float *out);
+
 /* ---- unit-level hooks used by the KAT tests */
 uint32_t oracle_xxhash32_1(uint32_t x);
 uint32_t oracle_xxhash32_2(uint32_t x, uint32_t y);
