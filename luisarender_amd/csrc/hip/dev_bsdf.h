@@ -279,13 +279,227 @@ LR_HD BsdfEval plastic_eval_local(const DClosure &c, GGX g, f3 wo_l, f3 wi_l) {
     return {(f_coat + f_diffuse) * abs_cos_theta(wi_l), lerp(pdf_coat, pdf_diffuse, w)};
 }
 
-// Surface::Closure::evaluate
+// ---- Disney (src/surfaces/disney.cpp): thick (:351-588) and thin (:590-841) closures on one structure
+LR_HD float schlick_weight(float c) {
+    auto m = saturate(1.f - c);
+    return sqr(sqr(m)) * m;
+}
+LR_HD float fr_schlick(float R0, float c) { return lerp(R0, 1.f, schlick_weight(c)); }
+LR_HD float gtr1(float c, float alpha) {// :210-214
+    auto a2 = alpha * alpha;
+    return (a2 - 1.f) / (kPi * logf(a2) * (1.f + (a2 - 1.f) * c * c));
+}
+LR_HD float smith_g_ggx(float c, float alpha) {// :217-221
+    auto a2 = alpha * alpha, c2 = c * c;
+    return 1.f / (c + sqrtf(a2 + c2 - a2 * c2));
+}
+
+struct DisneyLobes {
+    f3 Cdiff, Css, Csheen, Cspec0, Cst, Cdt;
+    float roughness, metallic, eta, eta_i, eta_t, clearcoat, gloss;
+    GGX dist, tdist;
+    float w[5];
+    uint32_t mask;  // bit i: technique i enabled; bits 8.. : has_diffuse(8) fake_ss(9) sheen(10) clearcoat(11) spec_trans(12) diff_trans(13)
+    uint32_t count;
+    bool thin, two_sided;
+};
+
+LR_HD DisneyLobes disney_setup(const DClosure &c) {
+    DisneyLobes L;
+    auto color = mk3(c.c0[0], c.c0[1], c.c0[2]);
+    auto color_lum = c.s0;
+    auto metallic = c.e[kDisneyMetallic], specular_trans = c.e[kDisneySpecularTrans], diffuse_trans = c.s1;
+    auto flatness = c.e[kDisneyFlatness], sheen = c.e[kDisneySheen], sheen_tint = c.e[kDisneySheenTint];
+    auto lobes = c.x[0];
+    L.thin = c.x[2] != 0u;
+    auto transmissive = c.x[1] != 0u;
+    auto diffuse_weight = (1.f - metallic) * (1.f - specular_trans);
+    auto diff_refl_weight = L.thin ? diffuse_weight * (1.f - diffuse_trans) : diffuse_weight;
+    auto diff_trans_weight = diffuse_weight * diffuse_trans;
+    auto tint_weight = color_lum > 0.f ? 1.f / color_lum : 1.f;
+    auto tint = saturate(color * tint_weight);
+    auto tint_lum = color_lum * tint_weight;
+    L.roughness = c.e[kDisneyRoughness], L.metallic = metallic;
+    L.mask = 0u;
+    L.Cdiff = L.Css = L.Csheen = L.Cst = L.Cdt = mk3(0.f);
+    L.w[0] = L.w[1] = L.w[2] = L.w[3] = L.w[4] = 0.f;
+    auto diffuse_like = diff_refl_weight * color_lum;
+    if (lobes & 3u) {
+        L.Cdiff = color * (diff_refl_weight * (1.f - flatness));
+        L.mask |= 1u | (1u << 8u);
+    }
+    if (lobes & 4u) {
+        auto Css_weight = L.thin ? diff_refl_weight * flatness * (1.f - diffuse_trans) : diffuse_weight * flatness;
+        L.Css = Css_weight * color;
+        L.mask |= 1u | (1u << 9u);
+    }
+    if (lobes & 8u) {
+        auto Csheen_weight = L.thin ? diff_refl_weight * sheen * (1.f - diffuse_trans) : diffuse_weight * sheen;
+        L.Csheen = Csheen_weight * (mk3(1.f) + sheen_tint * (tint - mk3(1.f)));
+        L.mask |= (1u << 10u) | (L.thin ? 0u : 1u);// the thin closure does not enable the technique for sheen alone
+        diffuse_like += Csheen_weight * lerp(1.f, tint_lum, sheen_tint) * .1f;
+    }
+    L.w[0] = saturate(diffuse_like);
+    L.eta_i = c.e[kDisneyEtaI], L.eta_t = c.e[kDisneyEtaT];
+    L.eta = L.eta_t / L.eta_i;
+    auto R0 = sqr((L.eta - 1.f) / (L.eta + 1.f));
+    auto spec_tint = c.e[kDisneySpecularTint];
+    auto base = (mk3(1.f) + spec_tint * (tint - mk3(1.f))) * R0;
+    L.Cspec0 = base + metallic * (color - base);
+    L.two_sided = L.thin ? false : !transmissive;
+    auto aspect = sqrtf(1.f - c.e[kDisneyAnisotropic] * .9f);
+    L.dist = make_ggx(fmaxf(0.001f, L.roughness / aspect), fmaxf(0.001f, L.roughness * aspect));
+    L.tdist = L.dist;
+    L.w[1] = saturate(lerp(lerp(1.f, tint_lum, spec_tint) * R0, color_lum, metallic));
+    L.mask |= 2u;
+    L.clearcoat = 0.f, L.gloss = 0.f;
+    if (lobes & 16u) {
+        L.gloss = lerp(.1f, .001f, c.e[kDisneyClearcoatGloss]);
+        L.clearcoat = c.e[kDisneyClearcoat];
+        L.w[2] = saturate(L.clearcoat * fr_schlick(.04f, 1.f));
+        L.mask |= 4u | (1u << 11u);
+    }
+    if (L.thin) {
+        L.count = 5u;
+        if (lobes & 128u) {
+            auto rscaled = (.65f * L.eta - .35f) * L.roughness;
+            L.tdist = make_ggx(fmaxf(.001f, rscaled / aspect), fmaxf(.001f, rscaled * aspect));
+            auto Cst_weight = (1.f - metallic) * specular_trans;
+            L.Cst = Cst_weight * color;
+            L.w[3] = saturate(Cst_weight * color_lum);
+            L.mask |= 8u | (1u << 12u);
+        }
+        if (lobes & 64u) {
+            L.Cdt = diff_trans_weight * color;
+            L.w[4] = saturate(diff_trans_weight * color_lum);
+            L.mask |= 16u | (1u << 13u);
+        }
+    } else {
+        L.count = transmissive ? 4u : 3u;
+        if (transmissive && (lobes & 128u)) {
+            auto Cst_weight = (1.f - metallic) * specular_trans;
+            L.Cst = Cst_weight * sqrt3(color);
+            L.w[3] = saturate(Cst_weight * sqrtf(color_lum));
+            L.mask |= 8u | (1u << 12u);
+        }
+    }
+    auto sum = 0.f;
+    for (auto i = 0u; i < 5u; i++) {
+        if (i < L.count && (L.mask & (1u << i))) { sum += L.w[i]; }
+    }
+    auto inv = sum == 0.f ? 0.f : 1.f / sum;
+    for (auto i = 0u; i < 5u; i++) {
+        if (i < L.count && (L.mask & (1u << i))) { L.w[i] *= inv; }
+    }
+    return L;
+}
+
+LR_HD f3 disney_fresnel(const DisneyLobes &L, float cos_in) {// DisneyFresnel::evaluate, :277-296
+    auto cosI = L.two_sided ? fabsf(cos_in) : cos_in;
+    auto fr = fresnel_dielectric(cosI, 1.f, L.eta);
+    auto sw = schlick_weight(cosI);
+    auto f0 = L.Cspec0 + sw * (mk3(1.f) - L.Cspec0);
+    return mk3(fr) + L.metallic * (f0 - mk3(fr));
+}
+
+LR_HD BsdfEval disney_eval_local(const DisneyLobes &L, f3 wo, f3 wi) {// _evaluate_local, :476-521 / :728-781
+    auto f = mk3(0.f);
+    auto pdf = 0.f;
+    if (same_hemisphere(wo, wi)) {
+        auto wh = wi + wo;
+        auto valid = wh.x != 0.f || wh.y != 0.f || wh.z != 0.f;
+        wh = normalize(wh);
+        if ((L.mask & (1u << 8u)) && L.w[0] > 0.f) {
+            auto Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
+            f += L.Cdiff * (kInvPi * (1.f - Fo * .5f) * (1.f - Fi * .5f));
+            auto cos_d = dot(wi, wh);
+            auto Rr = 2.f * L.roughness * cos_d * cos_d;
+            f += L.Cdiff * (valid ? kInvPi * Rr * (Fo + Fi + Fo * Fi * (Rr - 1.f)) : 0.f);
+            if (L.mask & (1u << 9u)) {
+                auto Fss90 = cos_d * cos_d * L.roughness;
+                auto Fss = lerp(1.0f, Fss90, Fo) * lerp(1.0f, Fss90, Fi);
+                auto ss = 1.25f * (Fss * (1.f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - .5f) + .5f);
+                f += L.Css * (valid ? kInvPi * ss : 0.f);
+            }
+            if (L.mask & (1u << 10u)) { f += L.Csheen * (valid ? schlick_weight(cos_d) : 0.f); }
+            pdf += L.w[0] * cosine_pdf(wo, wi);
+        }
+        if (L.w[1] > 0.f) {// MicrofacetReflection with the Disney Fresnel
+            if (valid) {
+                auto F = disney_fresnel(L, dot(wi, face_forward(wh, mk3(0.f, 0.f, 1.f))));
+                f += F * fabsf(0.25f * ggx_D(L.dist, wh) * ggx_G(L.dist, wo, wi) / (cos_theta(wi) * cos_theta(wo)));
+                pdf += L.w[1] * (ggx_pdf(L.dist, wo, wh) / (4.f * dot(wo, wh)));
+            }
+        }
+        if ((L.mask & (1u << 11u)) && L.w[2] > 0.f) {// DisneyClearcoat, :232-279
+            auto Dr = gtr1(abs_cos_theta(wh), L.gloss);
+            auto Fr = fr_schlick(.04f, dot(wo, wh));
+            auto Gr = smith_g_ggx(abs_cos_theta(wo), .25f) * smith_g_ggx(abs_cos_theta(wi), .25f);
+            f += mk3(valid ? L.clearcoat * Gr * Fr * Dr * .25f : 0.f);
+            pdf += L.w[2] * (valid ? Dr * abs_cos_theta(wh) / (4.f * dot(wo, wh)) : 0.f);
+        }
+    } else {
+        if ((L.mask & (1u << 12u)) && L.w[3] > 0.f) {
+            f += mf_transmission_eval(L.Cst, L.tdist, L.eta_i, L.eta_t, wo, wi);
+            pdf += L.w[3] * mf_transmission_pdf(L.tdist, L.eta_i, L.eta_t, wo, wi);
+        }
+        if ((L.mask & (1u << 13u)) && L.w[4] > 0.f) {// LambertianTransmission
+            f += L.Cdt * kInvPi;
+            pdf += L.w[4] * (abs_cos_theta(wi) * kInvPi);
+        }
+    }
+    return {f * abs_cos_theta(wi), pdf};
+}
+
+LR_HD void disney_sample_local(const DisneyLobes &L, f3 wo, float u_lobe, f2 u, f3 &wi, bool &valid, uint32_t &event) {// :538-587
+    auto tech = 0u;
+    auto sum = 0.f;
+    for (auto i = 0u; i < 5u; i++) {
+        if (i < L.count && (L.mask & (1u << i))) {
+            tech = u_lobe > sum ? i : tech;
+            sum += L.w[i];
+        }
+    }
+    event = kEventReflect;
+    valid = false;
+    wi = mk3(0.f);
+    if (tech == 0u && (L.mask & (1u << 8u))) {
+        wi = cosine_sample_wi(wo, u), valid = true;
+    } else if (tech == 1u) {
+        wi = reflect(-wo, ggx_sample_wh(L.dist, wo, u));
+        valid = same_hemisphere(wo, wi);
+    } else if (tech == 2u && (L.mask & (1u << 11u))) {// DisneyClearcoat::sample_wi, :250-265
+        auto a2 = L.gloss * L.gloss;
+        auto ct = sqrtf(fmaxf(0.f, (1.f - powf(a2, 1.f - u.x)) / (1.f - a2)));
+        auto st = sqrtf(fmaxf(0.f, 1.f - ct * ct));
+        auto phi = 2.f * kPi * u.y;
+        auto wh = mk3(st * cosf(phi), st * sinf(phi), ct);
+        wh = same_hemisphere(wo, wh) ? wh : -wh;
+        wi = reflect(-wo, wh);
+        valid = same_hemisphere(wo, wi);
+    } else if (tech == 3u && (L.mask & (1u << 12u))) {
+        auto e = cos_theta(wo) > 0.f ? L.eta_i / L.eta_t : L.eta_t / L.eta_i;
+        auto refr = refract_dir(wo, ggx_sample_wh(L.tdist, wo, u), e, wi);
+        valid = refr && !same_hemisphere(wo, wi);
+        event = L.thin ? 4u : (cos_theta(wo) > 0.f ? kEventEnter : kEventExit);// 4 = Surface::event_through
+    } else if (tech == 4u && (L.mask & (1u << 13u))) {
+        wi = sample_cosine_hemisphere(u);
+        wi.z *= -sign(cos_theta(wo));
+        valid = true;
+        event = 4u;
+    }
+}
+
+// Surface::Closure::evaluate.  FULL = false compiles the Disney interpreter out (lean kernel variant).
+template<bool FULL>
 LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo, f3 wi) {
     auto wo_l = to_local(sh, wo);
     auto wi_l = to_local(sh, wi);
     BsdfEval e{mk3(0.f), 0.f};
     auto g = make_ggx(c.alpha_x, c.alpha_y);
-    if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:86-96
+    if (FULL && c.kind == LR_SURFACE_DISNEY) {
+        e = disney_eval_local(disney_setup(c), wo_l, wi_l);
+    } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:86-96
         e.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
         e.pdf = cosine_pdf(wo_l, wi_l);
     } else if (c.kind == LR_SURFACE_PLASTIC) {// plastic.cpp:139-166
@@ -311,11 +525,22 @@ LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo
 }
 
 // Surface::Closure::sample
+template<bool FULL>
 LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo, float u_lobe, f2 u) {
     auto wo_l = to_local(sh, wo);
     BsdfSample s{mk3(0.f), 0.f, mk3(0.f, 0.f, 1.f), kEventReflect};
     auto g = make_ggx(c.alpha_x, c.alpha_y);
-    if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:98-112
+    if (FULL && c.kind == LR_SURFACE_DISNEY) {
+        auto L = disney_setup(c);
+        f3 wi_l;
+        bool valid;
+        disney_sample_local(L, wo_l, u_lobe, u, wi_l, valid, s.event);
+        s.wi = to_world(sh, wi_l);
+        if (valid) {
+            auto e = disney_eval_local(L, wo_l, wi_l);
+            s.f = e.f, s.pdf = e.pdf;
+        }
+    } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:98-112
         auto wi_l = cosine_sample_wi(wo_l, u);
         s.pdf = cosine_pdf(wo_l, wi_l);
         s.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
@@ -369,6 +594,13 @@ LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo
     }
     if (!valid_sides(ng, sh.n, wo, s.wi)) { s.f = mk3(0.f), s.pdf = 0.f; }
     return s;
+}
+
+// Surface::Closure::eta (glass.cpp:151-153, disney.cpp:531-533): the relative index a transmissive sample crosses
+LR_HD bool closure_eta(const DClosure &c, float &eta) {
+    if (c.kind == LR_SURFACE_GLASS) { eta = c.s1; return true; }
+    if (c.kind == LR_SURFACE_DISNEY && c.x[2] == 0u && c.x[1] != 0u && (c.x[0] & 128u) != 0u) { eta = c.e[kDisneyEtaT]; return true; }
+    return false;
 }
 
 }// namespace lrd

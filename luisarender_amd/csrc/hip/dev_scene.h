@@ -26,21 +26,30 @@ struct alignas(16) DInstance {
 static_assert(sizeof(DInstance) == 128, "DInstance must be one cache line");
 
 // Closure parameters with every constant texture folded in (what the reference's JIT does by
-// inlining ConstantTexture values, src/textures/constant.cpp:73-79).  64 bytes.
+// inlining ConstantTexture values, src/textures/constant.cpp:73-79).  128 bytes = one line; the five simple
+// closures only read the first 64.
 //   MATTE   c0 = Kd                 s0 = sigma (degrees)
 //   MIRROR  c0 = color              alpha
 //   GLASS   c0 = Kr  c1 = Kt        s0 = eta_i  s1 = eta_t  s2 = Kr_ratio   alpha
 //   PLASTIC c0 = Kd' c1 = sigma_a   s0 = Kd_weight  s1 = eta                alpha
 //   METAL   c0 = n   c1 = k  c2 = Kd tint  s0 = eta_i                        alpha
+//   DISNEY  c0 = color  s0 = color_lum   e[] = DisneyContext scalars (see kDisney* indices), x = lobes | flags
+//   MIX     s0 = ratio  x[0], x[1] = surface tags of a, b
 struct alignas(16) DClosure {
     uint32_t kind;
-    uint32_t dynamic;   // 1: some parameter is a non-constant texture -> resolve per hit
+    uint32_t dynamic;   // 1: some parameter is a non-constant texture or a normal map -> resolve per hit
     float alpha_x, alpha_y;
     float c0[3]; float s0;
     float c1[3]; float s1;
     float c2[3]; float s2;
+    float e[12];
+    uint32_t x[4];
 };
-static_assert(sizeof(DClosure) == 64, "DClosure is 4 x float4");
+static_assert(sizeof(DClosure) == 128, "DClosure is one cache line");
+enum : uint32_t {// DClosure::e slots of a Disney closure (DisneyContext, disney.cpp:304-321)
+    kDisneyMetallic = 0, kDisneyEtaI, kDisneyEtaT, kDisneyRoughness, kDisneySpecularTint, kDisneyAnisotropic,
+    kDisneySheen, kDisneySheenTint, kDisneyClearcoat, kDisneyClearcoatGloss, kDisneySpecularTrans, kDisneyFlatness
+};// diffuse_trans lives in s1; x[0] = lobe mask, x[1] = transmissive, x[2] = thin
 
 struct alignas(16) DLight {
     float L[3];          // emission * scale for constant emission

@@ -418,6 +418,29 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
             c.s0 = eta_i;
             break;
         }
+        case LR_SURFACE_DISNEY: {// disney.cpp:932-1003
+            albedo(s.tex[0], 1.f, v, strength);
+            store(c.c0, v);
+            c.s0 = strength;
+            auto scalar = [&](int slot, float dv) { return s.tex[slot] >= 0 ? tex(s.tex[slot]).x : dv; };
+            c.e[kDisneyMetallic] = scalar(1, 0.f);
+            c.e[kDisneyEtaI] = eta_i, c.e[kDisneyEtaT] = scalar(2, 1.5f);
+            auto roughness = scalar(3, .5f);
+            if (s.flags & LR_SURFACE_FLAG_REMAP_ROUGHNESS) { roughness = roughness_to_alpha(roughness); }
+            c.e[kDisneyRoughness] = roughness;
+            c.e[kDisneySpecularTint] = scalar(4, 0.f), c.e[kDisneyAnisotropic] = scalar(5, 0.f);
+            c.e[kDisneySheen] = scalar(6, 0.f), c.e[kDisneySheenTint] = scalar(7, 0.f);
+            c.e[kDisneyClearcoat] = scalar(8, 0.f), c.e[kDisneyClearcoatGloss] = scalar(9, 1.f);
+            c.e[kDisneySpecularTrans] = scalar(10, 0.f), c.e[kDisneyFlatness] = scalar(11, 0.f);
+            c.s1 = scalar(12, 0.f);// diffuse_trans
+            c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = (s.flags & LR_SURFACE_FLAG_THIN) ? 1u : 0u;
+            break;
+        }
+        case LR_SURFACE_MIX: {// mix.cpp:198-212
+            c.s0 = s.tex[0] >= 0 ? clampf(tex(s.tex[0]).x, 0.f, 1.f) : 0.5f;
+            c.x[0] = s.u[0], c.x[1] = s.u[1];
+            break;
+        }
         default: c.kind = LR_SURFACE_NULL; break;
     }
     return c;

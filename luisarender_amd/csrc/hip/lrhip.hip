@@ -63,6 +63,7 @@ struct lrhip_ctx {
     uint32_t grid_blocks{0};
     uint32_t cu_count{0};
     uint32_t bvh_depth{0};
+    bool full_surfaces{false};// scene uses Disney / Mix closures
 };
 
 namespace {
@@ -248,6 +249,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     release_scene(ctx);
     ctx->bvh_depth = bvh_depth(s->accel);
+    ctx->full_surfaces = false;
     if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");
@@ -297,10 +299,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     std::vector<lrd::DClosure> closures(s->surface_count);
     for (uint32_t i = 0; i < s->surface_count; i++) {
         auto &surf = s->surfaces[i];
-        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX) {
-            release_scene(ctx);
-            return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Disney/Mix closures are not built yet (SURVEY §8 f2)");
-        }
+        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX) { ctx->full_surfaces = true; }
         auto dynamic = surf.normal_tex >= 0;
         for (auto t : surf.tex) { dynamic = dynamic || !is_constant(t); }
         lrd::DClosure c{};
@@ -314,6 +313,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
                 [&](int32_t id) { return s->textures[id].channels; }, 1.f);
         } else {
             c.kind = surf.kind;
+            c.x[0] = surf.u[0], c.x[1] = surf.u[1];// Mix children / Disney masks are needed before resolution
         }
         c.dynamic = dynamic ? 1u : 0u;
         closures[i] = c;
@@ -385,7 +385,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
     // persistent grid: as many blocks as are resident
     int blocks_per_cu = 0;
-    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false, false>, lrd::kBlockThreads, 0));
+    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false, false, false>, lrd::kBlockThreads, 0));
     blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
     ctx->grid_blocks = ctx->cu_count * static_cast<uint32_t>(blocks_per_cu);
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
@@ -443,12 +443,21 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     auto blocks = std::min(ctx->grid_blocks, (args.item_count + 3u) / 4u);
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
-    auto pcg = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
+    auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
+    auto full = ctx->full_surfaces;                                      // Disney / Mix interpreters
     auto grid = dim3(blocks), block = dim3(lrd::kBlockThreads);
-    if (count && pcg) { hipLaunchKernelGGL((lrd::megapath_kernel<true, true>), grid, block, 0, ctx->stream, ctx->scene, args); }
-    else if (count) { hipLaunchKernelGGL((lrd::megapath_kernel<true, false>), grid, block, 0, ctx->stream, ctx->scene, args); }
-    else if (pcg) { hipLaunchKernelGGL((lrd::megapath_kernel<false, true>), grid, block, 0, ctx->stream, ctx->scene, args); }
-    else { hipLaunchKernelGGL((lrd::megapath_kernel<false, false>), grid, block, 0, ctx->stream, ctx->scene, args); }
+#define LR_LAUNCH(C, G, F) hipLaunchKernelGGL((lrd::megapath_kernel<C, G, F>), grid, block, 0, ctx->stream, ctx->scene, args)
+    switch ((count ? 4 : 0) | (generic ? 2 : 0) | (full ? 1 : 0)) {
+        case 0: LR_LAUNCH(false, false, false); break;
+        case 1: LR_LAUNCH(false, false, true); break;
+        case 2: LR_LAUNCH(false, true, false); break;
+        case 3: LR_LAUNCH(false, true, true); break;
+        case 4: LR_LAUNCH(true, false, false); break;
+        case 5: LR_LAUNCH(true, false, true); break;
+        case 6: LR_LAUNCH(true, true, false); break;
+        default: LR_LAUNCH(true, true, true); break;
+    }
+#undef LR_LAUNCH
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;

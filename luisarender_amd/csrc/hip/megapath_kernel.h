@@ -50,7 +50,8 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 
 // COUNT: gather diagnostics counters.  PCG ("generic sampler"): PCG32 / Sobol / PaddedSobol instead of the
 // default xxhash32 + LCG Independent stream.
-template<bool COUNT, bool PCG>
+// FULL: Disney + Mix closure interpreters compiled in (selected at upload when the scene uses them).
+template<bool COUNT, bool PCG, bool FULL>
 __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(DScene scene, RenderArgs args) {
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
@@ -186,22 +187,51 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             }
                         }
                         // ---- material, mega_path.cpp:111-143
-                        auto closure = scene.closures[(it.tags >> 12u) & 4095u];
-                        if (closure.dynamic) {
-                            auto &raw = scene.surfaces[(it.tags >> 12u) & 4095u];
-                            if (raw.normal_tex >= 0) {// NormalMapWrapper, surface.h:236-254
-                                auto v = texture_eval(scene, raw.normal_tex, it.uv);
-                                auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
-                                if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
-                                auto normal = to_world(it.shading, n_local);
-                                it.shading = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), it.shading.s);
+                        // load_lobe: closure record + shading frame of surface `t` on top of frame `base`
+                        // (NormalMapWrapper, surface.h:236-254, and per-hit texture resolution for dynamic closures)
+                        auto load_lobe = [&](uint32_t t, const Frame &base, DClosure &c, Frame &fr) {
+                            c = scene.closures[t];
+                            fr = base;
+                            if (c.dynamic) {
+                                auto &raw = scene.surfaces[t];
+                                if (raw.normal_tex >= 0) {
+                                    auto v = texture_eval(scene, raw.normal_tex, it.uv);
+                                    auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
+                                    if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
+                                    auto normal = to_world(base, n_local);
+                                    fr = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), base.s);
+                                }
+                                auto dyn = c.dynamic;
+                                c = resolve_closure(
+                                    raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
+                                    [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
+                                c.dynamic = dyn;
                             }
-                            closure = resolve_closure(
-                                raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
-                                [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
-                        }
+                        };
+                        DClosure closure;
+                        Frame sh;
+                        load_lobe((it.tags >> 12u) & 4095u, it.shading, closure, sh);
+                        const auto is_mix = FULL && closure.kind == LR_SURFACE_MIX;
+                        const auto ratio = closure.s0;
+                        const auto tag_a = closure.x[0], tag_b = closure.x[1];
+                        auto mix_eval = [](const BsdfEval &a, const BsdfEval &b, float r) {// MixSurfaceClosure::_mix, mix.cpp:97-104
+                            auto t = 1.f - r;
+                            return BsdfEval{a.f + t * (b.f - a.f), lerp(a.pdf, b.pdf, t)};
+                        };
+                        auto eval_child = [&](uint32_t t, f3 wi) {
+                            DClosure c;
+                            Frame fr;
+                            load_lobe(t, sh, c, fr);
+                            return closure_evaluate<FULL>(c, fr, it.ng, wo, wi);
+                        };
                         if (light_pdf > 0.0f) {
-                            auto eval = closure_evaluate(closure, it.shading, it.ng, wo, shadow.d);
+                            BsdfEval eval;
+                            if (is_mix) {// mix.cpp:169-177
+                                eval = mix_eval(eval_child(tag_a, shadow.d), eval_child(tag_b, shadow.d), ratio);
+                                if (!valid_sides(it.ng, sh.n, wo, shadow.d)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
+                            } else {
+                                eval = closure_evaluate<FULL>(closure, sh, it.ng, wo, shadow.d);
+                            }
                             auto w = balance(light_pdf, eval.pdf) / light_pdf;
                             nee = w * beta * eval.f * light_L;
                             // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
@@ -209,16 +239,37 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                         }
                         auto u_lobe = sampler.next_1d();
                         auto u_bsdf = sampler.next_2d();
-                        auto bs = closure_sample(closure, it.shading, it.ng, wo, u_lobe, u_bsdf);
+                        BsdfSample bs;
+                        auto has_eta = false;
+                        auto eta = 1.f;
+                        if (is_mix) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
+                            DClosure ca;
+                            Frame fa;
+                            load_lobe(tag_a, sh, ca, fa);
+                            auto first = u_lobe < ratio;
+                            bs = closure_sample<FULL>(ca, fa, it.ng, wo, first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio), u_bsdf);
+                            float eta_a = 1.f, eta_b = 1.f;
+                            auto has_a = closure_eta(ca, eta_a);
+                            auto eb = eval_child(tag_b, bs.wi);
+                            auto m = first ? mix_eval(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_eval(eb, BsdfEval{bs.f, bs.pdf}, ratio);
+                            bs.f = m.f, bs.pdf = m.pdf;
+                            if (!valid_sides(it.ng, sh.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
+                            auto has_b = closure_eta(scene.closures[tag_b], eta_b);// (eta never comes from an image texture here)
+                            has_eta = has_a || has_b;// MixSurfaceClosure::eta, mix.cpp:148-157
+                            eta = !has_a ? eta_b : (!has_b ? eta_a : lerp(eta_b, eta_a, ratio));
+                        } else {
+                            bs = closure_sample<FULL>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
+                            has_eta = closure_eta(closure, eta);
+                        }
                         ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
                         ray.d = bs.wi;
                         ray.t_min = 0.f, ray.t_max = kFloatMax;
                         pdf_bsdf = bs.pdf;
                         beta *= (bs.pdf > 0.f ? 1.f / bs.pdf : 0.f) * bs.f;
                         auto eta_scale = 1.f;
-                        if (closure.kind == LR_SURFACE_GLASS) {
-                            if (bs.event == kEventEnter) { eta_scale = sqr(closure.s1); }
-                            else if (bs.event == kEventExit) { eta_scale = sqr(1.f / closure.s1); }
+                        if (has_eta) {
+                            if (bs.event == kEventEnter) { eta_scale = sqr(eta); }
+                            else if (bs.event == kEventExit) { eta_scale = sqr(1.f / eta); }
                         }
                         if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
                         auto alive = !(beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f);

@@ -320,7 +320,8 @@ public:
             t.child[0] = load_texture(d->node_or_null("on"));
             t.child[1] = load_texture(d->node_or_null("off"));
             t.checker_scale = d->float_or("scale", 1.f);
-            t.channels = 4u;
+            auto child_channels = [&](int32_t c) { return c < 0 ? 4u : _out.textures[static_cast<size_t>(c)].channels; };
+            t.channels = std::min(child_channels(t.child[0]), child_channels(t.child[1]));// checkerboard.cpp:38-48
         } else {
             throw Error{"Unsupported texture implementation '" + impl + "'. [" + d->location() + "]"};
         }
@@ -451,6 +452,22 @@ public:
                 "clearcoat", "clearcoat_gloss", "specular_trans", "flatness", "diffuse_trans"};
             for (size_t i = 0; i < names.size(); i++) { s.tex[i + 1u] = tex(names[i]); }
             if (d->bool_or("thin", false)) { s.flags |= LR_SURFACE_FLAG_THIN; }
+            // used lobes (disney.cpp:969-991) from the static blackness of the parameter textures
+            auto present = [&](int slot) { return s.tex[slot] >= 0 && !texture_is_black(s.tex[slot]); };
+            auto lobes = 0u;
+            if (s.tex[0] < 0 || !texture_is_black(s.tex[0])) {
+                lobes |= 1u | 2u;// diffuse, retro
+                if (present(6)) { lobes |= 8u; }// sheen
+                if (present(11)) { lobes |= 4u; }// fake subsurface (flatness)
+            }
+            lobes |= 32u;// specular
+            if (present(8)) { lobes |= 16u; }  // clearcoat
+            if (present(10)) { lobes |= 128u; }// specular transmission
+            auto thin = (s.flags & LR_SURFACE_FLAG_THIN) != 0u;
+            if (thin && present(12)) { lobes |= 64u; }// diffuse transmission (texture only built for thin, :1011)
+            if (!thin) { s.tex[12] = -1; }
+            s.u[2] = lobes;
+            s.u[1] = (!thin && present(10)) ? 1u : 0u;// Surface::is_transmissive (disney.cpp:63-77)
         } else if (impl == "mix") {// mix.cpp:23-32
             s.kind = LR_SURFACE_MIX;
             auto a = d->node("a"), b = d->node("b");
@@ -458,9 +475,14 @@ public:
                 throw Error{"Mix surface with a null child is not supported. [" + d->location() + "]"};
             }
             children = {register_surface(a), register_surface(b)};
+            if (_out.surfaces[children[0]].kind == LR_SURFACE_MIX || _out.surfaces[children[1]].kind == LR_SURFACE_MIX) {
+                throw Error{"Nested Mix surfaces are not supported by the megakernel. [" + d->location() + "]"};
+            }
             s.u[0] = children[0], s.u[1] = children[1];
             s.tex[0] = tex("ratio");
-            wrappers = false;
+            wrappers = false;// NormalMapWrapper<MixSurface> only (mix.cpp:214-215)
+            s.normal_tex = tex("normal_map");
+            s.normal_strength = d->float_or("normal_map_strength", 1.f);
         } else if (impl == "layered") {
             throw Error{"Layered surface is scheduled after the closure bar (SURVEY §8f f2). [" + d->location() + "]"};
         } else {
@@ -954,6 +976,16 @@ public:
                      for (auto &i : _out.instances) { n += i.handle.z; }
                      return n;
                  }()) + " triangles.");
+        // Disney closures of one kind (disney / disney_trans / disney_thin) share ONE polymorphic closure object in
+        // the reference, whose lobe mask is the union over all materials of that kind (enable_lobes, disney.cpp:856)
+        uint32_t lobe_union[3] = {0u, 0u, 0u};
+        auto disney_class = [](const lr_surface &s) { return (s.flags & LR_SURFACE_FLAG_THIN) ? 2u : (s.u[1] ? 1u : 0u); };
+        for (auto &s : _out.surfaces) {
+            if (s.kind == LR_SURFACE_DISNEY) { lobe_union[disney_class(s)] |= s.u[2]; }
+        }
+        for (auto &s : _out.surfaces) {
+            if (s.kind == LR_SURFACE_DISNEY) { s.u[0] = lobe_union[disney_class(s)]; }
+        }
         // UniformLightSamplerInstance (uniform.cpp:31-48)
         _out.integrator.light_count = static_cast<uint32_t>(_out.lights.size());
         if (_out.environment.kind != LR_ENV_NONE) {

@@ -382,6 +382,241 @@ inline bool validate_surface_sides(float3 ng, float3 ns, float3 wo, float3 wi) {
     return sign(flip * dot(wo, ns)) == sign(dot(wo, ng)) && sign(flip * dot(wi, ns)) == sign(dot(wi, ng));
 }
 
+
+// ---------------------------------------------------------------- Disney (src/surfaces/disney.cpp)
+
+inline float schlick_weight(float cosTheta) {// :95-98
+    auto m = saturate(1.f - cosTheta);
+    return sqr(sqr(m)) * m;
+}
+inline float fr_schlick(float R0, float cosTheta) { return lerp(R0, 1.f, schlick_weight(cosTheta)); }// :100-102
+inline float schlick_r0_from_eta(float eta) { return sqr((eta - 1.f) / (eta + 1.f)); }             // :106-108
+inline float gtr1(float cosTheta, float alpha) {// :210-214
+    auto alpha2 = sqr(alpha);
+    auto denom = pi * std::log(alpha2) * (1.f + (alpha2 - 1.f) * sqr(cosTheta));
+    return (alpha2 - 1.f) / denom;
+}
+inline float smith_g_ggx(float cosTheta, float alpha) {// :217-221
+    auto alpha2 = sqr(alpha);
+    auto cosTheta2 = sqr(cosTheta);
+    return 1.f / (cosTheta + std::sqrt(alpha2 + cosTheta2 - alpha2 * cosTheta2));
+}
+
+enum : uint32_t {
+    DISNEY_LOBE_DIFFUSE = 1u << 0u, DISNEY_LOBE_RETRO = 1u << 1u, DISNEY_LOBE_FAKE_SS = 1u << 2u, DISNEY_LOBE_SHEEN = 1u << 3u,
+    DISNEY_LOBE_CLEARCOAT = 1u << 4u, DISNEY_LOBE_SPECULAR = 1u << 5u, DISNEY_LOBE_DIFF_TRANS = 1u << 6u, DISNEY_LOBE_SPEC_TRANS = 1u << 7u
+};// :323-330
+
+struct DisneyParams {// DisneyContext, :304-321
+    Spectrum3 color;
+    float color_lum, metallic, eta_i, eta_t, roughness, specular_tint, anisotropic, sheen, sheen_tint;
+    float clearcoat, clearcoat_gloss, specular_trans, flatness, diffuse_trans;
+    uint32_t lobes;
+    bool thin, transmissive;
+};
+
+// DisneyClosureImpl (:351-588) and ThinDisneyClosureImpl (:590-841) on one structure
+struct DisneyClosure {
+    bool thin{false}, transmissive{false};
+    bool has_diffuse{false}, has_fake_ss{false}, has_sheen{false}, has_clearcoat{false}, has_spec_trans{false}, has_diff_trans{false};
+    Spectrum3 Cdiff, Css, Csheen, Cspec0, Cst, Cdt;
+    float roughness{0.f}, metallic{0.f}, eta{1.f}, eta_i{1.f}, eta_t{1.f}, clearcoat{0.f}, gloss{0.f};
+    float2 alpha{0.f, 0.f}, thin_alpha{0.f, 0.f};
+    bool two_sided_fresnel{false};
+    float w[5]{0.f, 0.f, 0.f, 0.f, 0.f};
+    bool enabled[5]{false, false, false, false, false};
+    uint32_t technique_count{0u};
+
+    explicit DisneyClosure(const DisneyParams &c) {
+        thin = c.thin, transmissive = c.transmissive;
+        auto diffuse_weight = (1.f - c.metallic) * (1.f - c.specular_trans);
+        auto diff_refl_weight = thin ? diffuse_weight * (1.f - c.diffuse_trans) : diffuse_weight;
+        auto diff_trans_weight = diffuse_weight * c.diffuse_trans;
+        auto tint_weight = c.color_lum > 0.f ? 1.f / c.color_lum : 1.f;
+        auto tint = saturate(c.color * tint_weight);
+        auto tint_lum = c.color_lum * tint_weight;
+        roughness = c.roughness, metallic = c.metallic;
+        auto diffuse_like = diff_refl_weight * c.color_lum;
+        if (c.lobes & (DISNEY_LOBE_DIFFUSE | DISNEY_LOBE_RETRO)) {
+            Cdiff = c.color * (diff_refl_weight * (1.f - c.flatness));
+            has_diffuse = true, enabled[0] = true;
+        }
+        if (c.lobes & DISNEY_LOBE_FAKE_SS) {
+            auto Css_weight = thin ? diff_refl_weight * c.flatness * (1.f - c.diffuse_trans) : diffuse_weight * c.flatness;
+            Css = Css_weight * c.color;
+            has_fake_ss = true, enabled[0] = true;
+        }
+        if (c.lobes & DISNEY_LOBE_SHEEN) {
+            auto Csheen_weight = thin ? diff_refl_weight * c.sheen * (1.f - c.diffuse_trans) : diffuse_weight * c.sheen;
+            Csheen = Csheen_weight * lerp(f3(1.f), tint, c.sheen_tint);
+            has_sheen = true;
+            diffuse_like += Csheen_weight * lerp(1.f, tint_lum, c.sheen_tint) * .1f;
+            if (!thin) { enabled[0] = true; }// the thin closure does not enable the technique for sheen alone (:641-647)
+        }
+        w[0] = saturate(diffuse_like);
+        eta_i = c.eta_i, eta_t = c.eta_t;
+        eta = c.eta_t / c.eta_i;
+        auto R0 = schlick_r0_from_eta(eta);
+        Cspec0 = lerp(lerp(f3(1.f), tint, c.specular_tint) * R0, c.color, c.metallic);
+        two_sided_fresnel = thin ? false : !transmissive;
+        auto aspect = std::sqrt(1.f - c.anisotropic * .9f);
+        alpha = {std::max(0.001f, c.roughness / aspect), std::max(0.001f, c.roughness * aspect)};
+        w[1] = saturate(lerp(lerp(1.f, tint_lum, c.specular_tint) * R0, c.color_lum, c.metallic));
+        enabled[1] = true;
+        if (c.lobes & DISNEY_LOBE_CLEARCOAT) {
+            gloss = lerp(.1f, .001f, c.clearcoat_gloss);
+            clearcoat = c.clearcoat;
+            has_clearcoat = true;
+            w[2] = saturate(c.clearcoat * fr_schlick(.04f, 1.f));
+            enabled[2] = true;
+        }
+        if (thin) {
+            technique_count = 5u;
+            if (c.lobes & DISNEY_LOBE_SPEC_TRANS) {
+                auto rscaled = (.65f * eta - .35f) * c.roughness;
+                thin_alpha = {std::max(.001f, rscaled / aspect), std::max(.001f, rscaled * aspect)};
+                auto Cst_weight = (1.f - c.metallic) * c.specular_trans;
+                Cst = Cst_weight * c.color;
+                has_spec_trans = true;
+                w[3] = saturate(Cst_weight * c.color_lum);
+                enabled[3] = true;
+            }
+            if (c.lobes & DISNEY_LOBE_DIFF_TRANS) {
+                Cdt = diff_trans_weight * c.color;
+                has_diff_trans = true;
+                w[4] = saturate(diff_trans_weight * c.color_lum);
+                enabled[4] = true;
+            }
+        } else {
+            technique_count = transmissive ? 4u : 3u;
+            if (transmissive && (c.lobes & DISNEY_LOBE_SPEC_TRANS)) {
+                auto Cst_weight = (1.f - c.metallic) * c.specular_trans;
+                Cst = Cst_weight * sqrt3(c.color);
+                thin_alpha = alpha;
+                has_spec_trans = true;
+                w[3] = saturate(Cst_weight * std::sqrt(c.color_lum));
+                enabled[3] = true;
+            }
+        }
+        auto sum = 0.f;
+        for (auto i = 0u; i < technique_count; i++) {
+            if (enabled[i]) { sum += w[i]; }
+        }
+        auto inv = sum == 0.f ? 0.f : 1.f / sum;
+        for (auto i = 0u; i < technique_count; i++) {
+            if (enabled[i]) { w[i] *= inv; }
+        }
+    }
+
+    Spectrum3 disney_fresnel(float cosI_in) const {// DisneyFresnel::evaluate, :277-296
+        auto cosI = two_sided_fresnel ? std::abs(cosI_in) : cosI_in;
+        auto fr = fresnel_dielectric(cosI, 1.f, eta);
+        auto f0 = f3(fr_schlick(Cspec0.x, cosI), fr_schlick(Cspec0.y, cosI), fr_schlick(Cspec0.z, cosI));
+        return lerp(f3(fr), f0, metallic);
+    }
+    float clearcoat_eval(float3 wo, float3 wi) const {// :232-249
+        auto wh = wi + wo;
+        auto valid = wh.x != 0.f || wh.y != 0.f || wh.z != 0.f;
+        wh = normalize(wh);
+        auto Dr = gtr1(abs_cos_theta(wh), gloss);
+        auto Fr = fr_schlick(.04f, dot(wo, wh));
+        auto Gr = smith_g_ggx(abs_cos_theta(wo), .25f) * smith_g_ggx(abs_cos_theta(wi), .25f);
+        return valid ? clearcoat * Gr * Fr * Dr * .25f : 0.f;
+    }
+    float clearcoat_pdf(float3 wo, float3 wi) const {// :266-279
+        auto wh = wi + wo;
+        auto valid = same_hemisphere(wo, wi) && (wh.x != 0.f || wh.y != 0.f || wh.z != 0.f);
+        wh = normalize(wh);
+        auto Dr = gtr1(abs_cos_theta(wh), gloss);
+        return valid ? Dr * abs_cos_theta(wh) / (4.f * dot(wo, wh)) : 0.f;
+    }
+    SurfaceEval evaluate_local(float3 wo, float3 wi) const {// _evaluate_local, :476-521 / :728-781
+        Spectrum3 f{0.f, 0.f, 0.f};
+        auto pdf = 0.f;
+        if (same_hemisphere(wo, wi)) {
+            if (has_diffuse && w[0] > 0.f) {
+                auto Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
+                f += Cdiff * (inv_pi * (1.f - Fo * .5f) * (1.f - Fi * .5f));// DisneyDiffuse, :118-126
+                auto wh = wi + wo;
+                auto valid = wh.x != 0.f || wh.y != 0.f || wh.z != 0.f;
+                wh = normalize(wh);
+                auto cosThetaD = dot(wi, wh);
+                auto Rr = 2.f * roughness * cosThetaD * cosThetaD;// DisneyRetro, :173-186
+                f += Cdiff * (valid ? inv_pi * Rr * (Fo + Fi + Fo * Fi * (Rr - 1.f)) : 0.f);
+                if (has_fake_ss) {// DisneyFakeSS, :143-160
+                    auto Fss90 = cosThetaD * cosThetaD * roughness;
+                    auto Fss = lerp(1.0f, Fss90, Fo) * lerp(1.0f, Fss90, Fi);
+                    auto ss = 1.25f * (Fss * (1.f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - .5f) + .5f);
+                    f += Css * (valid ? inv_pi * ss : 0.f);
+                }
+                if (has_sheen) { f += Csheen * (valid ? schlick_weight(cosThetaD) : 0.f); }// DisneySheen, :198-207
+                pdf += w[0] * cosine_pdf(wo, wi);
+            }
+            if (w[1] > 0.f) {
+                TrowbridgeReitz dist{alpha};
+                f += microfacet_reflection_eval(f3(1.f), dist, [&](float c) { return disney_fresnel(c); }, wo, wi);
+                pdf += w[1] * microfacet_reflection_pdf(dist, wo, wi);
+            }
+            if (has_clearcoat && w[2] > 0.f) {
+                f += f3(clearcoat_eval(wo, wi));
+                pdf += w[2] * clearcoat_pdf(wo, wi);
+            }
+        } else {
+            if (has_spec_trans && w[3] > 0.f) {
+                TrowbridgeReitz dist{thin_alpha};
+                f += microfacet_transmission_eval(Cst, dist, eta_i, eta_t, wo, wi);
+                pdf += w[3] * microfacet_transmission_pdf(dist, eta_i, eta_t, wo, wi);
+            }
+            if (has_diff_trans && w[4] > 0.f) {// LambertianTransmission, scattering.cpp:271-284
+                f += Cdt * (!same_hemisphere(wo, wi) ? inv_pi : 0.f);
+                pdf += w[4] * (same_hemisphere(wo, wi) ? 0.0f : abs_cos_theta(wi) * inv_pi);
+            }
+        }
+        return {f * abs_cos_theta(wi), pdf};
+    }
+    // sample, :538-587 / :796-840.  Returns local wi, validity and the event
+    void sample_local(float3 wo, float u_lobe, float2 u, float3 &wi, bool &valid, uint32_t &event) const {
+        auto tech = 0u;
+        auto sum = 0.f;
+        for (auto i = 0u; i < technique_count; i++) {
+            if (enabled[i]) {
+                tech = u_lobe > sum ? i : tech;
+                sum += w[i];
+            }
+        }
+        event = EVENT_REFLECT;
+        valid = false;
+        wi = f3(0.f);
+        if (tech == 0u && has_diffuse) {
+            wi = cosine_sample_wi(wo, u), valid = true;
+        } else if (tech == 1u) {
+            TrowbridgeReitz dist{alpha};
+            wi = reflect(-wo, dist.sample_wh(wo, u));
+            valid = same_hemisphere(wo, wi);
+        } else if (tech == 2u && has_clearcoat) {// DisneyClearcoat::sample_wi, :250-265
+            auto alpha2 = gloss * gloss;
+            auto cosTheta = std::sqrt(std::max(0.f, (1.f - std::pow(alpha2, 1.f - u.x)) / (1.f - alpha2)));
+            auto sinTheta = std::sqrt(std::max(0.f, 1.f - cosTheta * cosTheta));
+            auto phi = 2.f * pi * u.y;
+            auto wh = f3(sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta);
+            wh = same_hemisphere(wo, wh) ? wh : -wh;
+            wi = reflect(-wo, wh);
+            valid = same_hemisphere(wo, wi);
+        } else if (tech == 3u && has_spec_trans) {
+            TrowbridgeReitz dist{thin_alpha};
+            auto e = cos_theta(wo) > 0.f ? eta_i / eta_t : eta_t / eta_i;
+            auto refr = refract(wo, dist.sample_wh(wo, u), e, wi);
+            valid = refr && !same_hemisphere(wo, wi);
+            event = thin ? 4u : (cos_theta(wo) > 0.f ? EVENT_ENTER : EVENT_EXIT);
+        } else if (tech == 4u && has_diff_trans) {// LambertianTransmission::sample_wi
+            wi = sample_cosine_hemisphere(u);
+            wi.z *= -sign(cos_theta(wo));
+            valid = true;
+            event = 4u;// Surface::event_through
+        }
+    }
+};
+
 struct Closure {
     uint32_t kind{LR_SURFACE_NULL};
     float3 ng;
@@ -392,6 +627,13 @@ struct Closure {
     float s0{0.f}, s1{0.f}, s2{0.f};
     bool has_eta{false};
     float eta_value{1.f};
+    DisneyParams disney{};
+    // Mix (src/surfaces/mix.cpp): children are full closures with their own (possibly normal-mapped) frames
+    const lr_scene *mix_scene{nullptr};
+    Interaction mix_it{};
+    float3 mix_wo{};
+    uint32_t mix_a{0u}, mix_b{0u};
+    float mix_eta_i{1.f};
 
     // resolve the `roughness` texture like every closure does (e.g. mirror.cpp:145-154)
     static float2 roughness_alpha(const lr_scene &scene, const lr_surface &s, int32_t tex, float2 uv, float2 dv) {
@@ -405,7 +647,10 @@ struct Closure {
 
     // Surface::Instance::closure -> populate_closure (+ NormalMapWrapper, surface.h:236-254)
     static Closure populate(const lr_scene &scene, const Interaction &it_in, float3 wo, float eta_i) {
-        auto &s = scene.surfaces[it_in.surface_tag()];
+        return populate_tag(scene, it_in.surface_tag(), it_in, wo, eta_i);
+    }
+    static Closure populate_tag(const lr_scene &scene, uint32_t tag, const Interaction &it_in, float3 wo, float eta_i) {
+        auto &s = scene.surfaces[tag];
         auto it = it_in;
         if (s.normal_tex >= 0) {
             auto v = texture_evaluate(scene, s.normal_tex, it.uv);
@@ -465,6 +710,35 @@ struct Closure {
                 c.s0 = eta_i;
                 break;
             }
+            case LR_SURFACE_DISNEY: {// disney.cpp:932-1003
+                auto &d = c.disney;
+                auto color = albedo_or(scene, s.tex[0], uv, 1.f);
+                d.color = color.value, d.color_lum = color.strength;
+                auto scalar = [&](int slot, float dv) { return s.tex[slot] >= 0 ? texture_evaluate(scene, s.tex[slot], uv).x : dv; };
+                d.metallic = scalar(1, 0.f);
+                d.eta_i = eta_i, d.eta_t = scalar(2, 1.5f);
+                d.roughness = scalar(3, .5f);
+                if (s.flags & LR_SURFACE_FLAG_REMAP_ROUGHNESS) { d.roughness = TrowbridgeReitz::roughness_to_alpha(d.roughness); }
+                d.specular_tint = scalar(4, 0.f), d.anisotropic = scalar(5, 0.f), d.sheen = scalar(6, 0.f), d.sheen_tint = scalar(7, 0.f);
+                d.clearcoat = scalar(8, 0.f), d.clearcoat_gloss = scalar(9, 1.f), d.specular_trans = scalar(10, 0.f);
+                d.flatness = scalar(11, 0.f), d.diffuse_trans = scalar(12, 0.f);
+                d.lobes = s.u[0];// union over the scene's Disney surfaces of the same kind (enable_lobes, :856)
+                d.thin = (s.flags & LR_SURFACE_FLAG_THIN) != 0u;
+                d.transmissive = s.u[1] != 0u;
+                // DisneyClosureImpl::eta (:531-533): only the thick closure with a specular-transmission lobe reports one
+                c.has_eta = !d.thin && d.transmissive && (d.lobes & DISNEY_LOBE_SPEC_TRANS) != 0u;
+                c.eta_value = d.eta_t;
+                break;
+            }
+            case LR_SURFACE_MIX: {// mix.cpp:198-212
+                c.s0 = s.tex[0] >= 0 ? clampf(texture_evaluate(scene, s.tex[0], uv).x, 0.f, 1.f) : 0.5f;
+                c.mix_scene = &scene, c.mix_it = it, c.mix_wo = wo, c.mix_a = s.u[0], c.mix_b = s.u[1], c.mix_eta_i = eta_i;
+                auto a = populate_tag(scene, s.u[0], it, wo, eta_i), b = populate_tag(scene, s.u[1], it, wo, eta_i);
+                if (!a.has_eta) { c.has_eta = b.has_eta, c.eta_value = b.eta_value; }// mix.cpp:148-157
+                else if (!b.has_eta) { c.has_eta = true, c.eta_value = a.eta_value; }
+                else { c.has_eta = true, c.eta_value = lerp(b.eta_value, a.eta_value, c.s0); }
+                break;
+            }
             default: break;
         }
         return c;
@@ -513,8 +787,19 @@ struct Closure {
                 auto f = microfacet_reflection_eval(f3(1.f), dist, fresnel, wo_local, wi_local) * c2;
                 return {f * abs_cos_theta(wi_local), microfacet_reflection_pdf(dist, wo_local, wi_local)};
             }
+            case LR_SURFACE_DISNEY: return DisneyClosure{disney}.evaluate_local(wo_local, wi_local);
+            case LR_SURFACE_MIX: {// mix.cpp:169-177: children through their public evaluate (side validation included)
+                auto ea = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
+                auto eb = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
+                return mix(ea, eb, s0);
+            }
             default: return {};
         }
+    }
+
+    static SurfaceEval mix(const SurfaceEval &a, const SurfaceEval &b, float ratio) {// mix.cpp:97-104
+        auto t = 1.f - ratio;
+        return {lerp(a.f, b.f, t), lerp(a.pdf, b.pdf, t)};
     }
 
     SurfaceSample sample_impl(float3 wo, float u_lobe, float2 u) const {
@@ -586,6 +871,32 @@ struct Closure {
                 s.f = s.f * c2;
                 out.wi = shading.local_to_world(s.wi);
                 out.eval = {s.f * abs_cos_theta(s.wi), s.pdf};
+                return out;
+            }
+            case LR_SURFACE_DISNEY: {
+                DisneyClosure dc{disney};
+                float3 wi_local;
+                bool valid;
+                dc.sample_local(wo_local, u_lobe, u, wi_local, valid, out.event);
+                out.wi = shading.local_to_world(wi_local);
+                if (valid) { out.eval = dc.evaluate_local(wo_local, wi_local); }
+                return out;
+            }
+            case LR_SURFACE_MIX: {// mix.cpp:178-196 — the "sample b" branch samples A and evaluates B (reference quirk, kept)
+                auto a = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i);
+                auto b = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i);
+                auto ratio = s0;
+                if (u_lobe < ratio) {
+                    auto sa = a.sample(wo, u_lobe / ratio, u);
+                    auto eb = b.evaluate(wo, sa.wi);
+                    out.eval = mix(sa.eval, eb, ratio);
+                    out.wi = sa.wi, out.event = sa.event;
+                } else {
+                    auto sb = a.sample(wo, (u_lobe - ratio) / (1.f - ratio), u);
+                    auto ea = b.evaluate(wo, sb.wi);
+                    out.eval = mix(ea, sb.eval, ratio);
+                    out.wi = sb.wi, out.event = sb.event;
+                }
                 return out;
             }
             default: return out;

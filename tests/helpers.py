@@ -10,6 +10,19 @@ MATERIALS = {
     "mirror": "Surface m : Mirror { color : Constant { v { 0.9, 0.8, 0.7 } } roughness : Constant { v { 0.3 } } }",
     "glass": "Surface m : Glass { Kr : Constant { v { 0.9, 0.9, 0.9 } } Kt : Constant { v { 0.95, 0.9, 0.85 } } roughness : Constant { v { 0.25 } } eta : Constant { v { 1.5 } } }",
     "plastic": "Surface m : Plastic { Kd : Constant { v { 0.5, 0.3, 0.2 } } roughness : Constant { v { 0.2 } } sigma_a : Constant { v { 0.1, 0.2, 0.3 } } eta : Constant { v { 1.5 } } thickness : Constant { v { 0.5 } } }",
+    "disney": "Surface m : Disney { color : Constant { v { 0.7, 0.4, 0.3 } } metallic : Constant { v { 0.3 } } roughness : Constant { v { 0.4 } } "
+              "specular_tint : Constant { v { 0.5 } } anisotropic : Constant { v { 0.4 } } sheen : Constant { v { 0.5 } } sheen_tint : Constant { v { 0.5 } } "
+              "clearcoat : Constant { v { 0.6 } } clearcoat_gloss : Constant { v { 0.8 } } eta : Constant { v { 1.5 } } }",
+    "disney_trans": "Surface m : Disney { color : Constant { v { 0.8, 0.85, 0.9 } } roughness : Constant { v { 0.3 } } "
+                    "specular_trans : Constant { v { 0.7 } } flatness : Constant { v { 0.3 } } eta : Constant { v { 1.45 } } }",
+    "disney_thin": "Surface m : Disney { thin { true } color : Constant { v { 0.6, 0.7, 0.5 } } roughness : Constant { v { 0.35 } } "
+                   "specular_trans : Constant { v { 0.4 } } diffuse_trans : Constant { v { 0.8 } } flatness : Constant { v { 0.5 } } eta : Constant { v { 1.3 } } }",
+    "mix": "Surface mix_a : Matte { Kd : Constant { v { 0.7, 0.2, 0.2 } } } "
+           "Surface mix_b : Mirror { color : Constant { v { 0.9, 0.9, 0.9 } } roughness : Constant { v { 0.2 } } } "
+           "Surface m : Mix { a { @mix_a } b { @mix_b } ratio : Constant { v { 0.3 } } }",
+    "mix_glass": "Surface mg_a : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.5 } } } "
+                 "Surface mg_b : Disney { color : Constant { v { 0.5, 0.6, 0.7 } } roughness : Constant { v { 0.5 } } } "
+                 "Surface m : Mix { a { @mg_a } b { @mg_b } ratio : Constant { v { 0.6 } } }",
     "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
 }
 
@@ -31,22 +44,23 @@ def sph(theta, phi):
 
 
 class SurfaceProbe:
-    """evaluate/sample of surface tag 0 on a flat patch (ng = +z) through the oracle hooks"""
+    """evaluate/sample of the patch surface on a flat patch (ng = +z) through the oracle hooks"""
 
     def __init__(self, scene, ns=(0.0, 0.0, 1.0)):
         self.o = _ffi.oracle_lib()
         self.scene = scene
         self.view = scene.view()
         self.ns = np.array(ns, np.float32)
+        self.tag = self.view.surface_count - 1  # the shape's surface is registered after a Mix's children
 
     def evaluate(self, wo, wi):
         wo, wi = np.ascontiguousarray(wo, np.float32), np.ascontiguousarray(wi, np.float32)
         out = np.zeros(4, np.float32)
-        self.o.oracle_surface_evaluate(C.byref(self.view), 0, self.ns.ctypes.data, wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
+        self.o.oracle_surface_evaluate(C.byref(self.view), self.tag, self.ns.ctypes.data, wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
         return out[:3].copy(), float(out[3])
 
     def sample(self, wo, u_lobe, ux, uy):
         wo = np.ascontiguousarray(wo, np.float32)
         out = np.zeros(8, np.float32)
-        self.o.oracle_surface_sample(C.byref(self.view), 0, self.ns.ctypes.data, wo.ctypes.data, u_lobe, ux, uy, out.ctypes.data)
+        self.o.oracle_surface_sample(C.byref(self.view), self.tag, self.ns.ctypes.data, wo.ctypes.data, u_lobe, ux, uy, out.ctypes.data)
         return out[:3].copy(), float(out[3]), out[4:7].copy(), int(out[7])

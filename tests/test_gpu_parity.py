@@ -77,7 +77,7 @@ def test_golden_fixtures(renderer):
         assert _rel_l1(gpu, ref["film"]) < (1e-4 if "materials" not in name else 2e-3), name
 
 
-@pytest.mark.parametrize("material", ["oren", "mirror", "glass", "plastic", "metal"])
+@pytest.mark.parametrize("material", ["oren", "mirror", "glass", "plastic", "metal", "disney", "disney_trans", "disney_thin", "mix", "mix_glass"])
 def test_each_closure_in_a_cornell_box(renderer, material):
     from helpers import MATERIALS
     extra = MATERIALS[material].replace("Surface m ", f"Surface {material} ") + "\n"
@@ -87,6 +87,25 @@ def test_each_closure_in_a_cornell_box(renderer, material):
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]  # rare branch flips (RR / lobe pick)
     assert _rel_l1(gpu, cpu) < 3e-3, material
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3  # no bias
+
+
+def test_textured_disney_and_mix(renderer):
+    """Row a14 on the per-hit ("dynamic") path: checkerboard-driven Disney parameters, a checkerboard Mix ratio and a
+    generic sampler (the <COUNT, GENERIC, FULL> instantiation)."""
+    extra = """
+Texture chk : Checkerboard { on : Constant { v { 0.8, 0.3, 0.2 } } off : Constant { v { 0.2, 0.5, 0.8 } } scale { 4 } }
+Texture chk1 : Checkerboard { on : Constant { v { 0.9 } } off : Constant { v { 0.1 } } scale { 3 } }
+Surface dis : Disney { color { @chk } metallic { @chk1 } roughness : Constant { v { 0.3 } } clearcoat : Constant { v { 0.5 } } eta : Constant { v { 1.5 } } }
+Surface ma : Matte { Kd { @chk } }
+Surface mb : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } }
+Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
+"""
+    sc = Scene.from_string(cornell_box(resolution=64, spp=16, short_box_surface="dis", tall_box_surface="mx", extra_surfaces=extra, sampler="PCG32"))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
+    assert _rel_l1(gpu, cpu) < 3e-3
+    assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
 def test_environment_and_thin_lens(renderer):

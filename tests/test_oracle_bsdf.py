@@ -7,6 +7,7 @@ import pytest
 from helpers import MATERIALS, SurfaceProbe, material_scene, sph
 
 RNG = np.random.default_rng(11)
+TRANSMISSIVE = ("glass", "disney_trans", "mix_glass")  # sample() may return SURFACE_EVENT_ENTER / EXIT
 
 
 @pytest.mark.parametrize("name", list(MATERIALS))
@@ -15,17 +16,22 @@ def test_sample_is_consistent_with_evaluate(name):
     checked = 0
     for _ in range(300):
         wo = sph(RNG.uniform(0.05, 1.45), RNG.uniform(0, 2 * np.pi))
-        if name == "glass" and RNG.random() < 0.5:
+        if name in TRANSMISSIVE and RNG.random() < 0.5:
             wo[2] = -wo[2]  # from inside
-        f, pdf, wi, event = probe.sample(wo, *RNG.random(3))
+        u = RNG.random(3)
+        if name.startswith("mix"):
+            u[0] *= 0.3 if name == "mix" else 0.6  # u_lobe < ratio, the "sample a" branch; the other is test_mix_sample_quirk
+        f, pdf, wi, event = probe.sample(wo, *u)
         if pdf <= 0:
             continue
         assert abs(np.linalg.norm(wi) - 1.0) < 1e-4
         f2, pdf2 = probe.evaluate(wo, wi)
         assert np.allclose(f, f2, rtol=2e-3, atol=1e-6), (name, f, f2)
         assert abs(pdf - pdf2) <= 2e-3 * max(pdf, 1e-3), (name, pdf, pdf2)
-        if name == "glass":
+        if name in TRANSMISSIVE:
             assert event == (0 if wi[2] * wo[2] > 0 else (1 if wo[2] > 0 else 2))
+        elif name == "disney_thin":
+            assert event == (0 if wi[2] * wo[2] > 0 else 4)  # SURFACE_EVENT_THROUGH
         else:
             assert event == 0 and wi[2] * wo[2] > 0
         checked += 1
@@ -55,7 +61,8 @@ def test_pdf_normalisation_and_energy(name):
                 albedo += f / pdf
                 alive += 1
         albedo /= n
-        assert (albedo < 1.05).all(), (name, theta, albedo)
+        if not name.startswith("mix"):  # Mix::sample draws both branches from child a (reference quirk): not an unbiased estimator
+            assert (albedo < 1.05).all(), (name, theta, albedo)
         assert alive > 0.5 * n
 
 
@@ -101,3 +108,47 @@ def test_plastic_and_metal_parameters():
     probe = SurfaceProbe(sc)
     f, _ = probe.evaluate(sph(0.3, 0.0), sph(0.3, np.pi))
     assert f[0] > f[2]  # copper reflects red more than blue
+
+
+def test_mix_evaluate_is_the_lerp_of_its_children():
+    """MixSurfaceClosure::_evaluate (mix.cpp:169-177): f = ratio * a + (1 - ratio) * b"""
+    from helpers import Scene, _PATCH
+    mix = SurfaceProbe(material_scene("mix"))
+    a, b = SurfaceProbe(material_scene("mix")), SurfaceProbe(material_scene("mix"))
+    a.tag, b.tag = 0, 1
+    for _ in range(50):
+        wo, wi = sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28)), sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28))
+        (fa, pa), (fb, pb), (fm, pm) = a.evaluate(wo, wi), b.evaluate(wo, wi), mix.evaluate(wo, wi)
+        assert np.allclose(fm, 0.3 * fa + 0.7 * fb, rtol=1e-5, atol=1e-7)
+        assert abs(pm - (0.3 * pa + 0.7 * pb)) < 1e-5 * max(pm, 1.0)
+
+
+def test_mix_sample_quirk():
+    """mix.cpp:186-193: the "sample b" branch draws from child a, evaluates child b and mixes with the roles swapped"""
+    mix = SurfaceProbe(material_scene("mix"))
+    a, b = SurfaceProbe(material_scene("mix")), SurfaceProbe(material_scene("mix"))
+    a.tag, b.tag = 0, 1
+    for _ in range(50):
+        wo = sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28))
+        u_lobe, ux, uy = RNG.uniform(0.3, 1.0), RNG.random(), RNG.random()
+        fm, pm, wim, _ = mix.sample(wo, u_lobe, ux, uy)
+        fa, pa, wia, _ = a.sample(wo, np.float32((np.float32(u_lobe) - np.float32(0.3)) / np.float32(0.7)), ux, uy)
+        assert np.allclose(wim, wia, atol=1e-6)
+        fb, pb = b.evaluate(wo, wia)
+        assert np.allclose(fm, 0.3 * fb + 0.7 * fa, rtol=1e-4, atol=1e-6)
+        assert abs(pm - (0.3 * pb + 0.7 * pa)) < 1e-4 * max(pm, 1.0)
+
+
+def test_disney_limits():
+    """metallic = 0, no sheen/clearcoat/specular: Disney's diffuse + retro-reflection at normal incidence, roughness 0.5,
+    equals Lambert scaled by the Burley terms; checked at wo = wi = n where Fo = Fi = 0: f = color / pi * (1 + Rr) with Rr = 2 r cos^2(0)... (disney.cpp:95-160)"""
+    from helpers import Scene, _PATCH
+    surface = ("Surface m : Disney { color : Constant { v { 0.5, 0.5, 0.5 } } roughness : Constant { v { 0.5 } } "
+               "specular_tint : Constant { v { 0 } } eta : Constant { v { 1.0001 } } }")
+    probe = SurfaceProbe(Scene.from_string(_PATCH.format(surface=surface), build_accel=False))
+    n = np.array([0, 0, 1], np.float32)
+    f, pdf = probe.evaluate(n, n)
+    # diffuse: R/pi (1 - Fo/2)(1 - Fi/2) = R/pi at normal incidence; retro: R/pi * Rr * (Fo + Fi + Fo Fi (Rr - 1)) = 0; the
+    # specular lobe at eta ~ 1 has R0 ~ 0 and Schlick weight 0 at normal incidence
+    assert np.allclose(f, 0.5 / np.pi, rtol=2e-3), f
+    assert pdf > 0
