@@ -511,6 +511,34 @@ LR_D void reconstruct(const DScene &scene, uint32_t inst_id, uint32_t prim, f3 b
     }
 }
 
+// Surface::Instance::evaluate_opacity: OpacitySurfaceWrapper (surface.h:183-189) and MixSurfaceInstance (mix.cpp:63-70)
+LR_D float surface_opacity(const DScene &scene, uint32_t tag, f2 uv) {
+    auto one = [&](uint32_t t) {
+        auto alpha_tex = scene.surfaces[t].alpha_tex;
+        return alpha_tex >= 0 ? texture_eval(scene, alpha_tex, uv).x : 1.f;
+    };
+    auto &s = scene.surfaces[tag];
+    return s.kind == LR_SURFACE_MIX ? one(s.u[0]) * one(s.u[1]) : one(tag);
+}
+
+// Geometry::_alpha_skip, geometry.cpp:165-192: a candidate hit is skipped when
+// xxhash32(inst, prim, bits(bary)) * 2^-32 > opacity(uv).  Called only for instances flagged maybe_non_opaque.
+LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float u, float v) {
+    auto ip = reinterpret_cast<const float4 *>(scene.instances + inst_id);
+    auto h = reinterpret_cast<const uint4 *>(ip)[0];
+    f2 uv{u, v};
+    if (h.x & LR_SHAPE_HAS_VERTEX_UV) {
+        auto vertex_offset = __float_as_uint(ip[1].w), tri_offset = __float_as_uint(ip[2].w);
+        auto tri = scene.triangles[tri_offset + prim];
+        auto vp = reinterpret_cast<const float4 *>(scene.vertices + vertex_offset);
+        auto a1 = vp[tri.i0 * 2u + 1u], b1 = vp[tri.i1 * 2u + 1u], c1 = vp[tri.i2 * 2u + 1u];
+        auto w = 1.f - u - v;
+        uv = f2{w * a1.z + u * b1.z + v * c1.z, w * a1.w + u * b1.w + v * c1.w};
+    }
+    auto xi = static_cast<float>(xxhash32_4(inst_id, prim, __float_as_uint(u), __float_as_uint(v))) * 0x1p-32f;
+    return xi > surface_opacity(scene, (h.y >> 12u) & 4095u, uv);
+}
+
 // LuisaCompute `offset_ray_origin` (Ray Tracing Gems ch. 6), restated from the published algorithm
 LR_D f3 offset_ray_origin(f3 p, f3 n) {
     constexpr auto origin = 1.0f / 32.0f;

@@ -113,10 +113,16 @@ LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
     tr.phase = phase;
 }
 
+// Geometry::_alpha_skip (geometry.cpp:165-192), defined in dev_shade.h next to the texture code
+LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float u, float v);
+
 // Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`
 // lanes have finished theirs.  A lane in kPhaseShadow that finishes switches to `next_closest`
 // (if has_next) without leaving the loop.  Must be called by all 64 lanes.
-template<bool COUNT>
+// ALPHA: candidate hits on maybe-non-opaque instances (triangle flag bit 1 clear) pass through the
+// stochastic alpha test before they are committed, for closest-hit and any-hit rays alike
+// (Geometry::trace_closest / trace_any ray-query branch, geometry.cpp:248-279).
+template<bool COUNT, bool ALPHA>
 LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next,
                       const Ray &next_closest, int refill, TraceStats &stats) {
     const auto lane = threadIdx.x & 63u;
@@ -216,6 +222,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 auto v = dot(tr.d, qvec) * inv_det;
                 auto t = dot(e2, qvec) * inv_det;
                 auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
+                if (ALPHA && ok && (flags & 2u) == 0u) { ok = !alpha_skip(scene, __float_as_uint(a.w), __float_as_uint(b.w), u, v); }
                 if (ok) {
                     tr.t_max = t;
                     found = true;

@@ -242,14 +242,11 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->environment.kind != LR_ENV_NONE && s->environment.kind != LR_ENV_SPHERICAL) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
     }
-    if (s->any_non_opaque) {
-        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: alpha-tested surfaces are not supported yet");
-    }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     release_scene(ctx);
     ctx->bvh_depth = bvh_depth(s->accel);
-    ctx->full_surfaces = false;
+    ctx->full_surfaces = s->any_non_opaque != 0u;// the alpha test lives in the full variant too
     if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");

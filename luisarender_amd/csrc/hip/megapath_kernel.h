@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
             if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
             // ==== (B) traverse until `refill` lanes have results to shade
             TraceStats ts{0u, 0u, 0u, 0u};
-            trace_steps<COUNT>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
+            trace_steps<COUNT, FULL>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
                 local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
                 local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy;

@@ -503,6 +503,7 @@ public:
 
     bool surface_maybe_non_opaque(uint32_t tag) const {// OpacitySurfaceWrapper::maybe_non_opaque
         auto &s = _out.surfaces[tag];
+        if (s.kind == LR_SURFACE_MIX) { return surface_maybe_non_opaque(s.u[0]) || surface_maybe_non_opaque(s.u[1]); }// mix.cpp:59-61
         if (s.alpha_tex < 0) { return false; }
         auto &t = _out.textures[static_cast<size_t>(s.alpha_tex)];
         // constant alpha >= 1 is treated as opaque (surface.h:204-216)

@@ -247,7 +247,30 @@ using namespace oracle;
 struct oracle_ctx {
     const lr_scene *scene;
     Accel accel;
-    explicit oracle_ctx(const lr_scene *s) : scene{s}, accel{*s} {}
+    explicit oracle_ctx(const lr_scene *s) : scene{s}, accel{*s} {
+        if (s->any_non_opaque) {// Geometry::trace_closest / trace_any take the ray-query branch (geometry.cpp:219,264)
+            accel.alpha_skip = [this](uint32_t inst, uint32_t prim, float u, float v) { return alpha_skip(inst, prim, u, v); };
+        }
+    }
+
+    // Surface::Instance::evaluate_opacity: OpacitySurfaceWrapper (surface.h:183-189), MixSurfaceInstance (mix.cpp:63-70)
+    float surface_opacity(uint32_t tag, float2 uv) const {
+        auto one = [&](uint32_t t) {
+            auto alpha_tex = scene->surfaces[t].alpha_tex;
+            return alpha_tex >= 0 ? texture_evaluate(*scene, alpha_tex, uv).x : 1.f;
+        };
+        auto &s = scene->surfaces[tag];
+        return s.kind == LR_SURFACE_MIX ? one(s.u[0]) * one(s.u[1]) : one(tag);
+    }
+    // Geometry::_alpha_skip, geometry.cpp:165-192
+    bool alpha_skip(uint32_t inst_id, uint32_t prim, float u, float v) const {
+        auto it = make_interaction(inst_id, prim, f3(1.f - u - v, u, v), true, f3(0.f, 0.f, 1.f));
+        if (!(it.flags() & LR_SHAPE_MAYBE_NON_OPAQUE) || !(it.flags() & LR_SHAPE_HAS_SURFACE)) { return false; }
+        uint32_t ub, vb;
+        std::memcpy(&ub, &u, 4), std::memcpy(&vb, &v, 4);
+        auto xi = static_cast<float>(xxhash32(inst_id, prim, ub, vb)) * 0x1p-32f;
+        return xi > surface_opacity(it.surface_tag(), it.uv);
+    }
 
     // Geometry::shading_point + Interaction ctor, geometry.cpp:345-389, interaction.h:94-99
     Interaction make_interaction(uint32_t inst_id, uint32_t prim_id, float3 bary, bool use_wo, float3 wo_or_pfrom) const {

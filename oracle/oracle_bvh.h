@@ -14,6 +14,7 @@
 #pragma once
 #include <array>
 #include <numeric>
+#include <functional>
 #include <vector>
 
 #include "../include/lr_scene.h"
@@ -195,6 +196,11 @@ inline bool hit_triangle(float3 o, float3 d, float t_min, float t_max, float3 p0
 }
 
 class Accel {
+public:
+    // Geometry::_alpha_skip hook (geometry.cpp:165-192): true = ignore this candidate hit
+    std::function<bool(uint32_t inst, uint32_t prim, float u, float v)> alpha_skip;
+
+private:
     const lr_scene &_scene;
     std::vector<Bvh2> _blas;                 // per mesh
     Bvh2 _tlas;
@@ -283,6 +289,7 @@ public:
                     counters.tris++;
                     float t, u, v;
                     if (hit_triangle(o, d, ray.t_min, t_max, p0, f3(v1.px, v1.py, v1.pz) - p0, f3(v2.px, v2.py, v2.pz) - p0, t, u, v)) {
+                        if (alpha_skip && (inst.handle.x & LR_SHAPE_MAYBE_NON_OPAQUE) && alpha_skip(inst_id, prim, u, v)) { continue; }
                         t_max = t;
                         hit.inst = inst_id, hit.prim = prim, hit.bary = {u, v}, hit.t = t;
                         if (any) { return true; }

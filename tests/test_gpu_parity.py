@@ -108,6 +108,35 @@ Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
+def test_alpha_tested_traversal(renderer):
+    """Rows a6/a12: stochastic alpha test inside traversal.  The skip decision hashes the candidate's barycentric BITS
+    (geometry.cpp:169), which depend on the intersector (world-space baked triangles here, object-space in the oracle;
+    the reference's own come from the backend's hardware/ray-query unit), so parity is statistical: 8x8 block means."""
+    extra = """
+Texture holes : Checkerboard { on : Constant { v { 1 } } off : Constant { v { 0.2 } } scale { 3 } }
+Surface cutout : Matte { Kd : Constant { v { 0.7, 0.6, 0.2 } } alpha { @holes } }
+Surface veil_a : Mirror { color : Constant { v { 0.9 } } roughness : Constant { v { 0.3 } } alpha : Constant { v { 0.5 } } }
+Surface veil_b : Matte { Kd : Constant { v { 0.2, 0.3, 0.8 } } }
+Surface veil : Mix { a { @veil_a } b { @veil_b } ratio : Constant { v { 0.5 } } }
+"""
+    spp = 256
+    sc = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface="cutout", tall_box_surface="veil", extra_surfaces=extra))
+    assert sc.view().any_non_opaque == 1
+    gpu, gc, cpu, cc = _render_both(renderer, sc, spp)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    blocks = lambda f: f[..., :3].reshape(8, 8, 8, 8, 3).mean(axis=(1, 3))
+    g, c = blocks(gpu), blocks(cpu)
+    assert np.abs(g - c).sum() / np.abs(c).sum() < 1.5e-2
+    assert abs(g.mean() - c.mean()) / c.mean() < 3e-3
+    # the alpha test changes the image: an opaque render of the same scene is far outside that tolerance
+    opaque = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface="cutout", tall_box_surface="veil",
+                                           extra_surfaces=extra.replace("alpha { @holes }", "").replace("alpha : Constant { v { 0.5 } }", "")))
+    renderer.upload(opaque)
+    renderer.render(0, spp, sync=True)
+    assert np.abs(blocks(renderer.download(converted=False)) - c).sum() / np.abs(c).sum() > 5e-2
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) < 5e-3 * cc["closest_rays"]
+
+
 def test_environment_and_thin_lens(renderer):
     text = cornell_box(resolution=64, spp=8).replace("Camera cam : Pinhole {", "Camera cam : ThinLens {\n  aperture { 1.4 } focal_length { 50 } focus_distance { 900 }")
     text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")

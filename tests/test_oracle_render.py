@@ -62,6 +62,23 @@ def test_diffuse_plane_under_uniform_environment():
     assert sc.view().integrator.env_prob == 1.0  # environment only (uniform.cpp:39-41)
 
 
+def test_alpha_tested_plane_closed_form():
+    """Geometry::_alpha_skip (geometry.cpp:165-192): a plane of opacity a under a constant environment shows
+    a * rho * L_env + (1 - a) * L_env; a checkerboard opacity of 0 / 1 averages the two cases."""
+    for alpha, a_mean in (("Constant { v { 0.25 } }", 0.25),
+                          ("Checkerboard { on : Constant { v { 1 } } off : Constant { v { 0 } } scale { 64 } }", 0.5)):
+        sc = Scene.from_string(ENV_QUAD.replace("Surface s : Matte {", "Surface s : Matte { alpha : " + alpha))
+        assert sc.view().any_non_opaque == 1
+        o = Oracle(sc)
+        film, _ = o.render(0, 1024)
+        img = o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0)
+        env = np.array([2.0, 3.0, 4.0])
+        expect = a_mean * np.array([0.6, 0.4, 0.2]) * env + (1 - a_mean) * env
+        assert np.allclose(img, expect, rtol=0.02), (alpha, img, expect)
+    opaque = Scene.from_string(ENV_QUAD.replace("Surface s : Matte {", "Surface s : Matte { alpha : Constant { v { 1 } }"))
+    assert opaque.view().any_non_opaque == 0  # OpacitySurfaceWrapper::maybe_non_opaque, surface.h:177-181
+
+
 def test_directly_visible_light_is_its_emission():
     sc = Scene.from_string(cornell_box(resolution=64, spp=2))
     o = Oracle(sc)
