@@ -17,7 +17,7 @@ BINDIR := luisarender_amd/bin
 HOSTDIR := luisarender_amd/csrc/host
 HIPDIR := luisarender_amd/csrc/hip
 
-HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/image_io.cpp \
+HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/image_io.cpp $(HOSTDIR)/environment.cpp \
             $(HOSTDIR)/accel.cpp $(HOSTDIR)/host_api.cpp $(HOSTDIR)/luisa_render_shim.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
@@ -29,7 +29,7 @@ all: host oracle hip cli
 host: $(LIBDIR)/liblrhost.so
 $(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR) Makefile
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl -pthread
 
 oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h Makefile

@@ -78,6 +78,22 @@ struct alignas(16) DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 64, "DNodeQ is half a cache line");
 
+// Non-constant environments (image-based Spherical with importance tables, Directional), read through a pointer so
+// that the kernel-argument block of the common case stays small.
+struct DEnvironment {
+    float world_to_env[9], env_to_world[9];// column-major 3x3
+    int32_t emission_tex;
+    float scale;
+    uint32_t map_width, map_height;        // 2048 x 1024 (spherical.cpp:22)
+    const lr_alias_entry *alias;           // [h] marginal + [h][w] conditional
+    const float *pdf;                      // [h][w]
+    float direction[3];
+    float cos_half_angle;
+    uint32_t visible, constant_emission, pad[2];
+};
+
+enum : uint32_t { kEnvNone = 0u, kEnvConstant = 1u, kEnvImage = 2u, kEnvDirectional = 3u };
+
 struct DScene {
     // acceleration structure
     const DNodeQ *nodes;
@@ -97,7 +113,7 @@ struct DScene {
     const float *texels;
     const lr_filter *filter;
     DCamera camera;
-    // environment (constant spherical)
+    // environment: kEnv*; kEnvConstant is served from env_L / env_to_world, the others from *env (FULL kernels)
     uint32_t env_kind;
     float env_L[3];
     float env_to_world[9];
@@ -112,6 +128,7 @@ struct DScene {
     uint32_t sobol_scale, pad[3];  // global Sobol pixel grid
     const uint32_t *sobol_matrices;// [1024][52]
     const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
+    const DEnvironment *env;
 };
 
 struct DCounters {

@@ -574,4 +574,73 @@ LR_D void light_evaluate(const DScene &scene, const SurfacePoint &lp, uint32_t p
     pdf = invalid ? 0.f : p;
 }
 
+// ---------------------------------------------------------------- environments (FULL kernels)
+
+LR_D f3 mul3(const float *m, f3 v) { return mk3(m[0], m[1], m[2]) * v.x + mk3(m[3], m[4], m[5]) * v.y + mk3(m[6], m[7], m[8]) * v.z; }
+
+LR_D f3 env_radiance(const DScene &scene, const DEnvironment &env, f2 uv) {// evaluate_illuminant_spectrum(...).value * scale
+    auto v = texture_eval(scene, env.emission_tex, uv);
+    auto rgb = env.constant_emission ? extend_rgb(v, scene.textures[env.emission_tex].channels) : mk3(v.x, v.y, v.z);
+    return max0(rgb);
+}
+LR_D float env_directional_pdf(float p, float theta) {// SphericalInstance::_directional_pdf, spherical.cpp:76-80
+    auto sn = sinf(theta);
+    auto inv_s = sn > 0.f ? 1.f / sn : 0.f;
+    return p * inv_s * (.5f * kInvPi * kInvPi);
+}
+LR_D void env_directional(const DScene &scene, const DEnvironment &env, f3 wi_local, f3 &L, float &pdf) {// directional.cpp:64-73
+    auto valid = env.cos_half_angle < wi_local.z;
+    L = env_radiance(scene, env, f2{.5f, .5f}) * (valid ? env.scale : 0.f);
+    pdf = valid ? 1.f / (2.f * kPi * (1.f - env.cos_half_angle)) : 0.f;
+}
+// Environment::Instance::evaluate: spherical.cpp:88-108, directional.cpp:80-88
+LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
+    auto &env = *scene.env;
+    if (scene.env_kind == kEnvDirectional) {
+        L = mk3(0.f), pdf = 0.f;
+        if (!env.visible) { return; }
+        auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
+        env_directional(scene, env, normalize(to_local(frame, mul3(env.world_to_env, wi))), L, pdf);
+        return;
+    }
+    auto w = normalize(mul3(env.world_to_env, wi));
+    auto theta = acosf(w.y), phi = atan2f(w.x, w.z);// Spherical::direction_to_uv
+    f2 uv{fract(1.f - 0.5f * kInvPi * phi), fract(theta * kInvPi)};
+    L = env_radiance(scene, env, uv) * env.scale;
+    auto sx = static_cast<float>(env.map_width), sy = static_cast<float>(env.map_height);
+    auto ix = static_cast<uint32_t>(clampf(uv.x * sx, 0.f, sx - 1.f)), iy = static_cast<uint32_t>(clampf(uv.y * sy, 0.f, sy - 1.f));
+    pdf = env_directional_pdf(env.pdf[iy * env.map_width + ix], theta);
+}
+// Environment::Instance::sample: spherical.cpp:110-141, directional.cpp:90-98
+LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
+    auto &env = *scene.env;
+    if (scene.env_kind == kEnvDirectional) {
+        auto cos_t = (1.f - u.x) + u.x * env.cos_half_angle;// sample_uniform_cone
+        auto sin_t = sqrtf(fmaxf(1.f - cos_t * cos_t, 0.f));
+        auto phi = 2.f * kPi * u.y;
+        auto wi_local = mk3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+        auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
+        env_directional(scene, env, wi_local, L, pdf);
+        wi = normalize(mul3(env.env_to_world, to_world(frame, wi_local)));
+        return;
+    }
+    auto W = env.map_width, H = env.map_height;
+    float ry, rx;
+    auto sy = alias_slot(u.y, H, ry);
+    auto ey = env.alias[sy];
+    auto py = alias_pick(ey.prob, ey.alias, sy, ry);
+    auto row = env.alias + H + py.index * W;
+    auto sx = alias_slot(u.x, W, rx);
+    auto ex = row[sx];
+    auto px = alias_pick(ex.prob, ex.alias, sx, rx);
+    f2 uv{(static_cast<float>(px.index) + px.u) / static_cast<float>(W), (static_cast<float>(py.index) + py.u) / static_cast<float>(H)};
+    auto p = env.pdf[py.index * W + px.index];
+    auto phi = 2.f * kPi * (1.f - uv.x), theta = kPi * uv.y;// Spherical::uv_to_direction
+    auto sin_theta = sinf(theta);
+    auto w = normalize(mk3(sinf(phi) * sin_theta, cosf(theta), cosf(phi) * sin_theta));
+    L = env_radiance(scene, env, uv) * env.scale;
+    pdf = env_directional_pdf(p, theta);
+    wi = normalize(mul3(env.env_to_world, w));
+}
+
 }// namespace lrd

@@ -239,7 +239,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
     }
-    if (s->environment.kind != LR_ENV_NONE && s->environment.kind != LR_ENV_SPHERICAL) {
+    if (s->environment.kind > LR_ENV_DIRECTIONAL) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
     }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
@@ -338,16 +338,44 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     cam.tan_half_fov = s->camera.tan_half_fov, cam.focus_distance = s->camera.focus_distance;
     cam.lens_radius = s->camera.lens_radius, cam.projected_pixel_size = s->camera.projected_pixel_size;
     cam.ortho_scale = s->camera.ortho_scale, cam.clip_near = s->camera.clip_near, cam.clip_far = s->camera.clip_far;
-    d.env_kind = s->environment.kind;
-    if (d.env_kind == LR_ENV_SPHERICAL) {
-        auto &t = s->textures[s->environment.emission_tex];
-        if (t.kind != LR_TEX_CONSTANT) {
-            release_scene(ctx);
-            return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: image-based environments are SURVEY §8 f1 (next)");
+    d.env_kind = lrd::kEnvNone;
+    d.env = nullptr;
+    if (s->environment.kind != LR_ENV_NONE) {
+        auto &e = s->environment;
+        auto &t = s->textures[e.emission_tex];
+        if (e.kind == LR_ENV_SPHERICAL && t.kind == LR_TEX_CONSTANT) {
+            d.env_kind = lrd::kEnvConstant;
+            auto sv = lrd::max0(lrd::extend_rgb(make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), t.channels)) * e.scale;
+            d.env_L[0] = sv.x, d.env_L[1] = sv.y, d.env_L[2] = sv.z;
+            std::memcpy(d.env_to_world, e.env_to_world, sizeof(d.env_to_world));
+        } else {
+            if (e.kind == LR_ENV_SPHERICAL && (e.alias == nullptr || e.pdf == nullptr || e.map_width == 0u || e.map_height == 0u)) {
+                release_scene(ctx);
+                return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: image-based Spherical environment without importance tables");
+            }
+            d.env_kind = e.kind == LR_ENV_SPHERICAL ? lrd::kEnvImage : lrd::kEnvDirectional;
+            ctx->full_surfaces = true;
+            lrd::DEnvironment de{};
+            std::memcpy(de.world_to_env, e.world_to_env, sizeof(de.world_to_env));
+            std::memcpy(de.env_to_world, e.env_to_world, sizeof(de.env_to_world));
+            de.emission_tex = e.emission_tex, de.scale = e.scale;
+            de.constant_emission = t.kind == LR_TEX_CONSTANT ? 1u : 0u;
+            std::memcpy(de.direction, e.direction, sizeof(de.direction));
+            de.cos_half_angle = e.cos_half_angle, de.visible = e.visible;
+            int rc2 = LRHIP_OK;
+            if (d.env_kind == lrd::kEnvImage) {
+                de.map_width = e.map_width, de.map_height = e.map_height;
+                auto texels = static_cast<size_t>(e.map_width) * e.map_height;
+                if ((rc2 = upload(ctx, e.alias, texels + e.map_height, &de.alias)) != LRHIP_OK || (rc2 = upload(ctx, e.pdf, texels, &de.pdf)) != LRHIP_OK) {
+                    release_scene(ctx);
+                    return rc2;
+                }
+            }
+            if ((rc2 = upload(ctx, &de, 1u, &d.env)) != LRHIP_OK) {
+                release_scene(ctx);
+                return rc2;
+            }
         }
-        auto sv = lrd::max0(lrd::extend_rgb(make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), t.channels)) * s->environment.scale;
-        d.env_L[0] = sv.x, d.env_L[1] = sv.y, d.env_L[2] = sv.z;
-        std::memcpy(d.env_to_world, s->environment.env_to_world, sizeof(d.env_to_world));
     }
     d.max_depth = s->integrator.max_depth, d.rr_depth = s->integrator.rr_depth;
     d.rr_threshold = s->integrator.rr_threshold, d.env_prob = s->integrator.env_prob;
@@ -415,7 +443,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     ctx->timed = false;
     if (p->spp_end == p->spp_begin || p->tile_begin == p->tile_end) { return LRHIP_OK; }
     // MegakernelPathTracingInstance::_render_one_camera (mega_path.cpp:40-47): no lights -> nothing rendered
-    if (!ctx->scene.has_lights && ctx->scene.env_kind == LR_ENV_NONE) { return LRHIP_OK; }
+    if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
     // chunking is a function of the frame only (tile_count, spp), never of the device or the shard

@@ -108,9 +108,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                     auto wo = -tr.d;
                     auto hit = tr.hit;
                     auto hit_valid = hit.inst != kInvalid;
-                    if (!hit_valid && scene.env_kind != LR_ENV_NONE) {// miss, mega_path.cpp:70-76
-                        auto pdf = (kInvPi * 0.25f) * scene.env_prob;
-                        Li += beta * mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]) * balance(pdf_bsdf, pdf);
+                    if (!hit_valid && scene.env_kind != kEnvNone) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
+                        f3 L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
+                        auto pdf = kInvPi * 0.25f;
+                        if (FULL && scene.env_kind != kEnvConstant) { env_evaluate(scene, tr.d, L, pdf); }
+                        Li += beta * L * balance(pdf_bsdf, pdf * scene.env_prob);
                     }
                     SurfacePoint it;
                     auto has_surface = false;
@@ -151,15 +153,21 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                                 is_env = u_light_selection < scene.env_prob;
                                 prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
                             }
-                            if (is_env) {// constant spherical environment: uniform sphere, spherical.cpp:114-118,138
-                                auto z = 1.0f - 2.0f * u_light_surface.x;
-                                auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
-                                auto phi = 2.0f * kPi * u_light_surface.y;
-                                auto w = mk3(r * cosf(phi), r * sinf(phi), z);
-                                auto e = scene.env_to_world;
-                                auto wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
-                                light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
-                                light_pdf = (kInvPi * 0.25f) * prob;
+                            if (is_env) {// _sample_environment, uniform.cpp:125-137
+                                f3 wi;
+                                if (FULL && scene.env_kind != kEnvConstant) {
+                                    env_sample(scene, u_light_surface, wi, light_L, light_pdf);
+                                    light_pdf *= prob;
+                                } else {// constant emission: uniform sphere, spherical.cpp:114-118,138
+                                    auto z = 1.0f - 2.0f * u_light_surface.x;
+                                    auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+                                    auto phi = 2.0f * kPi * u_light_surface.y;
+                                    auto w = mk3(r * cosf(phi), r * sinf(phi), z);
+                                    auto e = scene.env_to_world;
+                                    wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
+                                    light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
+                                    light_pdf = (kInvPi * 0.25f) * prob;
+                                }
                                 shadow.o = robust_origin(it, wi);
                                 shadow.d = wi;
                                 shadow.t_min = 0.f, shadow.t_max = kFloatMax;

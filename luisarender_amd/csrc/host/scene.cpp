@@ -1017,12 +1017,26 @@ void Builder::build_environment(const NodeDesc *d) {
         env.scale = std::max(d->float_or("scale", 1.f), 0.f);
         env.compensate_mis = d->bool_or("compensate_mis", true) ? 1u : 0u;
         if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
-        auto &t = _out.textures[static_cast<size_t>(env.emission_tex)];
-        if (env.kind != LR_ENV_NONE && t.kind != LR_TEX_CONSTANT) {
-            throw Error{"Image-based Spherical environments are row f1 of SURVEY §8 (next); only constant emission is built."};
+        if (env.kind != LR_ENV_NONE) { build_environment_tables(_out); }// no-op for constant emission
+    } else if (d->impl_type() == "directional") {// directional.cpp:27-47
+        env.kind = LR_ENV_DIRECTIONAL;
+        env.emission_tex = load_texture(d->node("emission"));
+        if (_out.textures[static_cast<size_t>(env.emission_tex)].kind != LR_TEX_CONSTANT) {
+            log_warning("Directional environment emission is not constant. This may lead to unexpected results. [" + d->location() + "]");
         }
+        auto scale = std::max(d->float_or("scale", 1.f), 0.f);
+        env.visible = d->bool_or("visible", true) ? 1u : 0u;
+        auto angle = std::clamp(d->float_or("angle", 1.f), 1e-3f, 360.f);
+        auto cos_half_angle = std::cos(.5 * angle * 3.14159265358979323846 / 180.0);
+        env.cos_half_angle = static_cast<float>(cos_half_angle);
+        if (d->bool_or("normalize", true)) { scale = static_cast<float>(2. * scale / (1. - cos_half_angle)); }
+        env.scale = scale;
+        auto dv = d->vector_opt("direction", 3u);
+        auto dir = dv ? normalize(float3{static_cast<float>((*dv)[0]), static_cast<float>((*dv)[1]), static_cast<float>((*dv)[2])}) : float3{0.f, 1.f, 0.f};
+        env.direction[0] = dir.x, env.direction[1] = dir.y, env.direction[2] = dir.z;
+        if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
     } else {
-        throw Error{"Environment '" + d->impl_type() + "' is row f1 of SURVEY §8 (next). [" + d->location() + "]"};
+        throw Error{"Environment '" + d->impl_type() + "' is not built (SURVEY §8 f1: Spherical and Directional are). [" + d->location() + "]"};
     }
 }
 

@@ -68,6 +68,9 @@ lr_uint4 encode_instance_handle(uint32_t buffer_base, uint32_t flags, uint32_t s
 
 std::unique_ptr<SceneData> build_scene(const SceneDesc &desc);
 
+// environment.cpp: importance tables of an image-based Spherical environment (spherical.cpp:144-235)
+void build_environment_tables(SceneData &scene);
+
 // accel.cpp: flatten instances to world space and build the 4-wide BVH for the HIP kernel
 void build_accel(SceneData &scene);
 

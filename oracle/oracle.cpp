@@ -350,6 +350,72 @@ struct oracle_ctx {
         return {invalid ? f3(0.f) : L, invalid ? 0.f : pdf};
     }
 
+    // ---- Environment::Instance::evaluate / sample: spherical.cpp:88-141 (constant emission -> uniform sphere;
+    // image emission -> 2048 x 1024 alias/pdf tables), directional.cpp:62-98
+    static float3 mul3(const float m[9], float3 v) {// column-major 3x3
+        return f3(m[0], m[1], m[2]) * v.x + f3(m[3], m[4], m[5]) * v.y + f3(m[6], m[7], m[8]) * v.z;
+    }
+    static float directional_pdf(float p, float theta) {// spherical.cpp:76-80
+        auto sn = std::sin(theta);
+        auto inv_s = sn > 0.f ? 1.f / sn : 0.f;
+        return p * inv_s * (.5f * inv_pi * inv_pi);
+    }
+    bool env_is_image() const { return scene->environment.kind == LR_ENV_SPHERICAL && scene->environment.map_width != 0u; }
+    LightEval env_directional(float3 wi_local) const {// DirectionalInstance::_evaluate
+        auto &env = scene->environment;
+        auto L = illuminant(*scene, env.emission_tex, {.5f, .5f}).value;
+        auto pdf = 1.f / (2.f * pi * (1.f - env.cos_half_angle));// uniform_cone_pdf, sampling.cpp:119-121
+        auto valid = env.cos_half_angle < cos_theta(wi_local);
+        return {L * (valid ? env.scale : 0.f), valid ? pdf : 0.f};
+    }
+    LightEval env_evaluate(float3 wi) const {
+        auto &env = scene->environment;
+        if (env.kind == LR_ENV_DIRECTIONAL) {
+            if (!env.visible) { return {}; }
+            auto frame = Frame::make(f3(env.direction[0], env.direction[1], env.direction[2]));
+            return env_directional(normalize(frame.world_to_local(mul3(env.world_to_env, wi))));
+        }
+        auto w = normalize(mul3(env.world_to_env, wi));
+        auto theta = std::acos(w.y), phi = std::atan2(w.x, w.z);// Spherical::direction_to_uv, spherical.cpp:51-57
+        float2 uv{fract(1.f - 0.5f * inv_pi * phi), fract(theta * inv_pi)};
+        auto L = illuminant(*scene, env.emission_tex, uv).value * env.scale;
+        if (!env_is_image()) { return {L, uniform_sphere_pdf}; }
+        auto sx = static_cast<float>(env.map_width), sy = static_cast<float>(env.map_height);
+        auto ix = static_cast<uint32_t>(clampf(uv.x * sx, 0.f, sx - 1.f)), iy = static_cast<uint32_t>(clampf(uv.y * sy, 0.f, sy - 1.f));
+        return {L, directional_pdf(env.pdf[iy * env.map_width + ix], theta)};
+    }
+    struct EnvSample {
+        LightEval eval;
+        float3 wi;
+    };
+    EnvSample env_sample(float2 u) const {
+        auto &env = scene->environment;
+        if (env.kind == LR_ENV_DIRECTIONAL) {
+            auto cos_t = (1.f - u.x) + u.x * env.cos_half_angle;// sample_uniform_cone, sampling.cpp:123-131
+            auto sin_t = std::sqrt(std::max(1.f - cos_t * cos_t, 0.f));
+            auto phi = 2.f * pi * u.y;
+            auto wi_local = f3(sin_t * std::cos(phi), sin_t * std::sin(phi), cos_t);
+            auto frame = Frame::make(f3(env.direction[0], env.direction[1], env.direction[2]));
+            return {env_directional(wi_local), normalize(mul3(env.env_to_world, frame.local_to_world(wi_local)))};
+        }
+        if (!env_is_image()) {
+            auto w = sample_uniform_sphere(u);
+            auto L = illuminant(*scene, env.emission_tex, {0.f, 0.f}).value * env.scale;
+            return {{L, uniform_sphere_pdf}, normalize(mul3(env.env_to_world, w))};
+        }
+        auto W = env.map_width, H = env.map_height;
+        auto sy = sample_alias_table([&](uint32_t i) { return env.alias[i].prob; }, [&](uint32_t i) { return env.alias[i].alias; }, H, u.y);
+        auto row = env.alias + H + sy.index * W;
+        auto sx = sample_alias_table([&](uint32_t i) { return row[i].prob; }, [&](uint32_t i) { return row[i].alias; }, W, u.x);
+        float2 uv{(static_cast<float>(sx.index) + sx.u) / static_cast<float>(W), (static_cast<float>(sy.index) + sy.u) / static_cast<float>(H)};
+        auto p = env.pdf[sy.index * W + sx.index];
+        auto phi = 2.f * pi * (1.f - uv.x), theta = pi * uv.y;// Spherical::uv_to_direction, spherical.cpp:42-50
+        auto sin_theta = std::sin(theta);
+        auto w = normalize(f3(std::sin(phi) * sin_theta, std::cos(theta), std::cos(phi) * sin_theta));
+        auto L = illuminant(*scene, env.emission_tex, uv).value * env.scale;
+        return {{L, directional_pdf(p, theta)}, normalize(mul3(env.env_to_world, w))};
+    }
+
     struct LightSample {
         LightEval eval;
         Ray shadow_ray{{0.f, 0.f, 0.f}, 0.f, {0.f, 0.f, 0.f}, 0.f};
@@ -373,14 +439,10 @@ struct oracle_ctx {
             prob = is_env ? env_prob : (1.f - env_prob) / n;
         }
         LightSample out;
-        if (is_env) {// spherical.cpp:110-141 (constant emission: uniform sphere)
-            auto &env = s.environment;
-            auto w = sample_uniform_sphere(u_light);
-            auto L = illuminant(s, env.emission_tex, {0.f, 0.f}).value * env.scale;
-            auto e2w = env.env_to_world;
-            auto wi = normalize(f3(e2w[0], e2w[1], e2w[2]) * w.x + f3(e2w[3], e2w[4], e2w[5]) * w.y + f3(e2w[6], e2w[7], e2w[8]) * w.z);
-            out.eval = {L, uniform_sphere_pdf * prob};
-            out.shadow_ray = spawn_ray(it, wi);
+        if (is_env) {// _sample_environment, uniform.cpp:125-137
+            auto es = env_sample(u_light);
+            out.eval = {es.eval.L, es.eval.pdf * prob};
+            out.shadow_ray = spawn_ray(it, es.wi);
             return out;
         }
         // _sample_area, uniform.cpp:107-123
@@ -423,9 +485,8 @@ struct oracle_ctx {
             auto hit = accel.trace(ray, false, stats.trace);
             if (hit.miss()) {
                 if (has_env) {// evaluate_miss, uniform.cpp:67-76
-                    auto L = illuminant(s, s.environment.emission_tex, {0.f, 0.f}).value * s.environment.scale;
-                    auto pdf = uniform_sphere_pdf * s.integrator.env_prob;
-                    Li += beta * L * balance_heuristic(pdf_bsdf, pdf);
+                    auto eval = env_evaluate(ray.d);
+                    Li += beta * eval.L * balance_heuristic(pdf_bsdf, eval.pdf * s.integrator.env_prob);
                 }
                 break;
             }

@@ -137,6 +137,44 @@ Surface veil : Mix { a { @veil_a } b { @veil_b } ratio : Constant { v { 0.5 } } 
     assert abs(gc["closest_rays"] - cc["closest_rays"]) < 5e-3 * cc["closest_rays"]
 
 
+ENV_SCENE = """
+Surface ground : Matte {{ Kd : Constant {{ v {{ 0.5, 0.5, 0.5 }} }} }}
+Surface shiny : Plastic {{ Kd : Constant {{ v {{ 0.7, 0.2, 0.1 }} }} roughness : Constant {{ v {{ 0.15 }} }} }}
+Shape quad : InlineMesh {{ positions {{ -20,0,-20, 20,0,-20, 20,0,20, -20,0,20 }} indices {{ 0,2,1, 0,3,2 }} surface {{ @ground }} }}
+Shape cube : InlineMesh {{
+  positions {{ -1,0,-1, 1,0,-1, 1,2,-1, -1,2,-1, -1,0,1, 1,0,1, 1,2,1, -1,2,1 }}
+  indices {{ 0,2,1, 0,3,2,  4,5,6, 4,6,7,  0,1,5, 0,5,4,  3,6,2, 3,7,6,  0,7,3, 0,4,7,  1,2,6, 1,6,5 }}
+  surface {{ @shiny }} transform : SRT {{ rotate {{ 0, 1, 0, 30 }} }} }}
+Camera cam : Pinhole {{ fov {{ 40 }} spp {{ {spp} }} film : Color {{ resolution {{ 64, 48 }} clamp {{ 64 }} }}
+  position {{ 0, 4, 9 }} look_at {{ 0, 1, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @quad, @cube }}
+  environment : {env}
+  integrator : MegaPath {{ depth {{ 6 }} rr_depth {{ 2 }} }} }}
+"""
+
+
+@pytest.mark.parametrize("kind", ["image", "image_rotated", "directional", "directional_hidden"])
+def test_image_and_directional_environments(renderer, tmp_path, kind):
+    """Rows a11 / f1: importance-sampled lat-long environment (alias + pdf tables built by lrhost, shared by both sides) and
+    the Directional cone, on the FULL kernel variant.  acos/atan2/sin differ by ulps between libm and the device, which can
+    move a lookup across a texel edge, hence 1e-3 instead of the 1e-4 of the all-arithmetic scenes."""
+    from test_environment import sky_image
+    from luisarender_amd.scene import save_image
+    path = str(tmp_path / "sky.exr")
+    save_image(path, sky_image())
+    env = {"image": f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} }}',
+           "image_rotated": f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} scale {{ 2 }} compensate_mis {{ false }} transform : SRT {{ rotate {{ 0.2, 1, 0.1, 130 }} }} }}',
+           "directional": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 6 } direction { 0.4, 1, 0.3 } }",
+           "directional_hidden": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 25 } direction { -0.5, 1, 0.2 } visible { false } normalize { false } scale { 4 } }"}[kind]
+    sc = Scene.from_string(ENV_SCENE.format(env=env, spp=16))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
+    assert cpu[..., :3].mean() > 0.01
+    assert _rel_l1(gpu, cpu) < 1e-3, kind
+    assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 3e-4
+
+
 def test_environment_and_thin_lens(renderer):
     text = cornell_box(resolution=64, spp=8).replace("Camera cam : Pinhole {", "Camera cam : ThinLens {\n  aperture { 1.4 } focal_length { 50 } focus_distance { 900 }")
     text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
