@@ -59,6 +59,8 @@ typedef struct lrhip_counters {
     /* SIMD-occupancy diagnostics: lane-iterations of the traversal loop (all lanes of every wave) and the
      * ones in which the lane had a ray in flight; shading blocks executed per lane / with a hit to shade */
     uint64_t trace_steps, trace_steps_busy, shade_calls, shade_busy;
+    uint64_t trace_steps_starved; /* lane-steps idle because the lane had no sample left to start */
+    uint64_t reserved;
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);

@@ -139,7 +139,7 @@ class OracleCounters(C.Structure):
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
-                                   "shade_calls", "shade_busy")]
+                                   "shade_calls", "shade_busy", "trace_steps_starved", "reserved")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -57,6 +57,7 @@ struct HitRecord {
 struct TraceStats {
     uint32_t nodes, tris;
     uint32_t steps, steps_busy;// loop iterations of the wave / iterations in which this lane did work
+    uint32_t steps_starved;    // iterations this lane sat out because its pixel had no samples left to start
 };
 
 struct TraversalStack {
@@ -134,7 +135,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
     const auto my_swz = (lane >> 2u) & 3u;
     auto idle_at_entry = tr.phase == kPhaseIdle;
     for (;;) {
-        if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u; }
+        if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
         auto live = tr.phase != kPhaseIdle;
         auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
         if (__any(is_inner)) {

@@ -43,7 +43,8 @@ struct DeviceBuffer {
 
 // persistent-grid sizing inputs that must not depend on the device actually present, so that the
 // chunking (and therefore the fp32 summation order of the film) is identical on every GPU
-constexpr uint32_t kChunkTargetItems = 4u * 256u * 8u;
+constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
+constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
 
 }// namespace
 
@@ -446,8 +447,13 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
-    // chunking is a function of the frame only (tile_count, spp), never of the device or the shard
-    auto chunk_count = std::max(1u, std::min(spp, (kChunkTargetItems + tile_count - 1u) / tile_count));
+    // Chunking is a function of the frame only (tile_count, spp), never of the device or the shard.  Two losses are
+    // balanced: the drain at the end of every item (the last paths of its queue finish with most lanes idle, a share
+    // of ~2.5 / S for S samples per pixel and item) and the tail of the launch (waves that run out of items while
+    // the last ones finish, ~S * waves / (2 * spp * tiles))  ->  S = sqrt(5 * spp * tiles / waves).
+    auto s_item = std::sqrt(5.0 * spp * tile_count / kNominalWaves);
+    auto chunk_count = static_cast<uint32_t>(std::lround(spp / std::max(s_item, 1.0)));
+    chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
     lrd::RenderArgs args{};
     args.film = ctx->film;
     args.spp_begin = p->spp_begin, args.spp_end = p->spp_end;

@@ -1,38 +1,38 @@
 // megapath_kernel.h — the persistent-threads megakernel path tracer for gfx950.
 //
 // One launch renders (tiles x sample-chunks) work items pulled from an atomic queue.  A
-// wavefront owns one 8x8-pixel tile at a time, lane <-> pixel, and each lane walks its pixel's
-// samples back to back ("path regeneration"): the moment a path dies the lane starts the next
-// sample, so the wave's 64 lanes stay occupied until the tile's samples run out.  Pixel sums live
-// in registers for the whole item and are written once — no film atomics (the reference does four
-// float atomics per sample, src/films/color.cpp:116-121).
+// wavefront owns one 8x8-pixel tile and a range of sample indices at a time: 64 x S samples, numbered
+// k = 64 * (s - s_begin) + pixel.  Lanes are NOT bound to pixels: whenever a lane's path dies it takes
+// the next unstarted k of the item ("path regeneration" from a wave-wide queue: ballot + prefix count,
+// no atomics), so short paths (pixels that see a light or the sky) do not leave their lanes idle while
+// the long ones finish.  Radiance is accumulated into a per-wave LDS copy of the tile (ds_add_f32) and
+// written to the film once per item — no global film atomics (the reference does four float atomics
+// per sample, src/films/color.cpp:116-121).  The order in which a wave picks and finishes samples is a
+// function of the item alone (wave-internal control flow only depends on its own data), so the sums are
+// bit-reproducible run to run and independent of how tiles are sharded over GPUs.
 //
-// Per loop iteration every live lane traces at most two rays in ONE traversal loop
-// (dev_trace.h trace_pair): the shadow ray of the bounce just shaded and the continuation ray.
-// A path whose only pending work is a shadow ray is retired into (Li_prev, nee) so the lane can
-// already start the next sample's camera ray in the same traversal.
+// Per loop iteration every lane without a ray in flight consumes its results, shades, and launches up
+// to two rays which are traced back to back in ONE resumable traversal loop (dev_trace.h): the shadow
+// ray of the bounce just shaded and the continuation ray.
 //
 // The estimator is the reference's MegakernelPathTracingInstance::Li
 // (src/integrators/mega_path.cpp:49-156) and film accumulation ColorFilmInstance::_accumulate
-// (src/films/color.cpp:107-130); sample order per pixel is the reference's (spp launches in
-// sequence, src/base/integrator.cpp:92-94), so sums are reproduced in the same order.
+// (src/films/color.cpp:107-130).
 #pragma once
 #include "dev_shade.h"
 
 namespace lrd {
 
-// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) on a pixel this lane owns
-// exclusively: plain read-modify-write of the float4, no atomics.  The 32 B/sample of film traffic are
-// lane-coalesced (8 pixels of a tile row = 128 B) and stay hot in L2.
+// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) into the wave's LDS copy of its tile.
 LR_D void film_accumulate(float4 *pixel, f3 rgb, float clamp) {
     if (!(any_nan(rgb) || any_inf(rgb))) {
         auto threshold = clamp * fmaxf(1.f, 1.f);
         auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
         auto c = rgb * (threshold / fmaxf(strength, threshold));
-        auto acc = *pixel;
-        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) { acc.x += c.x, acc.y += c.y, acc.z += c.z; }
-        acc.w += 1.f;
-        *pixel = acc;
+        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) {
+            atomicAdd(&pixel->x, c.x), atomicAdd(&pixel->y, c.y), atomicAdd(&pixel->z, c.z);
+        }
+        atomicAdd(&pixel->w, 1.f);
     }
 }
 
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
+    __shared__ float4 s_film[kWavesPerBlock * 64u];// per-wave tile accumulators (sum r, g, b, n)
     TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + (tid >> 6u) * 256u};
+    const auto film_tile = s_film + (tid >> 6u) * 64u;
     DCounters local{};
 
     for (;;) {
@@ -71,18 +73,16 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         const auto chunk = item - tile_index * args.chunk_count;
         const auto tile = args.tile_begin + tile_index * args.tile_stride;
         const auto tx = tile % args.tiles_x, ty = tile / args.tiles_x;
-        const auto px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3u);
-        const auto in_bounds = px < scene.camera.width && py < scene.camera.height;
-        const auto pixel_index = py * scene.camera.width + px;
         const auto spp_total = args.spp_end - args.spp_begin;
         const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
-        auto s_next = args.spp_begin + chunk * per_chunk;
-        const auto s_end = min(s_next + per_chunk, args.spp_end);
-        // chunk_count == 1: accumulate into the film itself; otherwise into this chunk's partial plane
-        auto pixel = args.chunk_count == 1u ? args.film + pixel_index :
-                                               args.partial + static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + pixel_index;
-        if (in_bounds && args.chunk_count != 1u) { *pixel = make_float4(0.f, 0.f, 0.f, 0.f); }
-
+        const auto s_begin = args.spp_begin + chunk * per_chunk;
+        const auto s_end = min(s_begin + per_chunk, args.spp_end);
+        // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile
+        const auto q_total = s_end > s_begin ? (s_end - s_begin) * 64u : 0u;
+        auto q_next = 0u;// wave-uniform
+        film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto px = 0u, py = 0u;
+        auto pixel = film_tile;// LDS accumulator of the pixel this lane's current sample belongs to
         // ---- per-lane path state
         PathSampler<PCG> sampler{};
         TravState tr{};
@@ -94,10 +94,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         auto path_open = false, traced_shadow = false, traced_closest = false;
 
         for (;;) {
-            // ==== (A) lanes without a ray in flight: consume results, shade, regenerate, launch rays
+            // ==== (A) lanes without a ray in flight: consume results and shade
+            auto want_shadow = false, want_closest = false;
+            Ray shadow{};
             if (tr.phase == kPhaseIdle) {
-                auto want_shadow = false, want_closest = false;
-                Ray shadow{};
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
                     if (!tr.occluded) { Li += nee; }
                     traced_shadow = false;
@@ -299,20 +299,33 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                     film_accumulate(pixel, Li, scene.film_clamp);
                     path_open = false;
                 }
-                if (!path_open && in_bounds && s_next < s_end) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
-                    sampler.start(scene, px, py, s_next);
-                    s_next++;
-                    auto u_filter = sampler.next_pixel_2d();
-                    auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
-                    float weight;
-                    camera_ray(scene, scene.filter, px, py, u_filter, u_lens, ray, weight);
-                    beta = mk3(weight);
-                    Li = mk3(0.f);
-                    pdf_bsdf = 1e16f;
-                    depth = 0u;
-                    path_open = true, want_closest = true;
-                    if (COUNT) { local.paths++; }
+            }
+            // ==== (A') path regeneration: lanes with no path take the next samples of the item's queue, in lane order
+            {
+                const auto need = tr.phase == kPhaseIdle && !path_open;
+                const auto mask = __ballot(need);
+                const auto k = q_next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+                q_next = min(q_next + static_cast<uint32_t>(__popcll(mask)), q_total);
+                if (need && k < q_total) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
+                    const auto pix = k & 63u;
+                    px = tx * 8u + (pix & 7u), py = ty * 8u + (pix >> 3u);
+                    pixel = film_tile + pix;
+                    if (px < scene.camera.width && py < scene.camera.height) {
+                        sampler.start(scene, px, py, s_begin + (k >> 6u));
+                        auto u_filter = sampler.next_pixel_2d();
+                        auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
+                        float weight;
+                        camera_ray(scene, scene.filter, px, py, u_filter, u_lens, ray, weight);
+                        beta = mk3(weight);
+                        Li = mk3(0.f);
+                        pdf_bsdf = 1e16f;
+                        depth = 0u;
+                        path_open = true, want_closest = true;
+                        if (COUNT) { local.paths++; }
+                    }
                 }
+            }
+            if (tr.phase == kPhaseIdle) {
                 // ---- launch: shadow ray first, the continuation ray follows inside the traversal loop
                 if (want_shadow || want_closest) {
                     tr.hit.inst = kInvalid, tr.hit.prim = kInvalid, tr.hit.u = 0.f, tr.hit.v = 0.f;
@@ -325,12 +338,28 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
             }
             if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
             // ==== (B) traverse until `refill` lanes have results to shade
-            TraceStats ts{0u, 0u, 0u, 0u};
+            TraceStats ts{0u, 0u, 0u, 0u, 0u};
             trace_steps<COUNT, FULL>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
                 local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
-                local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy;
+                local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy, local.trace_steps_starved += ts.steps_starved;
                 local.shade_calls++;
+            }
+        }
+        // ---- item complete: lane l adds pixel l of the tile to the film (or stores this chunk's partial plane)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
+            if (wx < scene.camera.width && wy < scene.camera.height) {
+                const auto acc = film_tile[lane];
+                const auto index = wy * scene.camera.width + wx;
+                if (args.chunk_count == 1u) {
+                    auto f = args.film[index];
+                    f.x += acc.x, f.y += acc.y, f.z += acc.z, f.w += acc.w;
+                    args.film[index] = f;
+                } else {
+                    args.partial[static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + index] = acc;
+                }
             }
         }
     }
@@ -352,6 +381,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         reduce(local.trace_steps_busy, &args.counters->trace_steps_busy);
         reduce(local.shade_calls, &args.counters->shade_calls);
         reduce(local.shade_busy, &args.counters->shade_busy);
+        reduce(local.trace_steps_starved, &args.counters->trace_steps_starved);
     }
 }
 

@@ -15,4 +15,5 @@ with tempfile.TemporaryDirectory() as tmp:
     print(c)
     print('ms', r.last_render_ms(), 'rays/sample', rays / c['paths'], 'nodes/ray', c['nodes_visited'] / rays, 'tris/ray', c['tris_tested'] / rays)
     print('trace lane utilisation', c['trace_steps_busy'] / max(c['trace_steps'], 1), 'steps per ray-lane', c['trace_steps_busy'] / rays)
+    print('trace lanes starved (no sample left for the pixel)', c['trace_steps_starved'] / max(c['trace_steps'], 1))
     print('shade lane utilisation', c['shade_busy'] / max(c['shade_calls'], 1))
