@@ -65,14 +65,31 @@ struct TraversalStack {
     uint32_t *spill;    // &spill[0][gtid]; stride total_threads
     uint32_t spill_stride;
     float4 *stage;      // this wave's 4 KiB staging area (256 x float4)
+    // explicit address spaces: with generic pointers the compiler folds the two paths into one flat_load/flat_store
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(1))) uint32_t global_u32;
     LR_D void push(uint32_t sp, uint32_t v) const {
-        if (sp < kStackLds) { lds[sp * kBlockThreads] = v; }
-        else { spill[static_cast<size_t>(sp - kStackLds) * spill_stride] = v; }
+        if (sp < kStackLds) { *(lds_u32 *)(lds + sp * kBlockThreads) = v; }
+        else { *(global_u32 *)(spill + static_cast<size_t>(sp - kStackLds) * spill_stride) = v; }
     }
     LR_D uint32_t pop(uint32_t sp) const {
-        return sp < kStackLds ? lds[sp * kBlockThreads] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride];
+        uint32_t v;
+        if (sp < kStackLds) { v = *(lds_u32 *)(lds + sp * kBlockThreads); }
+        else { v = *(global_u32 *)(spill + static_cast<size_t>(sp - kStackLds) * spill_stride); }
+        return v;
     }
 };
+
+#ifndef LR_SLAB_SIGN
+#define LR_SLAB_SIGN 1
+#endif
+#ifndef LR_TRI_PREFETCH
+#define LR_TRI_PREFETCH 1
+#endif
+#ifndef LR_PUSH_UNSORTED
+#define LR_PUSH_UNSORTED 0
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 LR_D void cswap(uint32_t &a, uint32_t &b) {
     auto lo = min(a, b), hi = max(a, b);
@@ -166,6 +183,14 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             __builtin_amdgcn_wave_barrier();
             if (is_inner) {
                 if (COUNT) { stats.nodes++; }
+#ifdef LR_PROBE_NODE
+                {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
+                    float dummy = tr.t_min;
+#pragma unroll
+                    for (auto i = 0; i < LR_PROBE_NODE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+                    asm volatile("" ::"v"(dummy));
+                }
+#endif
                 // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
                 //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
                 auto ax = q0.w * tr.inv.x, ay = q2.z * tr.inv.y, az = q2.w * tr.inv.z;
@@ -174,6 +199,31 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
                 uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
                 uint32_t key[4];
+#if LR_SLAB_SIGN
+                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis,
+                // and the 24 plane FMAs go out as 12 v_pk_fma_f32 over child pairs
+                auto nx = tr.inv.x < 0.f ? hix : lox, fx = tr.inv.x < 0.f ? lox : hix;
+                auto ny = tr.inv.y < 0.f ? hiy : loy, fy = tr.inv.y < 0.f ? loy : hiy;
+                auto nz = tr.inv.z < 0.f ? hiz : loz, fz = tr.inv.z < 0.f ? loz : hiz;
+                v2f a_x = {ax, ax}, a_y = {ay, ay}, a_z = {az, az}, b_x = {bx, bx}, b_y = {by, by}, b_z = {bz, bz};
+#pragma unroll
+                for (auto p = 0; p < 4; p += 2) {
+                    v2f qnx = {ubyte_to_float(nx, p), ubyte_to_float(nx, p + 1)}, qfx = {ubyte_to_float(fx, p), ubyte_to_float(fx, p + 1)};
+                    v2f qny = {ubyte_to_float(ny, p), ubyte_to_float(ny, p + 1)}, qfy = {ubyte_to_float(fy, p), ubyte_to_float(fy, p + 1)};
+                    v2f qnz = {ubyte_to_float(nz, p), ubyte_to_float(nz, p + 1)}, qfz = {ubyte_to_float(fz, p), ubyte_to_float(fz, p + 1)};
+                    auto tnx = __builtin_elementwise_fma(qnx, a_x, b_x), tfx = __builtin_elementwise_fma(qfx, a_x, b_x);
+                    auto tny = __builtin_elementwise_fma(qny, a_y, b_y), tfy = __builtin_elementwise_fma(qfy, a_y, b_y);
+                    auto tnz = __builtin_elementwise_fma(qnz, a_z, b_z), tfz = __builtin_elementwise_fma(qfz, a_z, b_z);
+#pragma unroll
+                    for (auto j = 0; j < 2; j++) {
+                        auto i = p + j;
+                        auto tn = fmaxf(fmaxf(tnx[j], tny[j]), fmaxf(tnz[j], tr.t_min));
+                        auto tf = fminf(fminf(tfx[j], tfy[j]), fminf(tfz[j], tr.t_max));
+                        auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
+                        key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
+                    }
+                }
+#else
 #pragma unroll
                 for (auto i = 0; i < 4; i++) {
                     auto t0x = fmaf(ubyte_to_float(lox, i), ax, bx), t1x = fmaf(ubyte_to_float(hix, i), ax, bx);
@@ -184,20 +234,32 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                     auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
                     key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
                 }
-                cswap(key[0], key[1]);
-                cswap(key[2], key[3]);
-                cswap(key[0], key[2]);
-                cswap(key[1], key[3]);
-                cswap(key[1], key[2]);
+#endif
                 auto ref_of = [&](uint32_t k) {// two-level v_cndmask select on the slot bits (no branches)
                     auto lo = (k & 1u) ? ch[1] : ch[0];
                     auto hi = (k & 1u) ? ch[3] : ch[2];
                     return (k & 2u) ? hi : lo;
                 };
+#if LR_PUSH_UNSORTED
+                // the nearest child continues in `cur`; the other hit children are pushed in slot order (their refs are
+                // plain registers then, no select) — only the order among the far children is not by distance
+                auto kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+#pragma unroll
+                for (auto i = 0; i < 4; i++) {
+                    if (key[i] != kInvalid && key[i] != kmin) { stack.push(tr.sp++, ch[i]); }
+                }
+                key[0] = kmin;
+#else
+                cswap(key[0], key[1]);
+                cswap(key[2], key[3]);
+                cswap(key[0], key[2]);
+                cswap(key[1], key[3]);
+                cswap(key[1], key[2]);
                 // push far -> near so that the nearest is popped first; keep the nearest in `cur`
                 if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
                 if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
                 if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
+#endif
                 if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
                 else if (tr.sp > 0u) { tr.cur = stack.pop(--tr.sp); }
                 else { tr.cur = kInvalid; }
@@ -208,15 +270,32 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             auto first = tr.cur & ((1u << 27u) - 1u);
             auto count = ((tr.cur >> 27u) & 15u) + 1u;
             auto found = false;
+#if LR_TRI_PREFETCH
+            auto tb = tris + static_cast<size_t>(first) * 3u;
+            auto na = tb[0], nb = tb[1], nc = tb[2];
+#endif
             for (auto k = 0u; k < count; k++) {
+#if LR_TRI_PREFETCH
+                auto a = na, b = nb, c = nc;
+                if (k + 1u < count) { tb += 3, na = tb[0], nb = tb[1], nc = tb[2]; }// next triangle in flight during this test
+#else
                 auto tb = tris + static_cast<size_t>(first + k) * 3u;
                 auto a = tb[0], b = tb[1], c = tb[2];
+#endif
                 if (COUNT) { stats.tris++; }
+#ifdef LR_PROBE_LEAF
+                {
+                    float dummy = tr.t_min;
+#pragma unroll
+                    for (auto i = 0; i < LR_PROBE_LEAF; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+                    asm volatile("" ::"v"(dummy));
+                }
+#endif
                 auto flags = __float_as_uint(c.w);
                 f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
                 auto pvec = cross(tr.d, e2);
                 auto det = dot(e1, pvec);
-                auto inv_det = 1.0f / det;
+                auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
                 auto tvec = tr.o - p0;
                 auto u = dot(tvec, pvec) * inv_det;
                 auto qvec = cross(tvec, e1);
