@@ -7,8 +7,14 @@ from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
 from luisarender_amd.oracle_check import Oracle
 from luisarender_amd.scenes import cornell_box
+MATERIALS = dict(MATERIALS)
+def mixof(a, b, ratio):
+    return (MATERIALS[a].replace("Surface m ", "Surface mix_a ") + " " + MATERIALS[b].replace("Surface m ", "Surface mix_b ") +
+            " Surface m : Mix { a { @mix_a } b { @mix_b } ratio : Constant { v { %g } } }" % ratio)
+MATERIALS.update({"mm": mixof("matte", "matte", 0.3), "rr": mixof("mirror", "mirror", 0.3), "mr1": mixof("matte", "mirror", 1.0),
+                  "mr0": mixof("matte", "mirror", 0.0), "rm": mixof("mirror", "matte", 0.3), "mr5": mixof("matte", "mirror", 0.5)})
 r = MegaPathRenderer(0)
-for material, force_full in [(m, f) for m in sys.argv[1:] for f in (False, True)]:
+for material, force_full in [(m, False) for m in sys.argv[1:]]:
     extra = MATERIALS[material].replace("Surface m ", f"Surface {material} ") + "\n"
     if force_full:
         extra += 'Surface dummy : Disney { color : Constant { v { 0.5 } } }\nShape far : InlineMesh { positions { 5000,5000,5000, 5001,5000,5000, 5000,5001,5000 } indices { 0,1,2 } surface { @dummy } }\n'
