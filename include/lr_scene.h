@@ -210,8 +210,9 @@ typedef struct lr_integrator {
 typedef struct lr_bvh4_node {   /* 128 B, 8 x float4: SoA over the 4 children */
     float lo_x[4], lo_y[4], lo_z[4];
     float hi_x[4], hi_y[4], hi_z[4];
-    /* child reference: bit31 = leaf; inner: node index; leaf: first triangle (27 bits) and
-     * count-1 in bits 27..30; 0xffffffff = empty slot */
+    /* child reference: bit31 = leaf; inner: node index; leaf: triangle index (27 bits), bits 27..30 =
+     * count-1 which MUST be 0 — the kernel's leaf step tests exactly one triangle (lrhip_upload_scene rejects
+     * anything else); 0xffffffff = empty slot */
     uint32_t child[4];
     uint32_t pad[4];
 } lr_bvh4_node;

@@ -83,9 +83,6 @@ struct TraversalStack {
 #ifndef LR_SLAB_SIGN
 #define LR_SLAB_SIGN 1
 #endif
-#ifndef LR_TRI_PREFETCH
-#define LR_TRI_PREFETCH 1
-#endif
 #ifndef LR_PUSH_UNSORTED
 #define LR_PUSH_UNSORTED 0
 #endif
@@ -265,23 +262,15 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 else { tr.cur = kInvalid; }
             }
         }
-        // ---- leaf: Moeller-Trumbore on 1..4 pre-transformed triangles (3 x dwordx4 each)
+        // ---- leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds one-triangle
+        // leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
+        // of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
+        // (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
         if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
-            auto first = tr.cur & ((1u << 27u) - 1u);
-            auto count = ((tr.cur >> 27u) & 15u) + 1u;
             auto found = false;
-#if LR_TRI_PREFETCH
-            auto tb = tris + static_cast<size_t>(first) * 3u;
-            auto na = tb[0], nb = tb[1], nc = tb[2];
-#endif
-            for (auto k = 0u; k < count; k++) {
-#if LR_TRI_PREFETCH
-                auto a = na, b = nb, c = nc;
-                if (k + 1u < count) { tb += 3, na = tb[0], nb = tb[1], nc = tb[2]; }// next triangle in flight during this test
-#else
-                auto tb = tris + static_cast<size_t>(first + k) * 3u;
+            {
+                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
                 auto a = tb[0], b = tb[1], c = tb[2];
-#endif
                 if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF
                 {

@@ -161,6 +161,7 @@ lrd::DNodeQ quantise_node(const lr_bvh4_node &n) {
     return q;
 }
 
+// depth of the tree; 0 if a leaf holds more than one triangle (the kernel's leaf step tests exactly one)
 uint32_t bvh_depth(const lr_accel &accel) {
     std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
     auto depth = 0u;
@@ -169,7 +170,9 @@ uint32_t bvh_depth(const lr_accel &accel) {
         stack.pop_back();
         depth = std::max(depth, d);
         for (auto c : accel.nodes[node].child) {
-            if (c != LR_INVALID_ID && !(c & 0x80000000u)) { stack.emplace_back(c, d + 1u); }
+            if (c == LR_INVALID_ID) { continue; }
+            if (!(c & 0x80000000u)) { stack.emplace_back(c, d + 1u); }
+            else if (((c >> 27u) & 15u) != 0u) { return 0u; }
         }
     }
     return depth;
@@ -247,6 +250,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     release_scene(ctx);
     ctx->bvh_depth = bvh_depth(s->accel);
+    if (ctx->bvh_depth == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the BVH must have one-triangle leaves (lrhost_scene_build_accel builds them)"); }
     ctx->full_surfaces = s->any_non_opaque != 0u;// the alpha test lives in the full variant too
     if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -40,7 +41,9 @@ struct Node2 {
     uint32_t first{0}, count{0};// ... or primitive range (leaf, count > 0)
 };
 
-constexpr auto max_leaf_size = 4u;
+// One triangle per leaf: the megakernel's lanes sit at different tree depths, so a leaf loop would run for the
+// longest leaf of the wave every traversal step (dev_trace.h); an extra level of boxes is cheaper.
+constexpr auto max_leaf_size = 1u;
 constexpr auto bin_count = 16u;
 
 class Builder2 {
