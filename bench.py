@@ -166,8 +166,11 @@ def main():
                     traffic = None
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false>", "kernel_ms": mean_kernel_ms,
+                "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false, false>", "kernel_ms": mean_kernel_ms,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
+                "note": "algorithmic bytes = canonical BVH2 walk of the oracle (SURVEY 8d); the quantised BVH4 + L2/LDS reuse "
+                        "serve most of them on chip, so `achieved` may exceed the HBM peak while `traffic` (PMC, per launch) "
+                        "stays far below it; the kernel is VALU-issue/latency bound (DESIGN.md section 5)",
             }
             print(json.dumps(out), flush=True)
         renderer.close()
