@@ -105,6 +105,14 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                 if (traced_closest) {// one iteration of the reference's depth loop, mega_path.cpp:63-154
                     traced_closest = false;
                     if (COUNT) { local.shade_busy++; }
+#ifdef LR_PROBE_SHADE
+                    {// sensitivity probe: LR_PROBE_SHADE extra dependent VALU ops per shaded vertex
+                        float dummy = pdf_bsdf;
+#pragma unroll
+                        for (auto i = 0; i < LR_PROBE_SHADE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+                        asm volatile("" ::"v"(dummy));
+                    }
+#endif
                     auto wo = -tr.d;
                     auto hit = tr.hit;
                     auto hit_valid = hit.inst != kInvalid;
