@@ -91,7 +91,9 @@ enum {
     LR_SURFACE_PLASTIC = 4, /* src/surfaces/plastic.cpp (alias Substrate) */
     LR_SURFACE_METAL = 5,   /* src/surfaces/metal.cpp   */
     LR_SURFACE_DISNEY = 6,  /* src/surfaces/disney.cpp  */
-    LR_SURFACE_MIX = 7      /* src/surfaces/mix.cpp     */
+    LR_SURFACE_MIX = 7,     /* src/surfaces/mix.cpp     */
+    LR_SURFACE_LAYERED = 8  /* src/surfaces/layered.cpp: tex[0] thickness, tex[1] g, tex[2] albedo; u[0] top tag, u[1] bottom tag,
+                             * u[2] max_depth, u[3] samples */
 };
 enum {
     LR_SURFACE_FLAG_REMAP_ROUGHNESS = 1u << 0,

@@ -196,7 +196,7 @@ LR_HD bool refract_dir(f3 wi, f3 n, float eta, f3 &wt) {// scattering.cpp:14-28
     wt = (eta * cos_i - cos_t) * n - eta * wi;
     return sin2_t < 1.0f;
 }
-LR_HD f3 mf_transmission_eval(f3 T, GGX g, float eta_a, float eta_b, f3 wo, f3 wi) {// scattering.cpp:322-346
+LR_HD f3 mf_transmission_eval(f3 T, GGX g, float eta_a, float eta_b, f3 wo, f3 wi, bool importance = false) {// scattering.cpp:322-346
     auto cos_o = cos_theta(wo), cos_i = cos_theta(wi);
     auto eta = cos_o > 0.f ? eta_b / eta_a : eta_a / eta_b;
     auto wh = normalize(wo + wi * eta);
@@ -208,6 +208,7 @@ LR_HD f3 mf_transmission_eval(f3 T, GGX g, float eta_a, float eta_b, f3 wo, f3 w
         auto F = fresnel_dielectric(dot(wo, wh), eta_a, eta_b);
         auto D = ggx_D(g, wh);
         f = (1.f - F) * T * D * G * dot(wi, wh) * dot(wo, wh) / (cos_i * cos_o * sqr(sqrt_denom));
+        if (importance) { f = f * sqr(eta); }// TransportMode::IMPORTANCE (Layered's reverse walks only)
     }
     return f;
 }
@@ -402,7 +403,7 @@ LR_HD f3 disney_fresnel(const DisneyLobes &L, float cos_in) {// DisneyFresnel::e
     return mk3(fr) + L.metallic * (f0 - mk3(fr));
 }
 
-LR_HD BsdfEval disney_eval_local(const DisneyLobes &L, f3 wo, f3 wi) {// _evaluate_local, :476-521 / :728-781
+LR_HD BsdfEval disney_eval_local(const DisneyLobes &L, f3 wo, f3 wi, bool importance = false) {// _evaluate_local, :476-521 / :728-781
     auto f = mk3(0.f);
     auto pdf = 0.f;
     if (same_hemisphere(wo, wi)) {
@@ -440,7 +441,7 @@ LR_HD BsdfEval disney_eval_local(const DisneyLobes &L, f3 wo, f3 wi) {// _evalua
         }
     } else {
         if ((L.mask & (1u << 12u)) && L.w[3] > 0.f) {
-            f += mf_transmission_eval(L.Cst, L.tdist, L.eta_i, L.eta_t, wo, wi);
+            f += mf_transmission_eval(L.Cst, L.tdist, L.eta_i, L.eta_t, wo, wi, importance);
             pdf += L.w[3] * mf_transmission_pdf(L.tdist, L.eta_i, L.eta_t, wo, wi);
         }
         if ((L.mask & (1u << 13u)) && L.w[4] > 0.f) {// LambertianTransmission
@@ -492,13 +493,13 @@ LR_HD void disney_sample_local(const DisneyLobes &L, f3 wo, float u_lobe, f2 u, 
 
 // Surface::Closure::evaluate.  FULL = false compiles the Disney interpreter out (lean kernel variant).
 template<bool FULL>
-LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo, f3 wi) {
+LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo, f3 wi, bool importance = false) {
     auto wo_l = to_local(sh, wo);
     auto wi_l = to_local(sh, wi);
     BsdfEval e{mk3(0.f), 0.f};
     auto g = make_ggx(c.alpha_x, c.alpha_y);
     if (FULL && c.kind == LR_SURFACE_DISNEY) {
-        e = disney_eval_local(disney_setup(c), wo_l, wi_l);
+        e = disney_eval_local(disney_setup(c), wo_l, wi_l, importance);
     } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:86-96
         e.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
         e.pdf = cosine_pdf(wo_l, wi_l);
@@ -508,7 +509,7 @@ LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo
         e = plastic_eval_local(c, g, wo_l, wi_l);
     } else if (c.kind == LR_SURFACE_GLASS && !same_hemisphere(wo_l, wi_l)) {// glass.cpp:186-190
         auto ratio = glass_refl_prob(c, wo_l);
-        e.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l) * abs_cos_theta(wi_l);
+        e.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l, importance) * abs_cos_theta(wi_l);
         e.pdf = mf_transmission_pdf(g, c.s0, c.s1, wo_l, wi_l) * (1.f - ratio);
     } else if (c.kind != LR_SURFACE_NULL) {// mirror.cpp:101-115, metal.cpp:228-241, glass.cpp:182-185
         auto fa = closure_fresnel(c);
@@ -526,7 +527,7 @@ LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo
 
 // Surface::Closure::sample
 template<bool FULL>
-LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo, float u_lobe, f2 u) {
+LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo, float u_lobe, f2 u, bool importance = false) {
     auto wo_l = to_local(sh, wo);
     BsdfSample s{mk3(0.f), 0.f, mk3(0.f, 0.f, 1.f), kEventReflect};
     auto g = make_ggx(c.alpha_x, c.alpha_y);
@@ -537,7 +538,7 @@ LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo
         disney_sample_local(L, wo_l, u_lobe, u, wi_l, valid, s.event);
         s.wi = to_world(sh, wi_l);
         if (valid) {
-            auto e = disney_eval_local(L, wo_l, wi_l);
+            auto e = disney_eval_local(L, wo_l, wi_l, importance);
             s.f = e.f, s.pdf = e.pdf;
         }
     } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:98-112
@@ -583,7 +584,7 @@ LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo
             wi_l = mk3(0.f);
             auto refr = refract_dir(wo_l, wh, eta, wi_l);
             if (refr && !same_hemisphere(wo_l, wi_l)) {
-                s.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l);
+                s.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l, importance);
                 s.pdf = mf_transmission_pdf(g, c.s0, c.s1, wo_l, wi_l);
             }
             s.pdf *= (1.f - ratio);

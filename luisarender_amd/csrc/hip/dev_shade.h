@@ -436,6 +436,14 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
             c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = (s.flags & LR_SURFACE_FLAG_THIN) ? 1u : 0u;
             break;
         }
+        case LR_SURFACE_LAYERED: {// layered.cpp:478-500
+            c.s0 = s.tex[0] >= 0 ? fmaxf(tex(s.tex[0]).x, 1.17549435e-38f) : 1e-2f;
+            c.s1 = s.tex[1] >= 0 ? tex(s.tex[1]).x : 0.f;
+            albedo(s.tex[2], 1.f, v, strength);
+            store(c.c0, v);
+            c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = s.u[2], c.x[3] = s.u[3];
+            break;
+        }
         case LR_SURFACE_MIX: {// mix.cpp:198-212
             c.s0 = s.tex[0] >= 0 ? clampf(tex(s.tex[0]).x, 0.f, 1.f) : 0.5f;
             c.x[0] = s.u[0], c.x[1] = s.u[1];

@@ -301,7 +301,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     std::vector<lrd::DClosure> closures(s->surface_count);
     for (uint32_t i = 0; i < s->surface_count; i++) {
         auto &surf = s->surfaces[i];
-        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX) { ctx->full_surfaces = true; }
+        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX || surf.kind == LR_SURFACE_LAYERED) { ctx->full_surfaces = true; }
         auto dynamic = surf.normal_tex >= 0;
         for (auto t : surf.tex) { dynamic = dynamic || !is_constant(t); }
         lrd::DClosure c{};
@@ -315,7 +315,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
                 [&](int32_t id) { return s->textures[id].channels; }, 1.f);
         } else {
             c.kind = surf.kind;
-            c.x[0] = surf.u[0], c.x[1] = surf.u[1];// Mix children / Disney masks are needed before resolution
+            c.x[0] = surf.u[0], c.x[1] = surf.u[1], c.x[2] = surf.u[2], c.x[3] = surf.u[3];// children / masks are needed before resolution
         }
         c.dynamic = dynamic ? 1u : 0u;
         closures[i] = c;

@@ -19,7 +19,7 @@
 // (src/integrators/mega_path.cpp:49-156) and film accumulation ColorFilmInstance::_accumulate
 // (src/films/color.cpp:107-130).
 #pragma once
-#include "dev_shade.h"
+#include "dev_layered.h"
 
 namespace lrd {
 
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                         // ---- material, mega_path.cpp:111-143
                         // load_lobe: closure record + shading frame of surface `t` on top of frame `base`
                         // (NormalMapWrapper, surface.h:236-254, and per-hit texture resolution for dynamic closures)
-                        auto load_lobe = [&](uint32_t t, const Frame &base, DClosure &c, Frame &fr) {
+                        auto load_lobe = [&](uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
                             c = scene.closures[t];
                             fr = base;
-                            if (c.dynamic) {
+                            if (c.dynamic || eta_i != 1.f) {// (eta_i != 1: the bottom of a Layered surface under a refractive top)
                                 auto &raw = scene.surfaces[t];
                                 if (raw.normal_tex >= 0) {
                                     auto v = texture_eval(scene, raw.normal_tex, it.uv);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                                 auto dyn = c.dynamic;
                                 c = resolve_closure(
                                     raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
-                                    [&](int32_t id) { return scene.textures[id].channels; }, 1.f);
+                                    [&](int32_t id) { return scene.textures[id].channels; }, eta_i);
                                 c.dynamic = dyn;
                             }
                         };
@@ -228,6 +228,18 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                         Frame sh;
                         load_lobe((it.tags >> 12u) & 4095u, it.shading, closure, sh);
                         const auto is_mix = FULL && closure.kind == LR_SURFACE_MIX;
+                        const auto is_layered = FULL && closure.kind == LR_SURFACE_LAYERED;
+                        LayerStack layers;
+                        if (is_layered) {// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500
+                            load_lobe(closure.x[0], sh, layers.top, layers.f_top);
+                            float eta_top = 1.f;
+                            closure_eta(layers.top, eta_top);
+                            load_lobe(closure.x[1], sh, layers.bottom, layers.f_bottom, eta_top);
+                            layers.own = sh, layers.ng = it.ng, layers.p = it.p;
+                            layers.thickness = closure.s0, layers.g = closure.s1;
+                            layers.albedo = mk3(closure.c0[0], closure.c0[1], closure.c0[2]);
+                            layers.max_depth = closure.x[2], layers.samples = closure.x[3];
+                        }
                         const auto ratio = closure.s0;
                         const auto tag_a = closure.x[0], tag_b = closure.x[1];
                         auto mix_eval = [](const BsdfEval &a, const BsdfEval &b, float r) {// MixSurfaceClosure::_mix, mix.cpp:97-104
@@ -245,6 +257,8 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             if (is_mix) {// mix.cpp:169-177
                                 eval = mix_eval(eval_child(tag_a, shadow.d), eval_child(tag_b, shadow.d), ratio);
                                 if (!valid_sides(it.ng, sh.n, wo, shadow.d)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
+                            } else if (is_layered) {
+                                eval = layered_evaluate(layers, wo, shadow.d);
                             } else {
                                 eval = closure_evaluate<FULL>(closure, sh, it.ng, wo, shadow.d);
                             }
@@ -273,6 +287,9 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             auto has_b = closure_eta(scene.closures[tag_b], eta_b);// (eta never comes from an image texture here)
                             has_eta = has_a || has_b;// MixSurfaceClosure::eta, mix.cpp:148-157
                             eta = !has_a ? eta_b : (!has_b ? eta_a : lerp(eta_b, eta_a, ratio));
+                        } else if (is_layered) {
+                            bs = layered_sample(layers, wo, u_lobe, u_bsdf);
+                            has_eta = closure_eta(layers.bottom, eta);// LayeredSurfaceClosure::eta, layered.cpp:252
                         } else {
                             bs = closure_sample<FULL>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
                             has_eta = closure_eta(closure, eta);

@@ -478,13 +478,31 @@ public:
             if (_out.surfaces[children[0]].kind == LR_SURFACE_MIX || _out.surfaces[children[1]].kind == LR_SURFACE_MIX) {
                 throw Error{"Nested Mix surfaces are not supported by the megakernel. [" + d->location() + "]"};
             }
+            if (_out.surfaces[children[0]].kind == LR_SURFACE_LAYERED || _out.surfaces[children[1]].kind == LR_SURFACE_LAYERED) {
+                throw Error{"Layered children of a Mix surface are not supported by the megakernel. [" + d->location() + "]"};
+            }
             s.u[0] = children[0], s.u[1] = children[1];
             s.tex[0] = tex("ratio");
             wrappers = false;// NormalMapWrapper<MixSurface> only (mix.cpp:214-215)
             s.normal_tex = tex("normal_map");
             s.normal_strength = d->float_or("normal_map_strength", 1.f);
-        } else if (impl == "layered") {
-            throw Error{"Layered surface is scheduled after the closure bar (SURVEY §8f f2). [" + d->location() + "]"};
+        } else if (impl == "layered") {// layered.cpp:107-126
+            s.kind = LR_SURFACE_LAYERED;
+            auto top = d->node("top"), bottom = d->node("bottom");
+            if (surface_is_null(top) || surface_is_null(bottom)) { throw Error{"Creating closure for null LayeredSurface. [" + d->location() + "]"}; }
+            children = {register_surface(top), register_surface(bottom)};
+            for (auto c : children) {
+                auto k = _out.surfaces[c].kind;
+                if (k == LR_SURFACE_MIX || k == LR_SURFACE_LAYERED) {
+                    throw Error{"Mix / Layered children of a Layered surface are not supported by the megakernel. [" + d->location() + "]"};
+                }
+            }
+            s.u[0] = children[0], s.u[1] = children[1];
+            s.tex[0] = tex("thickness"), s.tex[1] = tex("g"), s.tex[2] = tex("albedo");
+            s.u[2] = d->uint_or("max_depth", 10u), s.u[3] = d->uint_or("samples", 1u);
+            // TwoSidedWrapper (surface.h:300-309) populates the closure with the flipped frame and then again with the real
+            // one, i.e. it has no effect on the closure; only the flag is recorded
+            if (d->bool_or("two_sided", false)) { s.flags |= LR_SURFACE_FLAG_TWO_SIDED; }
         } else {
             throw Error{"Unknown surface implementation '" + impl + "'. [" + d->location() + "]"};
         }
@@ -504,6 +522,7 @@ public:
     bool surface_maybe_non_opaque(uint32_t tag) const {// OpacitySurfaceWrapper::maybe_non_opaque
         auto &s = _out.surfaces[tag];
         if (s.kind == LR_SURFACE_MIX) { return surface_maybe_non_opaque(s.u[0]) || surface_maybe_non_opaque(s.u[1]); }// mix.cpp:59-61
+        if (s.kind == LR_SURFACE_LAYERED && (surface_maybe_non_opaque(s.u[0]) || surface_maybe_non_opaque(s.u[1]))) { return true; }// layered.cpp:174-176
         if (s.alpha_tex < 0) { return false; }
         auto &t = _out.textures[static_cast<size_t>(s.alpha_tex)];
         // constant alpha >= 1 is treated as opaque (surface.h:204-216)

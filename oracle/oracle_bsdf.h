@@ -209,7 +209,8 @@ inline BxdfSample microfacet_reflection_sample(Spectrum3 R, const TrowbridgeReit
 }
 
 // MicrofacetTransmission (RADIANCE), :322-368
-inline Spectrum3 microfacet_transmission_eval(Spectrum3 T, const TrowbridgeReitz &dist, float eta_a, float eta_b, float3 wo, float3 wi) {
+inline Spectrum3 microfacet_transmission_eval(Spectrum3 T, const TrowbridgeReitz &dist, float eta_a, float eta_b, float3 wo, float3 wi,
+                                              bool importance = false) {
     auto cosThetaO = cos_theta(wo);
     auto cosThetaI = cos_theta(wi);
     auto eta = cosThetaO > 0.f ? eta_b / eta_a : eta_a / eta_b;
@@ -222,6 +223,7 @@ inline Spectrum3 microfacet_transmission_eval(Spectrum3 T, const TrowbridgeReitz
         auto F = fresnel_dielectric(dot(wo, wh), eta_a, eta_b);
         auto D = dist.D(wh);
         f = (1.f - F) * T * D * G * dot(wi, wh) * dot(wo, wh) / (cosThetaI * cosThetaO * sqr(sqrtDenom));
+        if (importance) { f = f * sqr(eta); }// TransportMode::IMPORTANCE, scattering.cpp:340-342 (Layered only)
     }
     return f;
 }
@@ -237,7 +239,8 @@ inline float microfacet_transmission_pdf(const TrowbridgeReitz &dist, float eta_
     }
     return pdf;
 }
-inline BxdfSample microfacet_transmission_sample(Spectrum3 T, const TrowbridgeReitz &dist, float eta_a, float eta_b, float3 wo, float2 u) {
+inline BxdfSample microfacet_transmission_sample(Spectrum3 T, const TrowbridgeReitz &dist, float eta_a, float eta_b, float3 wo, float2 u,
+                                                 bool importance = false) {
     BxdfSample s;
     auto eta = cos_theta(wo) > 0.f ? eta_a / eta_b : eta_b / eta_a;
     auto wh = dist.sample_wh(wo, u);
@@ -246,7 +249,7 @@ inline BxdfSample microfacet_transmission_sample(Spectrum3 T, const TrowbridgeRe
     auto valid = refr && !same_hemisphere(wo, wi);
     s.wi = wi;
     s.pdf = valid ? microfacet_transmission_pdf(dist, eta_a, eta_b, wo, wi) : 0.f;
-    s.f = valid ? microfacet_transmission_eval(T, dist, eta_a, eta_b, wo, wi) : f3(0.f);
+    s.f = valid ? microfacet_transmission_eval(T, dist, eta_a, eta_b, wo, wi, importance) : f3(0.f);
     return s;
 }
 
@@ -423,6 +426,7 @@ struct DisneyClosure {
     float roughness{0.f}, metallic{0.f}, eta{1.f}, eta_i{1.f}, eta_t{1.f}, clearcoat{0.f}, gloss{0.f};
     float2 alpha{0.f, 0.f}, thin_alpha{0.f, 0.f};
     bool two_sided_fresnel{false};
+    bool importance{false};// TransportMode::IMPORTANCE (set by Layered's reverse walks)
     float w[5]{0.f, 0.f, 0.f, 0.f, 0.f};
     bool enabled[5]{false, false, false, false, false};
     uint32_t technique_count{0u};
@@ -564,7 +568,7 @@ struct DisneyClosure {
         } else {
             if (has_spec_trans && w[3] > 0.f) {
                 TrowbridgeReitz dist{thin_alpha};
-                f += microfacet_transmission_eval(Cst, dist, eta_i, eta_t, wo, wi);
+                f += microfacet_transmission_eval(Cst, dist, eta_i, eta_t, wo, wi, importance);
                 pdf += w[3] * microfacet_transmission_pdf(dist, eta_i, eta_t, wo, wi);
             }
             if (has_diff_trans && w[4] > 0.f) {// LambertianTransmission, scattering.cpp:271-284
@@ -634,6 +638,9 @@ struct Closure {
     float3 mix_wo{};
     uint32_t mix_a{0u}, mix_b{0u};
     float mix_eta_i{1.f};
+    // Layered (src/surfaces/layered.cpp): mix_a = top, mix_b = bottom, s0 = thickness, s1 = g, c0 = albedo
+    uint32_t layer_max_depth{10u}, layer_samples{1u};
+    bool importance{false};// transport mode of this evaluation (IMPORTANCE only inside Layered)
 
     // resolve the `roughness` texture like every closure does (e.g. mirror.cpp:145-154)
     static float2 roughness_alpha(const lr_scene &scene, const lr_surface &s, int32_t tex, float2 uv, float2 dv) {
@@ -739,9 +746,251 @@ struct Closure {
                 else { c.has_eta = true, c.eta_value = lerp(b.eta_value, a.eta_value, c.s0); }
                 break;
             }
+            case LR_SURFACE_LAYERED: {// layered.cpp:478-500
+                c.s0 = s.tex[0] >= 0 ? std::max(texture_evaluate(scene, s.tex[0], uv).x, std::numeric_limits<float>::min()) : 1e-2f;
+                c.s1 = s.tex[1] >= 0 ? texture_evaluate(scene, s.tex[1], uv).x : 0.f;
+                c.c0 = albedo_or(scene, s.tex[2], uv, 1.f).value;
+                c.layer_max_depth = s.u[2], c.layer_samples = s.u[3];
+                c.mix_scene = &scene, c.mix_it = it, c.mix_wo = wo, c.mix_a = s.u[0], c.mix_b = s.u[1], c.mix_eta_i = eta_i;
+                auto top = populate_tag(scene, s.u[0], it, wo, eta_i);
+                auto bottom = populate_tag(scene, s.u[1], it, wo, top.has_eta ? top.eta_value : 1.f);
+                c.has_eta = bottom.has_eta, c.eta_value = bottom.eta_value;// LayeredSurfaceClosure::eta, :252
+                break;
+            }
             default: break;
         }
         return c;
+    }
+
+    // ---- Layered (layered.cpp:195-470, a port of PBRT-v4's LayeredBxDF onto nested closures).  The internal random
+    // walk draws from an LCG seeded by a hash of position / direction BITS; where the reference evaluates several
+    // lcg(seed) calls inside one argument list (C++ leaves their order unspecified) they are taken left to right.
+    std::vector<Closure> layers() const {// {top, bottom}
+        std::vector<Closure> l;
+        l.emplace_back(populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i));
+        l.emplace_back(populate_tag(*mix_scene, mix_b, mix_it, mix_wo, l[0].has_eta ? l[0].eta_value : 1.f));
+        return l;
+    }
+    static float layer_tr(float dz, float3 w) {// :214-217
+        return std::abs(dz) <= std::numeric_limits<float>::min() ? 1.f : std::exp(-std::abs(dz / w.z));
+    }
+    static float hg(float cos_theta_, float g) {// HGPhaseFunction::HenyeyGreenstein, :21-24
+        auto denom = 1.f + sqr(g) + 2.f * g * cos_theta_;
+        return inv_pi / 4.0f * (1.f - sqr(g)) / (denom * std::sqrt(denom));
+    }
+    static float3 hg_sample(float3 wo, float g, float2 u, float &pdf) {// :25-38
+        auto cos_t = std::abs(g) < 1e-3f ? 1.f - 2.f * u.x : -1.f / (2.f * g) * (1.f + sqr(g) - sqr((1.f - sqr(g)) / (1.f + g - 2.f * g * u.x)));
+        auto sin_t = std::sqrt(1.f - sqr(cos_t));
+        auto phi = 2.f * pi * u.y;
+        auto frame = Frame::make(wo);
+        auto wi = frame.local_to_world(f3(sin_t * std::cos(phi), sin_t * std::sin(phi), cos_t));
+        pdf = hg(cos_t, g);
+        return wi;
+    }
+    static float power_heuristic(float f, float g) {// sampling.cpp:142-159
+        auto ff = f * f, gg = g * g;
+        auto sum = ff + gg;
+        return std::isinf(ff) ? 1.f : (sum == 0.f ? 0.f : ff / sum);
+    }
+    static bool is_zero(Spectrum3 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
+    static uint32_t bits(float x) { return float_bits(x); }
+
+    SurfaceEval layered_evaluate(float3 wo, float3 wi) const {// :256-398
+        auto L = layers();
+        auto mode = importance, reverse_mode = !importance;
+        auto thickness = s0, g = s1;
+        auto albedo = c0;
+        auto samples = static_cast<float>(layer_samples);
+        auto wi_local = shading.world_to_local(wi), wo_local = shading.world_to_local(wo);
+        auto entered_top = wo_local.z > 0.f;
+        auto sh = same_hemisphere(wo_local, wi_local);
+        auto &enter = entered_top ? L[0] : L[1];
+        auto &exit = (sh != entered_top) ? L[1] : L[0];
+        auto &nonexit = (sh != entered_top) ? L[0] : L[1];
+        auto exit_z = (sh != entered_top) ? 0.f : thickness;
+        auto f = sh ? samples * enter.evaluate(wo, wi, mode).f : f3(0.f);
+        auto seed = xxhash32(bits(mix_it.pg.x), bits(mix_it.pg.y), bits(mix_it.pg.z), xxhash32(bits(wi.x), bits(wi.y), bits(wi.z)));
+        auto pdf_sum = sh ? samples * (entered_top ? L[0] : L[1]).evaluate(wo, wi, mode).pdf : 0.f;
+        auto draw3 = [&](float &uc, float2 &u) { uc = lcg(seed), u.x = lcg(seed), u.y = lcg(seed); };
+        for (auto i = 0u; i < layer_samples; i++) {
+            float uc;
+            float2 u;
+            draw3(uc, u);
+            auto wos = enter.sample(wo, uc, u, mode);
+            if (is_zero(wos.eval.f) || wos.eval.pdf <= 0.f) { continue; }
+            draw3(uc, u);
+            auto wis = exit.sample(wi, uc, u, reverse_mode);
+            auto wis_wi_local = exit.shading.world_to_local(wis.wi);
+            if (is_zero(wis.eval.f) || wis.eval.pdf <= 0.f) { continue; }
+            auto beta = wos.eval.f * (1.f / wos.eval.pdf);
+            auto z = entered_top ? thickness : 0.f;
+            auto w = wos.wi;
+            auto w_local = enter.shading.world_to_local(w);
+            for (auto depth = 0u; depth < layer_max_depth; depth++) {
+                if (depth > 3u && max_component(beta) < 0.25f) {
+                    auto q = std::max(0.f, 1.f - max_component(beta));
+                    if (lcg(seed) < q) { break; }
+                    beta = beta * (1.f / (1.f - q));
+                }
+                if (is_zero(albedo)) {
+                    z = z == thickness ? 0.f : thickness;
+                    beta = beta * layer_tr(thickness, w_local);
+                } else {
+                    auto sigma_t = 1.f;
+                    auto dz = -std::log(1.f - lcg(seed)) / (sigma_t / std::abs(w_local.z));
+                    auto zp = w_local.z > 0.f ? z + dz : z - dz;
+                    if (z == zp) { continue; }
+                    if (zp > 0.f && zp < thickness) {
+                        auto wt = power_heuristic(wis.eval.pdf, nonexit.evaluate(-w, -wis.wi, mode).pdf);
+                        f += beta * albedo * hg(dot(-w_local, -wis_wi_local), g) * wt * layer_tr(zp - exit_z, wis_wi_local) * wis.eval.f *
+                             (1.f / wis.eval.pdf);
+                        float2 up{lcg(seed), 0.f};
+                        up.y = lcg(seed);
+                        float ps_pdf;
+                        auto ps_wi = hg_sample(-w_local, g, up, ps_pdf);
+                        if (ps_pdf <= 0.f || ps_wi.z == 0.f) { continue; }
+                        beta = beta * albedo * (ps_pdf / ps_pdf);
+                        w_local = ps_wi;
+                        w = exit.shading.local_to_world(w_local);
+                        z = zp;
+                        if ((z < exit_z && w_local.z > 0.f) || (z > exit_z && w_local.z < 0.f)) {
+                            auto e = exit.evaluate(-w, wi, mode);
+                            if (!is_zero(e.f)) {
+                                auto wte = power_heuristic(ps_pdf, e.pdf);
+                                f += beta * layer_tr(zp - exit_z, w_local) * e.f * wte;
+                            }
+                        }
+                        continue;
+                    }
+                    z = clampf(zp, 0.f, thickness);
+                }
+                if (z == exit_z) {
+                    draw3(uc, u);
+                    auto bs = exit.sample(-w, uc, u, mode);
+                    if (is_zero(bs.eval.f) || bs.eval.pdf <= 0.f) { break; }
+                    beta = beta * bs.eval.f * (1.f / bs.eval.pdf);
+                    w = bs.wi;
+                    w_local = exit.shading.world_to_local(w);
+                } else {
+                    auto wns = nonexit.evaluate(-w, -wis.wi, mode);
+                    auto wt = power_heuristic(wis.eval.pdf, wns.pdf);
+                    f += beta * wns.f * wt * layer_tr(thickness, wis_wi_local) * wis.eval.f * (1.f / wis.eval.pdf);
+                    draw3(uc, u);
+                    auto bs = nonexit.sample(-w, uc, u, mode);
+                    if (is_zero(bs.eval.f) || bs.eval.pdf <= 0.f) { break; }
+                    beta = beta * bs.eval.f * (1.f / bs.eval.pdf);
+                    w = bs.wi;
+                    w_local = nonexit.shading.world_to_local(w);
+                    auto wes = exit.evaluate(-w, wi, mode);
+                    if (!is_zero(wes.f)) {
+                        auto wte = power_heuristic(bs.eval.pdf, wes.pdf);
+                        f += beta * layer_tr(thickness, nonexit.shading.world_to_local(bs.wi)) * wes.f * wte;
+                    }
+                }
+            }
+        }
+        for (auto i = 0u; i < layer_samples; i++) {// pdf estimate, :360-395
+            float uc;
+            float2 u;
+            if (sh) {
+                auto &r = entered_top ? L[1] : L[0];
+                auto &t = entered_top ? L[0] : L[1];
+                draw3(uc, u);
+                auto wos = t.sample(wo, uc, u, mode);
+                draw3(uc, u);
+                auto wis = t.sample(wi, uc, u, reverse_mode);
+                if (!is_zero(wos.eval.f) && wos.eval.pdf > 0.f && !is_zero(wis.eval.f) && wis.eval.pdf > 0.f) {
+                    draw3(uc, u);
+                    auto rs = r.sample(-wos.wi, uc, u, mode);
+                    if (!is_zero(rs.eval.f) && rs.eval.pdf > 0.f) {
+                        auto r_pdf = r.evaluate(-wos.wi, -wis.wi, mode).pdf;
+                        pdf_sum += power_heuristic(wis.eval.pdf, r_pdf) * r_pdf;
+                        auto t_pdf = t.evaluate(-rs.wi, wi, mode).pdf;
+                        pdf_sum += power_heuristic(rs.eval.pdf, t_pdf) * t_pdf;
+                    }
+                }
+            } else {
+                auto &ti = entered_top ? L[1] : L[0];
+                auto &to = entered_top ? L[0] : L[1];
+                draw3(uc, u);
+                auto wos = to.sample(wo, uc, u, mode);
+                draw3(uc, u);
+                auto wis = ti.sample(wi, uc, u, reverse_mode);
+                if (is_zero(wos.eval.f) || wos.eval.pdf <= 0.f || is_zero(wis.eval.f) || wis.eval.pdf <= 0.f) { continue; }
+                pdf_sum += .5f * (to.evaluate(wo, -wis.wi, mode).pdf + ti.evaluate(-wos.wi, wi, mode).pdf);
+            }
+        }
+        return {f * (1.f / samples), lerp(1.f / (4.f * pi), pdf_sum / samples, 0.9f)};
+    }
+
+    SurfaceSample layered_sample(float3 wo, float u_lobe, float2 u) const {// :399-470
+        auto L = layers();
+        auto mode = importance;
+        auto thickness = s0, g = s1;
+        auto albedo = c0;
+        auto wo_local = shading.world_to_local(wo);
+        auto entered_top = wo_local.z > 0.f;
+        auto bs = (entered_top ? L[0] : L[1]).sample(wo, u_lobe, u, mode);
+        SurfaceSample s;
+        s.eval = {f3(0.f), 0.f};
+        if (is_zero(bs.eval.f) || bs.eval.pdf == 0.f) { return s; }
+        auto wi_local = shading.world_to_local(bs.wi);
+        if (same_hemisphere(wi_local, wo_local)) { return bs; }
+        auto w = bs.wi;
+        auto w_local = wi_local;
+        auto seed = xxhash32(bits(u.x), bits(u.y), bits(u_lobe), xxhash32(bits(wo.x), bits(wo.y), bits(wo.z)));
+        auto f = bs.eval.f;
+        auto pdf = bs.eval.pdf;
+        auto z = entered_top ? thickness : 0.f;
+        for (auto depth = 0u; depth < layer_max_depth; depth++) {
+            auto rr_beta = max_component(f) / pdf;
+            if (depth > 3u && rr_beta < 0.25f) {
+                auto q = std::max(0.f, 1.f - rr_beta);
+                if (lcg(seed) < q) { break; }
+                pdf *= 1.f - q;
+            }
+            if (w_local.z == 0.f) { break; }
+            if (!is_zero(albedo)) {
+                auto sigma_t = 1.f;
+                auto dz = -std::log(1.f - lcg(seed)) / (sigma_t / std::abs(w_local.z));
+                auto zp = w_local.z > 0.f ? z + dz : z - dz;
+                if (z == zp) { break; }
+                if (0.f < zp && zp < thickness) {
+                    float2 up{lcg(seed), 0.f};
+                    up.y = lcg(seed);
+                    float ps_pdf;
+                    auto ps_wi = hg_sample(-w_local, g, up, ps_pdf);
+                    if (ps_pdf <= 0.f) { break; }
+                    f = f * albedo * ps_pdf;
+                    pdf *= ps_pdf;
+                    w = ps_wi;// (the reference assigns the phase sample, a LOCAL direction, to the world-space w: kept)
+                    w_local = shading.world_to_local(w);
+                    z = zp;
+                    continue;
+                }
+                z = clampf(zp, 0.f, thickness);
+            } else {
+                z = z == thickness ? 0.f : thickness;
+                f = f * layer_tr(thickness, w_local);
+            }
+            auto &interface = z == 0.f ? L[1] : L[0];
+            auto uc = lcg(seed);
+            float2 ub{lcg(seed), 0.f};
+            ub.y = lcg(seed);
+            auto is = interface.sample(-w, uc, ub, mode);
+            if (is_zero(is.eval.f) || is.eval.pdf <= 0.f) { break; }
+            f = f * is.eval.f;
+            pdf *= is.eval.pdf;
+            w = is.wi;
+            w_local = shading.world_to_local(w);
+            if (is.event == EVENT_ENTER || is.event == EVENT_EXIT) {// (bs.event & Surface::event_transmit) != 0
+                s.eval = {f, pdf};
+                s.wi = w;
+                s.event = same_hemisphere(w_local, wo_local) ? EVENT_REFLECT : (w_local.z > 0.f ? EVENT_EXIT : EVENT_ENTER);
+                break;
+            }
+        }
+        return s;
     }
 
     // ---- per-kind _evaluate / _sample in world space (f already includes |cos theta_i|)
@@ -770,7 +1019,7 @@ struct Closure {
                     f = microfacet_reflection_eval(c0, dist, fresnel, wo_local, wi_local);
                     pdf = microfacet_reflection_pdf(dist, wo_local, wi_local) * ratio;
                 } else {
-                    f = microfacet_transmission_eval(c1, dist, eta_i, eta_t, wo_local, wi_local);
+                    f = microfacet_transmission_eval(c1, dist, eta_i, eta_t, wo_local, wi_local, importance);
                     pdf = microfacet_transmission_pdf(dist, eta_i, eta_t, wo_local, wi_local) * (1.f - ratio);
                 }
                 return {f * abs_cos_theta(wi_local), pdf};
@@ -787,7 +1036,12 @@ struct Closure {
                 auto f = microfacet_reflection_eval(f3(1.f), dist, fresnel, wo_local, wi_local) * c2;
                 return {f * abs_cos_theta(wi_local), microfacet_reflection_pdf(dist, wo_local, wi_local)};
             }
-            case LR_SURFACE_DISNEY: return DisneyClosure{disney}.evaluate_local(wo_local, wi_local);
+            case LR_SURFACE_DISNEY: {
+                DisneyClosure dc{disney};
+                dc.importance = importance;
+                return dc.evaluate_local(wo_local, wi_local);
+            }
+            case LR_SURFACE_LAYERED: return layered_evaluate(wo, wi);
             case LR_SURFACE_MIX: {// mix.cpp:169-177: children through their public evaluate (side validation included)
                 auto ea = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
                 auto eb = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
@@ -833,7 +1087,7 @@ struct Closure {
                     s = microfacet_reflection_sample(c0, dist, fresnel, wo_local, u);
                     s.pdf *= ratio;
                 } else {
-                    s = microfacet_transmission_sample(c1, dist, eta_i, eta_t, wo_local, u);
+                    s = microfacet_transmission_sample(c1, dist, eta_i, eta_t, wo_local, u, importance);
                     s.pdf *= (1.f - ratio);
                     out.event = cos_theta(wo_local) > 0.f ? EVENT_ENTER : EVENT_EXIT;
                 }
@@ -875,6 +1129,7 @@ struct Closure {
             }
             case LR_SURFACE_DISNEY: {
                 DisneyClosure dc{disney};
+                dc.importance = importance;
                 float3 wi_local;
                 bool valid;
                 dc.sample_local(wo_local, u_lobe, u, wi_local, valid, out.event);
@@ -882,6 +1137,7 @@ struct Closure {
                 if (valid) { out.eval = dc.evaluate_local(wo_local, wi_local); }
                 return out;
             }
+            case LR_SURFACE_LAYERED: return layered_sample(wo, u_lobe, u);
             case LR_SURFACE_MIX: {// mix.cpp:178-196 — the "sample b" branch samples A and evaluates B (reference quirk, kept)
                 auto a = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i);
                 auto b = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i);
@@ -904,6 +1160,14 @@ struct Closure {
     }
 
     // Surface::Closure::evaluate / sample, surface.cpp:45-68
+    SurfaceEval evaluate(float3 wo, float3 wi, bool importance_mode) {
+        importance = importance_mode;
+        return evaluate(wo, wi);
+    }
+    SurfaceSample sample(float3 wo, float u_lobe, float2 u, bool importance_mode) {
+        importance = importance_mode;
+        return sample(wo, u_lobe, u);
+    }
     SurfaceEval evaluate(float3 wo, float3 wi) const {
         auto e = evaluate_impl(wo, wi);
         if (!validate_surface_sides(ng, shading.n, wo, wi)) { e.f = f3(0.f), e.pdf = 0.f; }

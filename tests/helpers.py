@@ -23,6 +23,13 @@ MATERIALS = {
     "mix_glass": "Surface mg_a : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.5 } } } "
                  "Surface mg_b : Disney { color : Constant { v { 0.5, 0.6, 0.7 } } roughness : Constant { v { 0.5 } } } "
                  "Surface m : Mix { a { @mg_a } b { @mg_b } ratio : Constant { v { 0.6 } } }",
+    "layered": "Surface lay_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.15 } } eta : Constant { v { 1.5 } } } "
+               "Surface lay_b : Matte { Kd : Constant { v { 0.7, 0.5, 0.3 } } } "
+               "Surface m : Layered { top { @lay_t } bottom { @lay_b } thickness : Constant { v { 0.05 } } }",
+    "layered_medium": "Surface lm_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.4 } } } "
+                      "Surface lm_b : Metal { eta { \"Au\" } roughness : Constant { v { 0.3 } } } "
+                      "Surface m : Layered { top { @lm_t } bottom { @lm_b } thickness : Constant { v { 0.3 } } g : Constant { v { 0.4 } } "
+                      "albedo : Constant { v { 0.8, 0.6, 0.4 } } max_depth { 12 } samples { 2 } two_sided { true } }",
     "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
 }
 

@@ -108,6 +108,31 @@ Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
+@pytest.mark.parametrize("material", ["layered", "layered_medium"])
+def test_layered_closure(renderer, material):
+    """Row a14, Layered (layered.cpp:195-470): its random walk is seeded from the BITS of the hit position and direction
+    (:271,416), which fp contraction changes between the device and the oracle, so parity is statistical (8x8 block means),
+    as for the alpha test."""
+    from helpers import MATERIALS
+    extra = MATERIALS[material].replace("Surface m ", f"Surface {material} ") + "\n"
+    spp = 1024  # the estimator is noisy (fireflies through the rough dielectric coat): many samples, block means
+    sc = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface=material, tall_box_surface=material, extra_surfaces=extra))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, spp)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    blocks = lambda f: f[..., :3].reshape(8, 8, 8, 8, 3).mean(axis=(1, 3))
+    g, c = blocks(gpu), blocks(cpu)
+    err, bias = np.abs(g - c).sum() / np.abs(c).sum(), abs(g.mean() - c.mean()) / c.mean()
+    print(f"layered parity: block rel-L1 {err:.4f}, mean {bias:.5f}")
+    assert err < 3e-2 and bias < 8e-3
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) < 5e-3 * cc["closest_rays"]
+    # and it is not the bare substrate: rendering the bottom closure alone is far outside that tolerance
+    bare = "lay_b" if material == "layered" else "lm_b"
+    sc2 = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface=bare, tall_box_surface=bare, extra_surfaces=extra))
+    renderer.upload(sc2)
+    renderer.render(0, spp, sync=True)
+    assert np.abs(blocks(renderer.download(converted=False)) - c).sum() / np.abs(c).sum() > 5e-2
+
+
 def test_alpha_tested_traversal(renderer):
     """Rows a6/a12: stochastic alpha test inside traversal.  The skip decision hashes the candidate's barycentric BITS
     (geometry.cpp:169), which depend on the intersector (world-space baked triangles here, object-space in the oracle;

@@ -10,7 +10,10 @@ RNG = np.random.default_rng(11)
 TRANSMISSIVE = ("glass", "disney_trans", "mix_glass")  # sample() may return SURFACE_EVENT_ENTER / EXIT
 
 
-@pytest.mark.parametrize("name", list(MATERIALS))
+STOCHASTIC = ("layered", "layered_medium")  # evaluate() is itself a random-walk estimator (layered.cpp:256-398)
+
+
+@pytest.mark.parametrize("name", [m for m in MATERIALS if m not in STOCHASTIC])
 def test_sample_is_consistent_with_evaluate(name):
     probe = SurfaceProbe(material_scene(name))
     checked = 0
@@ -52,7 +55,8 @@ def test_pdf_normalisation_and_energy(name):
         dirs = np.stack([r * np.cos(2 * np.pi * us[:, 1]), r * np.sin(2 * np.pi * us[:, 1]), z], -1).astype(np.float32)
         pdfs = np.array([probe.evaluate(wo, d)[1] for d in dirs]) * 4 * np.pi
         pdf_int, stderr = pdfs.mean(), pdfs.std() / np.sqrt(n)
-        assert pdf_int - 3 * stderr < 1.02, (name, theta, pdf_int, stderr)  # peaky GGX lobes: wide error bars
+        if name not in STOCHASTIC:  # Layered's pdf is an estimate built from unrestricted interface samples: not normalised
+            assert pdf_int - 3 * stderr < 1.02, (name, theta, pdf_int, stderr)  # peaky GGX lobes: wide error bars
         if name in ("matte", "oren"):
             assert abs(pdf_int - 1.0) < 0.08
         for _ in range(n):
@@ -62,7 +66,7 @@ def test_pdf_normalisation_and_energy(name):
                 alive += 1
         albedo /= n
         if not name.startswith("mix"):  # Mix::sample draws both branches from child a (reference quirk): not an unbiased estimator
-            assert (albedo < 1.05).all(), (name, theta, albedo)
+            assert (albedo < (1.15 if name in STOCHASTIC else 1.05)).all(), (name, theta, albedo)
         assert alive > 0.5 * n
 
 
@@ -152,3 +156,39 @@ def test_disney_limits():
     # specular lobe at eta ~ 1 has R0 ~ 0 and Schlick weight 0 at normal incidence
     assert np.allclose(f, 0.5 / np.pi, rtol=2e-3), f
     assert pdf > 0
+
+
+def test_layered_index_matched_coat_is_its_substrate():
+    """Layered with a clear, index-matched, smooth dielectric on top and no medium: every walk crosses the coat unchanged,
+    bounces once on the substrate and leaves, so the estimator's mean is the substrate's f * |cos| (layered.cpp:340-357).
+    evaluate() seeds its walk from the bits of wi, so neighbouring directions give independent estimates."""
+    from helpers import Scene, _PATCH
+    surface = ("Surface t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0 } } eta : Constant { v { 1.0001 } } } "
+               "Surface b : Matte { Kd : Constant { v { 0.7, 0.5, 0.3 } } } "
+               "Surface m : Layered { top { @t } bottom { @b } thickness : Constant { v { 0.01 } } }")
+    probe = SurfaceProbe(Scene.from_string(_PATCH.format(surface=surface), build_accel=False))
+    wo = sph(0.5, 0.3)
+    for theta in (0.2, 0.8):
+        fs = []
+        for _ in range(1500):
+            wi = sph(theta + RNG.uniform(-2e-3, 2e-3), 2.0 + RNG.uniform(-2e-3, 2e-3))
+            f, pdf = probe.evaluate(wo, wi)
+            assert pdf > 0 and np.isfinite(f).all()
+            fs.append(f)
+        mean = np.mean(fs, axis=0)
+        expect = np.array([0.7, 0.5, 0.3]) / np.pi * np.cos(theta)
+        assert np.allclose(mean, expect, rtol=0.06), (theta, mean, expect)
+
+
+def test_layered_is_deterministic_and_bounded():
+    """same (position, wi) -> same walk (hash-seeded LCG, layered.cpp:271); finite, non-negative values; the pdf is
+    blended with the uniform sphere (:396-397), so it never drops below 0.1 / (4 pi)"""
+    for name in STOCHASTIC:
+        probe = SurfaceProbe(material_scene(name))
+        for _ in range(100):
+            wo, wi = sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28)), sph(RNG.uniform(0.1, 1.4), RNG.uniform(0, 6.28))
+            a, b = probe.evaluate(wo, wi), probe.evaluate(wo, wi)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+            assert (a[0] >= 0).all() and np.isfinite(a[0]).all() and a[1] >= 0.1 / (4 * np.pi) - 1e-7
+            f, pdf, w, event = probe.sample(wo, *RNG.random(3))
+            assert np.isfinite(f).all() and pdf >= 0 and event in (0, 1, 2)
