@@ -31,7 +31,7 @@ all: host oracle hip cli
 host: $(LIBDIR)/liblrhost.so
 $(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR) Makefile
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl -pthread
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -ldl -pthread -lz
 
 oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h Makefile

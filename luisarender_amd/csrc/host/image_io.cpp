@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <filesystem>
+#include <zlib.h>
 #include <fstream>
 
 namespace lr {
@@ -248,52 +249,184 @@ LoadedImage read_exr(const fs::path &path) {
         p += size;
     }
     p++;
-    if (compression != 0u) { throw Error{"Compressed EXR input is not supported without zlib bindings: '" + path.string() + "'."}; }
+    // NO_COMPRESSION (0), ZIPS (2: one scanline per chunk), ZIP (3: 16 scanlines per chunk); the deflate streams go
+    // through zlib (the reference reads EXR with tinyexr + miniz, src/util/imageio.cpp:419-538)
+    if (compression != 0u && compression != 2u && compression != 3u) {
+        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / ZIPS / ZIP are): '" + path.string() + "'."};
+    }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
     LoadedImage img;
     img.width = w, img.height = h, img.is_hdr = true;
     img.pixels.assign(static_cast<size_t>(w) * h * 4u, 0.f);
     auto has_alpha = false;
     uint32_t color_channels = 0u;
+    size_t line_bytes = 0u;
     for (auto &c : channels) {
         if (c.name == "A") { has_alpha = true; } else { color_channels++; }
+        line_bytes += static_cast<size_t>(w) * (c.type == 1u ? 2u : 4u);
     }
     img.channels = has_alpha ? 4u : std::min(color_channels, 3u);
     if (!has_alpha) {
         for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) { img.pixels[i * 4u + 3u] = 1.f; }
     }
+    auto lines_per_chunk = compression == 3u ? 16u : 1u;
+    auto chunk_count = (h + lines_per_chunk - 1u) / lines_per_chunk;
     auto table = p;
-    for (uint32_t y = 0; y < h; y++) {
+    std::vector<uint8_t> raw, tmp;
+    for (uint32_t chunk = 0; chunk < chunk_count; chunk++) {
         uint64_t off;
-        std::memcpy(&off, data.data() + table + static_cast<size_t>(y) * 8u, 8);
+        std::memcpy(&off, data.data() + table + static_cast<size_t>(chunk) * 8u, 8);
+        if (off + 8u > data.size()) { throw Error{"Truncated EXR image '" + path.string() + "'."}; }
         int32_t yy;
+        uint32_t packed;
         std::memcpy(&yy, data.data() + off, 4);
-        auto q = static_cast<size_t>(off) + 8u;
-        auto row = static_cast<uint32_t>(yy - ymin);
-        for (auto &c : channels) {
-            auto slot = c.name == "R" ? 0 : c.name == "G" ? 1 : c.name == "B" ? 2 : c.name == "A" ? 3 : (c.name == "Y" ? 0 : -1);
-            auto bytes = c.type == 1u ? 2u : 4u;
-            for (uint32_t x = 0; x < w; x++) {
-                float v;
-                if (c.type == 1u) {
-                    uint16_t hb;
-                    std::memcpy(&hb, data.data() + q + static_cast<size_t>(x) * 2u, 2);
-                    v = half_to_float(hb);
-                } else if (c.type == 2u) {
-                    std::memcpy(&v, data.data() + q + static_cast<size_t>(x) * 4u, 4);
-                } else {
-                    uint32_t u;
-                    std::memcpy(&u, data.data() + q + static_cast<size_t>(x) * 4u, 4);
-                    v = static_cast<float>(u);
-                }
-                if (slot >= 0) { img.pixels[(static_cast<size_t>(row) * w + x) * 4u + static_cast<size_t>(slot)] = v; }
-                if (c.name == "Y") {
-                    img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 1u] = v;
-                    img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 2u] = v;
-                }
+        std::memcpy(&packed, data.data() + off + 4u, 4);
+        auto first_row = static_cast<uint32_t>(yy - ymin);
+        auto rows = std::min(lines_per_chunk, h - first_row);
+        auto expect = line_bytes * rows;
+        auto src = reinterpret_cast<const uint8_t *>(data.data()) + off + 8u;
+        if (off + 8u + packed > data.size()) { throw Error{"Truncated EXR image '" + path.string() + "'."}; }
+        if (compression == 0u || packed == expect) {// stored
+            raw.assign(src, src + expect);
+        } else {
+            tmp.resize(expect);
+            uLongf out_len = static_cast<uLongf>(expect);
+            if (uncompress(tmp.data(), &out_len, src, packed) != Z_OK || out_len != expect) {
+                throw Error{"Corrupt ZIP chunk in EXR image '" + path.string() + "'."};
             }
-            q += static_cast<size_t>(w) * bytes;
+            for (size_t i = 1; i < expect; i++) { tmp[i] = static_cast<uint8_t>(tmp[i - 1u] + tmp[i] - 128u); }// predictor
+            raw.resize(expect);
+            auto half = (expect + 1u) / 2u;// de-interleave: first half = even bytes, second half = odd bytes
+            for (size_t i = 0; i < expect; i++) { raw[i] = (i & 1u) ? tmp[half + i / 2u] : tmp[i / 2u]; }
         }
+        size_t q = 0u;
+        for (uint32_t r = 0; r < rows; r++) {
+            auto row = first_row + r;
+            for (auto &c : channels) {
+                auto slot = c.name == "R" ? 0 : c.name == "G" ? 1 : c.name == "B" ? 2 : c.name == "A" ? 3 : (c.name == "Y" ? 0 : -1);
+                auto bytes = c.type == 1u ? 2u : 4u;
+                for (uint32_t x = 0; x < w; x++) {
+                    float v;
+                    if (c.type == 1u) {
+                        uint16_t hb;
+                        std::memcpy(&hb, raw.data() + q + static_cast<size_t>(x) * 2u, 2);
+                        v = half_to_float(hb);
+                    } else if (c.type == 2u) {
+                        std::memcpy(&v, raw.data() + q + static_cast<size_t>(x) * 4u, 4);
+                    } else {
+                        uint32_t u;
+                        std::memcpy(&u, raw.data() + q + static_cast<size_t>(x) * 4u, 4);
+                        v = static_cast<float>(u);
+                    }
+                    if (slot >= 0) { img.pixels[(static_cast<size_t>(row) * w + x) * 4u + static_cast<size_t>(slot)] = v; }
+                    if (c.name == "Y") {
+                        img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 1u] = v;
+                        img.pixels[(static_cast<size_t>(row) * w + x) * 4u + 2u] = v;
+                    }
+                }
+                q += static_cast<size_t>(w) * bytes;
+            }
+        }
+    }
+    return img;
+}
+
+// PNG (8 / 16 bit, grey / grey+alpha / RGB / RGBA / palette, non-interlaced): chunks -> zlib inflate -> scanline
+// filters.  Values are returned in [0, 1] like stb_image's 8-bit path in the reference (imageio.cpp:500-538).
+LoadedImage read_png(const fs::path &path) {
+    std::ifstream f{path, std::ios::binary};
+    if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
+    std::string data{std::istreambuf_iterator<char>{f}, std::istreambuf_iterator<char>{}};
+    static const unsigned char magic[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (data.size() < 8u || std::memcmp(data.data(), magic, 8) != 0) { throw Error{"Invalid PNG image '" + path.string() + "'."}; }
+    auto be32 = [&](size_t at) {
+        auto d = reinterpret_cast<const uint8_t *>(data.data()) + at;
+        return (static_cast<uint32_t>(d[0]) << 24u) | (static_cast<uint32_t>(d[1]) << 16u) | (static_cast<uint32_t>(d[2]) << 8u) | d[3];
+    };
+    uint32_t w = 0, h = 0, depth = 0, color = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette, trns;
+    for (size_t p = 8; p + 12u <= data.size();) {
+        auto len = be32(p);
+        std::string type{data.data() + p + 4u, 4u};
+        auto body = reinterpret_cast<const uint8_t *>(data.data()) + p + 8u;
+        if (p + 12u + len > data.size()) { throw Error{"Truncated PNG image '" + path.string() + "'."}; }
+        if (type == "IHDR") {
+            w = be32(p + 8u), h = be32(p + 12u);
+            depth = body[8], color = body[9], interlace = body[12];
+        } else if (type == "PLTE") {
+            palette.assign(body, body + len);
+        } else if (type == "tRNS") {
+            trns.assign(body, body + len);
+        } else if (type == "IDAT") {
+            idat.insert(idat.end(), body, body + len);
+        } else if (type == "IEND") {
+            break;
+        }
+        p += 12u + len;
+    }
+    if (w == 0u || h == 0u || interlace != 0u || (depth != 8u && depth != 16u && !(color == 3u && depth <= 8u))) {
+        throw Error{"Unsupported PNG variant (interlaced or sub-byte samples) '" + path.string() + "'."};
+    }
+    auto samples = color == 0u ? 1u : color == 2u ? 3u : color == 3u ? 1u : color == 4u ? 2u : 4u;
+    auto bpp = std::max(1u, samples * depth / 8u);// bytes per pixel for the filters
+    auto stride = (static_cast<size_t>(w) * samples * depth + 7u) / 8u;
+    std::vector<uint8_t> raw((stride + 1u) * h);
+    uLongf out_len = static_cast<uLongf>(raw.size());
+    if (uncompress(raw.data(), &out_len, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || out_len != raw.size()) {
+        throw Error{"Corrupt PNG data '" + path.string() + "'."};
+    }
+    std::vector<uint8_t> prev(stride, 0u), cur(stride);
+    LoadedImage img;
+    img.width = w, img.height = h, img.is_hdr = false;
+    img.channels = color == 3u ? (trns.empty() ? 3u : 4u) : samples;
+    img.pixels.assign(static_cast<size_t>(w) * h * 4u, 0.f);
+    for (uint32_t y = 0; y < h; y++) {
+        auto line = raw.data() + (stride + 1u) * y;
+        auto filter = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int x = line[1u + i];
+            switch (filter) {
+                case 0: break;
+                case 1: x += a; break;
+                case 2: x += b; break;
+                case 3: x += (a + b) / 2; break;
+                case 4: {
+                    auto pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+                    x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: throw Error{"Invalid PNG filter in '" + path.string() + "'."};
+            }
+            cur[i] = static_cast<uint8_t>(x);
+        }
+        auto sample = [&](uint32_t px, uint32_t s) {
+            if (depth == 16u) {
+                auto d = cur.data() + (static_cast<size_t>(px) * samples + s) * 2u;
+                return static_cast<float>((d[0] << 8u) | d[1]) * (1.f / 65535.f);
+            }
+            return static_cast<float>(cur[static_cast<size_t>(px) * samples + s]) * (1.f / 255.f);
+        };
+        for (uint32_t x = 0; x < w; x++) {
+            auto dst = img.pixels.data() + (static_cast<size_t>(y) * w + x) * 4u;
+            dst[3] = 1.f;
+            if (color == 3u) {
+                uint32_t idx;
+                if (depth == 8u) { idx = cur[x]; }
+                else { idx = (cur[static_cast<size_t>(x) * depth / 8u] >> (8u - depth - (x * depth) % 8u)) & ((1u << depth) - 1u); }
+                if (static_cast<size_t>(idx) * 3u + 2u < palette.size()) {
+                    dst[0] = palette[idx * 3u] / 255.f, dst[1] = palette[idx * 3u + 1u] / 255.f, dst[2] = palette[idx * 3u + 2u] / 255.f;
+                }
+                if (idx < trns.size()) { dst[3] = trns[idx] / 255.f; }
+            } else if (samples <= 2u) {
+                dst[0] = dst[1] = dst[2] = sample(x, 0u);
+                if (samples == 2u) { dst[3] = sample(x, 1u); }
+            } else {
+                dst[0] = sample(x, 0u), dst[1] = sample(x, 1u), dst[2] = sample(x, 2u);
+                if (samples == 4u) { dst[3] = sample(x, 3u); }
+            }
+        }
+        std::swap(prev, cur);
     }
     return img;
 }
@@ -351,7 +484,8 @@ LoadedImage load_image(const std::string &path_in) {
     if (ext == ".hdr") { return read_hdr(path); }
     if (ext == ".exr") { return read_exr(path); }
     if (ext == ".ppm" || ext == ".pgm") { return read_pnm(path); }
-    throw Error{"Image format '" + ext + "' needs stb/tinyexr (absent); supported: .pfm .hdr .exr(uncompressed) .ppm .pgm — '" +
+    if (ext == ".png") { return read_png(path); }
+    throw Error{"Image format '" + ext + "' is not supported (stb is absent); supported: .pfm .hdr .exr (NONE/ZIPS/ZIP) .png .ppm .pgm — '" +
                 path.string() + "'."};
 }
 

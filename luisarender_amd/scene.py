@@ -103,3 +103,19 @@ def save_image(path: str, rgba: np.ndarray) -> None:
     h, w = rgba.shape[:2]
     if lib.lrhost_save_image(path.encode(), rgba.ctypes.data, w, h) != 0:
         raise HostError(lib.lrhost_last_error().decode())
+
+
+def load_image(path: str):
+    """LoadedImage::load of the reference (src/util/imageio.cpp:419-538) -> (float RGBA array [H, W, 4], channels)"""
+    import ctypes as C
+    lib = _ffi.host_lib()
+    lib.lrhost_load_image.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.lrhost_free.argtypes = [C.c_void_p]
+    ptr = C.POINTER(C.c_float)()
+    w, h, ch = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if lib.lrhost_load_image(path.encode(), C.byref(ptr), C.byref(w), C.byref(h), C.byref(ch)) != 0:
+        raise HostError(lib.lrhost_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 4)).copy(), ch.value
+    finally:
+        lib.lrhost_free(ptr)

@@ -1,0 +1,147 @@
+"""Image readers/writers of the host library (the reference uses stb + tinyexr, src/util/imageio.cpp:419-726; both are
+absent here, so the formats are read directly: PNG and EXR ZIP/ZIPS through zlib).  Test files are produced with
+Python's own zlib / struct so the readers are checked against an independent encoder."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from luisarender_amd.scene import HostError, load_image, save_image
+
+RNG = np.random.default_rng(3)
+
+
+def _png(path, arr, color_type, depth, filters=(0, 1, 2, 3, 4), palette=None):
+    h, w = arr.shape[:2]
+    raw = bytearray()
+    data = arr.astype(">u2" if depth == 16 else np.uint8).reshape(h, -1)
+    rows = [r.tobytes() for r in data]
+    bpp = max(1, len(rows[0]) // w)
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)]
+        out = bytearray(len(row))
+        for i, x in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (x - p) & 255
+        raw += bytes([ft]) + out
+        prev = row
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    z = zlib.compress(bytes(raw), 6)
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0))
+    if palette is not None:
+        body += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    body += chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + body)
+
+
+@pytest.mark.parametrize("color_type,samples,depth", [(0, 1, 8), (2, 3, 8), (6, 4, 8), (4, 2, 8), (2, 3, 16), (6, 4, 16)])
+def test_png_reader(tmp_path, color_type, samples, depth):
+    w, h = 37, 21
+    arr = RNG.integers(0, 1 << depth, (h, w, samples))
+    path = str(tmp_path / "t.png")
+    _png(path, arr, color_type, depth)
+    img, channels = load_image(path)
+    scale = float((1 << depth) - 1)
+    assert img.shape == (h, w, 4) and channels == samples
+    expect = np.ones((h, w, 4), np.float32)
+    if samples <= 2:
+        expect[..., :3] = arr[..., :1] / scale
+        if samples == 2:
+            expect[..., 3] = arr[..., 1] / scale
+    else:
+        expect[..., :samples] = arr / scale
+    assert np.allclose(img, expect, atol=1e-6)
+
+
+def test_png_palette(tmp_path):
+    w, h = 16, 9
+    palette = RNG.integers(0, 256, (7, 3))
+    idx = RNG.integers(0, 7, (h, w, 1))
+    path = str(tmp_path / "p.png")
+    _png(path, idx, 3, 8, palette=palette)
+    img, channels = load_image(path)
+    assert channels == 3 and np.allclose(img[..., :3], palette[idx[..., 0]] / 255.0, atol=1e-6) and (img[..., 3] == 1).all()
+
+
+def _exr(path, img, compression, half):
+    """scanline OpenEXR writer: compression 0 (none) / 2 (ZIPS) / 3 (ZIP), channels B G R (alphabetical) as half or float"""
+    h, w = img.shape[:2]
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+    ptype = 1 if half else 2
+    chlist = b"".join(n + b"\0" + struct.pack("<IBBBBii", ptype, 0, 0, 0, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    chunks = []
+    for y0 in range(0, h, lines):
+        raw = b""
+        for y in range(y0, min(y0 + lines, h)):
+            for c in (2, 1, 0):  # B, G, R
+                raw += img[y, :, c].astype(np.float16 if half else np.float32).tobytes()
+        if compression:
+            n = len(raw)
+            t = bytearray(n)
+            t[: (n + 1) // 2] = raw[0::2]
+            t[(n + 1) // 2:] = raw[1::2]
+            d = bytearray(n)
+            d[0] = t[0]
+            for i in range(1, n):
+                d[i] = (t[i] - t[i - 1] + 128 + 256) & 255
+            z = zlib.compress(bytes(d))
+            payload = z if len(z) < n else raw
+        else:
+            payload = raw
+        chunks.append(struct.pack("<iI", y0, len(payload)) + payload)
+    table_at = len(head)
+    offsets, pos = [], table_at + 8 * len(chunks)
+    for c in chunks:
+        offsets.append(pos)
+        pos += len(c)
+    open(path, "wb").write(head + b"".join(struct.pack("<Q", o) for o in offsets) + b"".join(chunks))
+
+
+@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("half", [True, False])
+def test_exr_reader_with_zip_compression(tmp_path, compression, half):
+    w, h = 53, 37  # not a multiple of the 16-line ZIP block
+    img = (RNG.random((h, w, 3)) * 8).astype(np.float16 if half else np.float32).astype(np.float32)
+    img[5:9] = 0.25  # compressible runs
+    path = str(tmp_path / "t.exr")
+    _exr(path, img, compression, half)
+    got, channels = load_image(path)
+    assert channels == 3 and got.shape == (h, w, 4)
+    assert np.array_equal(got[..., :3], img) and (got[..., 3] == 1).all()
+
+
+def test_exr_and_hdr_round_trip_of_our_own_writer(tmp_path):
+    img = np.concatenate([RNG.random((19, 23, 3)).astype(np.float32) * 4, np.ones((19, 23, 1), np.float32)], -1)
+    save_image(str(tmp_path / "a.exr"), img)
+    got, _ = load_image(str(tmp_path / "a.exr"))
+    assert np.allclose(got[..., :3], img[..., :3], rtol=1e-3, atol=1e-4)  # the writer stores halfs or floats
+    save_image(str(tmp_path / "a.hdr"), img)
+    got, _ = load_image(str(tmp_path / "a.hdr"))
+    step = img[..., :3].max(axis=-1, keepdims=True) / 128.0  # RGBE: 8-bit mantissas under the exponent of the largest channel
+    assert (np.abs(got[..., :3] - img[..., :3]) <= step).all()
+
+
+def test_unsupported_formats_fail_loudly(tmp_path):
+    p = tmp_path / "x.jpg"
+    p.write_bytes(b"\xff\xd8\xff")
+    with pytest.raises(HostError):
+        load_image(str(p))
