@@ -132,7 +132,8 @@ typedef struct lr_light {
 } lr_light;
 
 /* ---- environment (src/environments/{spherical,directional}.cpp) */
-enum { LR_ENV_NONE = 0, LR_ENV_SPHERICAL = 1, LR_ENV_DIRECTIONAL = 2 };
+enum { LR_ENV_NONE = 0, LR_ENV_SPHERICAL = 1, LR_ENV_DIRECTIONAL = 2,
+       LR_ENV_COMBINED = 3 /* src/environments/combined.cpp: two children in lr_scene.environment_children */ };
 typedef struct lr_environment {
     uint32_t kind;
     int32_t emission_tex;
@@ -149,7 +150,9 @@ typedef struct lr_environment {
     float direction[3];
     float cos_half_angle;
     uint32_t visible;
-    uint32_t pad[3];
+    /* combined: scales of children a and b (both > 0; a Combined with one live child is flattened by the host) */
+    float child_scale[2];
+    uint32_t pad;
 } lr_environment;
 
 /* ---- camera / filter / film / sampler / integrator */
@@ -257,7 +260,8 @@ typedef struct lr_scene {
     lr_integrator integrator;
     lr_accel accel;                    /* nodes == NULL when not built */
     uint32_t any_non_opaque;           /* Geometry::_any_non_opaque, geometry.cpp:124 */
-    uint32_t pad[3];
+    uint32_t environment_child_count;  /* 2 when environment.kind == LR_ENV_COMBINED, else 0 */
+    const lr_environment *environment_children; /* Spherical / Directional records with their own tables */
 } lr_scene;
 
 #ifdef __cplusplus

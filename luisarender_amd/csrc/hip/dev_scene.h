@@ -89,10 +89,14 @@ struct DEnvironment {
     const float *pdf;                      // [h][w]
     float direction[3];
     float cos_half_angle;
-    uint32_t visible, constant_emission, pad[2];
+    uint32_t visible, constant_emission;
+    uint32_t kind;                         // kEnv* of this record
+    float child_scale[2];                  // kEnvCombined (combined.cpp): scales and records of children a, b
+    uint32_t pad;
+    const DEnvironment *child[2];
 };
 
-enum : uint32_t { kEnvNone = 0u, kEnvConstant = 1u, kEnvImage = 2u, kEnvDirectional = 3u };
+enum : uint32_t { kEnvNone = 0u, kEnvConstant = 1u, kEnvImage = 2u, kEnvDirectional = 3u, kEnvCombined = 4u };
 
 struct DScene {
     // acceleration structure

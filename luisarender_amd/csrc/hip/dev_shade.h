@@ -601,10 +601,9 @@ LR_D void env_directional(const DScene &scene, const DEnvironment &env, f3 wi_lo
     L = env_radiance(scene, env, f2{.5f, .5f}) * (valid ? env.scale : 0.f);
     pdf = valid ? 1.f / (2.f * kPi * (1.f - env.cos_half_angle)) : 0.f;
 }
-// Environment::Instance::evaluate: spherical.cpp:88-108, directional.cpp:80-88
-LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
-    auto &env = *scene.env;
-    if (scene.env_kind == kEnvDirectional) {
+// Environment::Instance::evaluate of one Spherical / Directional record: spherical.cpp:88-108, directional.cpp:80-88
+LR_D void env_evaluate_one(const DScene &scene, const DEnvironment &env, f3 wi, f3 &L, float &pdf) {
+    if (env.kind == kEnvDirectional) {
         L = mk3(0.f), pdf = 0.f;
         if (!env.visible) { return; }
         auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
@@ -615,14 +614,14 @@ LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
     auto theta = acosf(w.y), phi = atan2f(w.x, w.z);// Spherical::direction_to_uv
     f2 uv{fract(1.f - 0.5f * kInvPi * phi), fract(theta * kInvPi)};
     L = env_radiance(scene, env, uv) * env.scale;
+    if (env.kind == kEnvConstant) { pdf = kInvPi * 0.25f; return; }
     auto sx = static_cast<float>(env.map_width), sy = static_cast<float>(env.map_height);
     auto ix = static_cast<uint32_t>(clampf(uv.x * sx, 0.f, sx - 1.f)), iy = static_cast<uint32_t>(clampf(uv.y * sy, 0.f, sy - 1.f));
     pdf = env_directional_pdf(env.pdf[iy * env.map_width + ix], theta);
 }
-// Environment::Instance::sample: spherical.cpp:110-141, directional.cpp:90-98
-LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
-    auto &env = *scene.env;
-    if (scene.env_kind == kEnvDirectional) {
+// Environment::Instance::sample of one record: spherical.cpp:110-141, directional.cpp:90-98
+LR_D void env_sample_one(const DScene &scene, const DEnvironment &env, f2 u, f3 &wi, f3 &L, float &pdf) {
+    if (env.kind == kEnvDirectional) {
         auto cos_t = (1.f - u.x) + u.x * env.cos_half_angle;// sample_uniform_cone
         auto sin_t = sqrtf(fmaxf(1.f - cos_t * cos_t, 0.f));
         auto phi = 2.f * kPi * u.y;
@@ -630,6 +629,15 @@ LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
         auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
         env_directional(scene, env, wi_local, L, pdf);
         wi = normalize(mul3(env.env_to_world, to_world(frame, wi_local)));
+        return;
+    }
+    if (env.kind == kEnvConstant) {// uniform sphere, spherical.cpp:114-118
+        auto z = 1.0f - 2.0f * u.x;
+        auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+        auto phi = 2.0f * kPi * u.y;
+        L = env_radiance(scene, env, f2{0.f, 0.f}) * env.scale;
+        pdf = kInvPi * 0.25f;
+        wi = normalize(mul3(env.env_to_world, mk3(r * cosf(phi), r * sinf(phi), z)));
         return;
     }
     auto W = env.map_width, H = env.map_height;
@@ -649,6 +657,42 @@ LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
     L = env_radiance(scene, env, uv) * env.scale;
     pdf = env_directional_pdf(p, theta);
     wi = normalize(mul3(env.env_to_world, w));
+}
+
+// root environment: one record, or CombinedInstance over two (combined.cpp:57-111)
+LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
+    auto &env = *scene.env;
+    if (env.kind != kEnvCombined) { env_evaluate_one(scene, env, wi, L, pdf); return; }
+    auto wi_local = normalize(mul3(env.world_to_env, wi));
+    f3 La, Lb;
+    float pa, pb;
+    env_evaluate_one(scene, *env.child[0], wi_local, La, pa);
+    env_evaluate_one(scene, *env.child[1], wi_local, Lb, pb);
+    auto sa = env.child_scale[0], sb = env.child_scale[1];
+    L = La * sa + Lb * sb;
+    pdf = lerp(pa, pb, sb / (sa + sb));
+}
+LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
+    auto &env = *scene.env;
+    if (env.kind != kEnvCombined) { env_sample_one(scene, env, u, wi, L, pdf); return; }
+    auto sa = env.child_scale[0], sb = env.child_scale[1];
+    auto weight_a = sa / (sa + sb);
+    f3 Lo;
+    float po;
+    if (u.x < weight_a) {// sample a, evaluate b
+        u.x = u.x / weight_a;
+        env_sample_one(scene, *env.child[0], u, wi, L, pdf);
+        env_evaluate_one(scene, *env.child[1], wi, Lo, po);
+        L = L * sa + Lo * sb;
+        pdf = lerp(pdf, po, 1.f - weight_a);
+    } else {
+        u.x = (u.x - weight_a) / (1.f - weight_a);
+        env_sample_one(scene, *env.child[1], u, wi, L, pdf);
+        env_evaluate_one(scene, *env.child[0], wi, Lo, po);
+        L = Lo * sa + L * sb;
+        pdf = lerp(po, pdf, 1.f - weight_a);
+    }
+    wi = normalize(mul3(env.env_to_world, wi));
 }
 
 }// namespace lrd

@@ -243,7 +243,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
     }
-    if (s->environment.kind > LR_ENV_DIRECTIONAL) {
+    if (s->environment.kind > LR_ENV_COMBINED || (s->environment.kind == LR_ENV_COMBINED && (s->environment_child_count != 2u || s->environment_children == nullptr))) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
     }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
@@ -347,39 +347,60 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     d.env = nullptr;
     if (s->environment.kind != LR_ENV_NONE) {
         auto &e = s->environment;
-        auto &t = s->textures[e.emission_tex];
+        if (e.kind != LR_ENV_COMBINED && (e.emission_tex < 0 || static_cast<uint32_t>(e.emission_tex) >= s->texture_count)) {
+            release_scene(ctx);
+            return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: environment without an emission texture");
+        }
+        auto &t = s->textures[e.kind == LR_ENV_COMBINED ? 0 : e.emission_tex];
         if (e.kind == LR_ENV_SPHERICAL && t.kind == LR_TEX_CONSTANT) {
             d.env_kind = lrd::kEnvConstant;
             auto sv = lrd::max0(lrd::extend_rgb(make_float4(t.v[0], t.v[1], t.v[2], t.v[3]), t.channels)) * e.scale;
             d.env_L[0] = sv.x, d.env_L[1] = sv.y, d.env_L[2] = sv.z;
             std::memcpy(d.env_to_world, e.env_to_world, sizeof(d.env_to_world));
         } else {
-            if (e.kind == LR_ENV_SPHERICAL && (e.alias == nullptr || e.pdf == nullptr || e.map_width == 0u || e.map_height == 0u)) {
-                release_scene(ctx);
-                return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: image-based Spherical environment without importance tables");
-            }
-            d.env_kind = e.kind == LR_ENV_SPHERICAL ? lrd::kEnvImage : lrd::kEnvDirectional;
-            ctx->full_surfaces = true;
-            lrd::DEnvironment de{};
-            std::memcpy(de.world_to_env, e.world_to_env, sizeof(de.world_to_env));
-            std::memcpy(de.env_to_world, e.env_to_world, sizeof(de.env_to_world));
-            de.emission_tex = e.emission_tex, de.scale = e.scale;
-            de.constant_emission = t.kind == LR_TEX_CONSTANT ? 1u : 0u;
-            std::memcpy(de.direction, e.direction, sizeof(de.direction));
-            de.cos_half_angle = e.cos_half_angle, de.visible = e.visible;
-            int rc2 = LRHIP_OK;
-            if (d.env_kind == lrd::kEnvImage) {
-                de.map_width = e.map_width, de.map_height = e.map_height;
-                auto texels = static_cast<size_t>(e.map_width) * e.map_height;
-                if ((rc2 = upload(ctx, e.alias, texels + e.map_height, &de.alias)) != LRHIP_OK || (rc2 = upload(ctx, e.pdf, texels, &de.pdf)) != LRHIP_OK) {
-                    release_scene(ctx);
-                    return rc2;
+            // one DEnvironment per record; a Combined root points at its two children
+            auto make_record = [&](const lr_environment &r, lrd::DEnvironment &de) -> int {
+                auto &rt = s->textures[r.emission_tex];
+                de = lrd::DEnvironment{};
+                std::memcpy(de.world_to_env, r.world_to_env, sizeof(de.world_to_env));
+                std::memcpy(de.env_to_world, r.env_to_world, sizeof(de.env_to_world));
+                de.emission_tex = r.emission_tex, de.scale = r.scale;
+                de.constant_emission = rt.kind == LR_TEX_CONSTANT ? 1u : 0u;
+                std::memcpy(de.direction, r.direction, sizeof(de.direction));
+                de.cos_half_angle = r.cos_half_angle, de.visible = r.visible;
+                if (r.kind == LR_ENV_DIRECTIONAL) { de.kind = lrd::kEnvDirectional; return LRHIP_OK; }
+                if (r.kind != LR_ENV_SPHERICAL) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: invalid environment record"); }
+                if (rt.kind == LR_TEX_CONSTANT) { de.kind = lrd::kEnvConstant; return LRHIP_OK; }
+                if (r.alias == nullptr || r.pdf == nullptr || r.map_width == 0u || r.map_height == 0u) {
+                    return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: image-based Spherical environment without importance tables");
                 }
+                de.kind = lrd::kEnvImage;
+                de.map_width = r.map_width, de.map_height = r.map_height;
+                auto texels = static_cast<size_t>(r.map_width) * r.map_height;
+                if (auto rc2 = upload(ctx, r.alias, texels + r.map_height, &de.alias); rc2 != LRHIP_OK) { return rc2; }
+                return upload(ctx, r.pdf, texels, &de.pdf);
+            };
+            ctx->full_surfaces = true;
+            lrd::DEnvironment root{};
+            int rc2 = LRHIP_OK;
+            if (e.kind == LR_ENV_COMBINED) {
+                std::memcpy(root.world_to_env, e.world_to_env, sizeof(root.world_to_env));
+                std::memcpy(root.env_to_world, e.env_to_world, sizeof(root.env_to_world));
+                root.kind = lrd::kEnvCombined;
+                root.child_scale[0] = e.child_scale[0], root.child_scale[1] = e.child_scale[1];
+                for (auto i = 0; i < 2 && rc2 == LRHIP_OK; i++) {
+                    lrd::DEnvironment child{};
+                    if ((rc2 = make_record(s->environment_children[i], child)) == LRHIP_OK) { rc2 = upload(ctx, &child, 1u, &root.child[i]); }
+                }
+            } else {
+                rc2 = make_record(e, root);
             }
-            if ((rc2 = upload(ctx, &de, 1u, &d.env)) != LRHIP_OK) {
+            if (rc2 == LRHIP_OK) { rc2 = upload(ctx, &root, 1u, &d.env); }
+            if (rc2 != LRHIP_OK) {
                 release_scene(ctx);
                 return rc2;
             }
+            d.env_kind = root.kind;
         }
     }
     d.max_depth = s->integrator.max_depth, d.rr_depth = s->integrator.rr_depth;

@@ -93,9 +93,8 @@ public:
 // ((pixel + .5 + k/8) / size, k = -8..8), so each band of map rows evaluates the texture once per grid
 // point (17 grid rows resident) and then accumulates the 17 x 17 taps in the reference's dy-outer /
 // dx-inner order.
-void build_environment_tables(SceneData &scene) {
-    auto &env = scene.environment;
-    scene.env_alias.clear(), scene.env_pdf.clear();
+void build_environment_tables(const SceneData &scene, lr_environment &env, std::vector<lr_alias_entry> &env_alias, std::vector<float> &env_pdf) {
+    env_alias.clear(), env_pdf.clear();
     env.map_width = env.map_height = 0u;
     if (env.kind != LR_ENV_SPHERICAL || env.emission_tex < 0) { return; }
     if (scene.textures[static_cast<size_t>(env.emission_tex)].kind == LR_TEX_CONSTANT) { return; }// uniform sphere sampling
@@ -165,8 +164,8 @@ void build_environment_tables(SceneData &scene) {
         for (auto &s : scale_map) { s = std::max(s - average_scale, 0.f); }
     }
     std::vector<float> row_averages(H);
-    scene.env_pdf.resize(pixel_count);
-    scene.env_alias.resize(H + pixel_count);
+    env_pdf.resize(pixel_count);
+    env_alias.resize(H + pixel_count);
     {// conditional tables, one per row (independent -> threaded)
         auto workers = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
         std::vector<std::thread> pool;
@@ -183,8 +182,8 @@ void build_environment_tables(SceneData &scene) {
                     for (auto x = 0u; x < W; x++) { sum += values[x]; }
                     row_averages[i] = static_cast<float>(sum * (1.0 / W));
                     create_alias_table(values, W, table, pdf);
-                    std::copy_n(pdf.data(), W, scene.env_pdf.data() + static_cast<size_t>(i) * W);
-                    std::copy_n(table.data(), W, scene.env_alias.data() + H + static_cast<size_t>(i) * W);
+                    std::copy_n(pdf.data(), W, env_pdf.data() + static_cast<size_t>(i) * W);
+                    std::copy_n(table.data(), W, env_alias.data() + H + static_cast<size_t>(i) * W);
                 }
             });
         }
@@ -193,10 +192,10 @@ void build_environment_tables(SceneData &scene) {
     std::vector<lr_alias_entry> table;
     std::vector<float> pdf;
     create_alias_table(row_averages.data(), H, table, pdf);// marginal over rows
-    std::copy_n(table.data(), H, scene.env_alias.data());
+    std::copy_n(table.data(), H, env_alias.data());
     for (auto y = 0u; y < H; y++) {
         auto scale = static_cast<float>(pdf[y] * pixel_count);
-        for (auto x = 0u; x < W; x++) { scene.env_pdf[static_cast<size_t>(y) * W + x] *= scale; }
+        for (auto x = 0u; x < W; x++) { env_pdf[static_cast<size_t>(y) * W + x] *= scale; }
     }
     env.map_width = W, env.map_height = H;
 }

@@ -91,6 +91,13 @@ lr_scene SceneData::view(size_t camera_index) const {
     s.environment = environment;
     s.environment.alias = env_alias.empty() ? nullptr : env_alias.data();
     s.environment.pdf = env_pdf.empty() ? nullptr : env_pdf.data();
+    env_children_view = env_children;
+    for (size_t i = 0; i < env_children_view.size(); i++) {
+        env_children_view[i].alias = env_child_alias[i].empty() ? nullptr : env_child_alias[i].data();
+        env_children_view[i].pdf = env_child_pdf[i].empty() ? nullptr : env_child_pdf[i].data();
+    }
+    s.environment_children = env_children_view.empty() ? nullptr : env_children_view.data();
+    s.environment_child_count = static_cast<uint32_t>(env_children_view.size());
     if (camera_index >= cameras.size()) { throw Error{"Camera index out of range."}; }
     s.camera = cameras[camera_index].camera;
     s.filter = cameras[camera_index].filter;
@@ -910,6 +917,7 @@ public:
     }
 
     void build_environment(const NodeDesc *d);
+    lr_environment build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf);
 
     // tables of src/util/sobolmatrices.cpp, re-derived by tools/gen_sobol_tables.py into data/sobol_tables.bin
     void load_sobol_tables() {
@@ -1016,11 +1024,12 @@ public:
     }
 };
 
-void Builder::build_environment(const NodeDesc *d) {
-    auto &env = _out.environment;
-    env = lr_environment{};
+// one Spherical / Directional record (kind LR_ENV_NONE when null or black)
+lr_environment Builder::build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf) {
+    lr_environment env{};
     env.emission_tex = -1;
-    if (d == nullptr || d->impl_type() == "null") { return; }
+    alias.clear(), pdf.clear();
+    if (d == nullptr || d->impl_type() == "null") { return env; }
     _check_tag(d, Tag::ENVIRONMENT);
     auto m = transform_matrix(d->node_or_null("transform"));
     // Environment::Instance::transform_to_world: 3x3 of the env transform (environment.cpp:17-19)
@@ -1036,7 +1045,7 @@ void Builder::build_environment(const NodeDesc *d) {
         env.scale = std::max(d->float_or("scale", 1.f), 0.f);
         env.compensate_mis = d->bool_or("compensate_mis", true) ? 1u : 0u;
         if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
-        if (env.kind != LR_ENV_NONE) { build_environment_tables(_out); }// no-op for constant emission
+        if (env.kind != LR_ENV_NONE) { build_environment_tables(_out, env, alias, pdf); }// no-op for constant emission
     } else if (d->impl_type() == "directional") {// directional.cpp:27-47
         env.kind = LR_ENV_DIRECTIONAL;
         env.emission_tex = load_texture(d->node("emission"));
@@ -1054,9 +1063,62 @@ void Builder::build_environment(const NodeDesc *d) {
         auto dir = dv ? normalize(float3{static_cast<float>((*dv)[0]), static_cast<float>((*dv)[1]), static_cast<float>((*dv)[2])}) : float3{0.f, 1.f, 0.f};
         env.direction[0] = dir.x, env.direction[1] = dir.y, env.direction[2] = dir.z;
         if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
+    } else if (d->impl_type() == "combined") {
+        throw Error{"A Combined environment nested inside a Combined environment is not supported. [" + d->location() + "]"};
     } else {
-        throw Error{"Environment '" + d->impl_type() + "' is not built (SURVEY §8 f1: Spherical and Directional are). [" + d->location() + "]"};
+        throw Error{"Unknown environment implementation '" + d->impl_type() + "'. [" + d->location() + "]"};
     }
+    return env;
+}
+
+void Builder::build_environment(const NodeDesc *d) {
+    _out.env_children.clear();
+    if (d == nullptr || d->impl_type() != "combined") {
+        _out.environment = build_environment_node(d, _out.env_alias, _out.env_pdf);
+        return;
+    }
+    // combined.cpp:23-36: a null or black child gets scale 0
+    _check_tag(d, Tag::ENVIRONMENT);
+    lr_environment child[2];
+    child[0] = build_environment_node(d->node_or_null("a"), _out.env_child_alias[0], _out.env_child_pdf[0]);
+    child[1] = build_environment_node(d->node_or_null("b"), _out.env_child_alias[1], _out.env_child_pdf[1]);
+    float scales[2] = {std::max(d->float_or("scale_a", 1.f), 0.f), std::max(d->float_or("scale_b", 1.f), 0.f)};
+    for (auto i = 0; i < 2; i++) {
+        if (child[i].kind == LR_ENV_NONE) { scales[i] = 0.f; }
+    }
+    auto m = transform_matrix(d->node_or_null("transform"));
+    float c2w[9], w2c[9];
+    for (auto c = 0; c < 3; c++) {
+        for (auto r = 0; r < 3; r++) { c2w[c * 3 + r] = m[c][r], w2c[c * 3 + r] = m[r][c]; }
+    }
+    auto &env = _out.environment;
+    env = lr_environment{};
+    env.emission_tex = -1;
+    if (scales[0] == 0.f && scales[1] == 0.f) { return; }// is_black, :36
+    if (scales[0] == 0.f || scales[1] == 0.f) {
+        // only one live child (combined.cpp:72-77,103-109): that child seen through the Combined node's transform with
+        // its radiance scaled — the same function as the child record with composed matrices and scale
+        auto live = scales[0] == 0.f ? 1 : 0;
+        env = child[live];
+        env.scale *= scales[live];
+        auto mul = [](const float *a, const float *b, float *out) {// out = a * b, column-major 3x3
+            for (auto c = 0; c < 3; c++) {
+                for (auto r = 0; r < 3; r++) { out[c * 3 + r] = a[0 * 3 + r] * b[c * 3 + 0] + a[1 * 3 + r] * b[c * 3 + 1] + a[2 * 3 + r] * b[c * 3 + 2]; }
+            }
+        };
+        float w[9], e[9];
+        mul(child[live].world_to_env, w2c, w);// wi_local = W_child (W_comb wi)
+        mul(c2w, child[live].env_to_world, e);// wi_world = E_comb (E_child w)
+        std::copy_n(w, 9, env.world_to_env), std::copy_n(e, 9, env.env_to_world);
+        _out.env_alias = std::move(_out.env_child_alias[live]), _out.env_pdf = std::move(_out.env_child_pdf[live]);
+        _out.env_child_alias[0].clear(), _out.env_child_alias[1].clear(), _out.env_child_pdf[0].clear(), _out.env_child_pdf[1].clear();
+        return;
+    }
+    env.kind = LR_ENV_COMBINED;
+    std::copy_n(c2w, 9, env.env_to_world), std::copy_n(w2c, 9, env.world_to_env);
+    env.child_scale[0] = scales[0], env.child_scale[1] = scales[1];
+    _out.env_children = {child[0], child[1]};
+    _out.env_alias.clear(), _out.env_pdf.clear();
 }
 
 }// namespace

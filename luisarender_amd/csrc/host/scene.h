@@ -39,6 +39,11 @@ struct SceneData {
     lr_environment environment{};
     std::vector<lr_alias_entry> env_alias;
     std::vector<float> env_pdf;
+    // children of a Combined environment (combined.cpp) with their own importance tables
+    std::vector<lr_environment> env_children;
+    std::vector<lr_alias_entry> env_child_alias[2];
+    std::vector<float> env_child_pdf[2];
+    mutable std::vector<lr_environment> env_children_view;// children with table pointers patched, for view()
     std::vector<CameraRecord> cameras;
     lr_sampler sampler{};
     std::vector<uint32_t> sobol_matrices;      // [1024][52] (Sobol samplers only)
@@ -69,7 +74,7 @@ lr_uint4 encode_instance_handle(uint32_t buffer_base, uint32_t flags, uint32_t s
 std::unique_ptr<SceneData> build_scene(const SceneDesc &desc);
 
 // environment.cpp: importance tables of an image-based Spherical environment (spherical.cpp:144-235)
-void build_environment_tables(SceneData &scene);
+void build_environment_tables(const SceneData &scene, lr_environment &env, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf);
 
 // accel.cpp: flatten instances to world space and build the 4-wide BVH for the HIP kernel
 void build_accel(SceneData &scene);

@@ -360,26 +360,32 @@ struct oracle_ctx {
         auto inv_s = sn > 0.f ? 1.f / sn : 0.f;
         return p * inv_s * (.5f * inv_pi * inv_pi);
     }
-    bool env_is_image() const { return scene->environment.kind == LR_ENV_SPHERICAL && scene->environment.map_width != 0u; }
-    LightEval env_directional(float3 wi_local) const {// DirectionalInstance::_evaluate
-        auto &env = scene->environment;
+    static bool env_is_image(const lr_environment &env) { return env.kind == LR_ENV_SPHERICAL && env.map_width != 0u; }
+    LightEval env_directional(const lr_environment &env, float3 wi_local) const {// DirectionalInstance::_evaluate
         auto L = illuminant(*scene, env.emission_tex, {.5f, .5f}).value;
         auto pdf = 1.f / (2.f * pi * (1.f - env.cos_half_angle));// uniform_cone_pdf, sampling.cpp:119-121
         auto valid = env.cos_half_angle < cos_theta(wi_local);
         return {L * (valid ? env.scale : 0.f), valid ? pdf : 0.f};
     }
-    LightEval env_evaluate(float3 wi) const {
-        auto &env = scene->environment;
+    LightEval env_evaluate(float3 wi) const { return env_evaluate(scene->environment, wi); }
+    LightEval env_evaluate(const lr_environment &env, float3 wi) const {
+        if (env.kind == LR_ENV_COMBINED) {// CombinedInstance::evaluate, combined.cpp:57-78 (both children live)
+            auto wi_local = normalize(mul3(env.world_to_env, wi));
+            auto a = env_evaluate(scene->environment_children[0], wi_local), b = env_evaluate(scene->environment_children[1], wi_local);
+            auto sa = env.child_scale[0], sb = env.child_scale[1];
+            auto t = sb / (sa + sb);
+            return {a.L * sa + b.L * sb, lerp(a.pdf, b.pdf, t)};
+        }
         if (env.kind == LR_ENV_DIRECTIONAL) {
             if (!env.visible) { return {}; }
             auto frame = Frame::make(f3(env.direction[0], env.direction[1], env.direction[2]));
-            return env_directional(normalize(frame.world_to_local(mul3(env.world_to_env, wi))));
+            return env_directional(env, normalize(frame.world_to_local(mul3(env.world_to_env, wi))));
         }
         auto w = normalize(mul3(env.world_to_env, wi));
         auto theta = std::acos(w.y), phi = std::atan2(w.x, w.z);// Spherical::direction_to_uv, spherical.cpp:51-57
         float2 uv{fract(1.f - 0.5f * inv_pi * phi), fract(theta * inv_pi)};
         auto L = illuminant(*scene, env.emission_tex, uv).value * env.scale;
-        if (!env_is_image()) { return {L, uniform_sphere_pdf}; }
+        if (!env_is_image(env)) { return {L, uniform_sphere_pdf}; }
         auto sx = static_cast<float>(env.map_width), sy = static_cast<float>(env.map_height);
         auto ix = static_cast<uint32_t>(clampf(uv.x * sx, 0.f, sx - 1.f)), iy = static_cast<uint32_t>(clampf(uv.y * sy, 0.f, sy - 1.f));
         return {L, directional_pdf(env.pdf[iy * env.map_width + ix], theta)};
@@ -388,17 +394,38 @@ struct oracle_ctx {
         LightEval eval;
         float3 wi;
     };
-    EnvSample env_sample(float2 u) const {
-        auto &env = scene->environment;
+    EnvSample env_sample(float2 u) const { return env_sample(scene->environment, u); }
+    EnvSample env_sample(const lr_environment &env, float2 u) const {
+        if (env.kind == LR_ENV_COMBINED) {// CombinedInstance::sample, combined.cpp:80-111
+            auto &ca = scene->environment_children[0], &cb = scene->environment_children[1];
+            auto sa = env.child_scale[0], sb = env.child_scale[1];
+            auto weight_a = sa / (sa + sb);
+            EnvSample s;
+            if (u.x < weight_a) {
+                u.x = u.x / weight_a;
+                s = env_sample(ca, u);
+                auto eb = env_evaluate(cb, s.wi);
+                s.eval.L = s.eval.L * sa + eb.L * sb;
+                s.eval.pdf = lerp(s.eval.pdf, eb.pdf, 1.f - weight_a);
+            } else {
+                u.x = (u.x - weight_a) / (1.f - weight_a);
+                s = env_sample(cb, u);
+                auto ea = env_evaluate(ca, s.wi);
+                s.eval.L = ea.L * sa + s.eval.L * sb;
+                s.eval.pdf = lerp(ea.pdf, s.eval.pdf, 1.f - weight_a);
+            }
+            s.wi = normalize(mul3(env.env_to_world, s.wi));
+            return s;
+        }
         if (env.kind == LR_ENV_DIRECTIONAL) {
             auto cos_t = (1.f - u.x) + u.x * env.cos_half_angle;// sample_uniform_cone, sampling.cpp:123-131
             auto sin_t = std::sqrt(std::max(1.f - cos_t * cos_t, 0.f));
             auto phi = 2.f * pi * u.y;
             auto wi_local = f3(sin_t * std::cos(phi), sin_t * std::sin(phi), cos_t);
             auto frame = Frame::make(f3(env.direction[0], env.direction[1], env.direction[2]));
-            return {env_directional(wi_local), normalize(mul3(env.env_to_world, frame.local_to_world(wi_local)))};
+            return {env_directional(env, wi_local), normalize(mul3(env.env_to_world, frame.local_to_world(wi_local)))};
         }
-        if (!env_is_image()) {
+        if (!env_is_image(env)) {
             auto w = sample_uniform_sphere(u);
             auto L = illuminant(*scene, env.emission_tex, {0.f, 0.f}).value * env.scale;
             return {{L, uniform_sphere_pdf}, normalize(mul3(env.env_to_world, w))};

@@ -151,3 +151,31 @@ def test_directional_environment_closed_form():
             assert (got < expect * 1.03).all() and (got > 0.3 * expect).all()
         else:
             assert np.allclose(got, expect, rtol=0.03), (got, expect)
+
+
+def test_combined_environment(sky):
+    """combined.cpp: L = a * scale_a + b * scale_b under the Combined node's transform; a Combined with one live child is
+    flattened by the host into that child (composed transform, scaled radiance)."""
+    path, img = sky
+    sun = "Directional { emission : Constant { v { 1, 2, 3 } } scale { 0.5 } angle { 10 } direction { 0, 1, 0 } }"
+    dome = f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} }}'
+    both = f"Combined {{ a : {dome} b : {sun} scale_a {{ 0.5 }} scale_b {{ 2 }} transform : SRT {{ rotate {{ 0, 1, 0, 40 }} }} }}"
+    sc = Scene.from_string(PLANE.format(env=both))
+    view = sc.view()
+    assert view.environment.kind == 3 and view.environment_child_count == 2
+    o = Oracle(sc)
+    film, _ = o.render(0, 1024)
+    got = o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0)
+    half = np.radians(5.0)
+    sun_part = np.array([0.6, 0.4, 0.2]) / np.pi * (np.array([1.0, 2.0, 3.0]) * 2 * 0.5 / (1 - np.cos(half))) * np.pi * np.sin(half) ** 2
+    expect = 0.5 * _plane_radiance(img) + 2.0 * sun_part
+    assert np.allclose(got, expect, rtol=0.03), (got, expect)
+    # one black child -> flattened into the other
+    lone = f"Combined {{ a : {dome} b : Spherical {{ emission : Constant {{ v {{ 0 }} }} }} scale_a {{ 0.25 }} transform : SRT {{ rotate {{ 0, 1, 0, 40 }} }} }}"
+    sc = Scene.from_string(PLANE.format(env=lone))
+    view = sc.view()
+    assert view.environment.kind == 1 and view.environment_child_count == 0 and view.environment.map_width == W
+    o = Oracle(sc)
+    film, _ = o.render(0, 512)
+    got = o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0)
+    assert np.allclose(got, 0.25 * _plane_radiance(img), rtol=0.03)

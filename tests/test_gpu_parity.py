@@ -178,7 +178,7 @@ render {{ cameras {{ @cam }} shapes {{ @quad, @cube }}
 """
 
 
-@pytest.mark.parametrize("kind", ["image", "image_rotated", "directional", "directional_hidden"])
+@pytest.mark.parametrize("kind", ["image", "image_rotated", "directional", "directional_hidden", "combined", "combined_constant"])
 def test_image_and_directional_environments(renderer, tmp_path, kind):
     """Rows a11 / f1: importance-sampled lat-long environment (alias + pdf tables built by lrhost, shared by both sides) and
     the Directional cone, on the FULL kernel variant.  acos/atan2/sin differ by ulps between libm and the device, which can
@@ -190,7 +190,12 @@ def test_image_and_directional_environments(renderer, tmp_path, kind):
     env = {"image": f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} }}',
            "image_rotated": f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} scale {{ 2 }} compensate_mis {{ false }} transform : SRT {{ rotate {{ 0.2, 1, 0.1, 130 }} }} }}',
            "directional": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 6 } direction { 0.4, 1, 0.3 } }",
-           "directional_hidden": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 25 } direction { -0.5, 1, 0.2 } visible { false } normalize { false } scale { 4 } }"}[kind]
+           "directional_hidden": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 25 } direction { -0.5, 1, 0.2 } visible { false } normalize { false } scale { 4 } }",
+           "combined": f'Combined {{ a : Spherical {{ emission : Image {{ file {{ "{path}" }} }} transform : SRT {{ rotate {{ 1, 0, 0, 20 }} }} }} '
+                       'b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } } scale_a { 0.7 } scale_b { 1.5 } '
+                       'transform : SRT { rotate { 0, 1, 0, 60 } } }',
+           "combined_constant": 'Combined { a : Spherical { emission : Constant { v { 0.4, 0.5, 0.7 } } } '
+                                'b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 12 } direction { -0.3, 1, 0.2 } } }'}[kind]
     sc = Scene.from_string(ENV_SCENE.format(env=env, spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
