@@ -25,7 +25,7 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean hip-variant
+.PHONY: all host hip oracle cli clean hip-variant variant-lib
 all: host oracle hip cli
 
 host: $(LIBDIR)/liblrhost.so
@@ -37,15 +37,32 @@ oracle: oracle/liboracle.so
 oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h Makefile
 	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/oracle.cpp
 
-hip: $(LIBDIR)/liblrhip.so
-$(LIBDIR)/liblrhip.so: $(HIP_SRC) $(HIP_HDR) Makefile
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+# The megakernel is precompiled for a curated set of feature masks (csrc/hip/variants.h), one object per mask so
+# that they build in parallel (make -j).  VARIANT_MASKS may be narrowed for experiments (a missing variant is a
+# run-time error of lrhip_render, never a fallback).
+VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127
+OBJDIR := $(LIBDIR)/obj
+VARIANT_OBJ := $(foreach m,$(VARIANT_MASKS),$(OBJDIR)/variant_$(m).o)
 
-# experimental kernel variants for A/B runs on the GPU box: make hip-variant NAME=w4 DEFS="-DLR_MIN_WAVES=4"
+hip: $(LIBDIR)/liblrhip.so
+$(OBJDIR)/variant_%.o: $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DLR_VARIANT=$* -c -o $@ $(HIPDIR)/megapath_variant.hip
+$(OBJDIR)/lrhip.o: $(HIP_SRC) $(HIP_HDR) Makefile
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(HIP_SRC)
+$(LIBDIR)/liblrhip.so: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $^
+
+# experimental kernel builds for A/B runs on the GPU box:
+#   make hip-variant NAME=w3 DEFS="-DLR_WAVES_HEAVY=3" [VARIANT_MASKS="0 1"]
+VOBJDIR := $(LIBDIR)/variants/obj_$(NAME)
 hip-variant:
-	@mkdir -p $(LIBDIR)/variants
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o $(LIBDIR)/variants/liblrhip_$(NAME).so $(HIP_SRC)
+	@mkdir -p $(VOBJDIR)
+	$(MAKE) --no-print-directory OBJDIR=$(VOBJDIR) HIPFLAGS='$(HIPFLAGS) $(DEFS)' VARIANT_MASKS='$(VARIANT_MASKS)' \
+	    LIBDIR_OUT=$(LIBDIR)/variants/liblrhip_$(NAME).so variant-lib
+variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -o $(LIBDIR_OUT) $^
 
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)
@@ -55,4 +72,4 @@ $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTDIR)/cli.cpp -L$(LIBDIR) -llrhost -ldl -pthread -Wl,-rpath,'$$ORIGIN/../lib'
 
 clean:
-	rm -f $(LIBDIR)/*.so $(BINDIR)/* oracle/liboracle.so
+	rm -rf $(LIBDIR)/*.so $(LIBDIR)/obj $(LIBDIR)/variants $(BINDIR)/* oracle/liboracle.so

@@ -32,12 +32,19 @@ WORKLOADS = {
     # name: (description, resolution, spp, depth)
     "c2": ("Contemporary Bathroom-class (procedural stand-in, ~600k tris), 1024x1024, 1024spp, depth 16", (1024, 1024), 1024, 16),
     "c1": ("Cornell Box, 512x512, 64spp, depth 8", (512, 512), 64, 8),
+    # parity-test configurations; benchable on request (--workload), never the default line
+    "c3": ("Bedroom-class (procedural stand-in: window openings, 10% glass, image environment), 1280x720, 4096spp, depth 16", (1280, 720), 4096, 16),
+    "c4": ("Camera-class (procedural stand-in: ~1M tris, Disney/Plastic/Matte on 8 2k images, thin lens, env), 3840x2160, 1024spp, depth 16", (3840, 2160), 1024, 16),
+    "c5": ("Kitchen-class (procedural stand-in: full surface closure set), 1280x720, 65536spp, depth 16", (1280, 720), 65536, 16),
 }
+# C5's 60.4 G samples take minutes per frame; throughput of the Independent sampler is spp-invariant, so the bench
+# times this many spp of the same frame unless --spp says otherwise and says so in config.note
+BENCH_SPP_CAP = {"c5": 2048}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per sample (SURVEY §8d formula on the oracle's canonical-BVH2 counters).  Measured live by
 # the cpu_baseline leg at N = 1 (and reported from that measurement); at N > 1 no oracle runs, so the N = 1
 # value of the same seeded workload is used (profiles/r01_bench_c2_1gpu.json).
-ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 2500.0}
+ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 2500.0, "c3": 15000.0, "c4": 15000.0, "c5": 15000.0}
 METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
@@ -45,11 +52,15 @@ def build_scene(workload: str, tmpdir: str, spp_override: int | None):
     from luisarender_amd import Scene
     from luisarender_amd.scenes import cornell_box, generate_room_scene
     desc, res, spp, depth = WORKLOADS[workload]
-    spp = spp_override or spp
+    spp = spp_override or min(spp, BENCH_SPP_CAP.get(workload, spp))
     if workload == "c1":
         scene = Scene.from_string(cornell_box(resolution=res[0], spp=spp, depth=depth))
-    else:
+    elif workload == "c2":
         scene = Scene.load(generate_room_scene(tmpdir, resolution=res, spp=spp, depth=depth))
+    else:
+        from luisarender_amd.scenes import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
+        gen = {"c3": generate_bedroom_scene, "c4": generate_camera_scene, "c5": generate_kitchen_scene}[workload]
+        scene = Scene.load(gen(tmpdir, resolution=res, spp=spp, depth=depth))
     return scene, desc, res, spp
 
 
@@ -150,6 +161,8 @@ def main():
             }
             if args.spp is not None:
                 out["config"]["note"] = "spp overridden: not the headline configuration"
+            elif args.workload in BENCH_SPP_CAP:
+                out["config"]["note"] = f"timed at {spp} spp of the same frame (Independent sampler: throughput is spp-invariant)"
             bytes_per_sample = ALGORITHMIC_BYTES_PER_SAMPLE[args.workload]
             if world == 1 and not args.no_cpu_baseline:  # the CPU leg runs on rank 0 at N = 1 only
                 cpu, bytes_per_sample, _ = cpu_baseline(scene, res, args.cpu_seconds)
@@ -166,7 +179,7 @@ def main():
                     traffic = None
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "kernel": "lrd::megapath_kernel<false, false, false>", "kernel_ms": mean_kernel_ms,
+                "traffic": traffic, "kernel": f"lrd::megapath_kernel<{renderer.last_variant()}u>", "kernel_ms": mean_kernel_ms,
                 "algorithmic_bytes_per_sample": bytes_per_sample,
                 "note": "algorithmic bytes = canonical BVH2 walk of the oracle (SURVEY 8d); the quantised BVH4 + L2/LDS reuse "
                         "serve most of them on chip, so `achieved` may exceed the HBM peak while `traffic` (PMC, per launch) "

@@ -60,7 +60,9 @@ typedef struct lrhip_counters {
      * ones in which the lane had a ray in flight; shading blocks executed per lane / with a hit to shade */
     uint64_t trace_steps, trace_steps_busy, shade_calls, shade_busy;
     uint64_t trace_steps_starved; /* lane-steps idle because the lane had no sample left to start */
-    uint64_t reserved;
+    /* wave-cycle diagnostics (s_memtime, summed over waves): inside the shading block (A), inside the traversal
+     * loop (B), and from a wave's first to its last instruction */
+    uint64_t shade_cycles, trace_cycles, wave_cycles;
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);
@@ -88,6 +90,18 @@ int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted);
 int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out); /* summed since upload; synchronises */
 /* HIP-event time of the megakernel launches of the last lrhip_render call, in ms; synchronises */
 double lrhip_last_render_ms(lrhip_ctx *ctx);
+/* Feature mask of the precompiled megakernel variant the last lrhip_render launched (the reference JIT-compiles one
+ * kernel per scene, src/base/integrator.cpp:56-77; here the smallest precompiled superset of the scene's needs is
+ * picked): bit 0 counters, 1 generic sampler, 2 image/directional environment, 3 alpha-tested traversal, 4 Disney,
+ * 5 Mix, 6 Layered.  The kernel's symbol is lrd::megapath_kernel<mask>.                                          */
+#define LRHIP_FEAT_COUNT 1u
+#define LRHIP_FEAT_GENERIC_SAMPLER 2u
+#define LRHIP_FEAT_ENVIRONMENT 4u
+#define LRHIP_FEAT_ALPHA 8u
+#define LRHIP_FEAT_DISNEY 16u
+#define LRHIP_FEAT_MIX 32u
+#define LRHIP_FEAT_LAYERED 64u
+uint32_t lrhip_last_variant(lrhip_ctx *ctx);
 
 const char *lrhip_last_error(void);
 

@@ -139,7 +139,7 @@ class OracleCounters(C.Structure):
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
-                                   "shade_calls", "shade_busy", "trace_steps_starved", "reserved")]
+                                   "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -232,5 +232,7 @@ def hip_lib() -> C.CDLL:
         lib.lrhip_last_render_ms.restype = C.c_double
         lib.lrhip_last_render_ms.argtypes = [C.c_void_p]
         lib.lrhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lrhip_last_variant.restype = C.c_uint32
+        lib.lrhip_last_variant.argtypes = [C.c_void_p]
         lib._lr_ready = True
     return lib

@@ -79,7 +79,7 @@ LR_D f3 layer_to_local(const LayerStack &L, bool is_top, f3 w) { return to_local
 LR_D f3 layer_to_world(const LayerStack &L, bool is_top, f3 w) { return to_world(is_top ? L.f_top : L.f_bottom, w); }
 
 // LayeredSurfaceClosure::_evaluate, :256-398 (+ the public wrapper's side validation, surface.cpp:45-56)
-LR_D BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
+LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
     constexpr auto mode = false, reverse_mode = true;// RADIANCE / IMPORTANCE
     auto samples = static_cast<float>(L.samples);
     auto wi_local = to_local(L.own, wi), wo_local = to_local(L.own, wo);
@@ -199,7 +199,7 @@ LR_D BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
 }
 
 // LayeredSurfaceClosure::_sample, :399-470
-LR_D BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 u) {
+LR_HEAVY BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 u) {
     constexpr auto mode = false;
     auto wo_local = to_local(L.own, wo);
     auto entered_top = wo_local.z > 0.f;

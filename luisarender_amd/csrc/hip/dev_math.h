@@ -9,6 +9,10 @@
 
 #define LR_HD __host__ __device__ __forceinline__
 #define LR_D __device__ __forceinline__
+// rare, register-hungry interpreters (Layered random walk): real calls, so that their registers are not the megakernel's
+#ifndef LR_HEAVY
+#define LR_HEAVY __device__ __noinline__
+#endif
 
 namespace lrd {
 

@@ -1,0 +1,34 @@
+// film_kernels.h — the small kernels around the megakernel: chunk resolve and the Color film's convert
+// (src/films/color.cpp:87-93).  Included by lrhip.hip only (the megakernel variants are separate objects).
+#pragma once
+#include "dev_scene.h"
+
+namespace lrd {
+
+// film += sum over chunks of the per-chunk partial sums, in chunk order (deterministic)
+__global__ void resolve_partial_kernel(float4 *film, const float4 *partial, uint32_t pixel_count, uint32_t chunk_count,
+                                       uint32_t width, uint32_t tiles_x, uint32_t tile_begin, uint32_t tile_end,
+                                       uint32_t tile_stride) {
+    auto i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixel_count) { return; }
+    auto px = i % width, py = i / width;
+    auto tile = (py / 8u) * tiles_x + px / 8u;
+    if (tile < tile_begin || tile >= tile_end || (tile - tile_begin) % tile_stride != 0u) { return; }
+    auto v = film[i];
+    for (auto c = 0u; c < chunk_count; c++) {
+        auto p = partial[static_cast<size_t>(c) * pixel_count + i];
+        v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+    }
+    film[i] = v;
+}
+
+// convert kernel of the Color film, color.cpp:87-93
+__global__ void film_convert_kernel(const float4 *film, float4 *out, uint32_t pixel_count, float sx, float sy, float sz) {
+    auto i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixel_count) { return; }
+    auto c = film[i];
+    auto inv = 1.f / fmaxf(c.w, 1.f);
+    out[i] = make_float4((inv * sx) * c.x, (inv * sy) * c.y, (inv * sz) * c.z, 1.f);
+}
+
+}// namespace lrd

@@ -13,9 +13,42 @@
 #include <string>
 #include <vector>
 
+#include "film_kernels.h"
 #include "megapath_kernel.h"
+#include "variants.h"
+
+// one translation unit per precompiled megakernel variant (megapath_variant.hip, -DLR_VARIANT=<mask>); weak, so that
+// experimental builds may leave variants out (tools/ab.sh) — a missing one is reported, never silently replaced
+#define LR_DECLARE_VARIANT(mask)                                                                                       \
+    extern "C" __attribute__((weak)) hipError_t lrhip_variant_launch_##mask(unsigned, hipStream_t, const lrd::DScene *, const lrd::RenderArgs *); \
+    extern "C" __attribute__((weak)) hipError_t lrhip_variant_occupancy_##mask(int *);
+LR_VARIANT_LIST(LR_DECLARE_VARIANT)
+#undef LR_DECLARE_VARIANT
 
 namespace {
+
+struct VariantEntry {
+    uint32_t mask;
+    hipError_t (*launch)(unsigned, hipStream_t, const lrd::DScene *, const lrd::RenderArgs *);
+    hipError_t (*occupancy)(int *);
+};
+#define LR_VARIANT_ENTRY(mask) VariantEntry{mask##u, lrhip_variant_launch_##mask, lrhip_variant_occupancy_##mask},
+const VariantEntry kVariants[] = {LR_VARIANT_LIST(LR_VARIANT_ENTRY)};
+#undef LR_VARIANT_ENTRY
+static_assert(sizeof(kVariants) / sizeof(kVariants[0]) == lrd::kSceneVariantCount * 4u, "variants.h and kSceneVariants disagree");
+
+// smallest precompiled superset of the scene's feature bits (+ the count / generic-sampler bits, which are exact)
+int pick_variant(uint32_t scene_features, bool count, bool generic) {
+    for (uint32_t i = 0u; i < lrd::kSceneVariantCount; i++) {
+        if ((lrd::kSceneVariants[i] & scene_features) == scene_features) {
+            auto mask = lrd::kSceneVariants[i] | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
+            for (uint32_t k = 0u; k < lrd::kSceneVariantCount * 4u; k++) {
+                if (kVariants[k].mask == mask) { return static_cast<int>(k); }
+            }
+        }
+    }
+    return -1;
+}
 
 thread_local std::string g_last_error;
 
@@ -45,6 +78,7 @@ struct DeviceBuffer {
 // chunking (and therefore the fp32 summation order of the film) is identical on every GPU
 constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
 constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
+constexpr uint32_t kMaxBlocksPerCu = 8u; // resident 256-thread blocks per CU the persistent grid may use
 
 }// namespace
 
@@ -64,7 +98,9 @@ struct lrhip_ctx {
     uint32_t grid_blocks{0};
     uint32_t cu_count{0};
     uint32_t bvh_depth{0};
-    bool full_surfaces{false};// scene uses Disney / Mix closures
+    uint32_t last_variant{0u};// feature mask of the kernel the last lrhip_render launched
+    uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
+    int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
 };
 
 namespace {
@@ -251,7 +287,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     release_scene(ctx);
     ctx->bvh_depth = bvh_depth(s->accel);
     if (ctx->bvh_depth == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the BVH must have one-triangle leaves (lrhost_scene_build_accel builds them)"); }
-    ctx->full_surfaces = s->any_non_opaque != 0u;// the alpha test lives in the full variant too
+    ctx->features = s->any_non_opaque != 0u ? lrd::kFeatAlpha : 0u;
     if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");
@@ -301,7 +337,9 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     std::vector<lrd::DClosure> closures(s->surface_count);
     for (uint32_t i = 0; i < s->surface_count; i++) {
         auto &surf = s->surfaces[i];
-        if (surf.kind == LR_SURFACE_DISNEY || surf.kind == LR_SURFACE_MIX || surf.kind == LR_SURFACE_LAYERED) { ctx->full_surfaces = true; }
+        if (surf.kind == LR_SURFACE_DISNEY) { ctx->features |= lrd::kFeatDisney; }
+        if (surf.kind == LR_SURFACE_MIX) { ctx->features |= lrd::kFeatMix; }
+        if (surf.kind == LR_SURFACE_LAYERED) { ctx->features |= lrd::kFeatLayered | lrd::kFeatDisney; }
         auto dynamic = surf.normal_tex >= 0;
         for (auto t : surf.tex) { dynamic = dynamic || !is_constant(t); }
         lrd::DClosure c{};
@@ -380,7 +418,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
                 if (auto rc2 = upload(ctx, r.alias, texels + r.map_height, &de.alias); rc2 != LRHIP_OK) { return rc2; }
                 return upload(ctx, r.pdf, texels, &de.pdf);
             };
-            ctx->full_surfaces = true;
+            ctx->features |= lrd::kFeatEnv;
             lrd::DEnvironment root{};
             int rc2 = LRHIP_OK;
             if (e.kind == LR_ENV_COMBINED) {
@@ -434,11 +472,10 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
     ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
     LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
-    // persistent grid: as many blocks as are resident
-    int blocks_per_cu = 0;
-    LR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, lrd::megapath_kernel<false, false, false>, lrd::kBlockThreads, 0));
-    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
-    ctx->grid_blocks = ctx->cu_count * static_cast<uint32_t>(blocks_per_cu);
+    // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
+    // traversal-stack overflow area is sized for the densest variant
+    for (auto &b : ctx->variant_blocks) { b = -1; }
+    ctx->grid_blocks = ctx->cu_count * kMaxBlocksPerCu;
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
     if (auto r = ensure(ctx->spill, total_threads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     ctx->scene_ready = true;
@@ -496,24 +533,24 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
         args.partial = static_cast<float4 *>(ctx->partial.ptr);
     }
     LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 4u, ctx->stream));
-    auto blocks = std::min(ctx->grid_blocks, (args.item_count + 3u) / 4u);
-    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
-    auto full = ctx->full_surfaces;                                      // Disney / Mix interpreters
-    auto grid = dim3(blocks), block = dim3(lrd::kBlockThreads);
-#define LR_LAUNCH(C, G, F) hipLaunchKernelGGL((lrd::megapath_kernel<C, G, F>), grid, block, 0, ctx->stream, ctx->scene, args)
-    switch ((count ? 4 : 0) | (generic ? 2 : 0) | (full ? 1 : 0)) {
-        case 0: LR_LAUNCH(false, false, false); break;
-        case 1: LR_LAUNCH(false, false, true); break;
-        case 2: LR_LAUNCH(false, true, false); break;
-        case 3: LR_LAUNCH(false, true, true); break;
-        case 4: LR_LAUNCH(true, false, false); break;
-        case 5: LR_LAUNCH(true, false, true); break;
-        case 6: LR_LAUNCH(true, true, false); break;
-        default: LR_LAUNCH(true, true, true); break;
+    auto vi = pick_variant(ctx->features, count, generic);
+    if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +
+                                                 " was compiled into this library");
     }
-#undef LR_LAUNCH
+    if (ctx->variant_blocks[vi] < 0) {
+        int blocks_per_cu = 0;
+        LR_HIP_CHECK(kVariants[vi].occupancy(&blocks_per_cu));
+        ctx->variant_blocks[vi] = std::max(1, std::min(blocks_per_cu, static_cast<int>(kMaxBlocksPerCu)));
+    }
+    auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
+    args.total_threads = resident * lrd::kBlockThreads;
+    auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
+    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    LR_HIP_CHECK(kVariants[vi].launch(blocks, ctx->stream, &ctx->scene, &args));
+    ctx->last_variant = kVariants[vi].mask;
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;
@@ -557,6 +594,8 @@ int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out) {
     LR_HIP_CHECK(hipMemcpy(out, ctx->counters.ptr, sizeof(lrhip_counters), hipMemcpyDeviceToHost));
     return LRHIP_OK;
 }
+
+uint32_t lrhip_last_variant(lrhip_ctx *ctx) { return ctx != nullptr ? ctx->last_variant : 0u; }
 
 double lrhip_last_render_ms(lrhip_ctx *ctx) {
     if (ctx == nullptr || !ctx->timed) { return 0.0; }

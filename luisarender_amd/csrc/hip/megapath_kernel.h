@@ -48,11 +48,45 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 #define LR_REFILL 36
 #endif
 
-// COUNT: gather diagnostics counters.  PCG ("generic sampler"): PCG32 / Sobol / PaddedSobol instead of the
-// default xxhash32 + LCG Independent stream.
-// FULL: Disney + Mix closure interpreters compiled in (selected at upload when the scene uses them).
-template<bool COUNT, bool PCG, bool FULL>
-__global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(DScene scene, RenderArgs args) {
+// The kernel is specialised by a FEATURE MASK (the reference JIT-compiles one kernel per scene, so a scene only pays
+// for the closures / environment / alpha test it uses; here a curated set of masks is precompiled, one translation
+// unit each, and lrhip_render picks the smallest superset of what the uploaded scene needs):
+//   kFeatCount    diagnostics counters (tests, tools)
+//   kFeatGeneric  PCG32 / Sobol / PaddedSobol sampler instead of the default xxhash32 + LCG Independent stream
+//   kFeatEnv      image-based Spherical / Directional / Combined environment (constant Spherical is always in)
+//   kFeatAlpha    alpha-tested traversal (Geometry::_alpha_skip) — candidate hits evaluated inside the leaf step
+//   kFeatDisney   Disney closure (thick + thin)
+//   kFeatMix      Mix closure (children: any non-Mix closure the mask holds)
+//   kFeatLayered  Layered closure (random walk over two nested closures; implies the Disney interpreter)
+enum : uint32_t {
+    kFeatCount = 1u, kFeatGeneric = 2u, kFeatEnv = 4u, kFeatAlpha = 8u, kFeatDisney = 16u, kFeatMix = 32u, kFeatLayered = 64u,
+    kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
+};
+// the precompiled scene-feature sets, smallest first (each also exists x {Count} x {Generic}); csrc/hip/variants/*.hip
+constexpr uint32_t kSceneVariants[] = {
+    0u,
+    kFeatEnv,
+    kFeatDisney,
+    kFeatEnv | kFeatDisney,
+    kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
+    kFeatSceneMask,
+};
+constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
+
+// waves per SIMD requested from the register allocator (512 VGPRs / waves).  Measured (Msamples/s at 2 / 3 / 4 waves):
+// lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 165 / 141 / 104 —
+// the Layered random walk nests two closure interpreters and spills ~1000 VGPRs at 128.
+#ifndef LR_WAVES_LAYERED
+#define LR_WAVES_LAYERED 2
+#endif
+constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : LR_MIN_WAVES; }
+
+template<uint32_t F>
+__global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kernel(DScene scene, RenderArgs args) {
+    constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u, ENV = (F & kFeatEnv) != 0u,
+                   ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
+                   LAYERED = (F & kFeatLayered) != 0u;
+    static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
     const auto tid = threadIdx.x;
@@ -62,6 +96,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
     TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + (tid >> 6u) * 256u};
     const auto film_tile = s_film + (tid >> 6u) * 64u;
     DCounters local{};
+    const auto t_wave = COUNT ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
         // ---- next work item of this wavefront
@@ -97,6 +132,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
             // ==== (A) lanes without a ray in flight: consume results and shade
             auto want_shadow = false, want_closest = false;
             Ray shadow{};
+            const auto t_shade = COUNT ? __builtin_readcyclecounter() : 0ull;
             if (tr.phase == kPhaseIdle) {
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
                     if (!tr.occluded) { Li += nee; }
@@ -119,7 +155,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                     if (!hit_valid && scene.env_kind != kEnvNone) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
                         f3 L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
                         auto pdf = kInvPi * 0.25f;
-                        if (FULL && scene.env_kind != kEnvConstant) { env_evaluate(scene, tr.d, L, pdf); }
+                        if (ENV && scene.env_kind != kEnvConstant) { env_evaluate(scene, tr.d, L, pdf); }
                         Li += beta * L * balance(pdf_bsdf, pdf * scene.env_prob);
                     }
                     SurfacePoint it;
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             }
                             if (is_env) {// _sample_environment, uniform.cpp:125-137
                                 f3 wi;
-                                if (FULL && scene.env_kind != kEnvConstant) {
+                                if (ENV && scene.env_kind != kEnvConstant) {
                                     env_sample(scene, u_light_surface, wi, light_L, light_pdf);
                                     light_pdf *= prob;
                                 } else {// constant emission: uniform sphere, spherical.cpp:114-118,138
@@ -227,8 +263,8 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                         DClosure closure;
                         Frame sh;
                         load_lobe((it.tags >> 12u) & 4095u, it.shading, closure, sh);
-                        const auto is_mix = FULL && closure.kind == LR_SURFACE_MIX;
-                        const auto is_layered = FULL && closure.kind == LR_SURFACE_LAYERED;
+                        const auto is_mix = MIX && closure.kind == LR_SURFACE_MIX;
+                        const auto is_layered = LAYERED && closure.kind == LR_SURFACE_LAYERED;
                         LayerStack layers;
                         if (is_layered) {// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500
                             load_lobe(closure.x[0], sh, layers.top, layers.f_top);
@@ -250,7 +286,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             DClosure c;
                             Frame fr;
                             load_lobe(t, sh, c, fr);
-                            return closure_evaluate<FULL>(c, fr, it.ng, wo, wi);
+                            return closure_evaluate<DISNEY>(c, fr, it.ng, wo, wi);
                         };
                         if (light_pdf > 0.0f) {
                             BsdfEval eval;
@@ -260,7 +296,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             } else if (is_layered) {
                                 eval = layered_evaluate(layers, wo, shadow.d);
                             } else {
-                                eval = closure_evaluate<FULL>(closure, sh, it.ng, wo, shadow.d);
+                                eval = closure_evaluate<DISNEY>(closure, sh, it.ng, wo, shadow.d);
                             }
                             auto w = balance(light_pdf, eval.pdf) / light_pdf;
                             nee = w * beta * eval.f * light_L;
@@ -277,7 +313,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             Frame fa;
                             load_lobe(tag_a, sh, ca, fa);
                             auto first = u_lobe < ratio;
-                            bs = closure_sample<FULL>(ca, fa, it.ng, wo, first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio), u_bsdf);
+                            bs = closure_sample<DISNEY>(ca, fa, it.ng, wo, first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio), u_bsdf);
                             float eta_a = 1.f, eta_b = 1.f;
                             auto has_a = closure_eta(ca, eta_a);
                             auto eb = eval_child(tag_b, bs.wi);
@@ -291,7 +327,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
                             bs = layered_sample(layers, wo, u_lobe, u_bsdf);
                             has_eta = closure_eta(layers.bottom, eta);// LayeredSurfaceClosure::eta, layered.cpp:252
                         } else {
-                            bs = closure_sample<FULL>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
+                            bs = closure_sample<DISNEY>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
                             has_eta = closure_eta(closure, eta);
                         }
                         ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
@@ -364,8 +400,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
             if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
             // ==== (B) traverse until `refill` lanes have results to shade
             TraceStats ts{0u, 0u, 0u, 0u, 0u};
-            trace_steps<COUNT, FULL>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
+            const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
+            trace_steps<COUNT, ALPHA>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
+                if (lane == 0u) { local.shade_cycles += t_trace - t_shade, local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
                 local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
                 local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy, local.trace_steps_starved += ts.steps_starved;
                 local.shade_calls++;
@@ -390,6 +428,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
     }
 
     if (COUNT) {// one atomic per counter per wave
+        if (lane == 0u) { local.wave_cycles = __builtin_readcyclecounter() - t_wave; }
         auto reduce = [&](unsigned long long v, unsigned long long *dst) {
             for (auto off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off); }
             if (lane == 0u) { atomicAdd(dst, v); }
@@ -407,33 +446,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapath_kernel(D
         reduce(local.shade_calls, &args.counters->shade_calls);
         reduce(local.shade_busy, &args.counters->shade_busy);
         reduce(local.trace_steps_starved, &args.counters->trace_steps_starved);
+        reduce(local.shade_cycles, &args.counters->shade_cycles);
+        reduce(local.trace_cycles, &args.counters->trace_cycles);
+        reduce(local.wave_cycles, &args.counters->wave_cycles);
     }
-}
-
-// film += sum over chunks of the per-chunk partial sums, in chunk order (deterministic)
-__global__ void resolve_partial_kernel(float4 *film, const float4 *partial, uint32_t pixel_count, uint32_t chunk_count,
-                                       uint32_t width, uint32_t tiles_x, uint32_t tile_begin, uint32_t tile_end,
-                                       uint32_t tile_stride) {
-    auto i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pixel_count) { return; }
-    auto px = i % width, py = i / width;
-    auto tile = (py / 8u) * tiles_x + px / 8u;
-    if (tile < tile_begin || tile >= tile_end || (tile - tile_begin) % tile_stride != 0u) { return; }
-    auto v = film[i];
-    for (auto c = 0u; c < chunk_count; c++) {
-        auto p = partial[static_cast<size_t>(c) * pixel_count + i];
-        v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
-    }
-    film[i] = v;
-}
-
-// convert kernel of the Color film, color.cpp:87-93
-__global__ void film_convert_kernel(const float4 *film, float4 *out, uint32_t pixel_count, float sx, float sy, float sz) {
-    auto i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pixel_count) { return; }
-    auto c = film[i];
-    auto inv = 1.f / fmaxf(c.w, 1.f);
-    out[i] = make_float4((inv * sx) * c.x, (inv * sy) * c.y, (inv * sz) * c.z, 1.f);
 }
 
 }// namespace lrd

@@ -1,0 +1,26 @@
+// megapath_variant.hip — ONE instantiation of the megakernel (feature mask LR_VARIANT, see megapath_kernel.h) and its
+// launch / occupancy entry points for lrhip.hip.  Compiled once per mask of variants.h into its own object so that
+// the variants build in parallel.
+#include <hip/hip_runtime.h>
+
+#include "megapath_kernel.h"
+
+#ifndef LR_VARIANT
+#error "compile with -DLR_VARIANT=<feature mask>"
+#endif
+#define LR_CAT2(a, b) a##b
+#define LR_CAT(a, b) LR_CAT2(a, b)
+
+namespace lrd {
+template __global__ void megapath_kernel<LR_VARIANT>(DScene, RenderArgs);
+}
+
+extern "C" hipError_t LR_CAT(lrhip_variant_launch_, LR_VARIANT)(unsigned blocks, hipStream_t stream, const lrd::DScene *scene,
+                                                               const lrd::RenderArgs *args) {
+    hipLaunchKernelGGL(lrd::megapath_kernel<LR_VARIANT>, dim3(blocks), dim3(lrd::kBlockThreads), 0, stream, *scene, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t LR_CAT(lrhip_variant_occupancy_, LR_VARIANT)(int *blocks_per_cu) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lrd::megapath_kernel<LR_VARIANT>, lrd::kBlockThreads, 0);
+}

@@ -1,0 +1,11 @@
+// variants.h — the precompiled megakernel feature masks: every entry of lrd::kSceneVariants (megapath_kernel.h)
+// x {counters} x {generic sampler}.  One object file each (megapath_variant.hip, -DLR_VARIANT=<mask>), built in
+// parallel by the Makefile (VARIANT_MASKS must list the same numbers).
+#pragma once
+#define LR_VARIANT_LIST(X)                                                                  \
+    X(0) X(1) X(2) X(3)         /* lean: Matte / Mirror / Glass / Plastic / Metal, lights */  \
+    X(4) X(5) X(6) X(7)         /* + image / directional / combined environment */           \
+    X(16) X(17) X(18) X(19)     /* + Disney */                                               \
+    X(20) X(21) X(22) X(23)     /* + environment + Disney */                                 \
+    X(60) X(61) X(62) X(63)     /* + environment + alpha test + Disney + Mix */              \
+    X(124) X(125) X(126) X(127) /* everything (+ Layered) */

@@ -75,6 +75,10 @@ class MegaPathRenderer:
     def last_render_ms(self) -> float:
         return float(self._lib.lrhip_last_render_ms(self._ctx))
 
+    def last_variant(self) -> int:
+        """feature mask of the precompiled megakernel variant the last render() launched (lrhip.h LRHIP_FEAT_*)"""
+        return int(self._lib.lrhip_last_variant(self._ctx))
+
     def close(self) -> None:
         if self._ctx:
             self._lib.lrhip_destroy(self._ctx)

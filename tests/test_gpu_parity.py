@@ -10,7 +10,8 @@ import pytest
 
 from luisarender_amd import Scene
 from luisarender_amd.oracle_check import Oracle
-from luisarender_amd.scenes import cornell_box, generate_room_scene
+from luisarender_amd.scenes import (cornell_box, generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene,
+                                    generate_room_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -247,6 +248,71 @@ def test_bathroom_class_instanced_scene(renderer, tmp_path):
     # at 4 spp.  Measured: ~1e-4 of the rays differ, rel-L1 4.7e-3, mean 3e-5.  Bars: rel-L1 < 2e-2, mean < 2e-3.
     assert _rel_l1(gpu, cpu) < 2e-2
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 2e-3
+
+
+def _blocks(f):
+    h, w = f.shape[0] // 8 * 8, f.shape[1] // 8 * 8
+    return f[:h, :w, :3].reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+
+
+def test_bedroom_class_scene(renderer, tmp_path):
+    """BASELINE C3 stand-in at reduced size: window openings, 10 % Glass (one dispersive), image-based Spherical
+    environment with a sun lobe — the <environment> kernel variant.  Measured: rel-L1 3.3e-3, mean 2e-4, 51 of 1.7 M
+    closest rays differ (texel-edge flips of the lat-long lookup, rough-glass lobe picks)."""
+    sc = Scene.load(generate_bedroom_scene(str(tmp_path), resolution=(256, 144), spp=16))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert renderer.last_variant() == 4 | 1  # LRHIP_FEAT_ENVIRONMENT | COUNT: nothing else is compiled in
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
+    assert _rel_l1(gpu, cpu) < 2e-2
+    assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 2e-3
+
+
+def test_camera_class_scene(renderer, tmp_path):
+    """BASELINE C4 stand-in at reduced size: ~1 M triangles, Disney / Plastic / Matte on 8 image textures (sRGB PNG
+    albedo, linear PNG roughness), thin lens, image environment + lamps — the <environment + Disney> variant.
+    Measured: rel-L1 4.2e-4, mean 6e-5, 1 closest ray of 419 k differs."""
+    sc = Scene.load(generate_camera_scene(str(tmp_path), resolution=(256, 144), spp=8, texture_size=1024))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 8)
+    assert renderer.last_variant() == 4 | 16 | 1
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
+    assert _rel_l1(gpu, cpu) < 5e-3
+    assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
+
+
+def test_kitchen_class_scene(renderer, tmp_path):
+    """BASELINE C5 stand-in at reduced size: every closure of SURVEY row a14 + NormalMap / alpha wrappers — the
+    all-features variant.  Layered and alpha-tested surfaces are statistical by construction (their internal streams are
+    seeded from hit-point bits), so the image is compared on 8x8 block means.  Measured: per-pixel rel-L1 4.8e-2,
+    block rel-L1 2.1e-2, mean 2e-5, closest rays 1 810 464 vs 1 810 586."""
+    sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert renderer.last_variant() == 124 | 1  # every scene feature + COUNT (Independent sampler: no generic bit)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-3 * cc["closest_rays"]
+    g, c = _blocks(gpu), _blocks(cpu)
+    assert np.abs(g - c).sum() / np.abs(c).sum() < 6e-2
+    assert abs(g.mean() - c.mean()) / c.mean() < 5e-3
+
+
+def test_kernel_variant_selection(renderer):
+    """lrhip_render launches the smallest precompiled superset of the scene's features (include/lrhip.h LRHIP_FEAT_*)."""
+    from helpers import MATERIALS
+
+    def variant(material, **kw):
+        extra = MATERIALS[material].replace("Surface m ", "Surface probe ") + "\n" if material else ""
+        sc = Scene.from_string(cornell_box(resolution=16, spp=1, short_box_surface="probe" if material else "white", extra_surfaces=extra, **kw))
+        renderer.upload(sc)
+        renderer.render(0, 1, sync=True)
+        return renderer.last_variant()
+
+    assert variant(None) == 0
+    assert variant(None, sampler="Sobol") == 2
+    assert variant("glass") == 0 and variant("metal") == 0
+    assert variant("disney") == 16 and variant("disney_thin") == 16
+    assert variant("mix") == 60          # no <Mix only> variant is precompiled: next superset
+    assert variant("layered") == 124
 
 
 def test_progressive_calls_and_determinism(renderer):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # extra PMC passes (instruction cache, LDS / SALU / VMEM issue) on the bench workload: tools/pmc_extra.sh <tag> <spp>
 set -u
-TAG=${1:-x}; SPP=${2:-256}
+TAG=${1:-x}; SPP=${2:-256}; WL=${3:-c2}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmcx_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --spp $SPP --steps 1 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --workload $WL --spp $SPP --steps 1 --warmup 1 --no-cpu-baseline"
 timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ --kernel-trace -d $OUT/ic -o pmc -- $CMD > $OUT/ic.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES --kernel-trace -d $OUT/iss -o pmc -- $CMD > $OUT/iss.log 2>&1
 python - << PY
