@@ -1,0 +1,140 @@
+// dev_heavy.h — closure loading shared by the megakernel and its out-of-line "heavy" closure path.
+//
+// The reference JIT inlines every closure a scene uses into one kernel.  On gfx950 that costs the whole kernel its
+// registers: with the Disney, Mix and Layered interpreters inlined into the shading block the <everything> variant
+// spilled ~1000 VGPRs and ran 5x slower than the lean one on a scene where 85 % of the hits are Matte / Plastic /
+// Metal / Glass.  So the megakernel keeps the five basic closures inline (closure_evaluate<false> / closure_sample<false>)
+// and reaches Disney / Mix / Layered surfaces through two REAL calls, heavy_evaluate and heavy_sample, which take
+// everything they need in a HeavyCtx record (scratch memory) and have their own register allocation.
+//
+//   Surface::Closure::evaluate / sample              src/base/surface.cpp:35-68
+//   MixSurfaceClosure                                src/surfaces/mix.cpp:82-212
+//   LayeredSurfaceInstance::populate_closure         src/surfaces/layered.cpp:478-500
+#pragma once
+#include "dev_layered.h"
+
+namespace lrd {
+
+struct LobeTables {// the scene tables closure loading reads
+    const DClosure *closures;
+    const lr_surface *surfaces;
+    const lr_texture *textures;
+    const float *texels;
+};
+
+// closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
+// per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
+LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
+    c = tb.closures[t];
+    fr = base;
+    if (c.dynamic || eta_i != 1.f) {// (eta_i != 1: the bottom of a Layered surface under a refractive top)
+        auto &raw = tb.surfaces[t];
+        if (raw.normal_tex >= 0) {
+            auto v = texture_eval_tables(tb.textures, tb.texels, raw.normal_tex, uv);
+            auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
+            if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
+            auto normal = to_world(base, n_local);
+            fr = frame_from_normal_tangent(clamp_shading_normal(normal, ng, wo), base.s);
+        }
+        auto dyn = c.dynamic;
+        c = resolve_closure(
+            raw, [&](int32_t id) { return texture_eval_tables(tb.textures, tb.texels, id, uv); },
+            [&](int32_t id) { return tb.textures[id].channels; }, eta_i);
+        c.dynamic = dyn;
+    }
+}
+
+struct HeavyCtx {// inputs of one heavy closure at one hit (lives in scratch: passed by pointer)
+    LobeTables tb;
+    f2 uv;
+    f3 ng, p, wo;
+    Frame shading;   // the surface's own (possibly normal-mapped) frame
+    DClosure closure;// the surface's record (kind Disney / Mix / Layered)
+};
+struct HeavySample {
+    BsdfSample bs;
+    float eta;
+    uint32_t has_eta;
+};
+
+LR_D BsdfEval mix_blend(const BsdfEval &a, const BsdfEval &b, float r) {// MixSurfaceClosure::_mix, mix.cpp:97-104
+    auto t = 1.f - r;
+    return BsdfEval{a.f + t * (b.f - a.f), lerp(a.pdf, b.pdf, t)};
+}
+
+LR_D void layer_stack(const HeavyCtx &cx, LayerStack &layers) {// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500
+    auto &c = cx.closure;
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[0], cx.shading, layers.top, layers.f_top);
+    float eta_top = 1.f;
+    closure_eta(layers.top, eta_top);
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[1], cx.shading, layers.bottom, layers.f_bottom, eta_top);
+    layers.own = cx.shading, layers.ng = cx.ng, layers.p = cx.p;
+    layers.thickness = c.s0, layers.g = c.s1;
+    layers.albedo = mk3(c.c0[0], c.c0[1], c.c0[2]);
+    layers.max_depth = c.x[2], layers.samples = c.x[3];
+}
+
+// evaluate of a Disney / Mix / Layered surface (MIX / LAYERED: which interpreters this kernel variant holds)
+template<bool MIX, bool LAYERED>
+LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
+    auto &cx = *cxp;
+    auto &c = cx.closure;
+    if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:169-177
+        BsdfEval e[2];
+#pragma nounroll
+        for (auto k = 0u; k < 2u; k++) {
+            DClosure child;
+            Frame fr;
+            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[k], cx.shading, child, fr);
+            e[k] = closure_evaluate<true>(child, fr, cx.ng, cx.wo, wi);
+        }
+        auto eval = mix_blend(e[0], e[1], c.s0);
+        if (!valid_sides(cx.ng, cx.shading.n, cx.wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
+        return eval;
+    }
+    if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
+        LayerStack layers;
+        layer_stack(cx, layers);
+        return layered_evaluate(layers, cx.wo, wi);
+    }
+    return closure_evaluate<true>(c, cx.shading, cx.ng, cx.wo, wi);// Disney
+}
+
+template<bool MIX, bool LAYERED>
+LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) {
+    auto &cx = *cxp;
+    auto &c = cx.closure;
+    HeavySample r;
+    r.eta = 1.f, r.has_eta = 0u;
+    if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
+        const auto ratio = c.s0;
+        DClosure ca, cb;
+        Frame fa, fb;
+        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[0], cx.shading, ca, fa);
+        auto first = u_lobe < ratio;
+        r.bs = closure_sample<true>(ca, fa, cx.ng, cx.wo, first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio), u_bsdf);
+        float eta_a = 1.f, eta_b = 1.f;
+        auto has_a = closure_eta(ca, eta_a);
+        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[1], cx.shading, cb, fb);
+        auto eb = closure_evaluate<true>(cb, fb, cx.ng, cx.wo, r.bs.wi);
+        auto m = first ? mix_blend(BsdfEval{r.bs.f, r.bs.pdf}, eb, ratio) : mix_blend(eb, BsdfEval{r.bs.f, r.bs.pdf}, ratio);
+        r.bs.f = m.f, r.bs.pdf = m.pdf;
+        if (!valid_sides(cx.ng, cx.shading.n, cx.wo, r.bs.wi)) { r.bs.f = mk3(0.f), r.bs.pdf = 0.f; }
+        auto has_b = closure_eta(cx.tb.closures[c.x[1]], eta_b);// (eta never comes from an image texture here)
+        r.has_eta = (has_a || has_b) ? 1u : 0u;// MixSurfaceClosure::eta, mix.cpp:148-157
+        r.eta = !has_a ? eta_b : (!has_b ? eta_a : lerp(eta_b, eta_a, ratio));
+        return r;
+    }
+    if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
+        LayerStack layers;
+        layer_stack(cx, layers);
+        r.bs = layered_sample(layers, cx.wo, u_lobe, u_bsdf);
+        r.has_eta = closure_eta(layers.bottom, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
+        return r;
+    }
+    r.bs = closure_sample<true>(c, cx.shading, cx.ng, cx.wo, u_lobe, u_bsdf);// Disney
+    r.has_eta = closure_eta(c, r.eta) ? 1u : 0u;
+    return r;
+}
+
+}// namespace lrd

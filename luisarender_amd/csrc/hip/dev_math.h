@@ -9,7 +9,18 @@
 
 #define LR_HD __host__ __device__ __forceinline__
 #define LR_D __device__ __forceinline__
-// rare, register-hungry interpreters (Layered random walk): real calls, so that their registers are not the megakernel's
+// Out-of-line device functions.  LR_HEAVY: the Disney / Mix / Layered path of the variants that hold Mix or Layered
+// (dev_heavy.h) is always a real call.  LR_CALL: the texture lookup and the environment evaluate / sample are real
+// calls only in those same variants (one copy instead of one per use: -60 % code, fewer spills in the main loop);
+// in the lean ones the call overhead costs more than it saves (measured inline vs call: C2 +2 %, C3 +1.4 %, C4 +7 %).
+// Every variant is its own translation unit (megapath_variant.hip defines LR_VARIANT), so this is a preprocessor choice.
+#ifndef LR_CALL
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 96)
+#define LR_CALL __device__ __noinline__
+#else
+#define LR_CALL __device__ __forceinline__
+#endif
+#endif
 #ifndef LR_HEAVY
 #define LR_HEAVY __device__ __noinline__
 #endif

@@ -276,7 +276,7 @@ LR_D void camera_ray(const DScene &scene, const lr_filter *filter, uint32_t px, 
 
 // ---------------------------------------------------------------- textures
 
-LR_D float4 texel_fetch(const DScene &scene, const lr_texture &t, int x, int y) {
+LR_D float4 texel_fetch(const float *texels, const lr_texture &t, int x, int y) {
     auto w = static_cast<int>(t.width), h = static_cast<int>(t.height);
     auto zero = false;
     auto wrap = [&](int v, int n) {
@@ -294,33 +294,36 @@ LR_D float4 texel_fetch(const DScene &scene, const lr_texture &t, int x, int y) 
     };
     auto xx = wrap(x, w), yy = wrap(y, h);
     if (zero) { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    return reinterpret_cast<const float4 *>(scene.texels)[t.texel_offset + static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx)];
+    return reinterpret_cast<const float4 *>(texels)[t.texel_offset + static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx)];
 }
 
-LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) {
-    auto &t = scene.textures[id];
+// Texture::Instance::evaluate (texture.cpp:21-79; image.cpp:132-168; checkerboard.cpp).  A REAL call (LR_CALL): one
+// copy of the format / address-mode / decode switches per kernel instead of one per use (it was 17 KB of code inlined
+// at every site: the <environment> variant carried eight copies), and its registers are not the megakernel's.
+LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texels, int32_t id, f2 uv_it) {
+    auto &t = textures[id];
     if (t.kind == LR_TEX_CONSTANT) { return make_float4(t.v[0], t.v[1], t.v[2], t.v[3]); }
     if (t.kind == LR_TEX_CHECKERBOARD) {
         auto parity = (static_cast<int>(floorf(uv_it.x * t.checker_scale)) + static_cast<int>(floorf(uv_it.y * t.checker_scale))) & 1;
         auto child = t.child[parity ? 1 : 0];
         if (child < 0) { return parity ? make_float4(0.f, 0.f, 0.f, 1.f) : make_float4(1.f, 1.f, 1.f, 1.f); }
-        auto &c = scene.textures[child];// one level of nesting: children are constant or image
+        auto &c = textures[child];// one level of nesting: children are constant or image
         if (c.kind == LR_TEX_CONSTANT) { return make_float4(c.v[0], c.v[1], c.v[2], c.v[3]); }
         id = child;
     }
-    auto &ti = scene.textures[id];
+    auto &ti = textures[id];
     f2 uv{uv_it.x * ti.uv_scale[0] + ti.uv_offset[0], uv_it.y * ti.uv_scale[1] + ti.uv_offset[1]};
     float4 v;
     if (ti.filter == LR_TEX_FILTER_POINT) {
-        v = texel_fetch(scene, ti, static_cast<int>(floorf(uv.x * static_cast<float>(ti.width))),
+        v = texel_fetch(texels, ti, static_cast<int>(floorf(uv.x * static_cast<float>(ti.width))),
                         static_cast<int>(floorf(uv.y * static_cast<float>(ti.height))));
     } else {
         auto fx = uv.x * static_cast<float>(ti.width) - 0.5f, fy = uv.y * static_cast<float>(ti.height) - 0.5f;
         auto x0 = floorf(fx), y0 = floorf(fy);
         auto tx = fx - x0, ty = fy - y0;
         auto ix = static_cast<int>(x0), iy = static_cast<int>(y0);
-        auto c00 = texel_fetch(scene, ti, ix, iy), c10 = texel_fetch(scene, ti, ix + 1, iy);
-        auto c01 = texel_fetch(scene, ti, ix, iy + 1), c11 = texel_fetch(scene, ti, ix + 1, iy + 1);
+        auto c00 = texel_fetch(texels, ti, ix, iy), c10 = texel_fetch(texels, ti, ix + 1, iy);
+        auto c01 = texel_fetch(texels, ti, ix, iy + 1), c11 = texel_fetch(texels, ti, ix + 1, iy + 1);
         auto mix = [&](float a, float b, float c, float d) {
             return (a * (1.f - tx) + b * tx) * (1.f - ty) + (c * (1.f - tx) + d * tx) * ty;
         };
@@ -337,6 +340,7 @@ LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) {
     };
     return make_float4(decode(v.x, 0), decode(v.y, 1), decode(v.z, 2), decode(v.w, 3));
 }
+LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) { return texture_eval_tables(scene.textures, scene.texels, id, uv_it); }
 
 // ---------------------------------------------------------------- closure resolution
 // Texture access is abstracted so the same code folds constants on the host at upload time
@@ -586,9 +590,22 @@ LR_D void light_evaluate(const DScene &scene, const SurfacePoint &lp, uint32_t p
 
 LR_D f3 mul3(const float *m, f3 v) { return mk3(m[0], m[1], m[2]) * v.x + mk3(m[3], m[4], m[5]) * v.y + mk3(m[6], m[7], m[8]) * v.z; }
 
-LR_D f3 env_radiance(const DScene &scene, const DEnvironment &env, f2 uv) {// evaluate_illuminant_spectrum(...).value * scale
-    auto v = texture_eval(scene, env.emission_tex, uv);
-    auto rgb = env.constant_emission ? extend_rgb(v, scene.textures[env.emission_tex].channels) : mk3(v.x, v.y, v.z);
+struct EnvTables {// what the environment code reads of the scene (passed by value to the out-of-line functions)
+    const lr_texture *textures;
+    const float *texels;
+};
+struct EnvEval {
+    f3 L;
+    float pdf;
+};
+struct EnvSample {
+    f3 wi, L;
+    float pdf;
+};
+
+LR_D f3 env_radiance(const EnvTables &tb, const DEnvironment &env, f2 uv) {// evaluate_illuminant_spectrum(...).value * scale
+    auto v = texture_eval_tables(tb.textures, tb.texels, env.emission_tex, uv);
+    auto rgb = env.constant_emission ? extend_rgb(v, tb.textures[env.emission_tex].channels) : mk3(v.x, v.y, v.z);
     return max0(rgb);
 }
 LR_D float env_directional_pdf(float p, float theta) {// SphericalInstance::_directional_pdf, spherical.cpp:76-80
@@ -596,49 +613,55 @@ LR_D float env_directional_pdf(float p, float theta) {// SphericalInstance::_dir
     auto inv_s = sn > 0.f ? 1.f / sn : 0.f;
     return p * inv_s * (.5f * kInvPi * kInvPi);
 }
-LR_D void env_directional(const DScene &scene, const DEnvironment &env, f3 wi_local, f3 &L, float &pdf) {// directional.cpp:64-73
+LR_D EnvEval env_directional(const EnvTables &tb, const DEnvironment &env, f3 wi_local) {// directional.cpp:64-73
     auto valid = env.cos_half_angle < wi_local.z;
-    L = env_radiance(scene, env, f2{.5f, .5f}) * (valid ? env.scale : 0.f);
-    pdf = valid ? 1.f / (2.f * kPi * (1.f - env.cos_half_angle)) : 0.f;
+    return EnvEval{env_radiance(tb, env, f2{.5f, .5f}) * (valid ? env.scale : 0.f), valid ? 1.f / (2.f * kPi * (1.f - env.cos_half_angle)) : 0.f};
 }
-// Environment::Instance::evaluate of one Spherical / Directional record: spherical.cpp:88-108, directional.cpp:80-88
-LR_D void env_evaluate_one(const DScene &scene, const DEnvironment &env, f3 wi, f3 &L, float &pdf) {
+// Environment::Instance::evaluate of one Spherical / Directional record: spherical.cpp:88-108, directional.cpp:80-88.
+// Out of line (LR_CALL): reached once per miss / environment NEE sample, and acosf / atan2f / the texture lookup are
+// large; inlined at every use (root, both Combined children, the evaluate-the-other-child of Combined::sample) the
+// environment code alone was 320 KB of the kernel.
+LR_CALL EnvEval env_evaluate_one(EnvTables tb, const DEnvironment *envp, f3 wi) {
+    auto &env = *envp;
     if (env.kind == kEnvDirectional) {
-        L = mk3(0.f), pdf = 0.f;
-        if (!env.visible) { return; }
+        if (!env.visible) { return EnvEval{mk3(0.f), 0.f}; }
         auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
-        env_directional(scene, env, normalize(to_local(frame, mul3(env.world_to_env, wi))), L, pdf);
-        return;
+        return env_directional(tb, env, normalize(to_local(frame, mul3(env.world_to_env, wi))));
     }
     auto w = normalize(mul3(env.world_to_env, wi));
     auto theta = acosf(w.y), phi = atan2f(w.x, w.z);// Spherical::direction_to_uv
     f2 uv{fract(1.f - 0.5f * kInvPi * phi), fract(theta * kInvPi)};
-    L = env_radiance(scene, env, uv) * env.scale;
-    if (env.kind == kEnvConstant) { pdf = kInvPi * 0.25f; return; }
+    EnvEval r;
+    r.L = env_radiance(tb, env, uv) * env.scale;
+    if (env.kind == kEnvConstant) { r.pdf = kInvPi * 0.25f; return r; }
     auto sx = static_cast<float>(env.map_width), sy = static_cast<float>(env.map_height);
     auto ix = static_cast<uint32_t>(clampf(uv.x * sx, 0.f, sx - 1.f)), iy = static_cast<uint32_t>(clampf(uv.y * sy, 0.f, sy - 1.f));
-    pdf = env_directional_pdf(env.pdf[iy * env.map_width + ix], theta);
+    r.pdf = env_directional_pdf(env.pdf[iy * env.map_width + ix], theta);
+    return r;
 }
 // Environment::Instance::sample of one record: spherical.cpp:110-141, directional.cpp:90-98
-LR_D void env_sample_one(const DScene &scene, const DEnvironment &env, f2 u, f3 &wi, f3 &L, float &pdf) {
+LR_CALL EnvSample env_sample_one(EnvTables tb, const DEnvironment *envp, f2 u) {
+    auto &env = *envp;
+    EnvSample r;
     if (env.kind == kEnvDirectional) {
         auto cos_t = (1.f - u.x) + u.x * env.cos_half_angle;// sample_uniform_cone
         auto sin_t = sqrtf(fmaxf(1.f - cos_t * cos_t, 0.f));
         auto phi = 2.f * kPi * u.y;
         auto wi_local = mk3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
         auto frame = frame_from_normal(mk3(env.direction[0], env.direction[1], env.direction[2]));
-        env_directional(scene, env, wi_local, L, pdf);
-        wi = normalize(mul3(env.env_to_world, to_world(frame, wi_local)));
-        return;
+        auto e = env_directional(tb, env, wi_local);
+        r.L = e.L, r.pdf = e.pdf;
+        r.wi = normalize(mul3(env.env_to_world, to_world(frame, wi_local)));
+        return r;
     }
     if (env.kind == kEnvConstant) {// uniform sphere, spherical.cpp:114-118
         auto z = 1.0f - 2.0f * u.x;
-        auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+        auto rr = sqrtf(fmaxf(1.0f - z * z, 0.0f));
         auto phi = 2.0f * kPi * u.y;
-        L = env_radiance(scene, env, f2{0.f, 0.f}) * env.scale;
-        pdf = kInvPi * 0.25f;
-        wi = normalize(mul3(env.env_to_world, mk3(r * cosf(phi), r * sinf(phi), z)));
-        return;
+        r.L = env_radiance(tb, env, f2{0.f, 0.f}) * env.scale;
+        r.pdf = kInvPi * 0.25f;
+        r.wi = normalize(mul3(env.env_to_world, mk3(rr * cosf(phi), rr * sinf(phi), z)));
+        return r;
     }
     auto W = env.map_width, H = env.map_height;
     float ry, rx;
@@ -654,45 +677,50 @@ LR_D void env_sample_one(const DScene &scene, const DEnvironment &env, f2 u, f3 
     auto phi = 2.f * kPi * (1.f - uv.x), theta = kPi * uv.y;// Spherical::uv_to_direction
     auto sin_theta = sinf(theta);
     auto w = normalize(mk3(sinf(phi) * sin_theta, cosf(theta), cosf(phi) * sin_theta));
-    L = env_radiance(scene, env, uv) * env.scale;
-    pdf = env_directional_pdf(p, theta);
-    wi = normalize(mul3(env.env_to_world, w));
+    r.L = env_radiance(tb, env, uv) * env.scale;
+    r.pdf = env_directional_pdf(p, theta);
+    r.wi = normalize(mul3(env.env_to_world, w));
+    return r;
 }
 
 // root environment: one record, or CombinedInstance over two (combined.cpp:57-111)
 LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
     auto &env = *scene.env;
-    if (env.kind != kEnvCombined) { env_evaluate_one(scene, env, wi, L, pdf); return; }
+    EnvTables tb{scene.textures, scene.texels};
+    if (env.kind != kEnvCombined) {
+        auto e = env_evaluate_one(tb, scene.env, wi);
+        L = e.L, pdf = e.pdf;
+        return;
+    }
     auto wi_local = normalize(mul3(env.world_to_env, wi));
-    f3 La, Lb;
-    float pa, pb;
-    env_evaluate_one(scene, *env.child[0], wi_local, La, pa);
-    env_evaluate_one(scene, *env.child[1], wi_local, Lb, pb);
+    auto a = env_evaluate_one(tb, env.child[0], wi_local);
+    auto b = env_evaluate_one(tb, env.child[1], wi_local);
     auto sa = env.child_scale[0], sb = env.child_scale[1];
-    L = La * sa + Lb * sb;
-    pdf = lerp(pa, pb, sb / (sa + sb));
+    L = a.L * sa + b.L * sb;
+    pdf = lerp(a.pdf, b.pdf, sb / (sa + sb));
 }
 LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
     auto &env = *scene.env;
-    if (env.kind != kEnvCombined) { env_sample_one(scene, env, u, wi, L, pdf); return; }
+    EnvTables tb{scene.textures, scene.texels};
+    if (env.kind != kEnvCombined) {
+        auto s = env_sample_one(tb, scene.env, u);
+        wi = s.wi, L = s.L, pdf = s.pdf;
+        return;
+    }
     auto sa = env.child_scale[0], sb = env.child_scale[1];
     auto weight_a = sa / (sa + sb);
-    f3 Lo;
-    float po;
-    if (u.x < weight_a) {// sample a, evaluate b
-        u.x = u.x / weight_a;
-        env_sample_one(scene, *env.child[0], u, wi, L, pdf);
-        env_evaluate_one(scene, *env.child[1], wi, Lo, po);
-        L = L * sa + Lo * sb;
-        pdf = lerp(pdf, po, 1.f - weight_a);
+    auto first = u.x < weight_a;// sample a and evaluate b, or the other way round
+    u.x = first ? u.x / weight_a : (u.x - weight_a) / (1.f - weight_a);
+    auto s = env_sample_one(tb, env.child[first ? 0 : 1], u);
+    auto o = env_evaluate_one(tb, env.child[first ? 1 : 0], s.wi);
+    if (first) {
+        L = s.L * sa + o.L * sb;
+        pdf = lerp(s.pdf, o.pdf, 1.f - weight_a);
     } else {
-        u.x = (u.x - weight_a) / (1.f - weight_a);
-        env_sample_one(scene, *env.child[1], u, wi, L, pdf);
-        env_evaluate_one(scene, *env.child[0], wi, Lo, po);
-        L = Lo * sa + L * sb;
-        pdf = lerp(po, pdf, 1.f - weight_a);
+        L = o.L * sa + s.L * sb;
+        pdf = lerp(o.pdf, s.pdf, 1.f - weight_a);
     }
-    wi = normalize(mul3(env.env_to_world, wi));
+    wi = normalize(mul3(env.env_to_world, s.wi));
 }
 
 }// namespace lrd

@@ -19,7 +19,7 @@
 // (src/integrators/mega_path.cpp:49-156) and film accumulation ColorFilmInstance::_accumulate
 // (src/films/color.cpp:107-130).
 #pragma once
-#include "dev_layered.h"
+#include "dev_heavy.h"
 
 namespace lrd {
 
@@ -74,8 +74,11 @@ constexpr uint32_t kSceneVariants[] = {
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
 // waves per SIMD requested from the register allocator (512 VGPRs / waves).  Measured (Msamples/s at 2 / 3 / 4 waves):
-// lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 165 / 141 / 104 —
-// the Layered random walk nests two closure interpreters and spills ~1000 VGPRs at 128.
+// lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 174 / 192 / 149
+// (with the heavy closures out of line; 165 / 141 / 104 when they were inlined into the shading block).  3 waves
+// (168 VGPRs) is NOT used for the Layered variants although it is the fastest: that build produced NaN samples in
+// tests/test_gpu_parity.py::test_layered_closure while 2 and 4 do not (unexplained; every function stays inside the
+// 168-register budget) — parity first.
 #ifndef LR_WAVES_LAYERED
 #define LR_WAVES_LAYERED 2
 #endif
@@ -238,66 +241,25 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                                 shadow.t_min = 0.f, shadow.t_max = dist * .9999f;
                             }
                         }
-                        // ---- material, mega_path.cpp:111-143
-                        // load_lobe: closure record + shading frame of surface `t` on top of frame `base`
-                        // (NormalMapWrapper, surface.h:236-254, and per-hit texture resolution for dynamic closures)
-                        auto load_lobe = [&](uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
-                            c = scene.closures[t];
-                            fr = base;
-                            if (c.dynamic || eta_i != 1.f) {// (eta_i != 1: the bottom of a Layered surface under a refractive top)
-                                auto &raw = scene.surfaces[t];
-                                if (raw.normal_tex >= 0) {
-                                    auto v = texture_eval(scene, raw.normal_tex, it.uv);
-                                    auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
-                                    if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
-                                    auto normal = to_world(base, n_local);
-                                    fr = frame_from_normal_tangent(clamp_shading_normal(normal, it.ng, wo), base.s);
-                                }
-                                auto dyn = c.dynamic;
-                                c = resolve_closure(
-                                    raw, [&](int32_t id) { return texture_eval(scene, id, it.uv); },
-                                    [&](int32_t id) { return scene.textures[id].channels; }, eta_i);
-                                c.dynamic = dyn;
-                            }
-                        };
+                        // ---- material, mega_path.cpp:111-143.  The five basic closures are evaluated inline; Disney / Mix /
+                        // Layered surfaces go through the out-of-line heavy path (dev_heavy.h) when this variant holds Mix or
+                        // Layered (HEAVY_CALL), so that their registers are not the main loop's.  A <Disney only> variant keeps
+                        // Disney inline (C4: 584 Msamples/s inline).
+                        constexpr bool HEAVY_CALL = MIX || LAYERED;
+                        const LobeTables tables{scene.closures, scene.surfaces, scene.textures, scene.texels};
                         DClosure closure;
                         Frame sh;
-                        load_lobe((it.tags >> 12u) & 4095u, it.shading, closure, sh);
-                        const auto is_mix = MIX && closure.kind == LR_SURFACE_MIX;
-                        const auto is_layered = LAYERED && closure.kind == LR_SURFACE_LAYERED;
-                        LayerStack layers;
-                        if (is_layered) {// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500
-                            load_lobe(closure.x[0], sh, layers.top, layers.f_top);
-                            float eta_top = 1.f;
-                            closure_eta(layers.top, eta_top);
-                            load_lobe(closure.x[1], sh, layers.bottom, layers.f_bottom, eta_top);
-                            layers.own = sh, layers.ng = it.ng, layers.p = it.p;
-                            layers.thickness = closure.s0, layers.g = closure.s1;
-                            layers.albedo = mk3(closure.c0[0], closure.c0[1], closure.c0[2]);
-                            layers.max_depth = closure.x[2], layers.samples = closure.x[3];
+                        load_lobe(tables, it.uv, it.ng, wo, (it.tags >> 12u) & 4095u, it.shading, closure, sh);
+                        const auto is_heavy = HEAVY_CALL && closure.kind >= LR_SURFACE_DISNEY;
+                        HeavyCtx heavy;
+                        if (is_heavy) {
+                            heavy.tb = tables, heavy.uv = it.uv, heavy.ng = it.ng, heavy.p = it.p, heavy.wo = wo;
+                            heavy.shading = sh, heavy.closure = closure;
                         }
-                        const auto ratio = closure.s0;
-                        const auto tag_a = closure.x[0], tag_b = closure.x[1];
-                        auto mix_eval = [](const BsdfEval &a, const BsdfEval &b, float r) {// MixSurfaceClosure::_mix, mix.cpp:97-104
-                            auto t = 1.f - r;
-                            return BsdfEval{a.f + t * (b.f - a.f), lerp(a.pdf, b.pdf, t)};
-                        };
-                        auto eval_child = [&](uint32_t t, f3 wi) {
-                            DClosure c;
-                            Frame fr;
-                            load_lobe(t, sh, c, fr);
-                            return closure_evaluate<DISNEY>(c, fr, it.ng, wo, wi);
-                        };
                         if (light_pdf > 0.0f) {
                             BsdfEval eval;
-                            if (is_mix) {// mix.cpp:169-177
-                                eval = mix_eval(eval_child(tag_a, shadow.d), eval_child(tag_b, shadow.d), ratio);
-                                if (!valid_sides(it.ng, sh.n, wo, shadow.d)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
-                            } else if (is_layered) {
-                                eval = layered_evaluate(layers, wo, shadow.d);
-                            } else {
-                                eval = closure_evaluate<DISNEY>(closure, sh, it.ng, wo, shadow.d);
-                            }
+                            if (is_heavy) { eval = heavy_evaluate<MIX, LAYERED>(&heavy, shadow.d); }
+                            else { eval = closure_evaluate<DISNEY && !HEAVY_CALL>(closure, sh, it.ng, wo, shadow.d); }
                             auto w = balance(light_pdf, eval.pdf) / light_pdf;
                             nee = w * beta * eval.f * light_L;
                             // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
@@ -308,26 +270,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                         BsdfSample bs;
                         auto has_eta = false;
                         auto eta = 1.f;
-                        if (is_mix) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
-                            DClosure ca;
-                            Frame fa;
-                            load_lobe(tag_a, sh, ca, fa);
-                            auto first = u_lobe < ratio;
-                            bs = closure_sample<DISNEY>(ca, fa, it.ng, wo, first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio), u_bsdf);
-                            float eta_a = 1.f, eta_b = 1.f;
-                            auto has_a = closure_eta(ca, eta_a);
-                            auto eb = eval_child(tag_b, bs.wi);
-                            auto m = first ? mix_eval(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_eval(eb, BsdfEval{bs.f, bs.pdf}, ratio);
-                            bs.f = m.f, bs.pdf = m.pdf;
-                            if (!valid_sides(it.ng, sh.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
-                            auto has_b = closure_eta(scene.closures[tag_b], eta_b);// (eta never comes from an image texture here)
-                            has_eta = has_a || has_b;// MixSurfaceClosure::eta, mix.cpp:148-157
-                            eta = !has_a ? eta_b : (!has_b ? eta_a : lerp(eta_b, eta_a, ratio));
-                        } else if (is_layered) {
-                            bs = layered_sample(layers, wo, u_lobe, u_bsdf);
-                            has_eta = closure_eta(layers.bottom, eta);// LayeredSurfaceClosure::eta, layered.cpp:252
+                        if (is_heavy) {
+                            auto hs = heavy_sample<MIX, LAYERED>(&heavy, u_lobe, u_bsdf);
+                            bs = hs.bs, has_eta = hs.has_eta != 0u, eta = hs.eta;
                         } else {
-                            bs = closure_sample<DISNEY>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
+                            bs = closure_sample<DISNEY && !HEAVY_CALL>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
                             has_eta = closure_eta(closure, eta);
                         }
                         ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
