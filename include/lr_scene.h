@@ -201,13 +201,27 @@ typedef struct lr_sampler {
     const uint64_t *vdc_sobol_inv;
 } lr_sampler;
 
+typedef enum lr_integrator_kind {
+    LR_INTEGRATOR_MEGAPATH = 0, /* src/integrators/mega_path.cpp (the hot path)                                  */
+    LR_INTEGRATOR_DIRECT = 1,   /* src/integrators/direct.cpp:66-200: one bounce, light / surface / both sampling  */
+    LR_INTEGRATOR_NORMAL = 2    /* src/integrators/normal.cpp:36-70: geometric / shading normal visualiser         */
+} lr_integrator_kind;
+enum {
+    LR_DIRECT_SAMPLE_LIGHTS = 1u,   /* importance_sampling "light" | "both"   (direct.cpp:27-42) */
+    LR_DIRECT_SAMPLE_SURFACES = 2u, /* importance_sampling "surface" | "both"                    */
+    LR_NORMAL_REMAP = 1u,           /* normal.cpp:21: ns * .5 + .5                                */
+    LR_NORMAL_SHADING = 2u          /* normal.cpp:22: shading normal of the closure instead of ng */
+};
+
 typedef struct lr_integrator {
     uint32_t max_depth;   /* mega_path.cpp:23 */
     uint32_t rr_depth;    /* :24 */
     float rr_threshold;   /* :25 */
     float env_prob;       /* UniformLightSampler::_env_prob, uniform.cpp:39-48 */
     uint32_t light_count; /* pipeline.lights().size(): number of distinct Light nodes, uniform.cpp:82 */
-    uint32_t pad[3];
+    uint32_t kind;        /* lr_integrator_kind */
+    uint32_t flags;       /* LR_DIRECT_* / LR_NORMAL_* */
+    uint32_t pad[1];
 } lr_integrator;
 
 /* ---- wide BVH for the HIP traversal kernel (built by the host library; the CPU oracle

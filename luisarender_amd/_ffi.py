@@ -88,7 +88,7 @@ class Sampler(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("max_depth", u32), ("rr_depth", u32), ("rr_threshold", f32), ("env_prob", f32),
-                ("light_count", u32), ("pad", u32 * 3)]
+                ("light_count", u32), ("kind", u32), ("flags", u32), ("pad", u32 * 1)]
 
 
 class Bvh4Node(C.Structure):

@@ -123,6 +123,7 @@ struct DScene {
     float env_to_world[9];
     // integrator / sampler / film
     uint32_t max_depth, rr_depth;
+    uint32_t integrator_kind, integrator_flags;// lr_integrator_kind / LR_DIRECT_* / LR_NORMAL_* (kFeatAux variants only)
     float rr_threshold, env_prob;
     uint32_t light_count;   // distinct Light nodes (uniform.cpp:82)
     uint32_t has_lights;

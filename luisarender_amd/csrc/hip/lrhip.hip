@@ -442,6 +442,10 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         }
     }
     d.max_depth = s->integrator.max_depth, d.rr_depth = s->integrator.rr_depth;
+    d.integrator_kind = s->integrator.kind, d.integrator_flags = s->integrator.flags;
+    if (s->integrator.kind > LR_INTEGRATOR_NORMAL) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: unknown integrator kind"); }
+    // the sibling integrators (Direct / Normal) live in the all-features variant only
+    if (s->integrator.kind != LR_INTEGRATOR_MEGAPATH) { ctx->features |= lrd::kFeatSceneMask | lrd::kFeatAux; }
     d.rr_threshold = s->integrator.rr_threshold, d.env_prob = s->integrator.env_prob;
     d.light_count = s->integrator.light_count;
     d.has_lights = s->light_count != 0u ? 1u : 0u;
@@ -506,7 +510,8 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     ctx->timed = false;
     if (p->spp_end == p->spp_begin || p->tile_begin == p->tile_end) { return LRHIP_OK; }
     // MegakernelPathTracingInstance::_render_one_camera (mega_path.cpp:40-47): no lights -> nothing rendered
-    if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone) { return LRHIP_OK; }
+    // (the normal visualiser needs no light: normal.cpp has no such check)
+    if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone && ctx->scene.integrator_kind != LR_INTEGRATOR_NORMAL) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
     // Chunking is a function of the frame only (tile_count, spp), never of the device or the shard.  Two losses are

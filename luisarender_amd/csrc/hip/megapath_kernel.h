@@ -58,8 +58,12 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 //   kFeatDisney   Disney closure (thick + thin)
 //   kFeatMix      Mix closure (children: any non-Mix closure the mask holds)
 //   kFeatLayered  Layered closure (random walk over two nested closures; implies the Disney interpreter)
+//   kFeatAux      the sibling integrators that reuse this kernel's pieces: DirectLighting
+//                 (src/integrators/direct.cpp:66-200) and NormalVisualizer (normal.cpp:36-70), selected at run time by
+//                 scene.integrator_kind; debug / AOV views, so they only exist on top of the all-features variant
 enum : uint32_t {
     kFeatCount = 1u, kFeatGeneric = 2u, kFeatEnv = 4u, kFeatAlpha = 8u, kFeatDisney = 16u, kFeatMix = 32u, kFeatLayered = 64u,
+    kFeatAux = 128u,
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 // the precompiled scene-feature sets, smallest first (each also exists x {Count} x {Generic}); csrc/hip/variants/*.hip
@@ -70,6 +74,7 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatEnv | kFeatDisney,
     kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
     kFeatSceneMask,
+    kFeatSceneMask | kFeatAux,
 };
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
@@ -88,7 +93,7 @@ template<uint32_t F>
 __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kernel(DScene scene, RenderArgs args) {
     constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u, ENV = (F & kFeatEnv) != 0u,
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
-                   LAYERED = (F & kFeatLayered) != 0u;
+                   LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u;
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
@@ -155,11 +160,21 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     auto wo = -tr.d;
                     auto hit = tr.hit;
                     auto hit_valid = hit.inst != kInvalid;
-                    if (!hit_valid && scene.env_kind != kEnvNone) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
+                    // sibling integrators (kFeatAux): DirectLighting = this loop cut after the BSDF-sampled vertex's emission,
+                    // with the estimator chosen by importance_sampling; NormalVisualizer = the first hit's normal
+                    const auto is_direct = AUX && scene.integrator_kind == LR_INTEGRATOR_DIRECT;
+                    const auto is_normal = AUX && scene.integrator_kind == LR_INTEGRATOR_NORMAL;
+                    const auto direct_lights = !is_direct || (scene.integrator_flags & LR_DIRECT_SAMPLE_LIGHTS) != 0u;
+                    const auto direct_surfaces = !is_direct || (scene.integrator_flags & LR_DIRECT_SAMPLE_SURFACES) != 0u;
+                    // MIS weight of an emission found by BSDF sampling: 1 for camera rays (pdf_bsdf = 1e16) and, in
+                    // DirectLighting, when lights are not sampled (direct.cpp:187-189)
+                    auto mis_bsdf = [&](float pdf_light) { return direct_lights ? balance(pdf_bsdf, pdf_light) : 1.f; };
+                    if (!hit_valid && scene.env_kind != kEnvNone && !is_normal) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
                         f3 L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
                         auto pdf = kInvPi * 0.25f;
                         if (ENV && scene.env_kind != kEnvConstant) { env_evaluate(scene, tr.d, L, pdf); }
-                        Li += beta * L * balance(pdf_bsdf, pdf * scene.env_prob);
+                        // (DirectLighting's camera-ray miss adds eval.L unweighted, :92-98: the same thing, pdf_bsdf = 1e16)
+                        Li += beta * L * mis_bsdf(pdf * scene.env_prob);
                     }
                     SurfacePoint it;
                     auto has_surface = false;
@@ -172,20 +187,38 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                             float pdf;
                             light_evaluate(scene, it, hit.prim, tr.o, L, pdf);
                             pdf *= (1.f - scene.env_prob) / static_cast<float>(scene.light_count);
-                            Li += beta * L * balance(pdf_bsdf, pdf);
+                            if (!is_direct || depth == 0u || pdf > 0.f) { Li += beta * L * mis_bsdf(pdf); }// (direct.cpp:185: light_eval.pdf > 0)
                         }
                         has_surface = (it.flags & LR_SHAPE_HAS_SURFACE) != 0u;
+                        if (is_direct && depth >= 1u) { has_surface = false; }// direct.cpp:194: the loop ends after the sampled vertex
+                        if (is_normal) {// normal.cpp:48-66
+                            auto ns = it.ng;
+                            if (scene.integrator_flags & LR_NORMAL_SHADING) {
+                                ns = it.shading.n;
+                                if (has_surface) {
+                                    DClosure c;
+                                    Frame fr;
+                                    load_lobe(LobeTables{scene.closures, scene.surfaces, scene.textures, scene.texels}, it.uv, it.ng, wo,
+                                              (it.tags >> 12u) & 4095u, it.shading, c, fr);
+                                    ns = fr.n;
+                                }
+                            }
+                            if (scene.integrator_flags & LR_NORMAL_REMAP) { ns = ns * .5f + mk3(.5f); }
+                            Li = beta * ns;
+                            has_surface = false;
+                        }
                     }
                     if (has_surface) {
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
                         // light selection, light surface (2), lobe, bsdf (2), [rr]
-                        auto u_light_selection = sampler.next_1d();
-                        auto u_light_surface = sampler.next_2d();
+                        // (DirectLighting in surface-only mode draws no light sample, direct.cpp:114-118)
+                        auto u_light_selection = direct_lights ? sampler.next_1d() : 0.f;
+                        auto u_light_surface = direct_lights ? sampler.next_2d() : f2{0.f, 0.f};
                         // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63
                         f3 light_L = mk3(0.f);
                         auto light_pdf = 0.f;
-                        {
+                        if (direct_lights) {
                             auto n = static_cast<float>(scene.light_count);
                             auto is_env = false;
                             auto tag = 0u;
@@ -260,13 +293,14 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                             BsdfEval eval;
                             if (is_heavy) { eval = heavy_evaluate<MIX, LAYERED>(&heavy, shadow.d); }
                             else { eval = closure_evaluate<DISNEY && !HEAVY_CALL>(closure, sh, it.ng, wo, shadow.d); }
-                            auto w = balance(light_pdf, eval.pdf) / light_pdf;
+                            auto w = (direct_surfaces ? balance(light_pdf, eval.pdf) : 1.f) / light_pdf;// (direct.cpp:151-153)
                             nee = w * beta * eval.f * light_L;
+                            if (is_direct && !(eval.pdf > 0.f)) { nee = mk3(0.f); }// direct.cpp:150
                             // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
                             want_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
                         }
                         auto u_lobe = sampler.next_1d();
-                        auto u_bsdf = sampler.next_2d();
+                        auto u_bsdf = direct_surfaces ? sampler.next_2d() : f2{0.f, 0.f};
                         BsdfSample bs;
                         auto has_eta = false;
                         auto eta = 1.f;
@@ -289,6 +323,8 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                         }
                         if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
                         auto alive = !(beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f);
+                        if (is_direct && !(bs.pdf > 0.f)) { alive = false; }// direct.cpp:185: surface_sample.eval.pdf > 0
+                        if (!direct_surfaces) { alive = false; }            // light-only sampling: no continuation ray
                         auto rr = depth + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
                         auto u_rr = 0.f;
                         if (rr) { u_rr = sampler.next_1d(); }// (drawn before the closure in the reference: same stream position)

@@ -6,6 +6,11 @@
 // instead of JIT-compiling a LuisaCompute kernel.  Host flow = ProgressiveIntegrator::Instance::
 // render / _render_one_camera (src/base/integrator.cpp:34-113): per camera prepare film -> render
 // spp -> download (convert) -> save_image, logging "Rendering finished in {} ms.".
+//
+// Compiled three times: LR_PLUGIN_IMPL = "megapath" (default), "direct" (DirectLighting, src/integrators/direct.cpp) and
+// "normal" (NormalVisualizer, src/integrators/normal.cpp) — the sibling integrators of SURVEY §8 f4 are run-time modes of
+// the same megakernel (lr_integrator.kind, set by the scene loader from the node's impl type), so their plugins differ
+// only in the name they register and in NormalVisualizer not needing a light.
 #include <dlfcn.h>
 
 #include <chrono>
@@ -15,6 +20,10 @@
 
 #include "../../../include/lrhip.h"
 #include "luisa_render_shim.h"
+
+#ifndef LR_PLUGIN_IMPL
+#define LR_PLUGIN_IMPL "megapath"
+#endif
 
 namespace luisa::render {
 
@@ -66,7 +75,7 @@ public:
     [[nodiscard]] auto max_depth() const noexcept { return _max_depth; }
     [[nodiscard]] auto rr_depth() const noexcept { return _rr_depth; }
     [[nodiscard]] auto rr_threshold() const noexcept { return _rr_threshold; }
-    [[nodiscard]] std::string_view impl_type() const noexcept override { return "megapath"; }
+    [[nodiscard]] std::string_view impl_type() const noexcept override { return LR_PLUGIN_IMPL; }
     [[nodiscard]] std::unique_ptr<Integrator::Instance> build(Pipeline &pipeline, CommandBuffer &command_buffer) const noexcept override;
 };
 
@@ -92,7 +101,7 @@ public:
             auto &camera = data.cameras[i];
             auto width = camera.camera.width, height = camera.camera.height;
             std::vector<float> pixels(static_cast<size_t>(width) * height * 4u, 0.f);
-            if (!pipeline().has_lighting()) {// mega_path.cpp:40-46: warn, still write a black image
+            if (!pipeline().has_lighting() && std::string_view{LR_PLUGIN_IMPL} != "normal") {// mega_path.cpp:40-46, direct.cpp:57-63: warn, still write a black image
                 lr::log_warning("No lights in scene. Rendering aborted.");
                 for (size_t p = 0; p < static_cast<size_t>(width) * height; p++) { pixels[p * 4u + 3u] = 1.f; }
             } else {

@@ -965,13 +965,35 @@ public:
         auto integrator = root->node("integrator");
         _check_tag(integrator, Tag::INTEGRATOR);
         _out.integrator_impl = integrator->impl_type();
-        if (integrator->impl_type() != "megapath") {
-            throw Error{"Integrator '" + integrator->impl_type() + "' is out of scope: this framework implements the "
-                        "MegaPath hot path only (SURVEY §2 row 21)."};
+        if (integrator->impl_type() == "megapath") {
+            _out.integrator.kind = LR_INTEGRATOR_MEGAPATH;
+            _out.integrator.max_depth = std::max(integrator->uint_or("depth", 10u), 1u);
+            _out.integrator.rr_depth = integrator->uint_or("rr_depth", 0u);
+            _out.integrator.rr_threshold = std::max(integrator->float_or("rr_threshold", 0.95f), 0.05f);
+        } else if (integrator->impl_type() == "direct") {// DirectLighting, direct.cpp:27-42
+            _out.integrator.kind = LR_INTEGRATOR_DIRECT;
+            auto is = integrator->string_or("importance_sampling", "both");
+            for (auto &c : is) { c = static_cast<char>(std::tolower(c)); }
+            if (is == "light") { _out.integrator.flags = LR_DIRECT_SAMPLE_LIGHTS; }
+            else if (is == "material" || is == "surface" || is == "bsdf") { _out.integrator.flags = LR_DIRECT_SAMPLE_SURFACES; }
+            else {
+                if (is != "both" && is != "mis" && is != "multiple") {
+                    log_warning("Unknown importance sampling method \"" + is + "\". Using \"both\" instead.");
+                }
+                _out.integrator.flags = LR_DIRECT_SAMPLE_LIGHTS | LR_DIRECT_SAMPLE_SURFACES;
+            }
+            _out.integrator.max_depth = 2u;// camera vertex + the BSDF-sampled one
+            _out.integrator.rr_depth = ~0u, _out.integrator.rr_threshold = 0.95f;
+        } else if (integrator->impl_type() == "normal") {// NormalVisualizer, normal.cpp:19-22
+            _out.integrator.kind = LR_INTEGRATOR_NORMAL;
+            _out.integrator.flags = (integrator->bool_or("remap", true) ? uint32_t{LR_NORMAL_REMAP} : 0u) |
+                                    (integrator->bool_or("shading", true) ? uint32_t{LR_NORMAL_SHADING} : 0u);
+            _out.integrator.max_depth = 1u;
+            _out.integrator.rr_depth = ~0u, _out.integrator.rr_threshold = 0.95f;
+        } else {
+            throw Error{"Integrator '" + integrator->impl_type() + "' is out of scope: this framework implements the MegaPath hot "
+                        "path and its sibling megakernels Direct / Normal (SURVEY §2 row 21, §8 f4)."};
         }
-        _out.integrator.max_depth = std::max(integrator->uint_or("depth", 10u), 1u);
-        _out.integrator.rr_depth = integrator->uint_or("rr_depth", 0u);
-        _out.integrator.rr_threshold = std::max(integrator->float_or("rr_threshold", 0.95f), 0.05f);
         auto sampler = integrator->node_or_null("sampler");
         if (sampler == nullptr) { sampler = NodeDesc::shared_default(Tag::SAMPLER, "independent"); }
         _check_tag(sampler, Tag::SAMPLER);

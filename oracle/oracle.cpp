@@ -493,9 +493,114 @@ struct oracle_ctx {
         uint64_t closest{0}, shadow{0}, hits{0}, nee{0}, bounces{0};
     };
 
+    // NormalVisualizerInstance::Li, normal.cpp:36-70
+    float3 Li_normal(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
+        auto &s = *scene;
+        Sampler sampler;
+        sampler.start(s.sampler, px, py, sample_index);
+        auto u_filter = sampler.generate_pixel_2d();
+        auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
+        auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
+        (void)sampler.generate_1d();// spectrum()->sample(generate_1d()), :42 (sRGB ignores it)
+        stats.closest++;
+        auto hit = accel.trace(cs.ray, false, stats.trace);
+        auto ns = f3(0.f);
+        auto wo = -cs.ray.d;
+        if (!hit.miss()) {
+            stats.hits++;
+            auto it = make_interaction(hit.inst, hit.prim, f3(1.f - hit.bary.x - hit.bary.y, hit.bary.x, hit.bary.y), true, wo);
+            if (s.integrator.flags & LR_NORMAL_SHADING) {
+                ns = it.has_surface() ? Closure::populate(s, it, wo, 1.f).shading.n : it.shading.n;
+            } else {
+                ns = it.ng;
+            }
+            if (s.integrator.flags & LR_NORMAL_REMAP) { ns = ns * .5f + f3(.5f); }
+        }
+        return f3(cs.weight) * ns;
+    }
+
+    // DirectLightingInstance::Li, direct.cpp:66-200: the loop body runs once (alpha_skip is never set)
+    float3 Li_direct(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
+        auto &s = *scene;
+        Sampler sampler;
+        sampler.start(s.sampler, px, py, sample_index);
+        auto u_filter = sampler.generate_pixel_2d();
+        auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
+        auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);// (fixed sRGB spectrum: no wavelength draw, :72)
+        const auto samples_lights = (s.integrator.flags & LR_DIRECT_SAMPLE_LIGHTS) != 0u;
+        const auto samples_surfaces = (s.integrator.flags & LR_DIRECT_SAMPLE_SURFACES) != 0u;
+        const auto has_env = s.environment.kind != LR_ENV_NONE;
+        const auto weight = f3(cs.weight);
+        Spectrum3 Li = f3(0.f);
+        auto ray = cs.ray;
+        auto wo = -ray.d;
+        stats.closest++;
+        auto hit = accel.trace(ray, false, stats.trace);
+        if (hit.miss()) {
+            if (has_env) { Li += weight * env_evaluate(ray.d).L; }// :92-98
+            return Li;
+        }
+        stats.hits++;
+        auto it = make_interaction(hit.inst, hit.prim, f3(1.f - hit.bary.x - hit.bary.y, hit.bary.x, hit.bary.y), true, wo);
+        if (s.light_count != 0u && it.has_light()) { Li += weight * light_evaluate(it, ray.o).L; }// :101-106
+        if (!it.has_surface()) { return Li; }
+        stats.bounces++;
+        LightSample light_sample{};
+        auto occluded = false;
+        if (samples_lights) {// :114-127
+            auto u_light_selection = sampler.generate_1d();
+            auto u_light_surface = sampler.generate_2d();
+            stats.nee++;
+            light_sample = this->light_sample(it, u_light_selection, u_light_surface);
+            auto &L = light_sample.eval.L;
+            if (light_sample.eval.pdf > 0.f && (L.x > 0.f || L.y > 0.f || L.z > 0.f)) {
+                stats.shadow++;
+                occluded = !accel.trace(light_sample.shadow_ray, true, stats.trace).miss();
+            }
+        }
+        auto u_lobe = sampler.generate_1d();
+        auto u_bsdf = samples_surfaces ? sampler.generate_2d() : float2{0.f, 0.f};
+        auto closure = Closure::populate(s, it, wo, 1.f);
+        if (samples_lights && light_sample.eval.pdf > 0.0f && !occluded) {// :146-157
+            auto eval = closure.evaluate(wo, light_sample.shadow_ray.d);
+            if (eval.pdf > 0.f) {
+                auto w = samples_surfaces ? balance_heuristic(light_sample.eval.pdf, eval.pdf) : 1.f;
+                Li += w * weight * eval.f * light_sample.eval.L / light_sample.eval.pdf;
+            }
+        }
+        if (samples_surfaces) {// :159-192
+            auto surface_sample = closure.sample(wo, u_lobe, u_bsdf);
+            ray = spawn_ray(it, surface_sample.wi);
+            stats.closest++;
+            auto bsdf_hit = accel.trace(ray, false, stats.trace);
+            Spectrum3 light_L = f3(0.f);
+            auto light_pdf = 0.f;
+            if (bsdf_hit.miss()) {
+                if (has_env) {// evaluate_miss, uniform.cpp:67-76
+                    auto eval = env_evaluate(ray.d);
+                    light_L = eval.L, light_pdf = eval.pdf * s.integrator.env_prob;
+                }
+            } else {
+                stats.hits++;
+                auto bsdf_it = make_interaction(bsdf_hit.inst, bsdf_hit.prim, f3(1.f - bsdf_hit.bary.x - bsdf_hit.bary.y, bsdf_hit.bary.x, bsdf_hit.bary.y), true, -ray.d);
+                if (s.light_count != 0u && bsdf_it.has_light()) {// evaluate_hit, uniform.cpp:50-65
+                    auto eval = light_evaluate(bsdf_it, ray.o);
+                    light_L = eval.L, light_pdf = eval.pdf * (1.f - s.integrator.env_prob) / static_cast<float>(s.integrator.light_count);
+                }
+            }
+            if (light_pdf > 0.f && surface_sample.eval.pdf > 0.f) {
+                auto w = samples_lights ? balance_heuristic(surface_sample.eval.pdf, light_pdf) : 1.f;
+                Li += weight * w * surface_sample.eval.f * light_L / surface_sample.eval.pdf;
+            }
+        }
+        return Li;
+    }
+
     // MegakernelPathTracingInstance::Li, mega_path.cpp:49-156
     float3 Li(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
         auto &s = *scene;
+        if (s.integrator.kind == LR_INTEGRATOR_NORMAL) { return Li_normal(px, py, sample_index, stats); }
+        if (s.integrator.kind == LR_INTEGRATOR_DIRECT) { return Li_direct(px, py, sample_index, stats); }
         Sampler sampler;
         sampler.start(s.sampler, px, py, sample_index);
         auto u_filter = sampler.generate_pixel_2d();
@@ -588,7 +693,8 @@ int oracle_render(oracle_ctx *ctx, uint32_t spp_begin, uint32_t spp_end, uint32_
                   int threads, float *film, oracle_counters *counters) {
     auto &scene = *ctx->scene;
     if (x1 > scene.camera.width || y1 > scene.camera.height || x0 > x1 || y0 > y1) { return -1; }
-    if (scene.light_count == 0u && scene.environment.kind == LR_ENV_NONE) { return 0; }// mega_path.cpp:40-46: no lights -> black
+    // mega_path.cpp:40-46, direct.cpp:57-63: no lights -> black (the normal visualiser needs none)
+    if (scene.light_count == 0u && scene.environment.kind == LR_ENV_NONE && scene.integrator.kind != LR_INTEGRATOR_NORMAL) { return 0; }
     threads = std::max(threads, 1);
     std::atomic<uint32_t> next_row{y0};
     std::vector<oracle_ctx::PathStats> stats(static_cast<size_t>(threads));

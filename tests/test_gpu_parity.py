@@ -384,3 +384,41 @@ def test_error_paths(renderer):
     assert lib.lrhip_render(ctx, C.byref(p)) < 0  # no scene uploaded
     assert lib.lrhip_create(99, C.byref(C.c_void_p())) < 0
     lib.lrhip_destroy(ctx)
+
+
+@pytest.mark.parametrize("integrator", ['Direct { importance_sampling { "both" }', 'Direct { importance_sampling { "light" }',
+                                        'Direct { importance_sampling { "surface" }', "Normal {", "Normal { remap { false } shading { false }"])
+def test_sibling_integrators(renderer, integrator):
+    """DirectLighting (direct.cpp:66-200) and NormalVisualizer (normal.cpp:36-70) on the device — the
+    all-features variant + kFeatAux — against their oracle restatements: same sampler streams, same paths."""
+    from helpers import MATERIALS
+    extra = MATERIALS["glass"].replace("Surface m ", "Surface probe ") + "\n"
+    text = cornell_box(resolution=64, spp=16, short_box_surface="probe", extra_surfaces=extra).replace("integrator : MegaPath {", "integrator : " + integrator)
+    text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
+    sc = Scene.from_string(text)
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert renderer.last_variant() == 252 | 1
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
+    assert np.abs(cpu[..., :3]).mean() > 0.01 and _rel_l1(gpu, cpu) < 1e-3, integrator
+
+
+def test_normal_visualiser_needs_no_light(renderer):
+    """normal.cpp has no "no lights -> abort" branch: a light-less scene renders (mega_path.cpp:40-46 would return black)."""
+    text = """
+Surface s : Matte { Kd : Constant { v { 0.5 } } }
+Shape quad : InlineMesh { positions { -5,0,-5, 5,0,-5, 5,0,5, -5,0,5 } indices { 0,2,1, 0,3,2 } surface { @s } }
+Shape cube : InlineMesh {
+  positions { -1,0,-1, 1,0,-1, 1,2,-1, -1,2,-1, -1,0,1, 1,0,1, 1,2,1, -1,2,1 }
+  indices { 0,2,1, 0,3,2,  4,5,6, 4,6,7,  0,1,5, 0,5,4,  3,6,2, 3,7,6,  0,7,3, 0,4,7,  1,2,6, 1,6,5 }
+  surface { @s } transform : SRT { rotate { 0, 1, 0, 30 } } }
+Camera cam : Pinhole { fov { 40 } spp { 2 } film : Color { resolution { 32, 32 } } position { 0, 4, 8 } look_at { 0, 1, 0 } }
+render { cameras { @cam } shapes { @quad, @cube } integrator : Normal { } }
+"""
+    sc = Scene.from_string(text)
+    assert not sc.has_lighting
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 2)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3]) and _rel_l1(gpu, cpu) < 1e-5
+    img = gpu[..., :3] / 2.0
+    assert img.min() >= -1e-6 and img.max() <= 1 + 1e-6
+    assert len(np.unique(np.round(img.reshape(-1, 3), 2), axis=0)) >= 4  # background, floor and at least two cube faces

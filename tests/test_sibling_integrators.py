@@ -1,0 +1,81 @@
+"""the sibling megakernels that reuse the hot path's pieces — DirectLighting (src/integrators/direct.cpp:66-200)
+and NormalVisualizer (src/integrators/normal.cpp:36-70).  Oracle pins (closed forms, relations to MegaPath)."""
+import numpy as np
+import pytest
+
+from luisarender_amd import Scene
+from luisarender_amd.oracle_check import Oracle
+from luisarender_amd.scenes import cornell_box
+
+ENV_QUAD = """
+Surface s : Matte { Kd : Constant { v { 0.6, 0.4, 0.2 } } }
+Shape quad : InlineMesh { positions { -50,0,-50, 50,0,-50, 50,0,50, -50,0,50 } indices { 0,2,1, 0,3,2 } surface { @s } }
+Camera cam : Pinhole { fov { 30 } spp { 1 } film : Color { resolution { 16, 16 } }
+  position { 0, 5, 0 } look_at { 0, 0, -3 } }
+render { cameras { @cam } shapes { @quad }
+  environment : Spherical { emission : Constant { v { 2, 3, 4 } } }
+  integrator : INTEGRATOR }
+"""
+
+
+def _mean(scene, spp):
+    o = Oracle(scene)
+    film, counters = o.render(0, spp)
+    return o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0), counters
+
+
+@pytest.mark.parametrize("mode", ["light", "surface", "both"])
+def test_direct_lighting_of_a_convex_receiver_is_rho_times_the_environment(mode):
+    """One bounce is everything a convex receiver under a constant environment sees: L = rho * L_env for each of the three
+    estimators (direct.cpp:27-42: light only, surface only, MIS of both)."""
+    sc = Scene.from_string(ENV_QUAD.replace("INTEGRATOR", f'Direct {{ importance_sampling {{ "{mode}" }} }}'))
+    v = sc.view()
+    assert v.integrator.kind == 1 and v.integrator.flags == {"light": 1, "surface": 2, "both": 3}[mode]
+    img, counters = _mean(sc, 256)
+    assert np.allclose(img, np.array([0.6 * 2, 0.4 * 3, 0.2 * 4]), rtol=0.02), (mode, img)
+    # light-only sampling traces no continuation ray; the others exactly one per surface hit
+    assert counters["closest_rays"] == counters["paths"] * (1 if mode == "light" else 2)
+
+
+def test_direct_is_the_first_bounce_of_the_path_tracer():
+    """In a Cornell box, direct lighting < full path tracing, and equal to it where only emission is seen."""
+    direct = Scene.from_string(cornell_box(resolution=32, spp=64).replace("integrator : MegaPath {", "integrator : Direct {"))
+    path = Scene.from_string(cornell_box(resolution=32, spp=64))
+    d, _ = Oracle(direct).render(0, 64)
+    p, _ = Oracle(path).render(0, 64)
+    assert 0.2 * p[..., :3].mean() < d[..., :3].mean() < 0.9 * p[..., :3].mean()
+    # unknown importance_sampling falls back to "both" with a warning (direct.cpp:35-41)
+    odd = Scene.from_string(ENV_QUAD.replace("INTEGRATOR", 'Direct { importance_sampling { "fancy" } }'))
+    assert odd.view().integrator.flags == 3
+
+
+@pytest.mark.parametrize("remap, shading", [(True, True), (False, True), (True, False), (False, False)])
+def test_normal_visualiser_shows_the_plane_normal(remap, shading):
+    """normal.cpp:44-67: weight * (remap ? n * .5 + .5 : n); a miss stays black; no light is needed."""
+    text = ENV_QUAD.replace("INTEGRATOR", f"Normal {{ remap {{ {str(remap).lower()} }} shading {{ {str(shading).lower()} }} }}")
+    text = text.replace("  environment : Spherical { emission : Constant { v { 2, 3, 4 } } }\n", "")
+    sc = Scene.from_string(text)
+    assert not sc.has_lighting and sc.view().integrator.kind == 2
+    img, counters = _mean(sc, 4)
+    n = np.array([0.0, 1.0, 0.0])
+    assert np.allclose(img, n * 0.5 + 0.5 if remap else n, atol=1e-5)
+    assert counters["closest_rays"] == counters["paths"]
+
+
+def test_normal_visualiser_uses_the_normal_mapped_shading_frame(tmp_path):
+    """`shading { true }` shows the closure's shading normal (NormalMapWrapper applied, surface.h:236-254), `false` ng."""
+    from luisarender_amd.scene import save_image
+    tilt = np.zeros((4, 4, 4), np.float32)
+    tilt[...] = [0.5 + 0.5 * 0.6, 0.5, 0.5 + 0.5 * 0.8, 1.0]  # tangent-space (0.6, 0, 0.8)
+    path = str(tmp_path / "n.exr")
+    save_image(path, tilt)
+    text = ENV_QUAD.replace("Surface s : Matte {", f'Surface s : Matte {{ normal_map : Image {{ file {{ "{path}" }} }}')
+    shaded, _ = _mean(Scene.from_string(text.replace("INTEGRATOR", "Normal { remap { false } }")), 4)
+    flat, _ = _mean(Scene.from_string(text.replace("INTEGRATOR", "Normal { remap { false } shading { false } }")), 4)
+    assert np.allclose(flat, [0, 1, 0], atol=1e-5)
+    assert abs(np.linalg.norm(shaded) - 1) < 1e-3 and abs(shaded[1] - 0.8) < 1e-3 and not np.allclose(shaded, flat, atol=0.1)
+
+
+def test_other_integrators_are_still_rejected():
+    with pytest.raises(Exception, match="out of scope"):
+        Scene.from_string(ENV_QUAD.replace("INTEGRATOR", "WavePath { }"))
