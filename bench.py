@@ -123,7 +123,7 @@ def main():
         def step():
             film.zero_()
             torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
-            renderer.render(0, spp, rank=rank, world=world)
+            renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
             renderer.synchronize()
             if world > 1:
                 reduce_film(film, dst=0)

@@ -46,7 +46,13 @@ typedef struct lrhip_render_params {
     uint32_t spp_begin, spp_end;
     uint32_t tile_begin, tile_end, tile_stride;
     uint32_t flags;          /* LRHIP_RENDER_* */
-    uint32_t pad[2];
+    /* Work-item sizing hint: the number of shards the frame is split into (0 = 1).  A frame is cut into
+     * (tile, sample-chunk) items whose size balances the drain at the end of every item against the tail of the
+     * launch; a 1/W shard has W times fewer tiles per GPU and wants smaller items (item size ~ sqrt(tiles per shard)).  The chunking —
+     * and with it the fp32 summation order of the film — is a function of (resolution, spp, balance_shards) ONLY:
+     * renders that pass the same value are bit-identical under any tile sharding and on any device.            */
+    uint32_t balance_shards;
+    uint32_t pad[1];
 } lrhip_render_params;
 
 #define LRHIP_RENDER_COUNTERS 1u /* gather per-ray node/triangle counters (slower kernel variant) */

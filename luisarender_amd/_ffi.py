@@ -148,7 +148,7 @@ class HipCounters(C.Structure):
 class RenderParams(C.Structure):
     """lrhip_render_params (include/lrhip.h)"""
     _fields_ = [("spp_begin", u32), ("spp_end", u32), ("tile_begin", u32), ("tile_end", u32),
-                ("tile_stride", u32), ("flags", u32), ("pad", u32 * 2)]
+                ("tile_stride", u32), ("flags", u32), ("balance_shards", u32), ("pad", u32 * 1)]
 
 
 _libs: dict[str, C.CDLL] = {}

@@ -514,11 +514,16 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone && ctx->scene.integrator_kind != LR_INTEGRATOR_NORMAL) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
-    // Chunking is a function of the frame only (tile_count, spp), never of the device or the shard.  Two losses are
-    // balanced: the drain at the end of every item (the last paths of its queue finish with most lanes idle, a share
-    // of ~2.5 / S for S samples per pixel and item) and the tail of the launch (waves that run out of items while
-    // the last ones finish, ~S * waves / (2 * spp * tiles))  ->  S = sqrt(5 * spp * tiles / waves).
-    auto s_item = std::sqrt(5.0 * spp * tile_count / kNominalWaves);
+    // Chunking is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile range
+    // of this call.  Two losses are balanced: the drain at the end of every item (the last paths of its queue finish
+    // with most lanes idle, a share of ~a / S for S samples per pixel and item) and the tail of the launch (waves that
+    // run out of items while the last ones finish, ~S * waves / (2 * spp * tiles))  ->  S = sqrt(2 a * spp * tiles / waves).
+    // a = 0.625 from sweeps on C2 (1024 spp, full frame: 7 / 14 / 28 chunks -> 1992 / 1987 / 1987 ms; the 1/8 shard:
+    // 14 / 28 / 56 / 64 chunks -> 305 / 271 / 266 / 265 ms).  tile_count is that of ONE shard of the frame as the caller
+    // declares it (balance_shards), so that every shard of a frame — and the unsharded frame rendered with the same
+    // hint — uses the same chunking.
+    auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
+    auto s_item = std::sqrt(1.25 * spp * shard_tiles / kNominalWaves);
     auto chunk_count = static_cast<uint32_t>(std::lround(spp / std::max(s_item, 1.0)));
     chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
     lrd::RenderArgs args{};

@@ -49,9 +49,12 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_film_clear(self._ctx))
 
     def render(self, spp_begin: int, spp_end: int, rank: int = 0, world: int = 1, counters: bool = False,
-               sync: bool = False) -> None:
-        """Render samples [spp_begin, spp_end) of the round-robin tile shard `rank` of `world`."""
+               sync: bool = False, balance_shards: int = 1) -> None:
+        """Render samples [spp_begin, spp_end) of the round-robin tile shard `rank` of `world`.
+        `balance_shards` sizes the work items for a frame split into that many shards (lrhip.h): films rendered with
+        the same value are bit-identical under any sharding; the multi-GPU bench passes its world size."""
         p = _ffi.RenderParams()
+        p.balance_shards = balance_shards
         p.spp_begin, p.spp_end = spp_begin, spp_end
         p.tile_begin, p.tile_end, p.tile_stride = rank, tile_count(self.width, self.height), world
         p.flags = 1 if counters else 0

@@ -350,6 +350,22 @@ def test_tile_shards_reproduce_full_frame(renderer):
             assert (part[~mask] == 0).all()
             total += part
         assert np.array_equal(total, full), world
+    # the item-size hint of the multi-GPU bench (lrhip_render_params.balance_shards): same hint -> same bits under any
+    # sharding; a different hint only regroups the fp32 sums (more, smaller sample chunks)
+    sc = Scene.from_string(cornell_box(resolution=(100, 76), spp=256))
+    renderer.upload(sc)
+    renderer.render(0, 256, sync=True, balance_shards=4)
+    full4 = renderer.download(False)
+    total = np.zeros_like(full4)
+    for rank in range(4):
+        renderer.clear()
+        renderer.render(0, 256, rank=rank, world=4, sync=True, balance_shards=4)
+        total += renderer.download(False)
+    assert np.array_equal(total, full4)
+    renderer.clear()
+    renderer.render(0, 256, sync=True)
+    full1 = renderer.download(False)
+    assert np.array_equal(full1[..., 3], full4[..., 3]) and np.allclose(full1, full4, rtol=1e-4, atol=1e-4)
 
 
 def test_full_size_c2_properties(renderer, tmp_path):
