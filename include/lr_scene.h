@@ -204,7 +204,8 @@ typedef struct lr_sampler {
 typedef enum lr_integrator_kind {
     LR_INTEGRATOR_MEGAPATH = 0, /* src/integrators/mega_path.cpp (the hot path)                                  */
     LR_INTEGRATOR_DIRECT = 1,   /* src/integrators/direct.cpp:66-200: one bounce, light / surface / both sampling  */
-    LR_INTEGRATOR_NORMAL = 2    /* src/integrators/normal.cpp:36-70: geometric / shading normal visualiser         */
+    LR_INTEGRATOR_NORMAL = 2,   /* src/integrators/normal.cpp:36-70: geometric / shading normal visualiser         */
+    LR_INTEGRATOR_VPT_NAIVE = 3 /* src/integrators/mega_vpt_naive.cpp:68-483: volumetric megakernel  */
 } lr_integrator_kind;
 enum {
     LR_DIRECT_SAMPLE_LIGHTS = 1u,   /* importance_sampling "light" | "both"   (direct.cpp:27-42) */
@@ -221,8 +222,23 @@ typedef struct lr_integrator {
     uint32_t light_count; /* pipeline.lights().size(): number of distinct Light nodes, uniform.cpp:82 */
     uint32_t kind;        /* lr_integrator_kind */
     uint32_t flags;       /* LR_DIRECT_* / LR_NORMAL_* */
-    uint32_t pad[1];
+    uint32_t environment_medium_tag; /* Pipeline::environment_medium_tag (pipeline.cpp:77-79); LR_INVALID_ID = none */
 } lr_integrator;
+
+/* Participating media (src/base/medium.h, src/media/{homogeneous,vacuum,null}.cpp) with their phase function
+ * (src/phasefunctions/henyey_greenstein.cpp).  Reached from the VPT integrator only; a Null medium registers nothing
+ * (geometry.cpp:139).  Coefficients are the textures' constant values (homogeneous.cpp:196-199 requires constants),
+ * decoded as unbounded sRGB spectra = the values themselves.                                                          */
+typedef enum lr_medium_kind { LR_MEDIUM_VACUUM = 0, LR_MEDIUM_HOMOGENEOUS = 1 } lr_medium_kind;
+#define LR_MEDIUM_VACUUM_PRIORITY 0xffffffffu /* Medium::VACUUM_PRIORITY, medium.h:27 */
+typedef struct lr_medium {  /* 64 B */
+    uint32_t kind;
+    uint32_t priority;      /* medium.cpp:13 (`priority`, default 0); Vacuum: VACUUM_PRIORITY (vacuum.cpp:69) */
+    float eta;              /* homogeneous.cpp:192 */
+    float g;                /* HenyeyGreenstein::_g clamped to [-1, 1], henyey_greenstein.cpp:64 */
+    float sigma_a[3], sigma_s[3], le[3];
+    uint32_t pad[3];
+} lr_medium;
 
 /* ---- wide BVH for the HIP traversal kernel (built by the host library; the CPU oracle
  * ignores it and builds its own canonical BVH2).  See DESIGN.md "BVH layout". */
@@ -276,6 +292,9 @@ typedef struct lr_scene {
     uint32_t any_non_opaque;           /* Geometry::_any_non_opaque, geometry.cpp:124 */
     uint32_t environment_child_count;  /* 2 when environment.kind == LR_ENV_COMBINED, else 0 */
     const lr_environment *environment_children; /* Spherical / Directional records with their own tables */
+    const lr_medium *media;            /* Pipeline::_media in registration order (tag = index) */
+    uint32_t medium_count;
+    uint32_t pad_media;
 } lr_scene;
 
 #ifdef __cplusplus

@@ -88,7 +88,12 @@ class Sampler(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("max_depth", u32), ("rr_depth", u32), ("rr_threshold", f32), ("env_prob", f32),
-                ("light_count", u32), ("kind", u32), ("flags", u32), ("pad", u32 * 1)]
+                ("light_count", u32), ("kind", u32), ("flags", u32), ("environment_medium_tag", u32)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("kind", u32), ("priority", u32), ("eta", f32), ("g", f32), ("sigma_a", f32 * 3), ("sigma_s", f32 * 3),
+                ("le", f32 * 3), ("pad", u32 * 3)]
 
 
 class Bvh4Node(C.Structure):
@@ -118,14 +123,15 @@ class Scene(C.Structure):
                 ("texels", C.POINTER(f32)), ("texel_count", u64),
                 ("environment", Environment), ("camera", Camera), ("filter", Filter), ("film", Film),
                 ("sampler", Sampler), ("integrator", Integrator), ("accel", Accel),
-                ("any_non_opaque", u32), ("environment_child_count", u32), ("environment_children", C.c_void_p)]
+                ("any_non_opaque", u32), ("environment_child_count", u32), ("environment_children", C.c_void_p),
+                ("media", C.POINTER(Medium)), ("medium_count", u32), ("pad_media", u32)]
 
 
 STRUCTS = {"lr_scene": Scene, "lr_vertex": Vertex, "lr_triangle": Triangle, "lr_alias_entry": AliasEntry,
            "lr_mesh": Mesh, "lr_instance": Instance, "lr_texture": Texture, "lr_surface": Surface,
            "lr_light": Light, "lr_environment": Environment, "lr_camera": Camera, "lr_filter": Filter,
            "lr_film": Film, "lr_sampler": Sampler, "lr_integrator": Integrator, "lr_bvh4_node": Bvh4Node,
-           "lr_bvh_triangle": BvhTriangle, "lr_accel": Accel, "lr_light_handle": LightHandle}
+           "lr_bvh_triangle": BvhTriangle, "lr_accel": Accel, "lr_light_handle": LightHandle, "lr_medium": Medium}
 
 
 class OracleCounters(C.Structure):

@@ -118,6 +118,7 @@ lr_scene SceneData::view(size_t camera_index) const {
         }
     }
     s.integrator = integrator;
+    s.media = media.empty() ? nullptr : media.data(), s.medium_count = static_cast<uint32_t>(media.size());
     s.accel.nodes = bvh_nodes.empty() ? nullptr : bvh_nodes.data();
     s.accel.node_count = static_cast<uint32_t>(bvh_nodes.size());
     s.accel.triangles = bvh_triangles.empty() ? nullptr : bvh_triangles.data();
@@ -538,6 +539,49 @@ public:
     }
 
     // ---------------- lights
+    // Pipeline::register_medium (pipeline.cpp:36-42) + the Medium / PhaseFunction node constructors
+    std::unordered_map<const NodeDesc *, uint32_t> _medium_tags;
+    uint32_t register_medium(const NodeDesc *d) {
+        _check_tag(d, Tag::MEDIUM);
+        if (auto it = _medium_tags.find(d); it != _medium_tags.end()) { return it->second; }
+        lr_medium m{};
+        m.priority = d->uint_or("priority", 0u);// medium.cpp:13
+        m.eta = 1.f;
+        auto constant3 = [&](const char *name, float out[3], bool required) {
+            auto t = d->node_or_null(name);
+            if (t == nullptr) {
+                if (required) { throw Error{std::string{name} + " must be specified as constant. [" + d->location() + "]"}; }
+                return;
+            }
+            _check_tag(t, Tag::TEXTURE);
+            if (t->impl_type() != "constant") { throw Error{std::string{name} + " must be specified as constant. [" + t->location() + "]"}; }
+            auto &tex = _out.textures[static_cast<size_t>(load_texture(t))];
+            for (auto c = 0; c < 3; c++) { out[c] = tex.channels == 1u ? tex.v[0] : tex.v[c]; }
+        };
+        if (d->impl_type() == "homogeneous") {// homogeneous.cpp:189-201
+            m.kind = LR_MEDIUM_HOMOGENEOUS;
+            m.eta = d->float_or("eta", 1.f);
+            constant3("sigma_a", m.sigma_a, true);
+            constant3("sigma_s", m.sigma_s, true);
+            constant3("Le", m.le, false);
+            auto pf = d->node_or_null("phasefunction");
+            if (pf == nullptr) { throw Error{"Phase function must be specified. [" + d->location() + "]"}; }
+            _check_tag(pf, Tag::PHASE_FUNCTION);
+            if (pf->impl_type() != "henyeygreenstein") { throw Error{"Unknown phase function '" + pf->impl_type() + "'. [" + pf->location() + "]"}; }
+            m.g = std::clamp(pf->float_or("g", 0.f), -1.f, 1.f);// henyey_greenstein.cpp:64
+        } else if (d->impl_type() == "vacuum") {// vacuum.cpp:66-70
+            m.kind = LR_MEDIUM_VACUUM;
+            m.priority = LR_MEDIUM_VACUUM_PRIORITY;
+        } else {
+            throw Error{"Medium '" + d->impl_type() + "' is not implemented (Homogeneous, Vacuum, Null are). [" + d->location() + "]"};
+        }
+        if (_out.media.size() >= 255u) { throw Error{"Too many media (8-bit medium tag, shape.h:131)."}; }
+        auto tag = static_cast<uint32_t>(_out.media.size());
+        _out.media.emplace_back(m);
+        _medium_tags.emplace(d, tag);
+        return tag;
+    }
+
     bool light_is_null(const NodeDesc *d) {
         if (d == nullptr || d->impl_type() == "null") { return true; }
         _check_tag(d, Tag::LIGHT);
@@ -677,7 +721,7 @@ public:
 
     // Geometry::_process_shape, geometry.cpp:29-163
     void process_shape(const NodeDesc *d, const NodeDesc *overridden_surface, const NodeDesc *overridden_light,
-                       bool overridden_visible) {
+                       bool overridden_visible, const NodeDesc *overridden_medium = nullptr) {
         _check_tag(d, Tag::SHAPE);
         auto info = shape_info(d);
         auto own_surface = d->node_or_null("surface");
@@ -685,9 +729,8 @@ public:
         auto surface = overridden_surface == nullptr ? own_surface : overridden_surface;
         auto light = overridden_light == nullptr ? own_light : overridden_light;
         auto visible = overridden_visible && info.visible;
-        if (d->node_or_null("medium") != nullptr) {
-            log_warning("Shape medium ignored: megapath never enters media (SURVEY §2 row 22). [" + d->location() + "]");
-        }
+        auto own_medium = d->node_or_null("medium");
+        auto medium = overridden_medium == nullptr ? own_medium : overridden_medium;// geometry.cpp:38
         auto local = transform_matrix(d->node_or_null("transform"));
         if (info.is_mesh) {
             uint32_t vertex_props = 0u;
@@ -718,13 +761,18 @@ public:
                 light_tag = register_light(light);
                 properties |= LR_SHAPE_HAS_LIGHT;
             }
+            auto medium_tag = 0u;
+            if (medium != nullptr && medium->impl_type() != "null") {// geometry.cpp:139-142
+                medium_tag = register_medium(medium);
+                properties |= LR_SHAPE_HAS_MEDIUM;
+            }
             // u16 round trip of the wrapper factors (geometry.cpp:92-101,143-148)
             auto fixed16 = [](float x) { return static_cast<uint16_t>(std::clamp(std::round(x * 65535.f), 0.f, 65535.f)); };
             auto has_normal = (vertex_props & LR_SHAPE_HAS_VERTEX_NORMAL) != 0u;
             auto shadow_term = fixed16(has_normal ? info.shadow_terminator : 0.f);
             auto isect_offset = fixed16(info.intersection_offset);
             lr_instance inst{};
-            inst.handle = encode_instance_handle(mesh_index, properties, surface_tag, light_tag, 0u, mesh.triangle_count,
+            inst.handle = encode_instance_handle(mesh_index, properties, surface_tag, light_tag, medium_tag, mesh.triangle_count,
                                                  static_cast<float>(shadow_term) / 65535.f,
                                                  static_cast<float>(isect_offset) / 65535.f);
             store_matrix(inst.object_to_world, object_to_world);
@@ -736,7 +784,7 @@ public:
             if (pushed) { _transform_stack.emplace_back(_transform_stack.back() * local); }
             auto children = d->impl_type() == "group" ? d->node_list_required("shapes") :
                                                         NodeDesc::node_list{d->node("shape")};
-            for (auto child : children) { process_shape(child, surface, light, visible); }
+            for (auto child : children) { process_shape(child, surface, light, visible, medium); }
             if (pushed) { _transform_stack.pop_back(); }
         }
     }
@@ -990,10 +1038,16 @@ public:
                                     (integrator->bool_or("shading", true) ? uint32_t{LR_NORMAL_SHADING} : 0u);
             _out.integrator.max_depth = 1u;
             _out.integrator.rr_depth = ~0u, _out.integrator.rr_threshold = 0.95f;
+        } else if (integrator->impl_type() == "megavptnaive") {// MegakernelVolumePathTracingNaive, mega_vpt_naive.cpp:29-32
+            _out.integrator.kind = LR_INTEGRATOR_VPT_NAIVE;
+            _out.integrator.max_depth = std::max(integrator->uint_or("depth", 20u), 1u);
+            _out.integrator.rr_depth = integrator->uint_or("rr_depth", 0u);
+            _out.integrator.rr_threshold = std::max(integrator->float_or("rr_threshold", 0.95f), 0.05f);
         } else {
             throw Error{"Integrator '" + integrator->impl_type() + "' is out of scope: this framework implements the MegaPath hot "
-                        "path and its sibling megakernels Direct / Normal (SURVEY §2 row 21, §8 f4)."};
+                        "path and its sibling megakernels Direct / Normal / MegaVPTNaive (SURVEY §2 row 21, §8 f3-f4)."};
         }
+        _out.integrator.environment_medium_tag = LR_INVALID_ID;
         auto sampler = integrator->node_or_null("sampler");
         if (sampler == nullptr) { sampler = NodeDesc::shared_default(Tag::SAMPLER, "independent"); }
         _check_tag(sampler, Tag::SAMPLER);
@@ -1035,6 +1089,10 @@ public:
         }
         for (auto &s : _out.surfaces) {
             if (s.kind == LR_SURFACE_DISNEY) { s.u[0] = lobe_union[disney_class(s)]; }
+        }
+        // the environment medium is registered after the geometry (pipeline.cpp:72-79): its tag follows the shapes' media
+        if (auto env_medium = root->node_or_null("environment_medium"); env_medium != nullptr && env_medium->impl_type() != "null") {
+            _out.integrator.environment_medium_tag = register_medium(env_medium);
         }
         // UniformLightSamplerInstance (uniform.cpp:31-48)
         _out.integrator.light_count = static_cast<uint32_t>(_out.lights.size());

@@ -34,6 +34,7 @@ struct SceneData {
     std::vector<lr_light_handle> light_instances;
     std::vector<lr_surface> surfaces;
     std::vector<lr_light> lights;
+    std::vector<lr_medium> media;
     std::vector<lr_texture> textures;
     std::vector<float> texels;// float4 units
     lr_environment environment{};

@@ -16,6 +16,7 @@
 #include "oracle.h"
 
 #include <atomic>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -596,11 +597,315 @@ struct oracle_ctx {
         return Li;
     }
 
+    // ---------------------------------------------------------------- volumetric megakernel
+    // MediumTracker, src/util/medium_tracker.{h,cpp}: media the ray is inside of, sorted by ascending priority
+    struct MediumInfo {
+        uint32_t priority{LR_MEDIUM_VACUUM_PRIORITY}, medium_tag{LR_INVALID_ID};
+        bool operator==(const MediumInfo &o) const { return priority == o.priority && medium_tag == o.medium_tag; }
+    };
+    struct MediumTracker {
+        static constexpr auto capacity = 32u;
+        uint32_t priority_list[capacity];
+        MediumInfo medium_list[capacity];
+        uint32_t size{0u};
+        MediumTracker() {
+            for (auto &p : priority_list) { p = LR_MEDIUM_VACUUM_PRIORITY; }
+        }
+        bool vacuum() const { return priority_list[0] == LR_MEDIUM_VACUUM_PRIORITY; }
+        bool true_hit(uint32_t priority) const { return priority <= priority_list[0]; }// medium_tracker.cpp:20-22
+        MediumInfo current() const { return vacuum() ? MediumInfo{} : medium_list[0]; }
+        void enter(uint32_t priority, MediumInfo value) {// :24-45 (overflow: error + no-op)
+            if (size == capacity) { return; }
+            size++;
+            auto x = priority;
+            auto v = value;
+            for (auto i = 0u; i < capacity; i++) {
+                auto p = priority_list[i];
+                auto m = medium_list[i];
+                auto should_swap = p > x;
+                priority_list[i] = should_swap ? x : p;
+                medium_list[i] = should_swap ? v : m;
+                x = should_swap ? p : x;
+                v = should_swap ? m : v;
+            }
+        }
+        void exit(uint32_t priority, MediumInfo value) {// :47-65 (a nonexistent entry: error + no-op)
+            auto remove_num = 0u;
+            for (auto i = 0u; i < capacity - 1u; i++) {
+                auto should_remove = priority_list[i] == priority && medium_list[i] == value && remove_num == 0u;
+                remove_num += should_remove ? 1u : 0u;
+                priority_list[i] = priority_list[i + remove_num];
+                medium_list[i] = medium_list[i + remove_num];
+            }
+            if (remove_num != 0u) {
+                size--;
+                priority_list[size] = LR_MEDIUM_VACUUM_PRIORITY;
+                medium_list[size] = MediumInfo{};
+            }
+        }
+    };
+    enum : uint32_t { MEDIUM_ABSORB = 0u, MEDIUM_SCATTER = 1u, MEDIUM_HIT_SURFACE = 3u, MEDIUM_INVALID = ~0u };// medium.h:28-32
+    struct MediumSample {// Medium::Sample::zero, medium.h:56-61
+        Spectrum3 f{0.f, 0.f, 0.f};
+        float pdf{1e16f};
+        Ray ray{{0.f, 0.f, 0.f}, 0.f, {0.f, 0.f, 0.f}, 0.f};
+        uint32_t event{MEDIUM_INVALID};
+    };
+    static uint32_t sample_discrete3(float3 w, float u) {// sampling.cpp:182-194 (out-of-range by rounding: last channel)
+        auto u_rescaled = u * (w.x + w.y + w.z);
+        auto accum = 0.f;
+        for (auto i = 0u; i < 3u; i++) {
+            accum += w[i];
+            if (u_rescaled <= accum) { return i; }
+        }
+        return 2u;
+    }
+    static float3 random_channel_pdf(PCG32 &rng) {// homogeneous.cpp:50-54
+        float3 pc;
+        pc.x = rng.uniform_float(), pc.y = rng.uniform_float(), pc.z = rng.uniform_float();
+        return pc / (pc.x + pc.y + pc.z);
+    }
+    static float hg_p(float g, float3 wo, float3 wi) {// henyey_greenstein.cpp:22-27
+        auto denom = 1.f + g * g + 2.f * g * dot(wo, wi);
+        return inv_pi * 0.25f * (1.f - g * g) / (denom * std::sqrt(std::max(0.f, denom)));
+    }
+    // HomogeneousMediumClosure::sample, homogeneous.cpp:48-122
+    static MediumSample medium_sample(const lr_medium &m, const Ray &ray, float t_max, PCG32 &rng) {
+        MediumSample out;
+        float3 sigma_a{m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]}, sigma_s{m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]};
+        auto sigma_t = sigma_a + sigma_s;
+        auto pdf_channels = random_channel_pdf(rng);
+        auto channel = sample_discrete3(pdf_channels, rng.uniform_float());
+        auto u = rng.uniform_float();
+        auto t = -std::log(std::max(1.f - u, std::numeric_limits<float>::min())) / sigma_t[channel];
+        auto transmittance = [&](float d) { return float3{std::exp(-sigma_t.x * d), std::exp(-sigma_t.y * d), std::exp(-sigma_t.z * d)}; };
+        if (t > t_max) {// hit surface
+            out.event = MEDIUM_HIT_SURFACE;
+            auto Tr = transmittance(t_max);
+            out.ray = Ray{ray.o + ray.d * t_max, 0.f, ray.d, std::numeric_limits<float>::max()};
+            auto pdf = pdf_channels * Tr;
+            out.f = Tr, out.pdf = pdf.x + pdf.y + pdf.z;
+        } else {
+            auto p_absorb = sigma_a[channel] / sigma_t[channel], p_scatter = sigma_s[channel] / sigma_t[channel];
+            auto index = rng.uniform_float() * (p_absorb + p_scatter) <= p_absorb ? 0u : 1u;// sample_discrete(float2), sampling.cpp:162-166
+            if (index == 0u) {// absorb
+                out.event = MEDIUM_ABSORB;
+                out.ray = ray;
+                out.f = f3(0.f);
+                auto pdf = pdf_channels * sigma_t;
+                out.pdf = pdf.x + pdf.y + pdf.z;
+            } else {// scatter: the sampled direction is built around the WORLD y axis, not around wo (henyey_greenstein.cpp:28-45; kept)
+                out.event = MEDIUM_SCATTER;
+                auto Tr = transmittance(t);
+                float2 up{0.f, 0.f};
+                up.x = rng.uniform_float(), up.y = rng.uniform_float();
+                auto g = m.g;
+                auto cos_theta = std::abs(g) < 1e-3f ? 1.f - 2.f * up.x :
+                                                       -1.f / (2.f * g) * (1.f + g * g - sqr((1.f - g * g) / (1.f + g - 2.f * g * up.x)));
+                auto sin_theta = std::sqrt(std::max(0.f, 1.f - cos_theta * cos_theta));
+                auto phi = 2.f * pi * up.y;
+                float3 wi{sin_theta * std::cos(phi), cos_theta, sin_theta * std::sin(phi)};
+                out.ray = Ray{ray.o + ray.d * t, 0.f, wi, std::numeric_limits<float>::max()};
+                auto pdf = pdf_channels * (sigma_t * Tr);
+                out.f = Tr * sigma_s, out.pdf = pdf.x + pdf.y + pdf.z;
+            }
+        }
+        return out;
+    }
+    struct TrEval {
+        Spectrum3 f{1.f, 1.f, 1.f};
+        float pdf{0.f};
+    };
+    // HomogeneousMediumClosure::transmittance, homogeneous.cpp:124-137; Vacuum: Evaluation::zero (f = 0, pdf = 1e16)
+    static TrEval medium_transmittance(const lr_medium &m, float t, PCG32 &rng) {
+        if (m.kind == LR_MEDIUM_VACUUM) { return TrEval{f3(0.f), 1e16f}; }
+        auto pdf_channels = random_channel_pdf(rng);
+        float3 Tr{std::exp(-(m.sigma_a[0] + m.sigma_s[0]) * t), std::exp(-(m.sigma_a[1] + m.sigma_s[1]) * t), std::exp(-(m.sigma_a[2] + m.sigma_s[2]) * t)};
+        auto pdf = pdf_channels * Tr;
+        return TrEval{Tr, pdf.x + pdf.y + pdf.z};
+    }
+    // MegakernelVolumePathTracingNaiveInstance::_event, mega_vpt_naive.cpp:68-93
+    uint32_t surface_event(const Interaction &it, float3 wo, float3 wi) const {
+        auto shading = it.has_surface() ? Closure::populate(*scene, it, wo, 1.f).shading : it.shading;
+        auto wo_local = shading.world_to_local(wo), wi_local = shading.world_to_local(wi);
+        return wo_local.z * wi_local.z > 0.f ? EVENT_REFLECT : (wi_local.z > 0.f ? EVENT_EXIT : EVENT_ENTER);
+    }
+    // _transmittance, mega_vpt_naive.cpp:95-168: walks the shadow segment through every surface on it
+    TrEval transmittance(PCG32 &rng, MediumTracker tracker, Ray origin_ray, PathStats &stats) const {
+        auto &s = *scene;
+        auto dir = origin_ray.d;
+        auto ray = origin_ray;
+        auto light_p = origin_ray.o + dir * origin_ray.t_max;
+        TrEval tr;
+        // The reference loops `while any(f > 0)` with no bound.  A shadow segment that lies IN a surface (a sample on the lamp
+        // the segment starts on) re-hits that surface every few ULPs and never gets there; on the GPU that is a hang.  Both
+        // the oracle and the device stop after kMaxCrossings surfaces (conscious deviation; real segments cross a handful).
+        constexpr auto kMaxCrossings = 64u;
+        auto crossings = 0u;
+        while (tr.f.x > 0.f || tr.f.y > 0.f || tr.f.z > 0.f) {
+            if (crossings++ == kMaxCrossings) { break; }
+            stats.closest++;
+            auto hit = accel.trace(ray, false, stats.trace);
+            if (hit.miss()) { break; }
+            stats.hits++;
+            auto wo = -dir, wi = dir;
+            auto it = make_interaction(hit.inst, hit.prim, f3(1.f - hit.bary.x - hit.bary.y, hit.bary.x, hit.bary.y), true, -ray.d);
+            auto t2surface = length(it.pg - ray.o);
+            auto has_medium = (it.flags() & LR_SHAPE_HAS_MEDIUM) != 0u;
+            auto medium_tag = it.handle.y >> 24u;
+            auto event = surface_event(it, wo, wi);
+            if (!tracker.vacuum()) {
+                auto e = medium_transmittance(s.media[tracker.current().medium_tag], t2surface, rng);
+                tr.f = tr.f * e.f, tr.pdf += e.pdf;
+            }
+            if (has_medium) {
+                auto priority = s.media[medium_tag].priority;
+                MediumInfo info{priority, medium_tag};
+                if (event == EVENT_EXIT) { tracker.exit(priority, info); } else { tracker.enter(priority, info); }
+            }
+            if (it.has_surface()) {
+                auto e = Closure::populate(s, it, wo, 1.f).evaluate(wo, wi);
+                tr.f = tr.f * e.f, tr.pdf += e.pdf;
+            }
+            ray = spawn_ray_to(it, light_p);
+        }
+        return tr;
+    }
+    // MegakernelVolumePathTracingNaiveInstance::Li, mega_vpt_naive.cpp:170-483 (VPT_NAIVE_ENABLE_DIRECT_LIGHTING defined, :16)
+    float3 Li_vpt(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
+        auto &s = *scene;
+        Sampler sampler;
+        sampler.start(s.sampler, px, py, sample_index);
+        auto u_filter = sampler.generate_pixel_2d();
+        auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
+        auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
+        Spectrum3 beta = f3(cs.weight);
+        Spectrum3 Li = f3(0.f);
+        MediumTracker tracker;
+        auto u_rng = sampler.generate_2d();// PCG32 rng(U64(as<UInt2>(generate_2d()))): x -> high word, y -> low word (u64.h:48-51)
+        uint32_t hi, lo;
+        std::memcpy(&hi, &u_rng.x, 4u), std::memcpy(&lo, &u_rng.y, 4u);
+        PCG32 rng{(static_cast<uint64_t>(hi) << 32u) | lo};
+        if (auto env = s.integrator.environment_medium_tag; env != LR_INVALID_ID) {
+            tracker.enter(s.media[env].priority, MediumInfo{s.media[env].priority, env});
+        }
+        auto ray = cs.ray;
+        auto pdf_bsdf = 1e16f;
+        auto eta_scale = 1.f;
+        auto has_env = s.environment.kind != LR_ENV_NONE;
+        auto rr_depth = s.integrator.rr_depth;
+        for (auto depth = 0u; depth < s.integrator.max_depth; depth++) {
+            auto eta = 1.f;
+            auto u_rr = 0.f;
+            if (depth + 1u >= rr_depth) { u_rr = sampler.generate_1d(); }
+            stats.closest++;
+            auto hit = accel.trace(ray, false, stats.trace);
+            Interaction it;
+            if (!hit.miss()) {
+                stats.hits++;
+                it = make_interaction(hit.inst, hit.prim, f3(1.f - hit.bary.x - hit.bary.y, hit.bary.x, hit.bary.y), true, -ray.d);
+            }
+            auto has_medium = it.valid() && (it.flags() & LR_SHAPE_HAS_MEDIUM) != 0u;
+            auto t_max = it.valid() ? length(it.pg - ray.o) : std::numeric_limits<float>::max();
+            MediumSample ms;
+            if (!tracker.vacuum()) {
+                // direct lighting of the medium point at the ray origin, :283-299
+                auto u_light_selection = sampler.generate_1d();
+                auto u_light_surface = sampler.generate_2d();
+                Interaction it_medium;// Interaction{pg}: ng = pg (interaction.h:77-78), identity frame, null shape
+                it_medium.pg = ray.o, it_medium.ng = ray.o, it_medium.ps = f3(0.f);
+                it_medium.shading = Frame{};
+                stats.nee++;
+                auto light_sample = this->light_sample(it_medium, u_light_selection, u_light_surface);
+                auto tr = transmittance(rng, tracker, light_sample.shadow_ray, stats);
+                if (tr.pdf > 0.f) {
+                    auto w = 1.f / (pdf_bsdf + tr.pdf + light_sample.eval.pdf);
+                    Li += w * beta * tr.f * light_sample.eval.L;
+                }
+                auto &medium = s.media[tracker.current().medium_tag];
+                eta = medium.eta;
+                if (medium.kind != LR_MEDIUM_VACUUM) {// :305-313
+                    ms = medium_sample(medium, ray, t_max, rng);
+                    ray = ms.ray;
+                    auto w = ms.pdf > 0.f ? 1.f / ms.pdf : 0.f;
+                    beta *= ms.f * w;
+                    pdf_bsdf = ms.pdf;
+                }
+            }
+            if (ms.event == MEDIUM_INVALID || ms.event == MEDIUM_HIT_SURFACE) {// sample the surface, :318-457
+                if (!it.valid()) {
+                    if (has_env) {
+                        auto eval = env_evaluate(ray.d);
+                        Li += beta * eval.L * balance_heuristic(pdf_bsdf, eval.pdf * s.integrator.env_prob);
+                    }
+                    break;
+                }
+                if (s.light_count != 0u && it.has_light()) {
+                    auto eval = light_evaluate(it, ray.o);
+                    eval.pdf *= (1.f - s.integrator.env_prob) / static_cast<float>(s.integrator.light_count);
+                    Li += beta * eval.L * balance_heuristic(pdf_bsdf, eval.pdf);
+                }
+                if (!it.has_surface()) { break; }
+                stats.bounces++;
+                auto u_light_selection = sampler.generate_1d();
+                auto u_light_surface = sampler.generate_2d();
+                auto u_lobe = sampler.generate_1d();
+                auto u_bsdf = sampler.generate_2d();
+                stats.nee++;
+                auto light_sample = this->light_sample(it, u_light_selection, u_light_surface);
+                auto tr = transmittance(rng, tracker, light_sample.shadow_ray, stats);
+                auto medium_tag = it.handle.y >> 24u;
+                auto medium_priority = LR_MEDIUM_VACUUM_PRIORITY;
+                auto eta_next = 1.f;
+                if (has_medium) { medium_priority = s.media[medium_tag].priority, eta_next = s.media[medium_tag].eta; }
+                MediumInfo info{medium_priority, medium_tag};
+                auto event_skip = surface_event(it, -ray.d, ray.d);
+                auto wo = -ray.d;
+                auto closure = Closure::populate(s, it, wo, eta);
+                uint32_t event;
+                if (!tracker.true_hit(info.medium_tag)) {// (the TAG is passed where a priority is expected, :384; kept)
+                    event = event_skip;
+                    ray = spawn_ray(it, ray.d);
+                    pdf_bsdf = 1e16f;
+                } else {
+                    if (light_sample.eval.pdf > 0.0f) {
+                        auto eval = closure.evaluate(wo, light_sample.shadow_ray.d);
+                        auto w = 1.f / (light_sample.eval.pdf + eval.pdf + tr.pdf);
+                        Li += w * beta * eval.f * light_sample.eval.L * tr.f;
+                    }
+                    auto ss = closure.sample(wo, u_lobe, u_bsdf);
+                    event = ss.event;
+                    auto w = ss.eval.pdf > 0.f ? 1.f / ss.eval.pdf : 0.f;
+                    pdf_bsdf = ss.eval.pdf;
+                    ray = spawn_ray(it, ss.wi);
+                    beta *= w * ss.eval.f;
+                    if (has_medium) {
+                        if (event == EVENT_ENTER) { eta_scale = sqr(eta_next / eta); }
+                        else if (event == EVENT_EXIT) { eta_scale = sqr(eta / eta_next); }
+                    }
+                }
+                if (has_medium) {
+                    if (event == EVENT_ENTER) { tracker.enter(medium_priority, info); }
+                    else if (event == EVENT_EXIT) { tracker.exit(medium_priority, info); }
+                }
+            }
+            if (any_nan(beta)) { beta = f3(0.f); }
+            if (beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f) { break; }
+            auto q = std::max(max_component(beta) * eta_scale, .05f);
+            if (depth + 1u >= rr_depth) {
+                if (q < s.integrator.rr_threshold && u_rr >= q) { break; }
+                beta *= q < s.integrator.rr_threshold ? 1.0f / q : 1.f;
+            }
+        }
+        return Li;
+    }
+
     // MegakernelPathTracingInstance::Li, mega_path.cpp:49-156
     float3 Li(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
         auto &s = *scene;
         if (s.integrator.kind == LR_INTEGRATOR_NORMAL) { return Li_normal(px, py, sample_index, stats); }
         if (s.integrator.kind == LR_INTEGRATOR_DIRECT) { return Li_direct(px, py, sample_index, stats); }
+        if (s.integrator.kind == LR_INTEGRATOR_VPT_NAIVE) { return Li_vpt(px, py, sample_index, stats); }
         Sampler sampler;
         sampler.start(s.sampler, px, py, sample_index);
         auto u_filter = sampler.generate_pixel_2d();
