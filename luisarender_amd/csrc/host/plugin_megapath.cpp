@@ -113,7 +113,7 @@ public:
                 std::fprintf(stderr, "[info] Rendering to '%s' of resolution %ux%u at %uspp.\n", camera.file.c_str(), width, height, camera.camera.spp);
                 api.film_clear(ctx);
                 auto tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
-                lrhip_render_params params{0u, camera.camera.spp, 0u, tiles, 1u, 0u, {0u, 0u}};
+                lrhip_render_params params{0u, camera.camera.spp, 0u, tiles, 1u, 0u, 1u, {0u}};
                 auto t0 = std::chrono::steady_clock::now();
                 if (api.render(ctx, &params) != LRHIP_OK || api.synchronize(ctx) != LRHIP_OK) {
                     std::fprintf(stderr, "[error] lrhip_render: %s\n", api.last_error());
