@@ -40,7 +40,7 @@ oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h
 # The megakernel is precompiled for a curated set of feature masks (csrc/hip/variants.h), one object per mask so
 # that they build in parallel (make -j).  VARIANT_MASKS may be narrowed for experiments (a missing variant is a
 # run-time error of lrhip_render, never a fallback).
-VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 252 253 254 255
+VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 252 253 254 255 256 257 258 259
 OBJDIR := $(LIBDIR)/obj
 VARIANT_OBJ := $(foreach m,$(VARIANT_MASKS),$(OBJDIR)/variant_$(m).o)
 
@@ -67,7 +67,7 @@ variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)
 	@mkdir -p $(BINDIR)
-	for impl in megapath direct normal; do \
+	for impl in megapath direct normal megavptnaive; do \
 	  $(CXX) $(CXXFLAGS) -DLR_PLUGIN_IMPL=\"$$impl\" -shared -o $(BINDIR)/libluisa-render-integrator-$$impl.so $(HOSTDIR)/plugin_megapath.cpp \
 	    -L$(LIBDIR) -llrhost -ldl -Wl,-rpath,'$$ORIGIN/../lib' || exit 1; done
 	$(CXX) $(CXXFLAGS) -o $@ $(HOSTDIR)/cli.cpp -L$(LIBDIR) -llrhost -ldl -pthread -Wl,-rpath,'$$ORIGIN/../lib'

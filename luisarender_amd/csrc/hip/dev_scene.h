@@ -123,6 +123,8 @@ struct DScene {
     float env_to_world[9];
     // integrator / sampler / film
     uint32_t max_depth, rr_depth;
+    const lr_medium *media;   // Pipeline::_media (the volumetric megakernel only)
+    uint32_t env_medium_tag;  // Pipeline::environment_medium_tag, LR_INVALID_ID = none
     uint32_t integrator_kind, integrator_flags;// lr_integrator_kind / LR_DIRECT_* / LR_NORMAL_* (kFeatAux variants only)
     float rr_threshold, env_prob;
     uint32_t light_count;   // distinct Light nodes (uniform.cpp:82)

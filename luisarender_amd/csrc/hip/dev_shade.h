@@ -723,4 +723,74 @@ LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
     wi = normalize(mul3(env.env_to_world, s.wi));
 }
 
+// ---------------------------------------------------------------- light sampling
+// LightSampler::Instance::sample (light_sampler.cpp:57-63) with UniformLightSamplerInstance::select / _sample_area /
+// _sample_environment (uniform.cpp:78-137): one light or the environment, its radiance towards `it`, the solid-angle
+// pdf (x the selection probability) and the shadow ray (Interaction::spawn_ray / spawn_ray_to, interaction.cpp:21-30).
+struct LightPick {
+    Ray shadow;
+    f3 L;
+    float pdf;
+};
+template<bool ENV>
+LR_D LightPick sample_one_light(const DScene &scene, const SurfacePoint &it, float u_light_selection, f2 u_light_surface) {
+    LightPick out;
+    out.L = mk3(0.f), out.pdf = 0.f;
+    auto n = static_cast<float>(scene.light_count);
+    auto is_env = false;
+    auto tag = 0u;
+    auto prob = 0.f;
+    if (scene.env_prob == 1.f) {
+        is_env = true, prob = 1.f;
+    } else if (scene.env_prob == 0.f) {
+        tag = static_cast<uint32_t>(clampf(u_light_selection * n, 0.f, n - 1.f)), prob = 1.f / n;
+    } else {
+        auto uu = (u_light_selection - scene.env_prob) / (1.f - scene.env_prob);
+        tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
+        is_env = u_light_selection < scene.env_prob;
+        prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
+    }
+    if (is_env) {// _sample_environment, uniform.cpp:125-137
+        f3 wi;
+        if (ENV && scene.env_kind != kEnvConstant) {
+            env_sample(scene, u_light_surface, wi, out.L, out.pdf);
+            out.pdf *= prob;
+        } else {// constant emission: uniform sphere, spherical.cpp:114-118,138
+            auto z = 1.0f - 2.0f * u_light_surface.x;
+            auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
+            auto phi = 2.0f * kPi * u_light_surface.y;
+            auto w = mk3(r * cosf(phi), r * sinf(phi), z);
+            auto e = scene.env_to_world;
+            wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
+            out.L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
+            out.pdf = (kInvPi * 0.25f) * prob;
+        }
+        out.shadow.o = robust_origin(it, wi);
+        out.shadow.d = wi;
+        out.shadow.t_min = 0.f, out.shadow.t_max = kFloatMax;
+    } else {// _sample_area, uniform.cpp:107-123
+        auto handle = scene.light_instances[tag];
+        auto lh = reinterpret_cast<const uint4 *>(scene.instances + handle.instance_id)[0];
+        auto l_tri_offset = scene.instances[handle.instance_id].triangle_offset;
+        float u_remapped;
+        auto slot = alias_slot(u_light_surface.x, lh.z, u_remapped);
+        auto entry = scene.tri_alias[l_tri_offset + slot];
+        auto pick = alias_pick(entry.prob, entry.alias, slot, u_remapped);
+        f2 ut{pick.u, u_light_surface.y};// sample_uniform_triangle, sampling.cpp:89-98
+        f2 uvt = ut.x < ut.y ? f2{0.5f * ut.x, -0.5f * ut.x + ut.y} : f2{-0.5f * ut.y + ut.x, 0.5f * ut.y};
+        SurfacePoint lp;
+        reconstruct<false>(scene, handle.instance_id, pick.index, mk3(uvt.x, uvt.y, 1.0f - uvt.x - uvt.y), lp);
+        lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
+        light_evaluate(scene, lp, pick.index, it.p, out.L, out.pdf);
+        out.pdf *= prob;
+        auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
+        auto Lv = lp.p - p_from;
+        auto dist = length(Lv);
+        out.shadow.o = p_from;
+        out.shadow.d = Lv * (1.f / dist);
+        out.shadow.t_min = 0.f, out.shadow.t_max = dist * .9999f;
+    }
+    return out;
+}
+
 }// namespace lrd

@@ -443,9 +443,22 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     }
     d.max_depth = s->integrator.max_depth, d.rr_depth = s->integrator.rr_depth;
     d.integrator_kind = s->integrator.kind, d.integrator_flags = s->integrator.flags;
-    if (s->integrator.kind > LR_INTEGRATOR_NORMAL) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: unknown integrator kind"); }
-    // the sibling integrators (Direct / Normal) live in the all-features variant only
-    if (s->integrator.kind != LR_INTEGRATOR_MEGAPATH) { ctx->features |= lrd::kFeatSceneMask | lrd::kFeatAux; }
+    if (s->integrator.kind > LR_INTEGRATOR_VPT_NAIVE) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: unknown integrator kind"); }
+    d.env_medium_tag = s->integrator.environment_medium_tag;
+    if (s->integrator.kind == LR_INTEGRATOR_VPT_NAIVE) {// the volumetric megakernel is one kernel with everything in it
+        for (uint32_t i = 0; i < s->instance_count; i++) {
+            if ((s->instances[i].handle.x & LR_SHAPE_HAS_MEDIUM) && (s->instances[i].handle.y >> 24u) >= s->medium_count) {
+                release_scene(ctx);
+                return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: an instance references a medium that is not in scene->media");
+            }
+        }
+        if (d.env_medium_tag != LR_INVALID_ID && d.env_medium_tag >= s->medium_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: invalid environment medium tag"); }
+        if (auto r = upload(ctx, s->media, s->medium_count, &d.media); r != LRHIP_OK) { release_scene(ctx); return r; }
+        ctx->features = lrd::kFeatVpt;
+    } else if (s->integrator.kind != LR_INTEGRATOR_MEGAPATH) {
+        // the sibling integrators (Direct / Normal) live in the all-features variant only
+        ctx->features |= lrd::kFeatSceneMask | lrd::kFeatAux;
+    }
     d.rr_threshold = s->integrator.rr_threshold, d.env_prob = s->integrator.env_prob;
     d.light_count = s->integrator.light_count;
     d.has_lights = s->light_count != 0u ? 1u : 0u;

@@ -64,6 +64,7 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 enum : uint32_t {
     kFeatCount = 1u, kFeatGeneric = 2u, kFeatEnv = 4u, kFeatAlpha = 8u, kFeatDisney = 16u, kFeatMix = 32u, kFeatLayered = 64u,
     kFeatAux = 128u,
+    kFeatVpt = 256u,// the volumetric megakernel (megavpt_kernel.h): a different kernel, same launch interface
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 // the precompiled scene-feature sets, smallest first (each also exists x {Count} x {Generic}); csrc/hip/variants/*.hip
@@ -75,6 +76,7 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
     kFeatSceneMask,
     kFeatSceneMask | kFeatAux,
+    kFeatVpt,
 };
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
@@ -215,64 +217,12 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                         // (DirectLighting in surface-only mode draws no light sample, direct.cpp:114-118)
                         auto u_light_selection = direct_lights ? sampler.next_1d() : 0.f;
                         auto u_light_surface = direct_lights ? sampler.next_2d() : f2{0.f, 0.f};
-                        // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63
+                        // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63 (dev_shade.h: sample_one_light)
                         f3 light_L = mk3(0.f);
                         auto light_pdf = 0.f;
                         if (direct_lights) {
-                            auto n = static_cast<float>(scene.light_count);
-                            auto is_env = false;
-                            auto tag = 0u;
-                            auto prob = 0.f;
-                            if (scene.env_prob == 1.f) {
-                                is_env = true, prob = 1.f;
-                            } else if (scene.env_prob == 0.f) {
-                                tag = static_cast<uint32_t>(clampf(u_light_selection * n, 0.f, n - 1.f)), prob = 1.f / n;
-                            } else {
-                                auto uu = (u_light_selection - scene.env_prob) / (1.f - scene.env_prob);
-                                tag = static_cast<uint32_t>(clampf(uu * n, 0.f, n - 1.f));
-                                is_env = u_light_selection < scene.env_prob;
-                                prob = is_env ? scene.env_prob : (1.f - scene.env_prob) / n;
-                            }
-                            if (is_env) {// _sample_environment, uniform.cpp:125-137
-                                f3 wi;
-                                if (ENV && scene.env_kind != kEnvConstant) {
-                                    env_sample(scene, u_light_surface, wi, light_L, light_pdf);
-                                    light_pdf *= prob;
-                                } else {// constant emission: uniform sphere, spherical.cpp:114-118,138
-                                    auto z = 1.0f - 2.0f * u_light_surface.x;
-                                    auto r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
-                                    auto phi = 2.0f * kPi * u_light_surface.y;
-                                    auto w = mk3(r * cosf(phi), r * sinf(phi), z);
-                                    auto e = scene.env_to_world;
-                                    wi = normalize(mk3(e[0], e[1], e[2]) * w.x + mk3(e[3], e[4], e[5]) * w.y + mk3(e[6], e[7], e[8]) * w.z);
-                                    light_L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
-                                    light_pdf = (kInvPi * 0.25f) * prob;
-                                }
-                                shadow.o = robust_origin(it, wi);
-                                shadow.d = wi;
-                                shadow.t_min = 0.f, shadow.t_max = kFloatMax;
-                            } else {// _sample_area, uniform.cpp:107-123
-                                auto handle = scene.light_instances[tag];
-                                auto lh = reinterpret_cast<const uint4 *>(scene.instances + handle.instance_id)[0];
-                                auto l_tri_offset = scene.instances[handle.instance_id].triangle_offset;
-                                float u_remapped;
-                                auto slot = alias_slot(u_light_surface.x, lh.z, u_remapped);
-                                auto entry = scene.tri_alias[l_tri_offset + slot];
-                                auto pick = alias_pick(entry.prob, entry.alias, slot, u_remapped);
-                                f2 ut{pick.u, u_light_surface.y};// sample_uniform_triangle, sampling.cpp:89-98
-                                f2 uvt = ut.x < ut.y ? f2{0.5f * ut.x, -0.5f * ut.x + ut.y} : f2{-0.5f * ut.y + ut.x, 0.5f * ut.y};
-                                SurfacePoint lp;
-                                reconstruct<false>(scene, handle.instance_id, pick.index, mk3(uvt.x, uvt.y, 1.0f - uvt.x - uvt.y), lp);
-                                lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
-                                light_evaluate(scene, lp, pick.index, it.p, light_L, light_pdf);
-                                light_pdf *= prob;
-                                auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
-                                auto Lv = lp.p - p_from;
-                                auto dist = length(Lv);
-                                shadow.o = p_from;
-                                shadow.d = Lv * (1.f / dist);
-                                shadow.t_min = 0.f, shadow.t_max = dist * .9999f;
-                            }
+                            auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
+                            shadow = pick.shadow, light_L = pick.L, light_pdf = pick.pdf;
                         }
                         // ---- material, mega_path.cpp:111-143.  The five basic closures are evaluated inline; Disney / Mix /
                         // Layered surfaces go through the out-of-line heavy path (dev_heavy.h) when this variant holds Mix or

@@ -3,24 +3,29 @@
 // the variants build in parallel.
 #include <hip/hip_runtime.h>
 
-#include "megapath_kernel.h"
-
 #ifndef LR_VARIANT
 #error "compile with -DLR_VARIANT=<feature mask>"
+#endif
+#if (LR_VARIANT) & 256// kFeatVpt: the volumetric megakernel
+#include "megavpt_kernel.h"
+#define LR_KERNEL megavpt_kernel
+#else
+#include "megapath_kernel.h"
+#define LR_KERNEL megapath_kernel
 #endif
 #define LR_CAT2(a, b) a##b
 #define LR_CAT(a, b) LR_CAT2(a, b)
 
 namespace lrd {
-template __global__ void megapath_kernel<LR_VARIANT>(DScene, RenderArgs);
+template __global__ void LR_KERNEL<LR_VARIANT>(DScene, RenderArgs);
 }
 
 extern "C" hipError_t LR_CAT(lrhip_variant_launch_, LR_VARIANT)(unsigned blocks, hipStream_t stream, const lrd::DScene *scene,
                                                                const lrd::RenderArgs *args) {
-    hipLaunchKernelGGL(lrd::megapath_kernel<LR_VARIANT>, dim3(blocks), dim3(lrd::kBlockThreads), 0, stream, *scene, *args);
+    hipLaunchKernelGGL(lrd::LR_KERNEL<LR_VARIANT>, dim3(blocks), dim3(lrd::kBlockThreads), 0, stream, *scene, *args);
     return hipGetLastError();
 }
 
 extern "C" hipError_t LR_CAT(lrhip_variant_occupancy_, LR_VARIANT)(int *blocks_per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lrd::megapath_kernel<LR_VARIANT>, lrd::kBlockThreads, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, lrd::LR_KERNEL<LR_VARIANT>, lrd::kBlockThreads, 0);
 }

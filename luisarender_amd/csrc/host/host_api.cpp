@@ -109,7 +109,7 @@ uint64_t lrhost_sizeof(const char *name) {
     LR_SIZEOF(lr_instance) LR_SIZEOF(lr_texture) LR_SIZEOF(lr_surface) LR_SIZEOF(lr_light) LR_SIZEOF(lr_environment)
     LR_SIZEOF(lr_camera) LR_SIZEOF(lr_filter) LR_SIZEOF(lr_film) LR_SIZEOF(lr_sampler) LR_SIZEOF(lr_integrator)
     LR_SIZEOF(lr_bvh4_node) LR_SIZEOF(lr_bvh_triangle) LR_SIZEOF(lr_accel) LR_SIZEOF(lr_light_handle)
-    LR_SIZEOF(lr_bvh4_node) LR_SIZEOF(lr_bvh_triangle) LR_SIZEOF(lr_accel) LR_SIZEOF(lr_medium)
+    LR_SIZEOF(lr_medium)
 #undef LR_SIZEOF
     return 0u;
 }

@@ -25,7 +25,7 @@ def test_cli_without_a_scene_prints_help_and_fails():
 
 
 def test_cli_plugins_exist_for_every_integrator_the_loader_accepts():
-    for impl in ("megapath", "direct", "normal"):  # `luisa-render-<tag>-<impl>` next to the executable, scene.cpp:54-75
+    for impl in ("megapath", "direct", "normal", "megavptnaive"):  # `luisa-render-<tag>-<impl>` next to the executable, scene.cpp:54-75
         assert os.path.exists(os.path.join(ROOT, "luisarender_amd", "bin", f"libluisa-render-integrator-{impl}.so"))
 
 
@@ -37,7 +37,7 @@ def test_cli_reports_scene_errors_and_unknown_options(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("integrator", ["MegaPath", "Direct", "Normal"])
+@pytest.mark.parametrize("integrator", ["MegaPath", "Direct", "Normal", "MegaVPTNaive"])
 def test_cli_renders_the_same_image_as_the_c_abi(tmp_path, integrator):
     from luisarender_amd.render import MegaPathRenderer
     from luisarender_amd.scene import load_image
