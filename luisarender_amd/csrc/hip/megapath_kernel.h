@@ -45,7 +45,7 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 #define LR_MIN_WAVES 4
 #endif
 #ifndef LR_REFILL
-#define LR_REFILL 36
+#define LR_REFILL 40
 #endif
 
 // The kernel is specialised by a FEATURE MASK (the reference JIT-compiles one kernel per scene, so a scene only pays
