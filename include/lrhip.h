@@ -69,6 +69,7 @@ typedef struct lrhip_counters {
     /* wave-cycle diagnostics (s_memtime, summed over waves): inside the shading block (A), inside the traversal
      * loop (B), and from a wave's first to its last instruction */
     uint64_t shade_cycles, trace_cycles, wave_cycles;
+    uint64_t nodes_empty;    /* node visits in which no child was hit (popped after the ray had already shortened, or plain misses) */
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);

@@ -145,7 +145,7 @@ class OracleCounters(C.Structure):
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
-                                   "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles")]
+                                   "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles", "nodes_empty")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -140,7 +140,7 @@ struct DScene {
 
 struct DCounters {
     unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
-        path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles;
+        path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles, nodes_empty;
 };
 
 struct RenderArgs {

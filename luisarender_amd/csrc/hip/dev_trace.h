@@ -58,6 +58,7 @@ struct TraceStats {
     uint32_t nodes, tris;
     uint32_t steps, steps_busy;// loop iterations of the wave / iterations in which this lane did work
     uint32_t steps_starved;    // iterations this lane sat out because its pixel had no samples left to start
+    uint32_t nodes_empty;      // node visits without a hit child
 };
 
 struct TraversalStack {
@@ -257,6 +258,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
                 if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
 #endif
+                if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
                 if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
                 else if (tr.sp > 0u) { tr.cur = stack.pop(--tr.sp); }
                 else { tr.cur = kInvalid; }

@@ -332,12 +332,12 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
             }
             if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
             // ==== (B) traverse until `refill` lanes have results to shade
-            TraceStats ts{0u, 0u, 0u, 0u, 0u};
+            TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
             const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
             trace_steps<COUNT, ALPHA>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
                 if (lane == 0u) { local.shade_cycles += t_trace - t_shade, local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
-                local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
+                local.nodes_visited += ts.nodes, local.tris_tested += ts.tris, local.nodes_empty += ts.nodes_empty;
                 local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy, local.trace_steps_starved += ts.steps_starved;
                 local.shade_calls++;
             }
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         reduce(local.shade_cycles, &args.counters->shade_cycles);
         reduce(local.trace_cycles, &args.counters->trace_cycles);
         reduce(local.wave_cycles, &args.counters->wave_cycles);
+        reduce(local.nodes_empty, &args.counters->nodes_empty);
     }
 }
 

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScene scene,
                 }
                 if (!__any(tr.phase != kPhaseIdle)) { break; }
                 // ==== trace every pending ray of the wave to completion
-                TraceStats ts{0u, 0u, 0u, 0u, 0u};
+                TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
                 trace_steps<COUNT, true>(scene, stack, tr, false, ray, 65, ts);
                 if (COUNT) {
                     local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;

@@ -16,6 +16,7 @@ with tempfile.TemporaryDirectory() as tmp:
     print('ms', r.last_render_ms(), 'rays/sample', rays / c['paths'], 'nodes/ray', c['nodes_visited'] / rays, 'tris/ray', c['tris_tested'] / rays)
     print('trace lane utilisation', c['trace_steps_busy'] / max(c['trace_steps'], 1), 'steps per ray-lane', c['trace_steps_busy'] / rays)
     print('trace lanes starved (no sample left for the pixel)', c['trace_steps_starved'] / max(c['trace_steps'], 1))
+    print('node visits without a hit child', c['nodes_empty'] / c['nodes_visited'])
     print('shade lane utilisation', c['shade_busy'] / max(c['shade_calls'], 1))
     print('wave cycles: shade %.3f  trace %.3f  of wave lifetime; cycles per wave-level trace step %.0f, per wave-level shade call %.0f' % (
         c['shade_cycles'] / c['wave_cycles'], c['trace_cycles'] / c['wave_cycles'], c['trace_cycles'] / (c['trace_steps'] / 64), c['shade_cycles'] / (c['shade_calls'] / 64)))
