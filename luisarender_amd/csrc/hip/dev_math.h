@@ -25,6 +25,12 @@
 #define LR_HEAVY __device__ __noinline__
 #endif
 
+// hit reconstruction gathers from the baked per-triangle records (dev_scene.h: DShadeTri): +2.6 % on C2;
+// -DLR_BAKED_SHADING=0 restores the instance -> triangle -> vertices chain of the reference for A/B
+#ifndef LR_BAKED_SHADING
+#define LR_BAKED_SHADING 1
+#endif
+
 namespace lrd {
 
 constexpr float kPi = 3.14159265358979323846f;

@@ -98,6 +98,22 @@ struct DEnvironment {
 
 enum : uint32_t { kEnvNone = 0u, kEnvConstant = 1u, kEnvImage = 2u, kEnvDirectional = 3u, kEnvCombined = 4u };
 
+// Shading record of one BAKED (world-space) BVH triangle, indexed by the triangle index the traversal ends on: everything
+// Geometry::shading_point (geometry.cpp:345-389) gathers through instance -> triangle indices -> three vertices — three
+// DEPENDENT round trips of 16 + 64 + 12 + 96 B — in ONE 128-byte line.  600 k triangles = 77 MB; 288 GB of HBM make the
+// replication free, the two saved round trips per hit are paid back in every shading block.
+struct DShadeTri {// 8 x float4
+    float p0[3];  uint32_t flags;        // world-space vertex 0 | shape property flags (handle.x & 1023)
+    float e1[3];  uint32_t tags;         // p1 - p0 | handle.y (light / surface / medium tags)
+    float e2[3];  uint32_t offset_bits;  // p2 - p0 | handle.w
+    float n0[3];  float uv0x;            // vertex normals through transpose(inverse(M)) (not normalised: shading_point
+    float n1[3];  float uv0y;            //   normalises the interpolated sum, which is linear in them)
+    float n2[3];  float uv1x;
+    float uv1y, uv2x, uv2y, tri_pdf;     // | pdf table entry of the primitive (lights)
+    uint32_t inst, prim, tri_offset, pad;
+};
+static_assert(sizeof(DShadeTri) == 128, "one line per triangle");
+
 struct DScene {
     // acceleration structure
     const DNodeQ *nodes;
@@ -123,6 +139,7 @@ struct DScene {
     float env_to_world[9];
     // integrator / sampler / film
     uint32_t max_depth, rr_depth;
+    const DShadeTri *shade_tris;// [accel.triangle_count], same order as bvh_tris
     const lr_medium *media;   // Pipeline::_media (the volumetric megakernel only)
     uint32_t env_medium_tag;  // Pipeline::environment_medium_tag, LR_INVALID_ID = none
     uint32_t integrator_kind, integrator_flags;// lr_integrator_kind / LR_DIRECT_* / LR_NORMAL_* (kFeatAux variants only)

@@ -523,6 +523,38 @@ LR_D void reconstruct(const DScene &scene, uint32_t inst_id, uint32_t prim, f3 b
     }
 }
 
+// Geometry::shading_point (geometry.cpp:345-389) of a traversal hit from the baked triangle's shading record: the same
+// quantities as reconstruct<true> (p, ng, area, uv, shading frame with the dpdu tangent) from ONE 128-byte gather instead of
+// three dependent ones.  World-space arithmetic (the record holds M p_i and M^-T n_i), so results differ from the
+// object-space form in the last bits only.
+LR_D void reconstruct_baked(const DScene &scene, uint32_t tri, float u, float v, SurfacePoint &sp) {
+    auto q = reinterpret_cast<const float4 *>(scene.shade_tris + tri);
+    auto q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    auto w = 1.f - u - v;
+    f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+    sp.p = p0 + e1 * u + e2 * v;
+    auto c = cross(e1, e2);
+    sp.area = length(c) * .5f;
+    sp.ng = normalize(c);
+    sp.flags = __float_as_uint(q0.w);
+    sp.tags = __float_as_uint(q1.w);
+    sp.offset_bits = __float_as_uint(q2.w);
+    sp.tri_offset = reinterpret_cast<const uint32_t *>(scene.shade_tris + tri)[30];
+    f2 uv0{q3.w, q4.w}, uv1{q5.w, q6.x}, uv2{q6.y, q6.z};
+    sp.uv = (sp.flags & LR_SHAPE_HAS_VERTEX_UV) ? f2{w * uv0.x + u * uv1.x + v * uv2.x, w * uv0.y + u * uv1.y + v * uv2.y} : f2{u, v};
+    f2 duv0{uv1.x - uv0.x, uv1.y - uv0.y}, duv1{uv2.x - uv0.x, uv2.y - uv0.y};
+    auto det = duv0.x * duv1.y - duv0.y * duv1.x;
+    auto inv_det = 1.f / det;
+    auto fallback = frame_from_normal(sp.ng);
+    auto dpdu = det == 0.f ? fallback.s : (e1 * duv1.y - e2 * duv0.y) * inv_det;
+    auto ns = (sp.flags & LR_SHAPE_HAS_VERTEX_NORMAL) ?
+                  normalize(mk3(q3.x, q3.y, q3.z) * w + mk3(q4.x, q4.y, q4.z) * u + mk3(q5.x, q5.y, q5.z) * v) :
+                  sp.ng;
+    sp.shading = frame_from_normal_tangent(face_forward(ns, sp.ng), dpdu);
+}
+
+
+
 // Surface::Instance::evaluate_opacity: OpacitySurfaceWrapper (surface.h:183-189) and MixSurfaceInstance (mix.cpp:63-70)
 LR_D float surface_opacity(const DScene &scene, uint32_t tag, f2 uv) {
     auto one = [&](uint32_t t) {
@@ -570,9 +602,13 @@ LR_D f3 robust_origin(const SurfacePoint &sp, f3 w) {// Interaction::p_robust, i
 }
 
 // DiffuseLightClosure::_evaluate, diffuse.cpp:67-88
+LR_D void light_evaluate_with(const DScene &scene, const SurfacePoint &lp, float tri_pdf, f3 p_from, f3 &L, float &pdf);
 LR_D void light_evaluate(const DScene &scene, const SurfacePoint &lp, uint32_t prim, f3 p_from, f3 &L, float &pdf) {
+    light_evaluate_with(scene, lp, scene.tri_pdf[lp.tri_offset + prim], p_from, L, pdf);
+}
+LR_D void light_evaluate_with(const DScene &scene, const SurfacePoint &lp, float tri_pdf, f3 p_from, f3 &L, float &pdf) {
     auto &light = scene.lights[lp.tags & 4095u];
-    auto pdf_area = scene.tri_pdf[lp.tri_offset + prim] / lp.area;
+    auto pdf_area = tri_pdf / lp.area;
     auto cos_wo = abs_dot(normalize(p_from - lp.p), lp.ng);
     f3 Le = mk3(light.L[0], light.L[1], light.L[2]);
     if (light.dynamic) {// evaluate_illuminant_spectrum of a non-constant texture: xyz as-is, clamp >= 0

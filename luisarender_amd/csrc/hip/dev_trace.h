@@ -52,6 +52,7 @@ struct Ray {
 struct HitRecord {
     uint32_t inst, prim;
     float u, v;
+    uint32_t tri;// index of the baked BVH triangle (-> DShadeTri)
 };
 
 struct TraceStats {
@@ -300,6 +301,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                     if (tr.phase == kPhaseClosest) {
                         tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
                         tr.hit.u = u, tr.hit.v = v;
+                        tr.hit.tri = tr.cur & ((1u << 27u) - 1u);
                     }
                 }
             }

@@ -332,6 +332,31 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         dst.triangle_offset = mesh.triangle_offset;
     }
     LR_UP(upload(ctx, instances.data(), instances.size(), &d.instances));
+    {// shading records of the baked triangles (dev_scene.h: DShadeTri), in BVH triangle order
+        std::vector<lrd::DShadeTri> shade(s->accel.triangle_count);
+        for (uint32_t i = 0; i < s->accel.triangle_count; i++) {
+            auto &bt = s->accel.triangles[i];
+            if (bt.inst >= s->instance_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: BVH triangle references an unknown instance"); }
+            auto &inst = s->instances[bt.inst];
+            auto &di = instances[bt.inst];
+            auto &mesh = s->meshes[inst.handle.x >> 10u];
+            if (bt.prim >= mesh.triangle_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: BVH triangle references an unknown primitive"); }
+            auto tri = s->triangles[mesh.triangle_offset + bt.prim];
+            const lr_vertex *v[3] = {s->vertices + mesh.vertex_offset + tri.i0, s->vertices + mesh.vertex_offset + tri.i1, s->vertices + mesh.vertex_offset + tri.i2};
+            auto &r = shade[i];
+            std::memset(&r, 0, sizeof(r));
+            for (auto c = 0; c < 3; c++) { r.p0[c] = bt.v0[c], r.e1[c] = bt.e1[c], r.e2[c] = bt.e2[c]; }
+            float *n[3] = {r.n0, r.n1, r.n2};
+            for (auto k = 0; k < 3; k++) {
+                for (auto c = 0; c < 3; c++) { n[k][c] = di.n0[c] * v[k]->nx + di.n1[c] * v[k]->ny + di.n2[c] * v[k]->nz; }
+            }
+            r.uv0x = v[0]->u, r.uv0y = v[0]->v, r.uv1x = v[1]->u, r.uv1y = v[1]->v, r.uv2x = v[2]->u, r.uv2y = v[2]->v;
+            r.flags = inst.handle.x & 1023u, r.tags = inst.handle.y, r.offset_bits = inst.handle.w;
+            r.tri_pdf = s->tri_pdf[mesh.triangle_offset + bt.prim];
+            r.inst = bt.inst, r.prim = bt.prim, r.tri_offset = mesh.triangle_offset;
+        }
+        LR_UP(upload(ctx, shade.data(), shade.size(), &d.shade_tris));
+    }
     // closures: fold constant textures on the host (same arithmetic as the per-hit device path)
     auto is_constant = [&](int32_t id) { return id < 0 || s->textures[id].kind == LR_TEX_CONSTANT; };
     std::vector<lrd::DClosure> closures(s->surface_count);

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     SurfacePoint it;
                     auto has_surface = false;
                     if (hit_valid) {
+#if LR_BAKED_SHADING
+                        reconstruct_baked(scene, hit.tri, hit.u, hit.v, it);
+#else
                         reconstruct<true>(scene, hit.inst, hit.prim, mk3(1.f - hit.u - hit.v, hit.u, hit.v), it);
+#endif
                         it.back_facing = dot(wo, it.ng) < 0.0f;
                         if (COUNT) { local.surface_hits++; }
                         if (scene.has_lights && (it.flags & LR_SHAPE_HAS_LIGHT)) {// hit light, mega_path.cpp:79-86
