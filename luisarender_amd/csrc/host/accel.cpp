@@ -6,11 +6,10 @@
 //   * instances are baked to world space (one level, no per-ray instance transform: 288 GB
 //     of HBM makes the memory trade irrelevant, the saved dependent fetch + matrix math is
 //     paid back on every ray);
-//   * binned-SAH BVH2 (16 bins) collapsed to a 4-wide BVH whose 128-byte nodes hold the four
-//     child boxes SoA (six float4) + four child references: one node = one 128 B cache line,
-//     read with eight coalescable dwordx4 loads per lane;
-//   * leaves reference contiguous runs of 48-byte pre-transformed triangles
-//     (v0, e1, e2 + instance id, primitive id, flags) for Moeller-Trumbore.
+//   * full-sweep SAH BVH2 collapsed (SAH-optimal dynamic programme) to a 4-wide BVH of fp32 child boxes SoA +
+//     four child references (lr_bvh4_node); lrhip_upload_scene quantises it to 64-byte packets;
+//   * every leaf is ONE 48-byte pre-transformed triangle (v0, e1, e2 + instance id, primitive id,
+//     flags) for Moeller-Trumbore, named by index.
 #include "scene.h"
 
 #include <algorithm>
@@ -45,6 +44,15 @@ struct Node2 {
 // longest leaf of the wave every traversal step (dev_trace.h); an extra level of boxes is cheaper.
 constexpr auto max_leaf_size = 1u;
 constexpr auto bin_count = 16u;
+// Builder choices, overridable from the environment for A/B runs (tools/bvh_sim.cpp counts node visits per ray on the CPU):
+//   * exact SAH sweep for ranges up to sweep_threshold references, 16-bin SAH above (C2: 19.1 -> 16.7 node steps per ray with
+//     the sweep everywhere; 32 / 64 / 128 bins: 18.2 / 18.0 / 17.2; C5 17.6 -> 16.4, C3 19.6 -> 19.2);
+//   * SAH-optimal BVH2 -> BVH4 collapse instead of "open the largest child" (20 % fewer nodes in memory, -1 % steps per ray);
+//   * node order in memory: breadth-first, or depth-first over sibling groups (a subtree's nodes are contiguous).
+uint32_t sweep_threshold = 1u << 22u;
+bool optimal_collapse = true;
+bool depth_first = false;
+float leaf_cost = 1.f;
 
 class Builder2 {
     const std::vector<Box> &_boxes;
@@ -72,6 +80,36 @@ public:
             return index;
         };
         if (count <= max_leaf_size) { return make_leaf(); }
+        if (count <= sweep_threshold) {// exact SAH sweep over the three axes (small ranges: bins are too coarse there)
+            auto best_cost = std::numeric_limits<float>::max();
+            auto best_axis = -1;
+            auto best_k = 0u;
+            std::vector<float> right_area(count);
+            for (auto axis = 0; axis < 3; axis++) {
+                std::sort(_indices.begin() + first, _indices.begin() + first + count,
+                          [&](uint32_t a, uint32_t b) { return _centroids[a][axis] < _centroids[b][axis]; });
+                Box acc;
+                for (auto k = count - 1u; k > 0u; k--) {
+                    acc.grow(_boxes[_indices[first + k]]);
+                    right_area[k] = acc.half_area();
+                }
+                acc = Box{};
+                for (auto k = 1u; k < count; k++) {
+                    acc.grow(_boxes[_indices[first + k - 1u]]);
+                    auto cost = acc.half_area() * static_cast<float>(k) + right_area[k] * static_cast<float>(count - k);
+                    if (cost < best_cost) { best_cost = cost, best_axis = axis, best_k = k; }
+                }
+            }
+            if (best_axis != 2) {
+                std::sort(_indices.begin() + first, _indices.begin() + first + count,
+                          [&](uint32_t a, uint32_t b) { return _centroids[a][best_axis] < _centroids[b][best_axis]; });
+            }
+            auto l = build(first, best_k);
+            auto r = build(first + best_k, count - best_k);
+            _nodes[index].left = l;
+            _nodes[index].right = r;
+            return index;
+        }
         // binned SAH over the widest centroid axis and the two others
         auto best_cost = std::numeric_limits<float>::max();
         auto best_axis = -1;
@@ -132,6 +170,10 @@ public:
 }// namespace
 
 void build_accel(SceneData &scene) {
+    if (auto e = std::getenv("LR_BVH_SWEEP")) { sweep_threshold = static_cast<uint32_t>(std::atoi(e)); }
+    if (auto e = std::getenv("LR_BVH_COLLAPSE")) { optimal_collapse = std::atoi(e) != 0; }
+    if (auto e = std::getenv("LR_BVH_DFS")) { depth_first = std::atoi(e) != 0; }
+    if (auto e = std::getenv("LR_BVH_LEAF_COST")) { leaf_cost = static_cast<float>(std::atof(e)); }
     // 1. bake instances into world-space triangles
     uint64_t total = 0;
     for (auto &inst : scene.instances) { total += inst.handle.z; }
@@ -162,26 +204,81 @@ void build_accel(SceneData &scene) {
         }
     }
     auto n = static_cast<uint32_t>(tris.size());
-    std::vector<Box> boxes(n);
-    std::vector<float3> centroids(n);
+    // references: (box, triangle); a one-triangle leaf names its triangle by index, so the builder is free to reorder (and a
+    // later splitting builder to duplicate) references.  Early split clipping of large triangles was measured with
+    // tools/bvh_sim.cpp and NOT kept: C2 tris/ray 3.8 -> 2.8 but nodes/ray 18.9 -> 22.0, and the node step is the expensive one.
+    struct Ref { Box box; uint32_t tri; };
+    std::vector<Ref> refs(n);
     for (uint32_t i = 0; i < n; i++) {
         float3 p0{tris[i].v0[0], tris[i].v0[1], tris[i].v0[2]};
-        float3 p1 = p0 + float3{tris[i].e1[0], tris[i].e1[1], tris[i].e1[2]};
-        float3 p2 = p0 + float3{tris[i].e2[0], tris[i].e2[1], tris[i].e2[2]};
-        boxes[i].grow(p0), boxes[i].grow(p1), boxes[i].grow(p2);
+        auto p1 = p0 + float3{tris[i].e1[0], tris[i].e1[1], tris[i].e1[2]};
+        auto p2 = p0 + float3{tris[i].e2[0], tris[i].e2[1], tris[i].e2[2]};
+        refs[i].tri = i;
+        refs[i].box.grow(p0), refs[i].box.grow(p1), refs[i].box.grow(p2);
+    }
+    auto ref_count = static_cast<uint32_t>(refs.size());
+    if (ref_count >= (1u << 27u)) { throw Error{"Too many BVH references."}; }
+    std::vector<Box> boxes(ref_count);
+    std::vector<float3> centroids(ref_count);
+    for (uint32_t i = 0; i < ref_count; i++) {
+        boxes[i] = refs[i].box;
         centroids[i] = (boxes[i].lo + boxes[i].hi) * 0.5f;
     }
     // 2. BVH2
-    std::vector<uint32_t> indices(n);
+    std::vector<uint32_t> indices(ref_count);
     std::iota(indices.begin(), indices.end(), 0u);
     std::vector<Node2> nodes2;
-    nodes2.reserve(static_cast<size_t>(n) * 2u / max_leaf_size + 16u);
-    Builder2{boxes, centroids, indices, nodes2}.build(0u, n);
-    // 3. collapse to BVH4 (expand the child with the largest area until four children)
+    nodes2.reserve(static_cast<size_t>(ref_count) * 2u / max_leaf_size + 16u);
+    Builder2{boxes, centroids, indices, nodes2}.build(0u, ref_count);
+    // 3. collapse to BVH4 (expand the child with the largest area until four children); triangles are stored in the
+    // order their first reference appears in the leaf sequence
     scene.bvh_nodes.clear();
-    scene.bvh_triangles.resize(n);
-    for (uint32_t i = 0; i < n; i++) { scene.bvh_triangles[i] = tris[indices[i]]; }
-    auto encode_leaf = [](const Node2 &leaf) { return 0x80000000u | ((leaf.count - 1u) << 27u) | leaf.first; };
+    scene.bvh_triangles.clear();
+    scene.bvh_triangles.reserve(n);
+    std::vector<uint32_t> tri_slot(n, LR_INVALID_ID), ref_slot(ref_count);
+    for (uint32_t i = 0; i < ref_count; i++) {
+        auto tri = refs[indices[i]].tri;
+        if (tri_slot[tri] == LR_INVALID_ID) {
+            tri_slot[tri] = static_cast<uint32_t>(scene.bvh_triangles.size());
+            scene.bvh_triangles.emplace_back(tris[tri]);
+        }
+        ref_slot[i] = tri_slot[tri];
+    }
+    auto encode_leaf = [&](const Node2 &leaf) { return 0x80000000u | ref_slot[leaf.first]; };// count == 1
+    // SAH-optimal collapse (dynamic programme over the BVH2, after Ylitie et al. 2017).  t(n) = cost of n as ONE child of a
+    // BVH4 node (a leaf: leaf_cost x area; else area(n) + D(n, 4)); F(n, i) = cheapest forest covering n in at most i slots of
+    // an ancestor's node = min(F(n, i-1), D(n, i)); D(n, j) = min_k F(left, k) + F(right, j-k).
+    std::vector<float> forest;    // [n][i-1], i = 1..3
+    std::vector<uint8_t> choice;  // [n][i-1]: the j <= i used by F(n, i) (1 = n stays one child)
+    std::vector<uint8_t> k_of;    // [n][j-2], j = 2..4: slots given to the left side by D(n, j)
+    if (optimal_collapse) {
+        forest.assign(nodes2.size() * 3u, 0.f);
+        choice.assign(nodes2.size() * 3u, 1u);
+        k_of.assign(nodes2.size() * 3u, 1u);
+        for (auto ni = nodes2.size(); ni-- > 0u;) {// children have larger indices than their parent
+            auto &nd = nodes2[ni];
+            auto f = &forest[ni * 3u];
+            auto area = nd.box.half_area();
+            if (nd.count > 0u) {
+                f[0] = f[1] = f[2] = area * leaf_cost;
+                continue;
+            }
+            auto fl = &forest[static_cast<size_t>(nd.left) * 3u], fr = &forest[static_cast<size_t>(nd.right) * 3u];
+            float d[5];
+            for (auto j = 2u; j <= 4u; j++) {
+                d[j] = std::numeric_limits<float>::max();
+                for (auto k = 1u; k < j; k++) {
+                    auto v = fl[k - 1u] + fr[j - k - 1u];
+                    if (v < d[j]) { d[j] = v, k_of[ni * 3u + j - 2u] = static_cast<uint8_t>(k); }
+                }
+            }
+            f[0] = area + d[4];
+            for (auto i = 2u; i <= 3u; i++) {
+                if (d[i] < f[i - 2u]) { f[i - 1u] = d[i], choice[ni * 3u + i - 1u] = static_cast<uint8_t>(i); }
+                else { f[i - 1u] = f[i - 2u], choice[ni * 3u + i - 1u] = choice[ni * 3u + i - 2u]; }
+            }
+        }
+    }
     struct Work { uint32_t node2, node4; };
     std::vector<Work> queue;
     if (nodes2[0].count > 0u) {// degenerate: the root is a leaf -> one BVH4 node with one leaf child
@@ -196,10 +293,32 @@ void build_accel(SceneData &scene) {
         scene.bvh_nodes.emplace_back();
         queue.push_back({0u, 0u});
     }
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        auto work = queue[qi];
+    // node order: breadth-first (queue) or depth-first over sibling groups (stack: a subtree's nodes are contiguous)
+    for (size_t qi = 0; depth_first ? !queue.empty() : qi < queue.size(); qi++) {
+        Work work;
+        if (depth_first) { work = queue.back(), queue.pop_back(); }
+        else { work = queue[qi]; }
         std::array<uint32_t, 4> children{};
-        auto child_count = 2u;
+        auto child_count = 0u;
+        if (optimal_collapse) {// follow the DP's choices
+            struct Pick { uint32_t node, slots; bool forced; };
+            std::vector<Pick> todo{{work.node2, 4u, true}};
+            while (!todo.empty()) {
+                auto pk = todo.back();
+                todo.pop_back();
+                auto &c = nodes2[pk.node];
+                auto j = pk.slots;
+                if (!pk.forced) {
+                    if (c.count > 0u) { children[child_count++] = pk.node; continue; }
+                    j = choice[static_cast<size_t>(pk.node) * 3u + pk.slots - 1u];
+                    if (j == 1u) { children[child_count++] = pk.node; continue; }
+                }
+                auto k = k_of[static_cast<size_t>(pk.node) * 3u + j - 2u];
+                todo.push_back({c.right, j - k, false});
+                todo.push_back({c.left, k, false});
+            }
+        } else {
+        child_count = 2u;
         children[0] = nodes2[work.node2].left, children[1] = nodes2[work.node2].right;
         while (child_count < 4u) {
             auto best = -1;
@@ -212,6 +331,7 @@ void build_accel(SceneData &scene) {
             auto expanded = children[static_cast<size_t>(best)];
             children[static_cast<size_t>(best)] = nodes2[expanded].left;
             children[child_count++] = nodes2[expanded].right;
+        }
         }
         lr_bvh4_node node{};
         for (auto &c : node.child) { c = LR_INVALID_ID; }
