@@ -9,6 +9,7 @@
  *   lrhip_create / lrhip_destroy   Context::create_device + Stream       src/apps/cli.cpp:166-172,181
  *   lrhip_upload_scene             Pipeline::create uploads               src/base/pipeline.cpp:44-99,
  *                                  Geometry::build                        src/base/geometry.cpp:12-27
+ *   lrhip_update_scene             Pipeline::update / Geometry::update    src/base/pipeline.cpp:101-113, geometry.cpp:194-216
  *   lrhip_film_clear               ColorFilmInstance::prepare/clear       src/films/color.cpp:132-144
  *   lrhip_render                   _render_one_camera's spp loop of       src/base/integrator.cpp:86-107
  *                                  render(sample_id, time, weight).dispatch(resolution), i.e.
@@ -52,10 +53,13 @@ typedef struct lrhip_render_params {
      * and with it the fp32 summation order of the film — is a function of (resolution, spp, balance_shards) ONLY:
      * renders that pass the same value are bit-identical under any tile sharding and on any device.            */
     uint32_t balance_shards;
-    uint32_t pad[1];
+    /* Camera::ShutterSample weight of these samples (src/base/integrator.cpp:74,91-95: film()->accumulate(pixel,
+     * shutter_weight * L)); read only when flags has LRHIP_RENDER_SHUTTER_WEIGHT, otherwise 1 */
+    float shutter_weight;
 } lrhip_render_params;
 
 #define LRHIP_RENDER_COUNTERS 1u /* gather per-ray node/triangle counters (slower kernel variant) */
+#define LRHIP_RENDER_SHUTTER_WEIGHT 2u /* lrhip_render_params.shutter_weight is valid */
 
 typedef struct lrhip_counters {
     uint64_t paths, closest_rays, shadow_rays;
@@ -80,6 +84,11 @@ int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream);
 
 /* scene->accel must be built (lrhost_scene_build_accel) */
 int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *scene);
+
+/* Pipeline::update (src/base/pipeline.cpp:101-113) for the next shutter sample of a motion-blurred frame: like lrhip_upload_scene
+ * with the tables moved to the sample's time (lrhost_scene_set_time), but the film, its binding and the counters carry on;
+ * the resolution must not change.  (Everything is uploaded again; only the instance, camera and BVH tables differ.) */
+int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *scene);
 
 /* optional: accumulate into a caller-owned device buffer float4[W*H] (e.g. a torch tensor that
  * RCCL reduces afterwards); NULL = library-owned film (default) */

@@ -33,6 +33,16 @@ int lrhost_scene_load_string(const char *source, const char *virtual_path, int i
                              int macro_count, lrhost_scene **out);
 /* bake instances + build the 4-wide BVH consumed by lrhip_upload_scene */
 int lrhost_scene_build_accel(lrhost_scene *scene);
+/* Motion blur.  The reference renders a frame as a sequence of shutter samples (Camera::shutter_samples,
+ * src/base/camera.cpp:163-203): for each one the scene is moved to the sample's time (Pipeline::update pipeline.cpp:101-113,
+ * Geometry::update geometry.cpp:194-216) and `spp` samples per pixel are rendered with their radiance scaled by `weight`
+ * (src/base/integrator.cpp:91-95).  A static camera has ONE sample (shutter_span.x, 1, spp).
+ *   lrhost_scene_set_time: re-evaluates every animated transform (src/transforms/lerp.cpp; instances, cameras, environment)
+ *   and refits the BVH when it is built; the tables behind lrhost_scene_view change in place (*updated = whether anything
+ *   moved: upload the scene again then). */
+int lrhost_scene_set_time(lrhost_scene *scene, float time, int *updated);
+int lrhost_scene_shutter_sample_count(const lrhost_scene *scene, int camera_index);
+int lrhost_scene_shutter_sample(const lrhost_scene *scene, int camera_index, int sample_index, float *time, float *weight, uint32_t *spp);
 int lrhost_scene_camera_count(const lrhost_scene *scene);
 /* fill *out with pointers into `scene` (valid until lrhost_scene_destroy) */
 int lrhost_scene_view(const lrhost_scene *scene, int camera_index, lr_scene *out);

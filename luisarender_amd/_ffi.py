@@ -154,7 +154,7 @@ class HipCounters(C.Structure):
 class RenderParams(C.Structure):
     """lrhip_render_params (include/lrhip.h)"""
     _fields_ = [("spp_begin", u32), ("spp_end", u32), ("tile_begin", u32), ("tile_end", u32),
-                ("tile_stride", u32), ("flags", u32), ("balance_shards", u32), ("pad", u32 * 1)]
+                ("tile_stride", u32), ("flags", u32), ("balance_shards", u32), ("shutter_weight", f32)]
 
 
 _libs: dict[str, C.CDLL] = {}
@@ -178,6 +178,9 @@ def host_lib() -> C.CDLL:
         lib.lrhost_scene_destroy.argtypes = [C.c_void_p]
         lib.lrhost_scene_view.argtypes = [C.c_void_p, C.c_int, C.POINTER(Scene)]
         lib.lrhost_scene_build_accel.argtypes = [C.c_void_p]
+        lib.lrhost_scene_set_time.argtypes = [C.c_void_p, f32, C.POINTER(C.c_int)]
+        lib.lrhost_scene_shutter_sample_count.argtypes = [C.c_void_p, C.c_int]
+        lib.lrhost_scene_shutter_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(f32), C.POINTER(f32), C.POINTER(u32)]
         lib.lrhost_scene_camera_count.argtypes = [C.c_void_p]
         lib.lrhost_scene_camera_file.argtypes = [C.c_void_p, C.c_int]
         lib.lrhost_scene_has_lighting.argtypes = [C.c_void_p]
@@ -193,6 +196,7 @@ def oracle_lib() -> C.CDLL:
         lib.oracle_create.restype = C.c_void_p
         lib.oracle_create.argtypes = [C.POINTER(Scene)]
         lib.oracle_destroy.argtypes = [C.c_void_p]
+        lib.oracle_set_shutter_weight.argtypes = [C.c_void_p, f32]
         lib.oracle_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u32, C.c_int, C.c_void_p,
                                       C.POINTER(OracleCounters)]
         lib.oracle_film_convert.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p]
@@ -229,6 +233,7 @@ def hip_lib() -> C.CDLL:
         lib.lrhip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         lib.lrhip_destroy.argtypes = [C.c_void_p]
         lib.lrhip_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
+        lib.lrhip_update_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
         lib.lrhip_bind_film.argtypes = [C.c_void_p, C.c_void_p]
         lib.lrhip_film_clear.argtypes = [C.c_void_p]
         lib.lrhip_render.argtypes = [C.c_void_p, C.POINTER(RenderParams)]

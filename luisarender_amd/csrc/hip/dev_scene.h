@@ -149,7 +149,9 @@ struct DScene {
     uint32_t sampler_kind, seed;
     float film_clamp;
     uint32_t sampler_spp;          // PaddedSobol permutation length
-    uint32_t sobol_scale, pad[3];  // global Sobol pixel grid
+    uint32_t sobol_scale;          // global Sobol pixel grid
+    float shutter_weight;          // radiance scale of the current lrhip_render call (integrator.cpp:74: film()->accumulate(pixel, shutter_weight * L))
+    uint32_t pad[2];
     const uint32_t *sobol_matrices;// [1024][52]
     const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
     const DEnvironment *env;

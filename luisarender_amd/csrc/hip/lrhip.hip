@@ -274,8 +274,21 @@ int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream) {
     return LRHIP_OK;
 }
 
-int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
+static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film);
+
+int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) { return upload_scene_impl(ctx, s, false); }
+
+int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
+    if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: no scene uploaded"); }
+    if (s == nullptr || s->camera.width != ctx->width || s->camera.height != ctx->height) {
+        return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: the film resolution must not change");
+    }
+    return upload_scene_impl(ctx, s, true);
+}
+
+static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) {
     if (ctx == nullptr || s == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: NULL argument"); }
+    auto bound_film = ctx->film;
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
     }
@@ -511,9 +524,13 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (auto r = ensure(ctx->converted, film_bytes); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->counters, sizeof(lrd::DCounters)); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->work_counter, 256u); r != LRHIP_OK) { return r; }
-    LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
-    ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
-    LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
+    if (keep_film) {// the next shutter sample of the same frame: film, binding and counters carry on
+        ctx->film = bound_film;
+    } else {
+        LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
+        ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
+        LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
+    }
     // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
     // traversal-stack overflow area is sized for the densest variant
     for (auto &b : ctx->variant_blocks) { b = -1; }
@@ -566,6 +583,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
     lrd::RenderArgs args{};
     args.film = ctx->film;
+    ctx->scene.shutter_weight = (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f;
     args.spp_begin = p->spp_begin, args.spp_end = p->spp_end;
     args.tile_begin = p->tile_begin, args.tile_end = p->tile_end, args.tile_stride = p->tile_stride;
     args.tiles_x = tiles_x, args.tiles_y = tiles_y;

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     }
                 }
                 if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
-                    film_accumulate(pixel, Li, scene.film_clamp);
+                    film_accumulate(pixel, Li * scene.shutter_weight, scene.film_clamp);
                     path_open = false;
                 }
             }

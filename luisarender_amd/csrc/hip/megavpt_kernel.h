@@ -460,7 +460,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScene scene,
                     local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy;
                 }
             }
-            if (inside) { film_accumulate(film_tile + lane, Li, scene.film_clamp); }
+            if (inside) { film_accumulate(film_tile + lane, Li * scene.shutter_weight, scene.film_clamp); }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (inside) {

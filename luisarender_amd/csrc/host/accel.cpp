@@ -353,4 +353,50 @@ void build_accel(SceneData &scene) {
     log_info("BVH4 built: " + std::to_string(scene.bvh_nodes.size()) + " nodes over " + std::to_string(n) + " triangles.");
 }
 
+// Geometry::update (geometry.cpp:194-216) sets the moved instances' transforms and rebuilds the top-level structure.  Instances are
+// baked here, so the moved triangles are re-baked and the boxes of the EXISTING tree are refitted bottom-up (children
+// have larger indices than their parent in both node orders): O(n), no rebuild per shutter sample.
+void refit_accel(SceneData &scene) {
+    std::vector<char> moved(scene.instances.size(), 0);
+    for (auto &d : scene.dynamic_instances) { moved[d.instance] = 1; }
+    for (auto &bt : scene.bvh_triangles) {
+        if (!moved[bt.inst]) { continue; }
+        auto &inst = scene.instances[bt.inst];
+        auto &mesh = scene.meshes[inst.handle.x >> 10u];
+        float4x4 m;
+        std::memcpy(&m, inst.object_to_world, sizeof(m));
+        auto t = scene.triangles[mesh.triangle_offset + bt.prim];
+        auto fetch = [&](uint32_t i) {
+            auto &v = scene.vertices[mesh.vertex_offset + i];
+            return transform_point(m, {v.px, v.py, v.pz});
+        };
+        auto p0 = fetch(t.i0), p1 = fetch(t.i1), p2 = fetch(t.i2);
+        auto e1 = p1 - p0, e2 = p2 - p0;
+        bt.v0[0] = p0.x, bt.v0[1] = p0.y, bt.v0[2] = p0.z;
+        bt.e1[0] = e1.x, bt.e1[1] = e1.y, bt.e1[2] = e1.z;
+        bt.e2[0] = e2.x, bt.e2[1] = e2.y, bt.e2[2] = e2.z;
+    }
+    for (auto ni = scene.bvh_nodes.size(); ni-- > 0u;) {
+        auto &node = scene.bvh_nodes[ni];
+        for (auto i = 0; i < 4; i++) {
+            auto c = node.child[i];
+            if (c == LR_INVALID_ID) { continue; }
+            Box b;
+            if (c & 0x80000000u) {
+                auto &bt = scene.bvh_triangles[c & ((1u << 27u) - 1u)];
+                float3 p0{bt.v0[0], bt.v0[1], bt.v0[2]};
+                b.grow(p0), b.grow(p0 + float3{bt.e1[0], bt.e1[1], bt.e1[2]}), b.grow(p0 + float3{bt.e2[0], bt.e2[1], bt.e2[2]});
+            } else {
+                auto &ch = scene.bvh_nodes[c];
+                for (auto k = 0; k < 4; k++) {
+                    if (ch.child[k] == LR_INVALID_ID) { continue; }
+                    b.grow(float3{ch.lo_x[k], ch.lo_y[k], ch.lo_z[k]}), b.grow(float3{ch.hi_x[k], ch.hi_y[k], ch.hi_z[k]});
+                }
+            }
+            node.lo_x[i] = b.lo.x, node.lo_y[i] = b.lo.y, node.lo_z[i] = b.lo.z;
+            node.hi_x[i] = b.hi.x, node.hi_y[i] = b.hi.y, node.hi_z[i] = b.hi.z;
+        }
+    }
+}
+
 }// namespace lr

@@ -72,6 +72,30 @@ int lrhost_scene_build_accel(lrhost_scene *scene) {
     return guarded([&] { lr::build_accel(*scene->data); });
 }
 
+int lrhost_scene_set_time(lrhost_scene *scene, float time, int *updated) {
+    return guarded([&] {
+        auto moved = lr::set_scene_time(*scene->data, time);
+        if (updated != nullptr) { *updated = moved ? 1 : 0; }
+    });
+}
+
+int lrhost_scene_shutter_sample_count(const lrhost_scene *scene, int camera_index) {
+    if (camera_index < 0 || static_cast<size_t>(camera_index) >= scene->data->cameras.size()) { return 0; }
+    return static_cast<int>(scene->data->cameras[static_cast<size_t>(camera_index)].shutter_samples.size());
+}
+
+int lrhost_scene_shutter_sample(const lrhost_scene *scene, int camera_index, int sample_index, float *time, float *weight, uint32_t *spp) {
+    return guarded([&] {
+        if (camera_index < 0 || static_cast<size_t>(camera_index) >= scene->data->cameras.size()) { throw lr::Error{"Camera index out of range."}; }
+        auto &samples = scene->data->cameras[static_cast<size_t>(camera_index)].shutter_samples;
+        if (sample_index < 0 || static_cast<size_t>(sample_index) >= samples.size()) { throw lr::Error{"Shutter sample index out of range."}; }
+        auto &s = samples[static_cast<size_t>(sample_index)];
+        if (time) { *time = s.time; }
+        if (weight) { *weight = s.weight; }
+        if (spp) { *spp = s.spp; }
+    });
+}
+
 int lrhost_scene_camera_count(const lrhost_scene *scene) { return static_cast<int>(scene->data->cameras.size()); }
 
 int lrhost_scene_view(const lrhost_scene *scene, int camera_index, lr_scene *out) {

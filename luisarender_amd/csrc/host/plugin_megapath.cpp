@@ -34,6 +34,7 @@ struct HipApi {
     decltype(&lrhip_create) create{};
     decltype(&lrhip_destroy) destroy{};
     decltype(&lrhip_upload_scene) upload_scene{};
+    decltype(&lrhip_update_scene) update_scene{};
     decltype(&lrhip_film_clear) film_clear{};
     decltype(&lrhip_render) render{};
     decltype(&lrhip_synchronize) synchronize{};
@@ -50,13 +51,14 @@ struct HipApi {
         LR_SYM(create, "lrhip_create");
         LR_SYM(destroy, "lrhip_destroy");
         LR_SYM(upload_scene, "lrhip_upload_scene");
+        LR_SYM(update_scene, "lrhip_update_scene");
         LR_SYM(film_clear, "lrhip_film_clear");
         LR_SYM(render, "lrhip_render");
         LR_SYM(synchronize, "lrhip_synchronize");
         LR_SYM(film_download, "lrhip_film_download");
         LR_SYM(last_error, "lrhip_last_error");
 #undef LR_SYM
-        return create && destroy && upload_scene && film_clear && render && synchronize && film_download && last_error;
+        return create && destroy && upload_scene && update_scene && film_clear && render && synchronize && film_download && last_error;
     }
 };
 
@@ -105,19 +107,31 @@ public:
                 lr::log_warning("No lights in scene. Rendering aborted.");
                 for (size_t p = 0; p < static_cast<size_t>(width) * height; p++) { pixels[p * 4u + 3u] = 1.f; }
             } else {
-                auto view = data.view(i);
-                if (api.upload_scene(ctx, &view) != LRHIP_OK) {
-                    std::fprintf(stderr, "[error] lrhip_upload_scene: %s\n", api.last_error());
-                    std::abort();
-                }
                 std::fprintf(stderr, "[info] Rendering to '%s' of resolution %ux%u at %uspp.\n", camera.file.c_str(), width, height, camera.camera.spp);
-                api.film_clear(ctx);
                 auto tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
-                lrhip_render_params params{0u, camera.camera.spp, 0u, tiles, 1u, 0u, 1u, {0u}};
                 auto t0 = std::chrono::steady_clock::now();
-                if (api.render(ctx, &params) != LRHIP_OK || api.synchronize(ctx) != LRHIP_OK) {
-                    std::fprintf(stderr, "[error] lrhip_render: %s\n", api.last_error());
-                    std::abort();
+                // the loop over shutter samples of _render_one_camera (src/base/integrator.cpp:86-107): pipeline().update(time),
+                // then `spp` launches of render(sample_id++, time, weight) — here one persistent launch per shutter sample
+                auto sample_id = 0u;
+                auto first = true;
+                auto &shutter = camera.shutter_samples;
+                for (auto &s : shutter) {
+                    auto moved = lr::set_scene_time(data, s.time);
+                    if (first || moved) {
+                        auto view = data.view(i);
+                        if ((first ? api.upload_scene(ctx, &view) : api.update_scene(ctx, &view)) != LRHIP_OK) {
+                            std::fprintf(stderr, "[error] lrhip_upload_scene: %s\n", api.last_error());
+                            std::abort();
+                        }
+                    }
+                    if (first) { api.film_clear(ctx); }
+                    first = false;
+                    lrhip_render_params params{sample_id, sample_id + s.spp, 0u, tiles, 1u, shutter.size() > 1u ? LRHIP_RENDER_SHUTTER_WEIGHT : 0u, 1u, s.weight};
+                    sample_id += s.spp;
+                    if (api.render(ctx, &params) != LRHIP_OK || api.synchronize(ctx) != LRHIP_OK) {
+                        std::fprintf(stderr, "[error] lrhip_render: %s\n", api.last_error());
+                        std::abort();
+                    }
                 }
                 auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 std::fprintf(stderr, "[info] Rendering finished in %g ms.\n", ms);

@@ -8,6 +8,10 @@
 #include <filesystem>
 #include <fstream>
 #include <functional>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <algorithm>
 #include <unordered_map>
 
 namespace lr {
@@ -193,6 +197,8 @@ class Builder {
     float _scene_shadow_terminator{0.f};
     float _scene_intersection_offset{0.f};
     std::vector<float4x4> _transform_stack;// TransformTree (src/base/transform.cpp:25-59)
+    struct ChainEntry { const NodeDesc *node; bool animated; };
+    std::vector<ChainEntry> _transform_chain;// the non-identity transform nodes above the current shape, root first
 
     static void _check_tag(const NodeDesc *d, Tag tag) {
         if (d->tag() != tag && d->tag() != Tag::INTERNAL) {
@@ -254,11 +260,59 @@ public:
             for (auto c : d->node_list_or_empty("transforms")) { m = transform_matrix(c) * m; }
             return m;
         }
-        if (impl == "lerp") {
-            throw Error{"Animated 'Lerp' transforms are out of scope of the megapath hot path (SURVEY §2 row 16). [" +
-                        d->location() + "]"};
-        }
+        if (impl == "lerp") { return evaluate_xform(_out, compile_transform(d), 0.f); }
         throw Error{"Unknown transform implementation '" + impl + "'. [" + d->location() + "]"};
+    }
+
+    // Transform::is_static (lerp.cpp:69, stack.cpp:31)
+    bool transform_is_animated(const NodeDesc *d) {
+        if (d == nullptr) { return false; }
+        auto &impl = d->impl_type();
+        if (impl == "lerp") { return true; }
+        if (impl == "stack") {
+            for (auto c : d->node_list_or_empty("transforms")) {
+                if (transform_is_animated(c)) { return true; }
+            }
+        }
+        return false;
+    }
+
+    uint32_t static_xform(const float4x4 &m) {
+        XformNode n;
+        n.m = m;
+        _out.xforms.emplace_back(std::move(n));
+        return static_cast<uint32_t>(_out.xforms.size() - 1u);
+    }
+
+    // compile a transform node into SceneData::xforms so that it can be evaluated at any time later on
+    uint32_t compile_transform(const NodeDesc *d) {
+        if (!transform_is_animated(d)) { return static_xform(transform_matrix(d)); }
+        _check_tag(d, Tag::TRANSFORM);
+        XformNode n;
+        n.is_static = false;
+        if (d->impl_type() == "stack") {// stack.cpp:22-47
+            n.kind = XformNode::STACK;
+            for (auto c : d->node_list_or_empty("transforms")) { n.children.push_back(compile_transform(c)); }
+        } else {// lerp.cpp:26-66
+            n.kind = XformNode::LERP;
+            auto nodes = d->node_list_required("transforms");
+            auto times = d->float_list_or_empty("time_points");
+            if (nodes.size() != times.size()) { throw Error{"Number of transforms and number of time points mismatch. [" + d->location() + "]"}; }
+            if (nodes.empty()) { throw Error{"Empty transform list. [" + d->location() + "]"}; }
+            std::vector<uint32_t> indices(times.size());
+            std::iota(indices.begin(), indices.end(), 0u);
+            std::sort(indices.begin(), indices.end(), [&](auto a, auto b) { return times[a] < times[b]; });
+            if (auto it = std::unique(indices.begin(), indices.end(), [&](auto a, auto b) { return times[a] == times[b]; }); it != indices.end()) {
+                log_warning("Duplicate time points (count = " + std::to_string(std::distance(it, indices.end())) + ") in LerpTransform will be removed. [" + d->location() + "]");
+                indices.erase(it, indices.end());
+            }
+            for (auto i : indices) {
+                n.times.push_back(times[i]);
+                n.children.push_back(compile_transform(nodes[i]));
+            }
+        }
+        _out.xforms.emplace_back(std::move(n));
+        return static_cast<uint32_t>(_out.xforms.size() - 1u);
     }
 
     // ---------------- textures
@@ -731,14 +785,23 @@ public:
         auto visible = overridden_visible && info.visible;
         auto own_medium = d->node_or_null("medium");
         auto medium = overridden_medium == nullptr ? own_medium : overridden_medium;// geometry.cpp:38
-        auto local = transform_matrix(d->node_or_null("transform"));
+        auto local_node = d->node_or_null("transform");
+        auto local = transform_matrix(local_node);// (animated transforms: value at time 0; set_scene_time finalises them)
+        auto local_animated = transform_is_animated(local_node);
         if (info.is_mesh) {
             uint32_t vertex_props = 0u;
             auto mesh_index = load_mesh(d, vertex_props);
             auto &mesh = _out.meshes[mesh_index];
             auto instance_id = static_cast<uint32_t>(_out.instances.size());
             // TransformTree::leaf + Node::matrix: M = M_root * ... * M_leaf
-            auto object_to_world = is_identity(local) ? _transform_stack.back() : _transform_stack.back() * local;
+            auto object_to_world = is_identity(local) && !local_animated ? _transform_stack.back() : _transform_stack.back() * local;
+            if (local_animated || std::any_of(_transform_chain.begin(), _transform_chain.end(), [](auto &e) { return e.animated; })) {
+                DynamicInstance dyn;
+                dyn.instance = instance_id;
+                for (auto &e : _transform_chain) { dyn.chain.push_back(compile_transform(e.node)); }
+                if (local_animated || !is_identity(local)) { dyn.chain.push_back(compile_transform(local_node)); }
+                _out.dynamic_instances.emplace_back(std::move(dyn));
+            }
             for (uint32_t i = 0; i < mesh.vertex_count; i++) {
                 auto &v = _out.vertices[mesh.vertex_offset + i];
                 auto p = transform_point(object_to_world, {v.px, v.py, v.pz});
@@ -780,13 +843,105 @@ public:
             _out.instances.emplace_back(inst);
             if (properties & LR_SHAPE_HAS_LIGHT) { _out.light_instances.push_back({instance_id, light_tag}); }
         } else {
-            auto pushed = !is_identity(local);
-            if (pushed) { _transform_stack.emplace_back(_transform_stack.back() * local); }
+            auto pushed = !is_identity(local) || local_animated;
+            if (pushed) {
+                _transform_stack.emplace_back(_transform_stack.back() * local);
+                _transform_chain.push_back({local_node, local_animated});
+            }
             auto children = d->impl_type() == "group" ? d->node_list_required("shapes") :
                                                         NodeDesc::node_list{d->node("shape")};
             for (auto child : children) { process_shape(child, surface, light, visible, medium); }
-            if (pushed) { _transform_stack.pop_back(); }
+            if (pushed) { _transform_stack.pop_back(), _transform_chain.pop_back(); }
         }
+    }
+
+    // ---------------- shutter (Camera::Camera camera.cpp:22-131, Camera::shutter_weight :150-161, Camera::shutter_samples :163-203)
+    // Kept quirks: the custom curve is appended BEHIND `n` zero-initialised points (`resize(n)` followed by a
+    // back_inserter, :109-114); bucket times are measured from 0, not from shutter_span.x (:172-176).  Conscious
+    // correction: the reference draws the bucket jitter and the spp shuffle from an unseeded std::random_device (:171), so
+    // two runs of it never agree; here the engine is seeded (19980810 + camera index) and the same samples reach the
+    // oracle and the device through lrhost_scene_shutter_sample.
+    void build_shutter(const NodeDesc *d, CameraRecord &rec, uint32_t camera_index) {
+        auto spp = rec.camera.spp;
+        float span[2];
+        if (auto s2 = d->vector_opt("shutter_span", 2u)) { span[0] = static_cast<float>((*s2)[0]), span[1] = static_cast<float>((*s2)[1]); }
+        else { span[0] = span[1] = d->float_or("shutter_span", 0.f); }
+        if (span[1] < span[0]) { throw Error{"Invalid time span: [" + std::to_string(span[0]) + ", " + std::to_string(span[1]) + "]. [" + d->location() + "]"}; }
+        rec.shutter_span[0] = span[0], rec.shutter_span[1] = span[1];
+        if (span[0] == span[1]) {
+            rec.shutter_samples = {ShutterSample{span[0], 1.f, spp}};
+            return;
+        }
+        auto shutter_samples = d->uint_or("shutter_samples", 0u);
+        if (shutter_samples == 0u) { shutter_samples = std::min(spp, 256u); }
+        else if (shutter_samples > spp) {
+            log_warning("Too many shutter samples (" + std::to_string(shutter_samples) + "), clamping to samples per pixel (" + std::to_string(spp) + "). [" + d->location() + "]");
+            shutter_samples = spp;
+        }
+        struct Point { float time, weight; };
+        std::vector<Point> points;
+        auto time_points = d->float_list_or_empty("shutter_time_points");
+        auto weights = d->float_list_or_empty("shutter_weights");
+        if (time_points.size() != weights.size()) { throw Error{"Number of shutter time points and number of shutter weights mismatch. [" + d->location() + "]"}; }
+        if (std::any_of(weights.begin(), weights.end(), [](auto w) { return w < 0.f; })) { throw Error{"Found negative shutter weight. [" + d->location() + "]"}; }
+        if (time_points.empty()) {
+            points = {{span[0], 1.f}, {span[1], 1.f}};
+        } else {
+            std::vector<uint32_t> indices(time_points.size());
+            std::iota(indices.begin(), indices.end(), 0u);
+            if (auto it = std::remove_if(indices.begin(), indices.end(), [&](auto i) { return time_points[i] < span[0] || time_points[i] > span[1]; }); it != indices.end()) {
+                log_warning("Out-of-shutter samples (count = " + std::to_string(std::distance(it, indices.end())) + ") are to be removed. [" + d->location() + "]");
+                indices.erase(it, indices.end());
+            }
+            std::sort(indices.begin(), indices.end(), [&](auto a, auto b) { return time_points[a] < time_points[b]; });
+            if (auto it = std::unique(indices.begin(), indices.end(), [&](auto a, auto b) { return time_points[a] == time_points[b]; }); it != indices.end()) {
+                log_warning("Duplicate shutter samples (count = " + std::to_string(std::distance(it, indices.end())) + ") are to be removed. [" + d->location() + "]");
+                indices.erase(it, indices.end());
+            }
+            points.resize(indices.size());// (sic, camera.cpp:110)
+            for (auto i : indices) { points.push_back({time_points[i], weights[i]}); }
+            if (!points.empty()) {
+                if (points.front().time > span[0]) { points.insert(points.begin(), Point{span[0], points.front().weight}); }
+                if (points.back().time < span[1]) { points.push_back({span[1], points.back().weight}); }
+            }
+        }
+        auto shutter_weight = [&](float time) {// camera.cpp:150-161
+            if (time < span[0] || time > span[1]) { return 0.f; }
+            auto ub = std::upper_bound(points.cbegin(), points.cend(), time, [](auto lhs, auto rhs) { return lhs < rhs.time; });
+            auto u = std::distance(points.cbegin(), ub);
+            if (u <= 0 || static_cast<size_t>(u) >= points.size()) { return u <= 0 ? points.front().weight : points.back().weight; }// (the reference reads out of range here)
+            auto p0 = points[static_cast<size_t>(u - 1)], p1 = points[static_cast<size_t>(u)];
+            auto t = (time - p0.time) / (p1.time - p0.time);
+            return p0.weight + t * (p1.weight - p0.weight);
+        };
+        auto duration = span[1] - span[0];
+        auto inv_n = 1.f / static_cast<float>(shutter_samples);
+        std::uniform_real_distribution<float> dist{};
+        std::default_random_engine random{19980810u + camera_index};
+        std::vector<ShutterSample> buckets(shutter_samples);
+        for (auto b = 0u; b < shutter_samples; b++) {
+            auto ts = static_cast<float>(b) * inv_n * duration;
+            auto te = static_cast<float>(b + 1u) * inv_n * duration;
+            auto a = dist(random);
+            auto t = ts + a * (te - ts);
+            buckets[b].time = t, buckets[b].weight = shutter_weight(t);
+        }
+        std::vector<uint32_t> order(shutter_samples);
+        std::iota(order.begin(), order.end(), 0u);
+        std::shuffle(order.begin(), order.end(), random);
+        auto remainder = spp % shutter_samples, per_bucket = spp / shutter_samples;
+        for (auto i = 0u; i < remainder; i++) { buckets[order[i]].spp = per_bucket + 1u; }
+        for (auto i = remainder; i < shutter_samples; i++) { buckets[order[i]].spp = per_bucket; }
+        auto sum_weights = 0.0;
+        for (auto &b : buckets) { sum_weights += static_cast<double>(b.weight * static_cast<float>(b.spp)); }
+        if (sum_weights == 0.0) {
+            log_warning("Invalid shutter samples generated. Falling back to uniform shutter curve.");
+            for (auto &b : buckets) { b.weight = 1.f; }
+        } else {
+            auto scale = static_cast<double>(spp) / sum_weights;
+            for (auto &b : buckets) { b.weight = static_cast<float>(static_cast<double>(b.weight) * scale); }
+        }
+        rec.shutter_samples = std::move(buckets);
     }
 
     // ---------------- camera, film, filter
@@ -885,6 +1040,7 @@ public:
         auto c2w = float4x4::identity();
         if (xform != nullptr) {
             c2w = transform_matrix(xform);
+            if (transform_is_animated(xform)) { rec.xform = static_cast<int32_t>(compile_transform(xform)); }
         } else {
             auto position = float3_or(d, "position", {0.f, 0.f, 0.f});
             auto front_opt = d->vector_opt("front", 3u);
@@ -905,10 +1061,7 @@ public:
         }
         store_matrix(cam.camera_to_world, c2w);
         cam.spp = d->uint_or("spp", 1024u);
-        auto span2 = d->vector_opt("shutter_span", 2u);
-        if (span2 ? (*span2)[0] != (*span2)[1] : false) {
-            throw Error{"Motion blur (shutter_span) is out of scope (SURVEY §2 row 16). [" + d->location() + "]"};
-        }
+        build_shutter(d, rec, static_cast<uint32_t>(_out.cameras.size()));
         // clip planes (camera.h:116-157)
         auto clip2 = d->vector_opt("clip", 2u);
         if (!clip2) { clip2 = d->vector_opt("clip_plane", 2u); }
@@ -1112,6 +1265,10 @@ lr_environment Builder::build_environment_node(const NodeDesc *d, std::vector<lr
     if (d == nullptr || d->impl_type() == "null") { return env; }
     _check_tag(d, Tag::ENVIRONMENT);
     auto m = transform_matrix(d->node_or_null("transform"));
+    if (transform_is_animated(d->node_or_null("transform"))) {
+        if (&alias != &_out.env_alias) { throw Error{"Animated transforms on the children of a Combined environment are not supported. [" + d->location() + "]"}; }
+        _out.environment_xform = static_cast<int32_t>(compile_transform(d->node_or_null("transform")));
+    }
     // Environment::Instance::transform_to_world: 3x3 of the env transform (environment.cpp:17-19)
     for (auto c = 0; c < 3; c++) {
         for (auto r = 0; r < 3; r++) {
@@ -1166,6 +1323,7 @@ void Builder::build_environment(const NodeDesc *d) {
     for (auto i = 0; i < 2; i++) {
         if (child[i].kind == LR_ENV_NONE) { scales[i] = 0.f; }
     }
+    if (transform_is_animated(d->node_or_null("transform"))) { throw Error{"Animated transforms on a Combined environment are not supported. [" + d->location() + "]"}; }
     auto m = transform_matrix(d->node_or_null("transform"));
     float c2w[9], w2c[9];
     for (auto c = 0; c < 3; c++) {
@@ -1203,9 +1361,162 @@ void Builder::build_environment(const NodeDesc *d) {
 
 }// namespace
 
+// ---------------- animation: Transform::matrix(time), Pipeline::update, Geometry::update
+namespace {
+
+// util/xform.cpp:12-117, restated on a plain column-major 3x3
+struct M3 { float3 c[3]; };
+M3 m3_of(const float4x4 &m) { return {{{m[0].x, m[0].y, m[0].z}, {m[1].x, m[1].y, m[1].z}, {m[2].x, m[2].y, m[2].z}}}; }
+M3 m3_transpose(const M3 &m) { return {{{m.c[0].x, m.c[1].x, m.c[2].x}, {m.c[0].y, m.c[1].y, m.c[2].y}, {m.c[0].z, m.c[1].z, m.c[2].z}}}; }
+M3 m3_mul(const M3 &a, const M3 &b) {
+    M3 r;
+    for (auto j = 0; j < 3; j++) { r.c[j] = a.c[0] * b.c[j].x + a.c[1] * b.c[j].y + a.c[2] * b.c[j].z; }
+    return r;
+}
+M3 m3_inverse(const M3 &m) {// adjugate / determinant (luisa::inverse(float3x3), core/mathematics.h; absent from the snapshot)
+    auto a = m.c[0], b = m.c[1], c = m.c[2];
+    auto r0 = cross(b, c), r1 = cross(c, a), r2 = cross(a, b);
+    auto inv_det = 1.f / dot(a, r0);
+    return m3_transpose({{r0 * inv_det, r1 * inv_det, r2 * inv_det}});
+}
+
+struct Quat { float3 v; float w; };
+struct Decomposed { float3 scaling; Quat q; float3 translation; };
+
+Quat quaternion_of(const M3 &m) {// xform.cpp:45-74
+    auto e = [&](int i, int j) { return m.c[i][j]; };
+    if (auto trace = e(0, 0) + e(1, 1) + e(2, 2); trace > 0.f) {
+        auto s = std::sqrt(trace + 1.f);
+        auto w = 0.5f * s;
+        s = 0.5f / s;
+        return {float3{e(1, 2) - e(2, 1), e(2, 0) - e(0, 2), e(0, 1) - e(1, 0)} * s, w};
+    }
+    const int next[3] = {1, 2, 0};
+    float3 v{};
+    auto i = 0;
+    if (e(1, 1) > e(0, 0)) { i = 1; }
+    if (e(2, 2) > e(i, i)) { i = 2; }
+    auto j = next[i], k = next[j];
+    auto s = std::sqrt(std::max(e(i, i) - (e(j, j) + e(k, k)) + 1.f, 0.f));
+    v[i] = s * 0.5f;
+    if (s != 0.f) { s = 0.5f / s; }
+    auto w = (e(j, k) - e(k, j)) * s;
+    v[j] = (e(i, j) + e(j, i)) * s;
+    v[k] = (e(i, k) + e(k, i)) * s;
+    return {v, w};
+}
+
+Decomposed decompose(const float4x4 &m) {// xform.cpp:12-43 (polar decomposition by averaging R with its inverse transpose)
+    float3 t{m[3].x, m[3].y, m[3].z};
+    auto N = m3_of(m);
+    auto R = N;
+    for (auto it = 0; it < 100; it++) {
+        auto R_it = m3_inverse(m3_transpose(R));
+        M3 R_next, diff;
+        for (auto c = 0; c < 3; c++) {
+            R_next.c[c] = (R.c[c] + R_it.c[c]) * 0.5f;
+            diff.c[c] = R.c[c] - R_next.c[c];
+        }
+        R = R_next;
+        float3 n{std::abs(diff.c[0].x) + std::abs(diff.c[1].x) + std::abs(diff.c[2].x),
+                 std::abs(diff.c[0].y) + std::abs(diff.c[1].y) + std::abs(diff.c[2].y),
+                 std::abs(diff.c[0].z) + std::abs(diff.c[1].z) + std::abs(diff.c[2].z)};
+        if (std::max({n.x, n.y, n.z}) <= 1e-4f) { break; }
+    }
+    auto S = m3_mul(m3_inverse(R), N);
+    auto near_zero = [](float f) { return std::abs(f) <= 1e-4f; };
+    if (!near_zero(S.c[0].y) || !near_zero(S.c[0].z) || !near_zero(S.c[1].x) || !near_zero(S.c[1].z) || !near_zero(S.c[2].x) || !near_zero(S.c[2].y)) {
+        log_warning("Non-zero entries found in decomposed scaling matrix.");
+    }
+    return {{S.c[0].x, S.c[1].y, S.c[2].z}, quaternion_of(R), t};
+}
+
+float q_dot(Quat a, Quat b) { return dot(a.v, b.v) + a.w * b.w; }
+float q_length(Quat a) { return std::sqrt(q_dot(a, a)); }
+Quat q_axpby(Quat a, float x, Quat b, float y) { return {a.v * x + b.v * y, a.w * x + b.w * y}; }
+
+Quat slerp(Quat q1, Quat q2, float t) {// xform.cpp:90-99
+    auto safe_asin = [](float x) { return std::asin(std::clamp(x, -1.f, 1.f)); };
+    auto sin_x_over_x = [](float x) { return 1.f + x * x == 1.f ? 1.f : std::sin(x) / x; };
+    constexpr auto pi = 3.14159265358979323846f;
+    auto theta = q_dot(q1, q2) < 0.f ? pi - 2.f * safe_asin(q_length(q_axpby(q1, 1.f, q2, 1.f)) * 0.5f) :
+                                       2.f * safe_asin(q_length(q_axpby(q1, 1.f, q2, -1.f)) * 0.5f);
+    auto sto = sin_x_over_x(theta);
+    auto q = q_axpby(q1, (1.f - t) * sin_x_over_x((1.f - t) * theta) / sto, q2, t * sin_x_over_x(t * theta) / sto);
+    auto l = q_length(q);
+    return {q.v * (1.f / l), q.w / l};
+}
+
+float4x4 rotation_of(Quat q) {// xform.cpp:76-79
+    auto l = std::sqrt(dot(q.v, q.v));
+    // conscious correction: the reference normalises a zero axis here (a key pair without rotation, e.g. a pure translation,
+    // gives q = (0, 0, 0, 1)) and turns the whole matrix into NaNs; a zero rotation is the identity
+    if (l == 0.f) { return float4x4::identity(); }
+    auto theta = 2.f * std::atan2(l, q.w);
+    return rotation(q.v * (1.f / l), theta);
+}
+
+}// namespace
+
+float4x4 evaluate_xform(const SceneData &scene, uint32_t id, float time) {
+    auto &n = scene.xforms[id];
+    if (n.kind == XformNode::STATIC) { return n.m; }
+    if (n.kind == XformNode::STACK) {// stack.cpp:38-47
+        auto m = float4x4::identity();
+        for (auto c : n.children) { m = evaluate_xform(scene, c, time) * m; }
+        return m;
+    }
+    // lerp.cpp:71-109
+    if (time <= n.times.front()) { return evaluate_xform(scene, n.children.front(), n.times.front()); }
+    if (time >= n.times.back()) { return evaluate_xform(scene, n.children.back(), n.times.back()); }
+    auto upper = static_cast<size_t>(std::upper_bound(n.times.begin(), n.times.end(), time) - n.times.begin());
+    // (the reference caches the two decompositions per interval at the time of the interval's first query; key transforms
+    // that are themselves animated would make its result depend on the query order — here they are evaluated at `time`)
+    auto t0 = decompose(evaluate_xform(scene, n.children[upper - 1u], time));
+    auto t1 = decompose(evaluate_xform(scene, n.children[upper], time));
+    auto t = (time - n.times[upper - 1u]) / (n.times[upper] - n.times[upper - 1u]);
+    auto S = t0.scaling + (t1.scaling - t0.scaling) * t;
+    auto R = slerp(t0.q, t1.q, t);
+    auto T = t0.translation + (t1.translation - t0.translation) * t;
+    return translation(T) * rotation_of(R) * scaling(S);
+}
+
+bool set_scene_time(SceneData &scene, float time) {
+    scene.time = time;
+    auto moved = false;
+    for (auto &dyn : scene.dynamic_instances) {
+        auto m = float4x4::identity();
+        for (auto id : dyn.chain) { m = m * evaluate_xform(scene, id, time); }
+        store_matrix(scene.instances[dyn.instance].object_to_world, m);
+        moved = true;
+    }
+    for (auto &cam : scene.cameras) {
+        if (cam.xform >= 0) {
+            store_matrix(cam.camera.camera_to_world, evaluate_xform(scene, static_cast<uint32_t>(cam.xform), time));
+            moved = true;
+        }
+    }
+    if (scene.environment_xform >= 0) {
+        auto m = evaluate_xform(scene, static_cast<uint32_t>(scene.environment_xform), time);
+        for (auto c = 0; c < 3; c++) {
+            for (auto r = 0; r < 3; r++) {
+                scene.environment.env_to_world[c * 3 + r] = m[c][r];
+                scene.environment.world_to_env[c * 3 + r] = m[r][c];
+            }
+        }
+        moved = true;
+    }
+    if (!scene.dynamic_instances.empty() && !scene.bvh_nodes.empty()) { refit_accel(scene); }
+    return moved;
+}
+
 std::unique_ptr<SceneData> build_scene(const SceneDesc &desc) {
     auto out = std::make_unique<SceneData>();
     Builder{desc, *out}.build();
+    // Pipeline::create: the tables are built at the earliest shutter opening of any camera (pipeline.cpp:50-56,72)
+    auto initial_time = std::numeric_limits<float>::max();
+    for (auto &c : out->cameras) { initial_time = std::min(initial_time, c.shutter_span[0]); }
+    set_scene_time(*out, out->cameras.empty() ? 0.f : initial_time);
     return out;
 }
 

@@ -17,11 +17,36 @@
 
 namespace lr {
 
+// A compiled Transform node (src/transforms/*.cpp): evaluable at any time after the scene description is gone.
+struct XformNode {
+    enum Kind : uint32_t { STATIC, STACK, LERP } kind{STATIC};
+    float4x4 m{float4x4::identity()};// STATIC (and the value of a fully static STACK)
+    std::vector<uint32_t> children;  // STACK: m = t_i(time) * m (stack.cpp:22-36); LERP: key transforms sorted by time
+    std::vector<float> times;        // LERP time points (lerp.cpp:29-66)
+    bool is_static{true};
+};
+
+// Camera::ShutterSample (src/base/camera.h:81-89): `spp` samples rendered with the scene at `time`, radiance x `weight`
+struct ShutterSample {
+    float time{0.f}, weight{1.f};
+    uint32_t spp{0u};
+};
+
 struct CameraRecord {
     lr_camera camera{};
     lr_filter filter{};
     lr_film film{};
     std::string file;// output image path (src/base/camera.cpp:138-147)
+    int32_t xform{-1};// compiled transform when it is animated
+    float shutter_span[2]{0.f, 0.f};
+    std::vector<ShutterSample> shutter_samples;// Camera::shutter_samples(), camera.cpp:163-203
+};
+
+// an instance below at least one animated transform: object_to_world(time) = M_root(time) * ... * M_leaf(time)
+// (TransformTree::Node::matrix, src/base/transform.cpp:17-23)
+struct DynamicInstance {
+    uint32_t instance{0u};
+    std::vector<uint32_t> chain;// XformNode ids, root first
 };
 
 struct SceneData {
@@ -52,6 +77,11 @@ struct SceneData {
     lr_integrator integrator{};
     std::string integrator_impl;
     bool any_non_opaque{false};
+    // animation (src/transforms/lerp.cpp, Geometry::update geometry.cpp:194-216, Pipeline::update pipeline.cpp:101-113)
+    std::vector<XformNode> xforms;
+    std::vector<DynamicInstance> dynamic_instances;
+    int32_t environment_xform{-1};
+    float time{0.f};// the time the tables currently hold (initially min over cameras of shutter_span.x, pipeline.cpp:50-56)
     // wide BVH (accel.cpp)
     std::vector<lr_bvh4_node> bvh_nodes;
     std::vector<lr_bvh_triangle> bvh_triangles;
@@ -79,6 +109,14 @@ void build_environment_tables(const SceneData &scene, lr_environment &env, std::
 
 // accel.cpp: flatten instances to world space and build the 4-wide BVH for the HIP kernel
 void build_accel(SceneData &scene);
+// accel.cpp: re-bake the triangles of moved instances and refit the boxes of the existing BVH (same topology)
+void refit_accel(SceneData &scene);
+
+// scene.cpp: evaluate a compiled transform (Transform::matrix(time))
+float4x4 evaluate_xform(const SceneData &scene, uint32_t id, float time);
+// scene.cpp: Pipeline::update (pipeline.cpp:101-113) + Geometry::update (geometry.cpp:194-216): re-evaluate every animated
+// transform at `time` (instances, cameras, environment), refit the BVH if it is built; returns whether anything moved
+bool set_scene_time(SceneData &scene, float time);
 
 // mesh_io.cpp: OBJ loader standing in for assimp (src/shapes/mesh.cpp:46-69 flag semantics)
 struct LoadedMesh {

@@ -33,6 +33,21 @@ class Oracle:
             raise RuntimeError("oracle_render failed")
         return film, cnt.as_dict()
 
+    @staticmethod
+    def render_frame(scene: Scene, camera: int = 0, threads: int | None = None):
+        """The reference's loop over shutter samples (src/base/integrator.cpp:86-107) on the CPU: one oracle per sample time"""
+        film, total = None, None
+        begin = 0
+        for time, weight, spp in scene.shutter_samples(camera):
+            scene.set_time(time)
+            o = Oracle(scene, camera)
+            o._lib.oracle_set_shutter_weight(o._ctx, weight)
+            film, cnt = o.render(begin, begin + spp, threads=threads, film=film)
+            total = cnt if total is None else {k: total[k] + v for k, v in cnt.items()}
+            begin += spp
+            o.close()
+        return film, total
+
     def convert(self, film: np.ndarray) -> np.ndarray:
         out = np.empty_like(film)
         self._lib.oracle_film_convert(C.byref(self._view), film.ctypes.data, out.ctypes.data)

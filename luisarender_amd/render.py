@@ -36,9 +36,10 @@ class MegaPathRenderer:
     def set_stream(self, hip_stream: int | None) -> None:
         self._check(self._lib.lrhip_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))
 
-    def upload(self, scene: Scene, camera: int = 0) -> None:
+    def upload(self, scene: Scene, camera: int = 0, keep_film: bool = False) -> None:
+        """keep_film: lrhip_update_scene (the next shutter sample of a frame: film and counters carry on)"""
         view = scene.view(camera)
-        self._check(self._lib.lrhip_upload_scene(self._ctx, C.byref(view)))
+        self._check((self._lib.lrhip_update_scene if keep_film else self._lib.lrhip_upload_scene)(self._ctx, C.byref(view)))
         self._scene = scene
         self.width, self.height = int(view.camera.width), int(view.camera.height)
 
@@ -49,7 +50,7 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_film_clear(self._ctx))
 
     def render(self, spp_begin: int, spp_end: int, rank: int = 0, world: int = 1, counters: bool = False,
-               sync: bool = False, balance_shards: int = 1) -> None:
+               sync: bool = False, balance_shards: int = 1, shutter_weight: float | None = None) -> None:
         """Render samples [spp_begin, spp_end) of the round-robin tile shard `rank` of `world`.
         `balance_shards` sizes the work items for a frame split into that many shards (lrhip.h): films rendered with
         the same value are bit-identical under any sharding; the multi-GPU bench passes its world size."""
@@ -58,9 +59,27 @@ class MegaPathRenderer:
         p.spp_begin, p.spp_end = spp_begin, spp_end
         p.tile_begin, p.tile_end, p.tile_stride = rank, tile_count(self.width, self.height), world
         p.flags = 1 if counters else 0
+        if shutter_weight is not None:  # Camera::ShutterSample weight of these samples (integrator.cpp:74)
+            p.flags |= 2
+            p.shutter_weight = shutter_weight
         self._check(self._lib.lrhip_render(self._ctx, C.byref(p)))
         if sync:
             self.synchronize()
+
+    def render_frame(self, scene: Scene, camera: int = 0, rank: int = 0, world: int = 1, balance_shards: int = 1) -> None:
+        """ProgressiveIntegrator::Instance::_render_one_camera's loop over shutter samples (src/base/integrator.cpp:86-107):
+        move the scene to each sample's time, upload it, render the sample's spp range with its weight."""
+        samples = scene.shutter_samples(camera)
+        begin = 0
+        for i, (time, weight, spp) in enumerate(samples):
+            moved = scene.set_time(time)
+            if i == 0 or moved:
+                self.upload(scene, camera, keep_film=i > 0)
+            self.render(begin, begin + spp, rank=rank, world=world, balance_shards=balance_shards,
+                        shutter_weight=weight if len(samples) > 1 else None)
+            begin += spp
+            if moved:
+                self.synchronize()  # the next set_time rewrites the host tables the upload reads from
 
     def synchronize(self) -> None:
         self._check(self._lib.lrhip_synchronize(self._ctx))

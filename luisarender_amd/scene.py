@@ -59,6 +59,25 @@ class Scene:
             raise HostError(self._lib.lrhost_last_error().decode())
         self._views.clear()
 
+    def set_time(self, time: float) -> bool:
+        """Pipeline::update (src/base/pipeline.cpp:101-113): move every animated transform to `time`; the tables behind
+        view() change in place (upload / create the oracle again).  -> whether anything moved"""
+        updated = C.c_int(0)
+        if self._lib.lrhost_scene_set_time(self._handle, time, C.byref(updated)) != 0:
+            raise HostError(self._lib.lrhost_last_error().decode())
+        self._views.clear()
+        return bool(updated.value)
+
+    def shutter_samples(self, camera: int = 0) -> list[tuple[float, float, int]]:
+        """Camera::shutter_samples (src/base/camera.cpp:163-203) -> [(time, weight, spp)]"""
+        out = []
+        for i in range(self._lib.lrhost_scene_shutter_sample_count(self._handle, camera)):
+            t, w, n = C.c_float(), C.c_float(), C.c_uint32()
+            if self._lib.lrhost_scene_shutter_sample(self._handle, camera, i, C.byref(t), C.byref(w), C.byref(n)) != 0:
+                raise HostError(self._lib.lrhost_last_error().decode())
+            out.append((t.value, w.value, n.value))
+        return out
+
     @property
     def camera_count(self) -> int:
         return self._lib.lrhost_scene_camera_count(self._handle)

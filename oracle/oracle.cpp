@@ -248,6 +248,7 @@ using namespace oracle;
 struct oracle_ctx {
     const lr_scene *scene;
     Accel accel;
+    float shutter_weight{1.f};// Camera::ShutterSample::point.weight of the samples being rendered (integrator.cpp:74)
     explicit oracle_ctx(const lr_scene *s) : scene{s}, accel{*s} {
         if (s->any_non_opaque) {// Geometry::trace_closest / trace_any take the ray-query branch (geometry.cpp:219,264)
             accel.alpha_skip = [this](uint32_t inst, uint32_t prim, float u, float v) { return alpha_skip(inst, prim, u, v); };
@@ -993,6 +994,7 @@ extern "C" {
 
 oracle_ctx *oracle_create(const lr_scene *scene) { return new oracle_ctx{scene}; }
 void oracle_destroy(oracle_ctx *ctx) { delete ctx; }
+void oracle_set_shutter_weight(oracle_ctx *ctx, float weight) { ctx->shutter_weight = weight; }
 
 int oracle_render(oracle_ctx *ctx, uint32_t spp_begin, uint32_t spp_end, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                   int threads, float *film, oracle_counters *counters) {
@@ -1011,7 +1013,7 @@ int oracle_render(oracle_ctx *ctx, uint32_t spp_begin, uint32_t spp_end, uint32_
             for (auto x = x0; x < x1; x++) {
                 for (auto sidx = spp_begin; sidx < spp_end; sidx++) {
                     auto L = ctx->Li(x, y, sidx, st);
-                    film_accumulate(scene, film, x, y, 1.f * L);// shutter weight 1 (static camera)
+                    film_accumulate(scene, film, x, y, ctx->shutter_weight * L);// integrator.cpp:74
                 }
             }
         }

@@ -37,6 +37,10 @@ typedef struct oracle_counters {
 /* builds the canonical two-level BVH2 over `scene`; the scene tables must outlive the ctx */
 oracle_ctx *oracle_create(const lr_scene *scene);
 void oracle_destroy(oracle_ctx *ctx);
+/* Motion blur: the reference renders one Camera::ShutterSample after the other (src/base/integrator.cpp:91-95), the scene moved
+ * to the sample's time and the radiance scaled by the sample's weight (:74).  The caller moves the scene (lrhost_scene_set_time),
+ * creates a ctx over the moved tables and sets the weight (default 1) before oracle_render of that sample's spp range. */
+void oracle_set_shutter_weight(oracle_ctx *ctx, float weight);
 
 /* Accumulates samples [spp_begin, spp_end) of every pixel of the rectangle
  * [x0, x1) x [y0, y1) into `film` (float4[W*H] = (sum r, sum g, sum b, n), the reference's

@@ -56,3 +56,23 @@ def test_cli_renders_the_same_image_as_the_c_abi(tmp_path, integrator):
     renderer.close()
     assert img.shape == ref.shape and np.array_equal(img, ref)  # same kernel, same chunking: bit-identical
     assert img[..., :3].mean() > 0.01 and (img[..., 3] == 1).all()
+
+
+@pytest.mark.gpu
+def test_cli_renders_motion_blur_like_the_c_abi(tmp_path):
+    """the plugin's loop over shutter samples (integrator.cpp:86-107) against MegaPathRenderer.render_frame"""
+    from luisarender_amd.render import MegaPathRenderer
+    from luisarender_amd.scene import load_image
+    from test_motion_blur import MOVING_STRIP
+    scene_file = tmp_path / "strip.luisa"
+    scene_file.write_text(MOVING_STRIP.replace("SPP", "16").replace("SHUTTER", "4").replace("spp { 16 }", 'spp { 16 } file { "blur.exr" }'))
+    r = _run("-b", "hip", str(scene_file))
+    assert r.returncode == 0, r.stderr
+    img, _ = load_image(str(tmp_path / "blur.exr"))
+    sc = Scene.load(str(scene_file))
+    renderer = MegaPathRenderer(0)
+    renderer.render_frame(sc)
+    ref = renderer.download(converted=True)
+    renderer.close()
+    assert np.array_equal(img, ref)
+    assert (img[..., 0] > 0.01).mean() > 0.3  # the streak of the moving strip
