@@ -261,25 +261,6 @@ LR_HD float plastic_substrate_weight(float Fo, float kd_weight) {// plastic.cpp:
     auto w = kd_weight * (1.0f - Fo);
     return w == 0.f ? 0.f : w / (w + Fo);
 }
-// coat + absorbing diffuse substrate in the flipped-to-+z local frame, plastic.cpp:147-163
-LR_HD BsdfEval plastic_eval_local(const DClosure &c, GGX g, f3 wo_l, f3 wi_l) {
-    FresnelArgs fa;
-    fa.mode = kFresnelDielectric, fa.e0 = 1.f, fa.e1 = c.s1, fa.p0 = mk3(0.f), fa.p1 = mk3(0.f);
-    auto eta = c.s1;
-    auto f_coat = mf_reflection_eval(mk3(1.f), g, fa, wo_l, wi_l);
-    auto pdf_coat = mf_reflection_pdf(g, wo_l, wi_l);
-    auto Fi = fresnel_dielectric(abs_cos_theta(wi_l), 1.f, eta);
-    auto Fo = fresnel_dielectric(abs_cos_theta(wo_l), 1.f, eta);
-    auto sigma_a = mk3(c.c1[0], c.c1[1], c.c1[2]);
-    auto a = exp3(-(1.f / abs_cos_theta(wi_l) + 1.f / abs_cos_theta(wo_l)) * sigma_a);
-    auto kd = mk3(c.c0[0], c.c0[1], c.c0[2]);
-    auto lambert = kd * (same_hemisphere(wo_l, wi_l) ? kInvPi : 0.f);
-    auto f_diffuse = (1.f - Fi) * (1.f - Fo) * sqr(1.f / eta) * a * lambert;
-    auto pdf_diffuse = cosine_pdf(wo_l, wi_l);
-    auto w = plastic_substrate_weight(Fo, c.s0);
-    return {(f_coat + f_diffuse) * abs_cos_theta(wi_l), lerp(pdf_coat, pdf_diffuse, w)};
-}
-
 // ---- Disney (src/surfaces/disney.cpp): thick (:351-588) and thin (:590-841) closures on one structure
 LR_HD float schlick_weight(float c) {
     auto m = saturate(1.f - c);
@@ -491,35 +472,68 @@ LR_HD void disney_sample_local(const DisneyLobes &L, f3 wo, float u_lobe, f2 u, 
     }
 }
 
+// ---- the five basic closures in the local shading frame.
+// Divergence is what the shading block pays for (every closure kind present in a wave runs one after the other), so the
+// kinds share code wherever the reference's arithmetic is the same: ONE microfacet-reflection block serves Mirror, Metal,
+// the reflection lobe of Glass and the coat of Plastic; ONE visible-normal sample serves all of them; and
+// Surface::Closure::sample is "pick wi per kind, then evaluate" on the SAME evaluation code as Surface::Closure::evaluate
+// (the reference evaluates the sampled direction with the same functions: BxDF::sample = sample_wi + evaluate + pdf,
+// scattering.cpp:247-254).  Static VALU of evaluate + sample: 3456 -> see DESIGN.md §4.1.
+// Inputs of basic_eval_local are in the frame Plastic works in (flipped so that wo is in +z, plastic.cpp:141-145).
+LR_HD BsdfEval basic_eval_local(const DClosure &c, GGX g, f3 wo_l, f3 wi_l, bool importance) {
+    BsdfEval e{mk3(0.f), 0.f};
+    const auto kind = c.kind;
+    const auto same = same_hemisphere(wo_l, wi_l);
+    const auto reflective = kind == LR_SURFACE_PLASTIC || kind == LR_SURFACE_MIRROR || kind == LR_SURFACE_METAL || (kind == LR_SURFACE_GLASS && same);
+    auto f_r = mk3(0.f);
+    auto pdf_r = 0.f;
+    if (reflective) {// mirror.cpp:101-115, metal.cpp:228-241, glass.cpp:182-185, plastic.cpp:147-150
+        auto fa = closure_fresnel(c);
+        auto R = (kind == LR_SURFACE_METAL || kind == LR_SURFACE_PLASTIC) ? mk3(1.f) : mk3(c.c0[0], c.c0[1], c.c0[2]);
+        f_r = mf_reflection_eval(R, g, fa, wo_l, wi_l);
+        pdf_r = mf_reflection_pdf(g, wo_l, wi_l);
+    }
+    if (kind == LR_SURFACE_MATTE) {// matte.cpp:86-96
+        e.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
+        e.pdf = cosine_pdf(wo_l, wi_l);
+    } else if (kind == LR_SURFACE_PLASTIC) {// coat + absorbing diffuse substrate, plastic.cpp:147-163
+        auto eta = c.s1;
+        auto Fi = fresnel_dielectric(abs_cos_theta(wi_l), 1.f, eta);
+        auto Fo = fresnel_dielectric(abs_cos_theta(wo_l), 1.f, eta);
+        auto sigma_a = mk3(c.c1[0], c.c1[1], c.c1[2]);
+        auto a = exp3(-(1.f / abs_cos_theta(wi_l) + 1.f / abs_cos_theta(wo_l)) * sigma_a);
+        auto kd = mk3(c.c0[0], c.c0[1], c.c0[2]);
+        auto lambert = kd * (same ? kInvPi : 0.f);
+        auto f_diffuse = (1.f - Fi) * (1.f - Fo) * sqr(1.f / eta) * a * lambert;
+        auto pdf_diffuse = cosine_pdf(wo_l, wi_l);
+        auto w = plastic_substrate_weight(Fo, c.s0);
+        e.f = (f_r + f_diffuse) * abs_cos_theta(wi_l);
+        e.pdf = lerp(pdf_r, pdf_diffuse, w);
+    } else if (kind == LR_SURFACE_GLASS && !same) {// glass.cpp:186-190
+        auto ratio = glass_refl_prob(c, wo_l);
+        e.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l, importance) * abs_cos_theta(wi_l);
+        e.pdf = mf_transmission_pdf(g, c.s0, c.s1, wo_l, wi_l) * (1.f - ratio);
+    } else if (kind != LR_SURFACE_NULL) {
+        if (kind == LR_SURFACE_METAL) { f_r = f_r * mk3(c.c2[0], c.c2[1], c.c2[2]); }
+        if (kind == LR_SURFACE_GLASS) { pdf_r *= glass_refl_prob(c, wo_l); }
+        e.f = f_r * abs_cos_theta(wi_l);
+        e.pdf = pdf_r;
+    }
+    return e;
+}
+
 // Surface::Closure::evaluate.  FULL = false compiles the Disney interpreter out (lean kernel variant).
 template<bool FULL>
 LR_HD BsdfEval closure_evaluate(const DClosure &c, const Frame &sh, f3 ng, f3 wo, f3 wi, bool importance = false) {
     auto wo_l = to_local(sh, wo);
     auto wi_l = to_local(sh, wi);
     BsdfEval e{mk3(0.f), 0.f};
-    auto g = make_ggx(c.alpha_x, c.alpha_y);
     if (FULL && c.kind == LR_SURFACE_DISNEY) {
         e = disney_eval_local(disney_setup(c), wo_l, wi_l, importance);
-    } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:86-96
-        e.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
-        e.pdf = cosine_pdf(wo_l, wi_l);
-    } else if (c.kind == LR_SURFACE_PLASTIC) {// plastic.cpp:139-166
-        auto flip = cos_theta(wo_l) < 0.f ? -1.f : 1.f;
+    } else {
+        auto flip = (c.kind == LR_SURFACE_PLASTIC && cos_theta(wo_l) < 0.f) ? -1.f : 1.f;// plastic.cpp:141-145
         wo_l.z *= flip, wi_l.z *= flip;
-        e = plastic_eval_local(c, g, wo_l, wi_l);
-    } else if (c.kind == LR_SURFACE_GLASS && !same_hemisphere(wo_l, wi_l)) {// glass.cpp:186-190
-        auto ratio = glass_refl_prob(c, wo_l);
-        e.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l, importance) * abs_cos_theta(wi_l);
-        e.pdf = mf_transmission_pdf(g, c.s0, c.s1, wo_l, wi_l) * (1.f - ratio);
-    } else if (c.kind != LR_SURFACE_NULL) {// mirror.cpp:101-115, metal.cpp:228-241, glass.cpp:182-185
-        auto fa = closure_fresnel(c);
-        auto R = c.kind == LR_SURFACE_METAL ? mk3(1.f) : mk3(c.c0[0], c.c0[1], c.c0[2]);
-        auto f = mf_reflection_eval(R, g, fa, wo_l, wi_l);
-        auto pdf = mf_reflection_pdf(g, wo_l, wi_l);
-        if (c.kind == LR_SURFACE_METAL) { f = f * mk3(c.c2[0], c.c2[1], c.c2[2]); }
-        if (c.kind == LR_SURFACE_GLASS) { pdf *= glass_refl_prob(c, wo_l); }
-        e.f = f * abs_cos_theta(wi_l);
-        e.pdf = pdf;
+        e = basic_eval_local(c, make_ggx(c.alpha_x, c.alpha_y), wo_l, wi_l, importance);
     }
     if (!valid_sides(ng, sh.n, wo, wi)) { e.f = mk3(0.f), e.pdf = 0.f; }
     return e;
@@ -530,7 +544,6 @@ template<bool FULL>
 LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo, float u_lobe, f2 u, bool importance = false) {
     auto wo_l = to_local(sh, wo);
     BsdfSample s{mk3(0.f), 0.f, mk3(0.f, 0.f, 1.f), kEventReflect};
-    auto g = make_ggx(c.alpha_x, c.alpha_y);
     if (FULL && c.kind == LR_SURFACE_DISNEY) {
         auto L = disney_setup(c);
         f3 wi_l;
@@ -541,57 +554,47 @@ LR_HD BsdfSample closure_sample(const DClosure &c, const Frame &sh, f3 ng, f3 wo
             auto e = disney_eval_local(L, wo_l, wi_l, importance);
             s.f = e.f, s.pdf = e.pdf;
         }
-    } else if (c.kind == LR_SURFACE_MATTE) {// matte.cpp:98-112
-        auto wi_l = cosine_sample_wi(wo_l, u);
-        s.pdf = cosine_pdf(wo_l, wi_l);
-        s.f = oren_nayar_eval(mk3(c.c0[0], c.c0[1], c.c0[2]), c.s0, wo_l, wi_l) * abs_cos_theta(wi_l);
-        s.wi = to_world(sh, wi_l);
-    } else if (c.kind == LR_SURFACE_PLASTIC) {// plastic.cpp:168-213
-        auto flip = cos_theta(wo_l) < 0.f ? -1.f : 1.f;
+    } else if (c.kind != LR_SURFACE_NULL) {
+        const auto kind = c.kind;
+        auto g = make_ggx(c.alpha_x, c.alpha_y);
+        auto flip = (kind == LR_SURFACE_PLASTIC && cos_theta(wo_l) < 0.f) ? -1.f : 1.f;
         wo_l.z *= flip;
-        auto Fo = fresnel_dielectric(abs_cos_theta(wo_l), 1.f, c.s1);
-        auto w = plastic_substrate_weight(Fo, c.s0);
+        // ---- which lobe (plastic.cpp:168-181, glass.cpp:203-207)
+        auto diffuse = kind == LR_SURFACE_MATTE;
+        auto transmit = false;
+        if (kind == LR_SURFACE_PLASTIC) {
+            auto Fo = fresnel_dielectric(abs_cos_theta(wo_l), 1.f, c.s1);
+            diffuse = u_lobe < plastic_substrate_weight(Fo, c.s0);
+        } else if (kind == LR_SURFACE_GLASS) {
+            transmit = !(u_lobe < glass_refl_prob(c, wo_l));
+        }
+        // ---- the direction
         f3 wi_l;
         auto valid = true;
-        if (u_lobe < w) {
+        if (diffuse) {// matte.cpp:98-112, plastic.cpp:183-186
             wi_l = cosine_sample_wi(wo_l, u);
         } else {
-            wi_l = reflect(-wo_l, ggx_sample_wh(g, wo_l, u));
-            valid = same_hemisphere(wo_l, wi_l);
+            auto wh = ggx_sample_wh(g, wo_l, u);
+            if (!transmit) {// reflection: BxDF::sample, scattering.cpp:247-254
+                wi_l = reflect(-wo_l, wh);
+                valid = same_hemisphere(wo_l, wi_l);
+            } else {// glass transmission, glass.cpp:216-223, scattering.cpp:348-353
+                auto eta = cos_theta(wo_l) > 0.f ? c.s0 / c.s1 : c.s1 / c.s0;
+                wi_l = mk3(0.f);
+                auto refr = refract_dir(wo_l, wh, eta, wi_l);
+                valid = refr && !same_hemisphere(wo_l, wi_l);
+                s.event = cos_theta(wo_l) > 0.f ? kEventEnter : kEventExit;
+            }
         }
+        // ---- its value: the same code Surface::Closure::evaluate runs
         if (valid) {
-            auto e = plastic_eval_local(c, g, wo_l, wi_l);
+            auto e = basic_eval_local(c, g, wo_l, wi_l, importance);
             s.f = e.f, s.pdf = e.pdf;
+        }
+        if (valid || kind != LR_SURFACE_PLASTIC) {// (an invalid Plastic sample leaves wi at its default, plastic.cpp:196-206)
             wi_l.z *= flip;
             s.wi = to_world(sh, wi_l);
         }
-    } else if (c.kind != LR_SURFACE_NULL) {
-        auto ratio = c.kind == LR_SURFACE_GLASS ? glass_refl_prob(c, wo_l) : 1.f;
-        auto wh = ggx_sample_wh(g, wo_l, u);
-        f3 wi_l;
-        if (c.kind != LR_SURFACE_GLASS || u_lobe < ratio) {// reflection: BxDF::sample, scattering.cpp:247-254
-            wi_l = reflect(-wo_l, wh);
-            if (same_hemisphere(wo_l, wi_l)) {
-                auto fa = closure_fresnel(c);
-                auto R = c.kind == LR_SURFACE_METAL ? mk3(1.f) : mk3(c.c0[0], c.c0[1], c.c0[2]);
-                s.f = mf_reflection_eval(R, g, fa, wo_l, wi_l);
-                s.pdf = mf_reflection_pdf(g, wo_l, wi_l);
-                if (c.kind == LR_SURFACE_METAL) { s.f = s.f * mk3(c.c2[0], c.c2[1], c.c2[2]); }
-            }
-            s.pdf *= ratio;
-        } else {// glass transmission, glass.cpp:216-223, scattering.cpp:348-353
-            auto eta = cos_theta(wo_l) > 0.f ? c.s0 / c.s1 : c.s1 / c.s0;
-            wi_l = mk3(0.f);
-            auto refr = refract_dir(wo_l, wh, eta, wi_l);
-            if (refr && !same_hemisphere(wo_l, wi_l)) {
-                s.f = mf_transmission_eval(mk3(c.c1[0], c.c1[1], c.c1[2]), g, c.s0, c.s1, wo_l, wi_l, importance);
-                s.pdf = mf_transmission_pdf(g, c.s0, c.s1, wo_l, wi_l);
-            }
-            s.pdf *= (1.f - ratio);
-            s.event = cos_theta(wo_l) > 0.f ? kEventEnter : kEventExit;
-        }
-        s.f = s.f * abs_cos_theta(wi_l);
-        s.wi = to_world(sh, wi_l);
     }
     if (!valid_sides(ng, sh.n, wo, s.wi)) { s.f = mk3(0.f), s.pdf = 0.f; }
     return s;

@@ -241,6 +241,14 @@ class Reinserter {
     }
     // make `fresh` the parent of (target, x) in target's place
     void insert(uint32_t x, uint32_t target, uint32_t fresh) {
+        if (target == 0u) {// pairing with the whole tree: the root keeps index 0, its old content moves into `fresh`
+            _n[fresh] = _n[0];
+            if (_n[fresh].count == 0u) { _parent[_n[fresh].left] = fresh, _parent[_n[fresh].right] = fresh; }
+            _n[0].left = fresh, _n[0].right = x, _n[0].count = 0u;
+            _parent[fresh] = 0u, _parent[x] = 0u;
+            refit_up(0u);
+            return;
+        }
         auto p = _parent[target];
         _n[fresh].left = target, _n[fresh].right = x, _n[fresh].count = 0u;
         _parent[fresh] = p;
@@ -320,6 +328,7 @@ void relinearise(std::vector<Node2> &nodes, std::vector<uint32_t> &indices) {
             stack.push_back({nd.left, id, false});
         }
     }
+    if (new_indices.size() != indices.size()) { throw Error{"BVH2 lost references during optimisation (internal error)."}; }
     nodes = std::move(out);
     indices = std::move(new_indices);
 }
