@@ -35,7 +35,7 @@ namespace lrd {
 constexpr uint32_t kBlockThreads = 256u;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / 64u;
 #ifndef LR_STACK_LDS
-#define LR_STACK_LDS 12
+#define LR_STACK_LDS 16
 #endif
 constexpr uint32_t kStackLds = LR_STACK_LDS; // entries per lane kept in LDS
 constexpr uint32_t kSpillEntries = 88u;      // HBM overflow entries per lane
