@@ -485,7 +485,10 @@ LoadedImage load_image(const std::string &path_in) {
     if (ext == ".exr") { return read_exr(path); }
     if (ext == ".ppm" || ext == ".pgm") { return read_pnm(path); }
     if (ext == ".png") { return read_png(path); }
-    throw Error{"Image format '" + ext + "' is not supported (stb is absent); supported: .pfm .hdr .exr (NONE/ZIPS/ZIP) .png .ppm .pgm — '" +
+    if (ext == ".jpg" || ext == ".jpeg") { return read_jpeg(path.string()); }
+    if (ext == ".bmp") { return read_bmp(path.string()); }
+    if (ext == ".tga") { return read_tga(path.string()); }
+    throw Error{"Image format '" + ext + "' is not supported (stb is absent); supported: .pfm .hdr .exr (NONE/ZIPS/ZIP) .png .jpg .bmp .tga .ppm .pgm — '" +
                 path.string() + "'."};
 }
 

@@ -134,5 +134,9 @@ struct LoadedImage {
     std::vector<float> pixels;// float4 per pixel, row 0 = top
 };
 LoadedImage load_image(const std::string &path);
+// image_codecs.cpp: the LDR formats the reference reads through stb_image (imageio.cpp:486-538)
+LoadedImage read_jpeg(const std::string &path);
+LoadedImage read_bmp(const std::string &path);
+LoadedImage read_tga(const std::string &path);
 
 }// namespace lr

@@ -140,8 +140,106 @@ def test_exr_and_hdr_round_trip_of_our_own_writer(tmp_path):
     assert (np.abs(got[..., :3] - img[..., :3]) <= step).all()
 
 
+def _test_picture(w, h, seed=3):
+    """smooth colour ramps + a few hard edges + noise: exercises DC / AC coefficients and chroma upsampling"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 100 * np.sin(x / 7.0), 127 + 100 * np.cos(y / 5.0 + x / 11.0), (x * 255 // max(w - 1, 1))], axis=-1)
+    img[h // 3: h // 2, w // 4: w // 2] = (250, 20, 30)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.mark.parametrize("mode,subsampling,progressive,size,restart", [
+    ("RGB", 0, False, (64, 48), 0),     # 4:4:4 baseline
+    ("RGB", 1, False, (67, 45), 0),     # 4:2:2, ragged size
+    ("RGB", 2, False, (70, 53), 0),     # 4:2:0 (the usual texture file)
+    ("RGB", 2, True, (70, 53), 0),      # progressive: spectral selection + successive approximation
+    ("RGB", 0, True, (33, 17), 0),
+    ("L", 0, False, (40, 40), 0),       # greyscale
+    ("L", 0, True, (41, 23), 0),
+    ("RGB", 2, False, (120, 90), 4),    # restart intervals
+    ("RGB", 2, False, (1, 1), 0),
+    ("RGB", 2, False, (9, 3), 0),
+])
+def test_jpeg_reader_against_libjpeg(tmp_path, mode, subsampling, progressive, size, restart):
+    """Our decoder restates stb_image's numerics (integer LLM IDCT, 3:1 triangle chroma upsampling, fixed-point YCbCr);
+    PIL decodes with libjpeg's (ISLOW IDCT, its own fancy upsampling): the same picture within a few code values."""
+    w, h = size
+    pic = _test_picture(w, h)
+    im = PIL.fromarray(pic if mode == "RGB" else pic[..., 1], mode)
+    path = tmp_path / "t.jpg"
+    kw = dict(quality=92, progressive=progressive)
+    if mode == "RGB":
+        kw["subsampling"] = subsampling
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    im.save(path, **kw)
+    got, ch = load_image(str(path))
+    ref = np.asarray(PIL.open(path).convert("RGB"), np.float32) / 255.0
+    assert ch == (3 if mode == "RGB" else 1) and got.shape == (h, w, 4) and (got[..., 3] == 1).all()
+    err = np.abs(got[..., :3] - ref)
+    # IDCT / upsampling / colour rounding differ by a code value or two; 4:2:0 edges a little more
+    assert err.mean() < (1.2 if subsampling else 0.6) / 255 and np.quantile(err, 0.99) <= 6 / 255 and err.max() <= 24 / 255, (err.mean() * 255, err.max() * 255)
+    # and both are the picture that went in, up to the quantisation
+    assert np.abs(got[..., :3] - (pic if mode == "RGB" else pic[..., 1:2].repeat(3, -1)) / 255.0).mean() < 8 / 255
+
+
+def test_jpeg_flat_blocks_are_exact(tmp_path):
+    """a constant picture has only DC coefficients: every decoder must reproduce the same flat value"""
+    im = PIL.fromarray(np.full((16, 24, 3), (200, 100, 50), np.uint8), "RGB")
+    im.save(tmp_path / "flat.jpg", quality=100, subsampling=0)
+    got, _ = load_image(str(tmp_path / "flat.jpg"))
+    ref = np.asarray(PIL.open(tmp_path / "flat.jpg").convert("RGB"), np.float32) / 255.0
+    assert np.abs(got[..., :3] - ref).max() <= 1 / 255 + 1e-6
+    assert np.ptp(got[..., 0]) == 0 and np.ptp(got[..., 1]) == 0
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P"])
+def test_bmp_reader(tmp_path, mode):
+    pic = _test_picture(37, 21)
+    if mode == "RGBA":
+        src = np.concatenate([pic, (pic[..., :1] // 2 + 100)], axis=-1)
+    elif mode == "L":
+        src = pic[..., 0]
+    else:
+        src = pic
+    im = PIL.fromarray(src, "RGB" if mode == "P" else mode)
+    if mode == "P":
+        im = im.quantize(64)
+    im.save(tmp_path / "t.bmp")
+    got, ch = load_image(str(tmp_path / "t.bmp"))
+    ref = np.asarray(PIL.open(tmp_path / "t.bmp").convert("RGBA"), np.float32) / 255.0
+    if mode == "RGBA":  # PIL drops the alpha byte of a 32-bit BI_RGB file when reading; stb_image (and this reader) keep it
+        ref[..., 3] = src[..., 3] / 255.0
+    assert got.shape == ref.shape and np.allclose(got, ref, atol=1e-6), mode
+    assert ch == (4 if mode == "RGBA" else 3)
+
+
+@pytest.mark.parametrize("mode,rle", [("RGB", False), ("RGB", True), ("RGBA", False), ("RGBA", True), ("L", False), ("L", True), ("P", False)])
+def test_tga_reader(tmp_path, mode, rle):
+    pic = _test_picture(29, 18)
+    pic[4:9, 3:20] = (10, 200, 30)  # runs for the RLE packets
+    src = np.concatenate([pic, (pic[..., :1] // 2 + 100)], axis=-1) if mode == "RGBA" else (pic[..., 0] if mode == "L" else pic)
+    im = PIL.fromarray(src, "RGB" if mode == "P" else mode)
+    if mode == "P":
+        im = im.quantize(32)
+    im.save(tmp_path / "t.tga", compression="tga_rle" if rle else None)
+    got, ch = load_image(str(tmp_path / "t.tga"))
+    ref = np.asarray(PIL.open(tmp_path / "t.tga").convert("RGBA"), np.float32) / 255.0
+    assert got.shape == ref.shape and np.allclose(got, ref, atol=1e-6), (mode, rle)
+    assert ch == {"RGB": 3, "RGBA": 4, "L": 1, "P": 3}[mode]
+
+
 def test_unsupported_formats_fail_loudly(tmp_path):
     p = tmp_path / "x.jpg"
     p.write_bytes(b"\xff\xd8\xff")
     with pytest.raises(HostError):
         load_image(str(p))
+    q = tmp_path / "x.gif"
+    q.write_bytes(b"GIF89a")
+    with pytest.raises(HostError):
+        load_image(str(q))
