@@ -251,8 +251,9 @@ LoadedImage read_exr(const fs::path &path) {
     p++;
     // NO_COMPRESSION (0), ZIPS (2: one scanline per chunk), ZIP (3: 16 scanlines per chunk); the deflate streams go
     // through zlib (the reference reads EXR with tinyexr + miniz, src/util/imageio.cpp:419-538)
-    if (compression != 0u && compression != 2u && compression != 3u) {
-        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / ZIPS / ZIP are): '" + path.string() + "'."};
+    // and RLE (1: one scanline per chunk; signed run bytes, then the same predictor + byte de-interleave as ZIP)
+    if (compression > 3u) {
+        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP are): '" + path.string() + "'."};
     }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
     LoadedImage img;
@@ -290,9 +291,28 @@ LoadedImage read_exr(const fs::path &path) {
             raw.assign(src, src + expect);
         } else {
             tmp.resize(expect);
+            if (compression == 1u) {// a count byte n: n >= 0 -> the next byte n + 1 times; n < 0 -> -n literal bytes
+                size_t in = 0u, out = 0u;
+                while (in < packed && out < expect) {
+                    auto n = static_cast<int8_t>(src[in++]);
+                    if (n < 0) {
+                        auto count = static_cast<size_t>(-static_cast<int>(n));
+                        if (in + count > packed || out + count > expect) { break; }
+                        std::memcpy(tmp.data() + out, src + in, count);
+                        in += count, out += count;
+                    } else {
+                        auto count = static_cast<size_t>(n) + 1u;
+                        if (in >= packed || out + count > expect) { break; }
+                        std::memset(tmp.data() + out, src[in++], count);
+                        out += count;
+                    }
+                }
+                if (out != expect) { throw Error{"Corrupt RLE chunk in EXR image '" + path.string() + "'."}; }
+            } else {
             uLongf out_len = static_cast<uLongf>(expect);
             if (uncompress(tmp.data(), &out_len, src, packed) != Z_OK || out_len != expect) {
                 throw Error{"Corrupt ZIP chunk in EXR image '" + path.string() + "'."};
+            }
             }
             for (size_t i = 1; i < expect; i++) { tmp[i] = static_cast<uint8_t>(tmp[i - 1u] + tmp[i] - 128u); }// predictor
             raw.resize(expect);

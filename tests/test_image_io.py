@@ -75,6 +75,25 @@ def test_png_palette(tmp_path):
     assert channels == 3 and np.allclose(img[..., :3], palette[idx[..., 0]] / 255.0, atol=1e-6) and (img[..., 3] == 1).all()
 
 
+def _rle(data):
+    """OpenEXR's run-length code: count byte n >= 0 -> next byte repeated n + 1 times (runs of 3..128); n < 0 -> -n literals"""
+    out, i, n = bytearray(), 0, len(data)
+    while i < n:
+        run = 1
+        while i + run < n and data[i + run] == data[i] and run < 128:
+            run += 1
+        if run >= 3:
+            out += bytes([run - 1, data[i]])
+            i += run
+        else:
+            j = i
+            while j < n and j - i < 127 and not (j + 2 < n and data[j] == data[j + 1] == data[j + 2]):
+                j += 1
+            out += bytes([(256 - (j - i)) & 255]) + data[i:j]
+            i = j
+    return bytes(out)
+
+
 def _exr(path, img, compression, half):
     """scanline OpenEXR writer: compression 0 (none) / 2 (ZIPS) / 3 (ZIP), channels B G R (alphabetical) as half or float"""
     h, w = img.shape[:2]
@@ -103,7 +122,7 @@ def _exr(path, img, compression, half):
             d[0] = t[0]
             for i in range(1, n):
                 d[i] = (t[i] - t[i - 1] + 128 + 256) & 255
-            z = zlib.compress(bytes(d))
+            z = _rle(bytes(d)) if compression == 1 else zlib.compress(bytes(d))
             payload = z if len(z) < n else raw
         else:
             payload = raw
@@ -116,7 +135,7 @@ def _exr(path, img, compression, half):
     open(path, "wb").write(head + b"".join(struct.pack("<Q", o) for o in offsets) + b"".join(chunks))
 
 
-@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
 @pytest.mark.parametrize("half", [True, False])
 def test_exr_reader_with_zip_compression(tmp_path, compression, half):
     w, h = 53, 37  # not a multiple of the 16-line ZIP block
