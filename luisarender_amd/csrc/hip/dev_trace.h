@@ -88,6 +88,9 @@ struct TraversalStack {
 #ifndef LR_PUSH_UNSORTED
 #define LR_PUSH_UNSORTED 0
 #endif
+#ifndef LR_LDS_DIRECT
+#define LR_LDS_DIRECT 1
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 LR_D void cswap(uint32_t &a, uint32_t &b) {
@@ -161,6 +164,22 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             auto n1 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 16u)));
             auto n2 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 32u)));
             auto n3 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 48u)));
+#if LR_LDS_DIRECT
+            // global_load_lds_dwordx4: the 16 bytes of lane l land at stage[l] without a trip through the VGPRs; the XOR
+            // swizzle moves from the LDS address to WHICH part of the packet a lane asks for
+            {
+                typedef __attribute__((address_space(3))) void lds_void;
+                typedef __attribute__((address_space(1))) const void global_void;
+                const auto psw = part ^ ((owner0 >> 2u) & 3u);
+                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n0) * 4u + psw), (lds_void *)(stack.stage), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n1) * 4u + psw), (lds_void *)(stack.stage + 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n2) * 4u + psw), (lds_void *)(stack.stage + 128), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n3) * 4u + psw), (lds_void *)(stack.stage + 192), 16, 0, 0);
+                __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+#else
             auto v0 = nodes[static_cast<size_t>(n0) * 4u + part];
             auto v1 = nodes[static_cast<size_t>(n1) * 4u + part];
             auto v2 = nodes[static_cast<size_t>(n2) * 4u + part];
@@ -174,6 +193,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
             auto q0 = stack.stage[lane * 4u + (0u ^ my_swz)];
             auto q1 = stack.stage[lane * 4u + (1u ^ my_swz)];
             auto q2 = stack.stage[lane * 4u + (2u ^ my_swz)];

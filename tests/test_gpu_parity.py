@@ -498,3 +498,22 @@ def test_volumetric_megakernel(renderer, case):
         renderer.render(0, 64, sync=True)
         p = _blocks(renderer.download(converted=False))
         assert np.abs(p - c).sum() / np.abs(c).sum() > 0.25
+
+
+def test_edge_cases(renderer):
+    """tiny and ragged films, one sample, a one-triangle scene (the BVH root is a leaf), an empty sample range"""
+    for res, spp in (((1, 1), 1), ((3, 5), 2), ((9, 8), 1), ((17, 1), 3)):
+        sc = Scene.from_string(cornell_box(resolution=res, spp=spp))
+        gpu, gc, cpu, cc = _render_both(renderer, sc, spp)
+        assert gpu.shape == (res[1], res[0], 4) and np.array_equal(gpu[..., 3], cpu[..., 3]) and (gpu[..., 3] == spp).all()
+        assert gc["closest_rays"] == cc["closest_rays"] and _rel_l1(gpu, cpu) < 1e-4, res
+    one = Scene.from_string("""
+Shape tri : InlineMesh { positions { -1,-1,0, 1,-1,0, 0,1,0 } indices { 0,1,2 } light : Diffuse { emission : Constant { v { 2, 3, 4 } } two_sided { true } } }
+Camera cam : Pinhole { fov { 50 } spp { 4 } film : Color { resolution { 24, 24 } } position { 0, 0, 3 } look_at { 0, 0, 0 } }
+render { cameras { @cam } shapes { @tri } integrator : MegaPath { depth { 3 } } }
+""")
+    gpu, gc, cpu, cc = _render_both(renderer, one, 4)
+    assert gc["closest_rays"] == cc["closest_rays"] and _rel_l1(gpu, cpu) < 1e-5 and gpu[12, 12, 0] > 0 and gpu[0, 0, 0] == 0
+    renderer.upload(one)
+    renderer.render(2, 2, sync=True)  # empty sample range: nothing happens
+    assert not renderer.download(converted=False).any()
