@@ -4,15 +4,22 @@ sys.path.insert(0, '.')
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
 from luisarender_amd.scenes import generate_room_scene
+from luisarender_amd.scenes.configs import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"   # c2 | c3 | c4 | c5 (the bench's stand-ins, at 1024 x 1024 / 1280 x 720)
 with tempfile.TemporaryDirectory() as tmp:
-    sc = Scene.load(generate_room_scene(tmp, resolution=(1024, 1024), spp=spp))
+    gen = {"c2": lambda: generate_room_scene(tmp, resolution=(1024, 1024), spp=spp),
+           "c3": lambda: generate_bedroom_scene(tmp, resolution=(1280, 720), spp=spp),
+           "c4": lambda: generate_camera_scene(tmp, resolution=(1280, 720), spp=spp),
+           "c5": lambda: generate_kitchen_scene(tmp, resolution=(1280, 720), spp=spp)}[workload]
+    sc = Scene.load(gen())
     r = MegaPathRenderer(0)
     r.upload(sc)
     r.render(0, spp, counters=True, sync=True)
     c = r.counters()
     rays = c['closest_rays'] + c['shadow_rays']
     print(c)
+    print('variant', r.last_variant())
     print('ms', r.last_render_ms(), 'rays/sample', rays / c['paths'], 'nodes/ray', c['nodes_visited'] / rays, 'tris/ray', c['tris_tested'] / rays)
     print('trace lane utilisation', c['trace_steps_busy'] / max(c['trace_steps'], 1), 'steps per ray-lane', c['trace_steps_busy'] / rays)
     print('trace lanes starved (no sample left for the pixel)', c['trace_steps_starved'] / max(c['trace_steps'], 1))
