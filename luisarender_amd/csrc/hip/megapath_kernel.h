@@ -83,9 +83,9 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 // waves per SIMD requested from the register allocator (512 VGPRs / waves).  Measured (Msamples/s at 2 / 3 / 4 waves):
 // lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 174 / 192 / 149
 // (with the heavy closures out of line; 165 / 141 / 104 when they were inlined into the shading block).  3 waves
-// (168 VGPRs) is NOT used for the Layered variants although it is the fastest: that build produced NaN samples in
-// tests/test_gpu_parity.py::test_layered_closure while 2 and 4 do not (unexplained; every function stays inside the
-// 168-register budget) — parity first.
+// (168 VGPRs) is NOT used for the Layered variants although it is the fastest: that build is miscompiled — NaN samples
+// all over tests/test_gpu_parity.py::test_layered_closure — by the compiler's SGPR-to-VGPR-lane spilling around the
+// out-of-line calls (with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 it is bit-identical to the 2-wave build, and slow).
 #ifndef LR_WAVES_LAYERED
 #define LR_WAVES_LAYERED 2
 #endif
