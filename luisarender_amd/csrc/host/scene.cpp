@@ -678,7 +678,7 @@ public:
     ShapeInfo shape_info(const NodeDesc *d) const {
         auto &impl = d->impl_type();
         ShapeInfo info{};
-        info.is_mesh = impl == "mesh" || impl == "inlinemesh" || impl == "sphere";
+        info.is_mesh = impl == "mesh" || impl == "inlinemesh" || impl == "sphere" || impl == "loopsubdiv";
         if (!info.is_mesh && impl != "group" && impl != "instance") {
             throw Error{"Unsupported shape implementation '" + impl + "'. [" + d->location() + "]"};
         }
@@ -690,11 +690,8 @@ public:
         return info;
     }
 
-    uint32_t load_mesh(const NodeDesc *d, uint32_t &properties) {
-        if (auto it = _shape_meshes.find(d); it != _shape_meshes.end()) {
-            properties = _shape_props.at(d);
-            return it->second;
-        }
+    // Shape::mesh() of the mesh-like shapes (vertices, triangles, vertex property flags)
+    LoadedMesh mesh_data(const NodeDesc *d) {
         LoadedMesh mesh;
         auto &impl = d->impl_type();
         if (impl == "inlinemesh") {// inline_mesh.cpp:21-58
@@ -732,10 +729,34 @@ public:
                 throw Error{"Mesh subdivision is not supported (SURVEY §2 row 17). [" + d->location() + "]"};
             }
             mesh = load_obj_mesh(path, d->bool_or("flip_uv", false), d->bool_or("drop_normal", false), d->bool_or("drop_uv", false));
+        } else if (impl == "sphere") {// sphere.cpp:113-117
+            mesh = make_sphere_mesh(std::min(d->uint_or("subdivision", 0u), 8u));
+        } else if (impl == "loopsubdiv") {// loop_subdiv.cpp:24-58
+            auto base = d->node_or_null("mesh");
+            if (base == nullptr) { base = d->node_or_null("shape"); }
+            if (base == nullptr) { base = d->node("base"); }
+            _check_tag(base, Tag::SHAPE);
+            if (!shape_info(base).is_mesh) { throw Error{"LoopSubdiv only supports mesh shapes. [" + d->location() + "]"}; }
+            auto level = std::min(d->uint_or("level", 1u), 10u);
+            mesh = mesh_data(base);
+            if (level == 0u) {
+                log_warning("LoopSubdiv level is 0, which is equivalent to no subdivision. [" + d->location() + "]");
+            } else {
+                mesh = loop_subdivide(mesh.vertices, mesh.triangles, level);// (normals only: "TODO: preserve uv mapping", :17)
+            }
         } else {
-            throw Error{"Shape '" + impl + "' is scheduled after the bar (SURVEY §2 row 17). [" + d->location() + "]"};
+            throw Error{"Unknown mesh shape '" + impl + "'. [" + d->location() + "]"};
         }
         if (mesh.vertices.empty() || mesh.triangles.empty()) { throw Error{"Empty mesh. [" + d->location() + "]"}; }
+        return mesh;
+    }
+
+    uint32_t load_mesh(const NodeDesc *d, uint32_t &properties) {
+        if (auto it = _shape_meshes.find(d); it != _shape_meshes.end()) {
+            properties = _shape_props.at(d);
+            return it->second;
+        }
+        auto mesh = mesh_data(d);
         // dedup by content (geometry.cpp:53-57)
         auto hash = fnv1a(mesh.vertices.data(), mesh.vertices.size() * sizeof(lr_vertex));
         hash = fnv1a(mesh.triangles.data(), mesh.triangles.size() * sizeof(lr_triangle), hash);

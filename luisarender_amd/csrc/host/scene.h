@@ -125,6 +125,9 @@ struct LoadedMesh {
     uint32_t properties{0u};
 };
 LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv);
+// subdiv.cpp: Loop subdivision (src/util/loop_subdiv.cpp) and the icosphere of the Sphere shape (src/shapes/sphere.cpp)
+LoadedMesh loop_subdivide(const std::vector<lr_vertex> &vertices, const std::vector<lr_triangle> &triangles, uint32_t levels);
+LoadedMesh make_sphere_mesh(uint32_t subdivision);
 
 // image_io.cpp
 void save_image(const std::string &path, const float *rgba, uint32_t width, uint32_t height);// src/util/imageio.cpp:694-726

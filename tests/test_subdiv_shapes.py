@@ -1,0 +1,93 @@
+"""Sphere (src/shapes/sphere.cpp) and LoopSubdiv (src/shapes/loop_subdiv.cpp, src/util/loop_subdiv.cpp) shapes: closed forms
+of the subdivision (counts, watertightness, the limit surface of an icosahedron, boundary rules on an open grid) and a render."""
+import numpy as np
+import pytest
+
+from luisarender_amd import Scene
+from luisarender_amd.oracle_check import Oracle
+
+SPHERE = """
+Shape ball : Sphere { subdivision { LEVEL } surface : Matte { Kd : Constant { v { 0.8 } } } transform : SRT { scale { 2, 2, 2 } translate { 0, 1, 0 } } }
+Camera cam : Pinhole { fov { 40 } spp { 16 } film : Color { resolution { 32, 32 } } position { 0, 1, 9 } look_at { 0, 1, 0 } }
+render { cameras { @cam } shapes { @ball } environment : Spherical { emission : Constant { v { 1 } } } integrator : MegaPath { depth { 6 } } }
+"""
+
+
+def _mesh(sc, m=0):
+    v = sc.view()
+    mesh = v.meshes[m]
+    verts = np.array([[v.vertices[mesh.vertex_offset + i].px, v.vertices[mesh.vertex_offset + i].py, v.vertices[mesh.vertex_offset + i].pz,
+                       v.vertices[mesh.vertex_offset + i].nx, v.vertices[mesh.vertex_offset + i].ny, v.vertices[mesh.vertex_offset + i].nz,
+                       v.vertices[mesh.vertex_offset + i].u, v.vertices[mesh.vertex_offset + i].v] for i in range(mesh.vertex_count)])
+    tris = np.array([[v.triangles[mesh.triangle_offset + i].i0, v.triangles[mesh.triangle_offset + i].i1, v.triangles[mesh.triangle_offset + i].i2]
+                     for i in range(mesh.triangle_count)])
+    return verts, tris
+
+
+def _edges(tris):
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]])
+    return e
+
+
+@pytest.mark.parametrize("level", [0, 1, 3])
+def test_sphere_is_a_watertight_unit_icosphere(level):
+    sc = Scene.from_string(SPHERE.replace("LEVEL", str(level)), build_accel=False)
+    verts, tris = _mesh(sc)
+    assert len(tris) == 20 * 4 ** level and len(verts) == 10 * 4 ** level + 2  # Euler: V - E + F = 2
+    p, n, uv = verts[:, :3], verts[:, 3:6], verts[:, 6:]
+    assert np.allclose(np.linalg.norm(p, axis=1), 1, atol=1e-6) and np.allclose(n, p, atol=1e-7)  # pushed to the unit sphere
+    assert np.isfinite(uv).all() and ((uv >= 0) & (uv <= 1)).all()  # fract(-tiny) rounds to 1.0f
+    e = _edges(tris)
+    directed = {(a, b) for a, b in e.tolist()}
+    assert len(directed) == len(e) and all((b, a) in directed for a, b in directed)  # every edge twice, opposite ways
+    # outward orientation: the face normal points away from the centre
+    fn = np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]])
+    assert (np.einsum("ij,ij->i", fn, p[tris].mean(axis=1)) > 0).all()
+    # area converges to 4 pi from below
+    area = 0.5 * np.linalg.norm(fn, axis=1).sum()
+    assert area < 4 * np.pi and area > 4 * np.pi * {0: 0.75, 1: 0.92, 3: 0.99}[level]
+
+
+def test_loop_subdivision_rules_on_an_open_grid():
+    """a flat 2 x 2 grid of quads (8 triangles, boundary all around): the limit surface stays in the plane, the boundary stays on
+    the boundary, corners follow the boundary rule, every limit normal is the plane normal"""
+    pos = [(x, y, 0) for y in range(3) for x in range(3)]
+    idx = []
+    for y in range(2):
+        for x in range(2):
+            a, b, c, d = y * 3 + x, y * 3 + x + 1, (y + 1) * 3 + x + 1, (y + 1) * 3 + x
+            idx += [a, b, c, a, c, d]
+    text = f"""
+Shape grid : InlineMesh {{ positions {{ {", ".join(str(c) for p in pos for c in p)} }} indices {{ {", ".join(map(str, idx))} }} }}
+Shape smooth : LoopSubdiv {{ mesh {{ @grid }} level {{ 2 }} surface : Matte {{ }} }}
+Camera cam : Pinhole {{ spp {{ 1 }} film : Color {{ resolution {{ 4, 4 }} }} position {{ 1, 1, 5 }} look_at {{ 1, 1, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @smooth }} environment : Spherical {{ emission : Constant {{ v {{ 1 }} }} }} integrator : MegaPath {{ }} }}
+"""
+    sc = Scene.from_string(text, build_accel=False)
+    verts, tris = _mesh(sc)
+    assert len(tris) == 8 * 16 and len(verts) == 81  # 9 x 9 grid points
+    p, n = verts[:, :3], verts[:, 3:6]
+    assert np.allclose(p[:, 2], 0, atol=1e-7) and np.allclose(np.abs(n), [[0, 0, 1]] * len(n), atol=1e-6)
+    assert p[:, 0].min() > -1e-6 and p[:, 0].max() < 2 + 1e-6  # the boundary curve shrinks at the corners, never grows
+    # the regular interior vertex keeps its place (symmetric stencil), the 4 corners moved inwards along the diagonal
+    assert np.any(np.all(np.isclose(p[:, :2], [1, 1], atol=1e-6), axis=1))
+    corner = p[np.argmin(p[:, 0] + p[:, 1])]
+    assert 0 < corner[0] < 0.5 and corner[0] == pytest.approx(corner[1], abs=1e-6)
+    v = sc.view()
+    assert v.instances[0].handle.x & 0x3ff  # vertex-normal flag set: the subdivided mesh carries normals
+
+
+def test_sphere_renders_like_a_ball_under_a_white_sky():
+    """white furnace: a grey ball under a constant white environment has radiance <= 1 everywhere, 1 on the background, and its
+    silhouette covers the disc a unit-2 sphere projects to"""
+    sc = Scene.from_string(SPHERE.replace("LEVEL", "4"))
+    film, _ = Oracle(sc).render(0, 16)
+    img = film[..., :3] / film[..., 3:4]
+    assert np.isfinite(img).all() and img.max() < 1.5 and img.mean() < 1.0  # (16 spp: single pixels scatter around their mean)
+    assert img[0, 0, 0] == pytest.approx(1.0, abs=1e-5)  # background
+    centre = img[14:18, 14:18].mean()
+    assert 0.5 < centre < 0.98  # rho / (1 - ...) < 1: darker than the sky, lit from everywhere
+    covered = (img[..., 0] < 0.999).mean()
+    # the ball of radius 2 at distance 9 subtends asin(2/9); the 40 degree fov spans 32 px
+    r_px = np.tan(np.arcsin(2 / 9)) / np.tan(np.radians(20)) * 16
+    assert covered == pytest.approx(np.pi * r_px ** 2 / 32 ** 2, rel=0.12)
