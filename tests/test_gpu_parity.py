@@ -517,3 +517,27 @@ render { cameras { @cam } shapes { @tri } integrator : MegaPath { depth { 3 } } 
     renderer.upload(one)
     renderer.render(2, 2, sync=True)  # empty sample range: nothing happens
     assert not renderer.download(converted=False).any()
+
+
+def test_sphere_loopsubdiv_and_jpeg_texture(renderer, tmp_path):
+    """the shapes of csrc/host/subdiv.cpp and a texture read by csrc/host/image_codecs.cpp, through the device path"""
+    PIL = pytest.importorskip("PIL.Image")
+    y, x = np.mgrid[0:64, 0:64]
+    pic = np.stack([128 + 100 * np.sin(x / 5.0), 128 + 100 * np.cos(y / 7.0), 4 * x], axis=-1).clip(0, 255).astype(np.uint8)
+    PIL.fromarray(pic, "RGB").save(tmp_path / "tex.jpg", quality=90, subsampling=2)
+    text = """
+Shape ball : Sphere { subdivision { 3 } surface : Plastic { Kd : Constant { v { 0.7, 0.3, 0.2 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.5 } } }
+  transform : SRT { translate { -1.2, 1, 0 } } }
+Shape tetra : InlineMesh { positions { 1,1,1, -1,-1,1, -1,1,-1, 1,-1,-1 } indices { 0,1,2, 0,3,1, 0,2,3, 1,3,2 } }
+Shape blob : LoopSubdiv { mesh { @tetra } level { 3 } surface : Metal { eta { "Cu" } roughness : Constant { v { 0.25 } } } transform : SRT { translate { 1.2, 1, 0 } } }
+Shape floor : InlineMesh { positions { -4,0,-4, 4,0,-4, 4,0,4, -4,0,4 } indices { 0,2,1, 0,3,2 } uvs { 0,0, 1,0, 1,1, 0,1 }
+  surface : Matte { Kd : Image { file { "tex.jpg" } } } }
+Shape lamp : InlineMesh { positions { -1,4,-1, 1,4,-1, 1,4,1, -1,4,1 } indices { 0,1,2, 0,2,3 } light : Diffuse { emission : Constant { v { 12, 11, 10 } } } }
+Camera cam : Pinhole { fov { 45 } spp { 16 } film : Color { resolution { 96, 64 } } position { 0, 2.5, 7 } look_at { 0, 0.8, 0 } }
+render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : MegaPath { depth { 6 } } }
+"""
+    (tmp_path / "scene.luisa").write_text(text)
+    sc = Scene.load(str(tmp_path / "scene.luisa"))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3]) and abs(gc["closest_rays"] - cc["closest_rays"]) <= 4
+    assert _rel_l1(gpu, cpu) < 2e-3 and gpu[..., :3].mean() > 0.01
