@@ -123,7 +123,9 @@ public:
                 for (auto k = 1u; k < count; k++) {
                     acc.grow(_boxes[_indices[first + k - 1u]]);
                     auto cost = acc.half_area() * static_cast<float>(k) + right_area[k] * static_cast<float>(count - k);
-                    if (cost < best_cost) { best_cost = cost, best_axis = axis, best_k = k; }
+                    // (ties — degenerate boxes of area 0, stacks of identical triangles — go to the most balanced split)
+                    auto off_centre = [&](uint32_t q) { return q > count / 2u ? q - count / 2u : count / 2u - q; };
+                    if (cost < best_cost || (cost == best_cost && off_centre(k) < off_centre(best_k))) { best_cost = cost, best_axis = axis, best_k = k; }
                 }
             }
             if (best_axis != 2) {
@@ -209,12 +211,15 @@ class Reinserter {
         u.grow(b);
         return u.half_area();
     }
-    // best node to pair `x` with: minimises (area of the new parent) + (growth of all ancestors)
-    uint32_t find_target(uint32_t x) {
+    // best node to pair `x` with: minimises (area of the new parent) + (growth of all ancestors).  `fallback` is the pairing
+    // that restores the tree as it was: another place is taken only if it is STRICTLY cheaper (degenerate inputs — stacks of
+    // identical or zero-area boxes, where every place costs the same — keep their balanced sweep tree instead of growing chains)
+    uint32_t find_target(uint32_t x, uint32_t fallback) {
         auto &bx = _n[x].box;
         auto ax = bx.half_area();
-        auto best = 0u;
-        auto best_cost = std::numeric_limits<float>::max();
+        auto best = fallback;
+        auto best_cost = union_area(_n[fallback].box, bx);
+        for (auto a = _parent[fallback]; a != LR_INVALID_ID; a = _parent[a]) { best_cost += union_area(_n[a].box, bx) - _n[a].box.half_area(); }
         struct Item { float induced; uint32_t node; };
         auto cmp = [](const Item &a, const Item &b) { return a.induced > b.induced; };
         std::vector<Item> heap{{0.f, 0u}};
@@ -296,8 +301,8 @@ public:
                 refit_up(g);
                 _parent[l] = _parent[r] = LR_INVALID_ID;
                 if (_n[l].box.half_area() < _n[r].box.half_area()) { std::swap(l, r); }// the larger subtree first
-                insert(l, find_target(l), p);
-                insert(r, find_target(r), i);
+                insert(l, find_target(l, s), p);// (l next to s, then r next to l, is the tree as it was)
+                insert(r, find_target(r, l), i);
             }
         }
     }

@@ -135,3 +135,41 @@ def test_golden_cornell_fixture():
     film, counters = Oracle(sc).render(0, 8)
     assert int(ref["closest_rays"]) == counters["closest_rays"]
     assert np.allclose(film, ref["film"], rtol=1e-5, atol=1e-6)
+
+
+def test_degenerate_geometry_keeps_a_shallow_bvh():
+    """stacks of identical triangles and collinear (zero-area) ones: every split / every reinsertion place costs the same; the
+    builder must keep a balanced tree (the device's traversal stack bounds the depth, lrhip_upload_scene rejects deeper trees)"""
+    n = 3000
+    pos, idx = [], []
+    for i in range(n):
+        b = len(pos) // 3
+        pos += [0, 0, 0, 1, 0, 0, 0, 1, 0]
+        idx += [b, b + 1, b + 2]
+    for i in range(n):
+        b = len(pos) // 3
+        pos += [i * 1e-3, 2, 0, i * 1e-3 + 1e-3, 2, 0, i * 1e-3 + 2e-3, 2, 0]
+        idx += [b, b + 1, b + 2]
+    text = f"""
+Shape s : InlineMesh {{ positions {{ {", ".join(map(str, pos))} }} indices {{ {", ".join(map(str, idx))} }} light : Diffuse {{ emission : Constant {{ v {{ 1 }} }} two_sided {{ true }} }} }}
+Camera cam : Pinhole {{ spp {{ 1 }} film : Color {{ resolution {{ 8, 8 }} }} position {{ 0.3, 0.3, 3 }} look_at {{ 0.3, 0.3, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @s }} integrator : MegaPath {{ }} }}
+"""
+    sc = Scene.from_string(text)
+    v = sc.view()
+    nodes, depth, stack = v.accel.nodes, 0, [(0, 1)]
+    leaves = 0
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        for k in range(4):
+            c = nodes[i].child[k]
+            if c == 0xFFFFFFFF:
+                continue
+            if c & 0x80000000:
+                leaves += 1
+            else:
+                stack.append((c, d + 1))
+    assert leaves == 2 * n and depth <= 20, depth  # log4(6000) = 6.3; the stack allows 34
+    film, _ = Oracle(sc).render(0, 1)
+    assert film[4, 4, 0] == 1.0
