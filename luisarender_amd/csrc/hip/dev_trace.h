@@ -12,16 +12,19 @@
 //   * nodes are 64-byte quantised BVH4 packets (DNodeQ: box origin + per-axis scale + 8-bit child
 //     planes + 4 child references) — half the bytes of fp32 child boxes, conservative by
 //     construction (lo rounded down, hi rounded up);
-//   * each wave fetches the 64 packets its lanes need with FOUR fully coalesced dwordx4 loads
-//     (4 consecutive lanes read one packet = 16 lines per instruction instead of 64), parks them in
-//     a 4 KiB per-wave LDS staging area with an XOR swizzle, and every lane reads its own packet
-//     back with four conflict-free ds_read_b128;
+//   * each wave fetches the 64 packets its lanes need with FOUR fully coalesced 16-byte-per-lane loads
+//     (4 consecutive lanes read one packet = 16 lines per instruction instead of 64) straight into a
+//     4 KiB per-wave LDS staging area (gfx950: global_load_lds_dwordx4), XOR-swizzled by which quarter
+//     of the packet a lane asks for, and every lane reads its own packet back with four conflict-free
+//     ds_read_b128;
 //   * slab tests run directly on the quantised planes: t = fma(q, scale * inv_d, (origin - o) * inv_d),
-//     24 v_cvt_f32_ubyteN + 24 v_fma per packet;
+//     near / far plane words picked by the sign of the ray direction, 24 v_cvt_f32_ubyteN + 12 v_pk_fma_f32
+//     per packet;
 //   * hits are ordered near->far with a 5-comparator network on packed (t | slot) integer keys;
 //   * the traversal stack lives in LDS, [entry][lane] interleaved (conflict-free push/pop); entries
 //     beyond kStackLds spill to a per-thread HBM area (lane-coalesced);
-//   * leaves are 1..4 pre-transformed 48-byte triangles (Moeller-Trumbore, 3 x dwordx4 each);
+//   * every leaf is ONE pre-transformed 48-byte triangle (Moeller-Trumbore, 3 x dwordx4), named by index
+//     (the host builder, accel.cpp, may reference a triangle from more than one leaf);
 //   * the traversal is RESUMABLE (TravState): the wave leaves the loop as soon as `refill` lanes have
 //     finished their rays, those lanes shade and spawn new rays, and everybody re-enters — measured
 //     lane occupancy of the loop was 28 % when every lane had to wait for the slowest ray;
