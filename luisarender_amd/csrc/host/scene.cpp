@@ -316,6 +316,59 @@ public:
     }
 
     // ---------------- textures
+    // SwizzleTexture over texture `base` (src/textures/swizzle.cpp), materialised: returns the id of a plain texture
+    int32_t swizzled_texture(int32_t base, const std::vector<uint32_t> &channels, const NodeDesc *d) {
+        auto n = channels.size();
+        auto b = _out.textures[static_cast<size_t>(base)];// (copy: _out.textures grows below)
+        auto pick = [&](const float in[4], float out[4], float pad_w) {// the value SwizzleTextureInstance::evaluate returns
+            for (size_t i = 0; i < 4u; i++) { out[i] = i < n ? in[channels[i]] : (n == 1u ? in[channels[0]] : (i == 3u ? pad_w : 0.f)); }
+        };
+        lr_texture t = b;
+        t.channels = static_cast<uint32_t>(n);
+        if (b.kind == LR_TEX_CONSTANT) {
+            float out[4];
+            pick(b.v, out, 1.f);
+            for (size_t i = 0; i < 4u; i++) { t.v[i] = i < n ? out[i] : 0.f; }// (evaluate_static leaves the unused channels 0)
+        } else if (b.kind == LR_TEX_IMAGE) {
+            // per-channel decode parameters move with their channel; the padded 0 / 1 pass through every encoding unchanged
+            float scale[4];
+            pick(b.scale, scale, 1.f);
+            for (size_t i = n; i < 4u && n != 1u; i++) { scale[i] = 1.f; }
+            if (b.encoding == LR_TEX_ENC_GAMMA) {// gamma[min(channel, 2)]: the alpha slot shares the blue exponent
+                float g[4];
+                for (size_t i = 0; i < 4u; i++) { g[i] = b.gamma[std::min<size_t>(i < n ? channels[i] : (n == 1u ? channels[0] : i), 2u)]; }
+                if (n == 4u && g[3] != g[2]) { throw Error{"Swizzle of a gamma-encoded image whose alpha would need its own exponent is not supported. [" + d->location() + "]"}; }
+                t.gamma[0] = g[0], t.gamma[1] = g[1], t.gamma[2] = g[2];
+            }
+            std::copy_n(scale, 4, t.scale);
+            auto texels = static_cast<size_t>(b.width) * b.height;
+            t.texel_offset = _out.texels.size() / 4u;
+            _out.texels.resize(_out.texels.size() + texels * 4u);
+            for (size_t k = 0; k < texels; k++) {
+                float in[4], out[4];
+                std::copy_n(_out.texels.data() + (b.texel_offset + k) * 4u, 4, in);
+                pick(in, out, 1.f);
+                std::copy_n(out, 4, _out.texels.data() + (t.texel_offset + k) * 4u);
+            }
+        } else {// checkerboard: swizzle the children (a missing child is the default on = 1 / off = (0, 0, 0, 1), checkerboard.cpp)
+            for (auto k = 0; k < 2; k++) {
+                auto child = b.child[k];
+                if (child < 0) {
+                    lr_texture c{};
+                    c.kind = LR_TEX_CONSTANT, c.channels = 4u;
+                    c.v[0] = c.v[1] = c.v[2] = k == 0 ? 1.f : 0.f, c.v[3] = 1.f;
+                    c.child[0] = c.child[1] = -1;
+                    child = static_cast<int32_t>(_out.textures.size());
+                    _out.textures.emplace_back(c);
+                }
+                t.child[k] = swizzled_texture(child, channels, d);
+            }
+        }
+        auto id = static_cast<int32_t>(_out.textures.size());
+        _out.textures.emplace_back(t);
+        return id;
+    }
+
     int32_t load_texture(const NodeDesc *d) {
         if (d == nullptr) { return -1; }
         _check_tag(d, Tag::TEXTURE);
@@ -382,8 +435,49 @@ public:
             t.child[0] = load_texture(d->node_or_null("on"));
             t.child[1] = load_texture(d->node_or_null("off"));
             t.checker_scale = d->float_or("scale", 1.f);
+            for (auto c : t.child) {// (the device evaluates one level of nesting: constant or image children)
+                if (c >= 0 && _out.textures[static_cast<size_t>(c)].kind != LR_TEX_CONSTANT && _out.textures[static_cast<size_t>(c)].kind != LR_TEX_IMAGE) {
+                    throw Error{"Checkerboard children must be Constant or Image textures. [" + d->location() + "]"};
+                }
+            }
             auto child_channels = [&](int32_t c) { return c < 0 ? 4u : _out.textures[static_cast<size_t>(c)].channels; };
             t.channels = std::min(child_channels(t.child[0]), child_channels(t.child[1]));// checkerboard.cpp:38-48
+        } else if (impl == "swizzle") {// swizzle.cpp:18-53
+            auto base = load_texture(d->node("base"));
+            std::vector<uint32_t> channels;
+            if (auto s = d->string_opt("swizzle")) {
+                for (auto c : *s) {
+                    switch (c) {
+                        case 'r': case 'x': channels.push_back(0u); break;
+                        case 'g': case 'y': channels.push_back(1u); break;
+                        case 'b': case 'z': channels.push_back(2u); break;
+                        case 'a': case 'w': channels.push_back(3u); break;
+                        default: throw Error{std::string{"Invalid swizzle channel '"} + c + "'. [" + d->location() + "]"};
+                    }
+                }
+            } else if (d->has_property("swizzle")) {
+                channels = d->uint_list("swizzle");
+            } else {
+                channels = {0u, 1u, 2u, 3u};
+            }
+            if (channels.size() > 4u) {
+                log_warning("Too many swizzle channels (count = " + std::to_string(channels.size()) + ") for SwizzleTexture. Additional channels will be discarded. [" + d->location() + "]");
+                channels.resize(4u);
+            }
+            if (channels.empty()) { throw Error{"Empty swizzle. [" + d->location() + "]"}; }
+            for (auto c : channels) {
+                if (c >= 4u) { throw Error{"Swizzle channel '" + std::to_string(c) + "' out of range. [" + d->location() + "]"}; }
+            }
+            // The swizzle is applied HERE, once, to the base texture's data — a swizzled constant is a constant
+            // (evaluate_static, :60-67), a swizzled image is the image with its texel channels (and per-channel scale)
+            // permuted, a swizzled checkerboard is the checkerboard of its swizzled children — so the device interprets no
+            // Swizzle node per lookup (that cost the LEAN kernel 2.7 % on a scene without a single texture: registers).
+            // Per lookup the reference computes (SwizzleTextureInstance::evaluate, :100-113): 1 channel -> (s0, s0, s0, s0),
+            // 2 -> (s0, s1, 0, 1), 3 -> (s0, s1, s2, 1), 4 -> all four; permuting before the bilinear filter and the
+            // per-channel decode gives the same values because both act on each channel separately.
+            auto id = swizzled_texture(base, channels, d);
+            _texture_ids.emplace(d, id);
+            return id;
         } else {
             throw Error{"Unsupported texture implementation '" + impl + "'. [" + d->location() + "]"};
         }

@@ -520,7 +520,7 @@ render { cameras { @cam } shapes { @tri } integrator : MegaPath { depth { 3 } } 
 
 
 def test_sphere_loopsubdiv_and_jpeg_texture(renderer, tmp_path):
-    """the shapes of csrc/host/subdiv.cpp and a texture read by csrc/host/image_codecs.cpp, through the device path"""
+    """the shapes of csrc/host/subdiv.cpp and a (swizzled) texture read by csrc/host/image_codecs.cpp, through the device path"""
     PIL = pytest.importorskip("PIL.Image")
     y, x = np.mgrid[0:64, 0:64]
     pic = np.stack([128 + 100 * np.sin(x / 5.0), 128 + 100 * np.cos(y / 7.0), 4 * x], axis=-1).clip(0, 255).astype(np.uint8)
@@ -531,7 +531,7 @@ Shape ball : Sphere { subdivision { 3 } surface : Plastic { Kd : Constant { v { 
 Shape tetra : InlineMesh { positions { 1,1,1, -1,-1,1, -1,1,-1, 1,-1,-1 } indices { 0,1,2, 0,3,1, 0,2,3, 1,3,2 } }
 Shape blob : LoopSubdiv { mesh { @tetra } level { 3 } surface : Metal { eta { "Cu" } roughness : Constant { v { 0.25 } } } transform : SRT { translate { 1.2, 1, 0 } } }
 Shape floor : InlineMesh { positions { -4,0,-4, 4,0,-4, 4,0,4, -4,0,4 } indices { 0,2,1, 0,3,2 } uvs { 0,0, 1,0, 1,1, 0,1 }
-  surface : Matte { Kd : Image { file { "tex.jpg" } } } }
+  surface : Matte { Kd : Swizzle { base : Image { file { "tex.jpg" } } swizzle { "bgr" } } } }
 Shape lamp : InlineMesh { positions { -1,4,-1, 1,4,-1, 1,4,1, -1,4,1 } indices { 0,1,2, 0,2,3 } light : Diffuse { emission : Constant { v { 12, 11, 10 } } } }
 Camera cam : Pinhole { fov { 45 } spp { 16 } film : Color { resolution { 96, 64 } } position { 0, 2.5, 7 } look_at { 0, 0.8, 0 } }
 render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : MegaPath { depth { 6 } } }

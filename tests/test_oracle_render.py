@@ -173,3 +173,37 @@ render {{ cameras {{ @cam }} shapes {{ @s }} integrator : MegaPath {{ }} }}
     assert leaves == 2 * n and depth <= 20, depth  # log4(6000) = 6.3; the stack allows 34
     film, _ = Oracle(sc).render(0, 1)
     assert film[4, 4, 0] == 1.0
+
+
+def test_swizzle_texture(tmp_path):
+    """src/textures/swizzle.cpp: a swizzled constant folds to a constant (evaluate_static); a swizzled image permutes the
+    base's channels per lookup — a Matte surface with Kd = image.bgr under a white sky shows the image's colours swapped"""
+    from luisarender_amd.scene import save_image
+    img = np.zeros((4, 4, 4), np.float32)
+    img[..., 0], img[..., 1], img[..., 2], img[..., 3] = 0.8, 0.4, 0.1, 1.0
+    save_image(str(tmp_path / "rgb.exr"), img)
+    text = """
+Texture base : Image { file { "rgb.exr" } encoding { "linear" } }
+Texture swapped : Swizzle { base { @base } swizzle { "bgr" } }
+Texture red_as_grey : Swizzle { base { @base } swizzle { 0 } }
+Texture folded : Swizzle { base : Constant { v { 0.1, 0.2, 0.3 } } swizzle { "zy" } }
+Surface s : Matte { Kd { @KD } }
+Shape quad : InlineMesh { positions { -50,0,-50, 50,0,-50, 50,0,50, -50,0,50 } indices { 0,2,1, 0,3,2 } uvs { 0,0, 1,0, 1,1, 0,1 } surface { @s } }
+Camera cam : Pinhole { fov { 30 } spp { 1 } film : Color { resolution { 8, 8 } } position { 0, 5, 0 } look_at { 0, 0, -3 } }
+render { cameras { @cam } shapes { @quad } environment : Spherical { emission : Constant { v { 1 } } } integrator : MegaPath { depth { 2 } } }
+"""
+    def mean(kd):
+        (tmp_path / "s.luisa").write_text(text.replace("@KD", "@" + kd))
+        sc = Scene.load(str(tmp_path / "s.luisa"))
+        film, _ = Oracle(sc).render(0, 64)
+        return sc, (film[..., :3] / film[..., 3:4]).reshape(-1, 3).mean(axis=0)
+    _, plain = mean("base")
+    sc, swapped = mean("swapped")
+    assert np.allclose(plain, [0.8, 0.4, 0.1], rtol=0.03) and np.allclose(swapped, [0.1, 0.4, 0.8], rtol=0.03)
+    _, grey = mean("red_as_grey")
+    assert np.allclose(grey, [0.8, 0.8, 0.8], rtol=0.03)  # one channel: extended to rgb (texture.cpp:14-18)
+    sc, folded = mean("folded")
+    v = sc.view()
+    t = [v.textures[i] for i in range(v.texture_count) if v.textures[i].kind == 0 and v.textures[i].channels == 2]
+    assert any(np.allclose(x.v[:2], [0.3, 0.2]) for x in t)  # evaluate_static: (z, y) of the constant
+    assert np.allclose(folded, [0.3, 0.2, 1.0], rtol=0.03)  # two channels extend to (x, y, 1)
