@@ -94,6 +94,7 @@ struct lrhip_ctx {
     uint32_t width{0}, height{0};
     float film_scale[3]{1.f, 1.f, 1.f};
     DeviceBuffer film_own, converted, partial, spill, counters, work_counter;
+    DeviceBuffer scene_record;// lrd::DScene in device memory: the kernels read it through scalar loads (dev_scene.h: DScenePtr)
     float4 *film{nullptr};// bound film (own or external)
     uint32_t grid_blocks{0};
     uint32_t cu_count{0};
@@ -252,7 +253,7 @@ void lrhip_destroy(lrhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     release_scene(ctx);
     ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
-    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release();
+    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -614,8 +615,12 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
     auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
+    // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
+    // the copy has left it when the call returns
+    if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
+    LR_HIP_CHECK(hipMemcpyAsync(ctx->scene_record.ptr, &ctx->scene, sizeof(lrd::DScene), hipMemcpyHostToDevice, ctx->stream));
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
-    LR_HIP_CHECK(kVariants[vi].launch(blocks, ctx->stream, &ctx->scene, &args));
+    LR_HIP_CHECK(kVariants[vi].launch(blocks, ctx->stream, static_cast<const lrd::DScene *>(ctx->scene_record.ptr), &args));
     ctx->last_variant = kVariants[vi].mask;
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));

@@ -92,7 +92,8 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : LR_MIN_WAVES; }
 
 template<uint32_t F>
-__global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kernel(DScene scene, RenderArgs args) {
+__global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kernel(DScenePtr scene_ptr, RenderArgs args) {
+    const DScene &scene = *(const DScene *)scene_ptr;
     constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u, ENV = (F & kFeatEnv) != 0u,
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
                    LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u;

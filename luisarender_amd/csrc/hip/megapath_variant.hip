@@ -17,12 +17,14 @@
 #define LR_CAT(a, b) LR_CAT2(a, b)
 
 namespace lrd {
-template __global__ void LR_KERNEL<LR_VARIANT>(DScene, RenderArgs);
+template __global__ void LR_KERNEL<LR_VARIANT>(DScenePtr, RenderArgs);
 }
 
-extern "C" hipError_t LR_CAT(lrhip_variant_launch_, LR_VARIANT)(unsigned blocks, hipStream_t stream, const lrd::DScene *scene,
+// `device_scene`: the lrd::DScene record in device memory (lrhip_render copies it there ahead of every launch)
+extern "C" hipError_t LR_CAT(lrhip_variant_launch_, LR_VARIANT)(unsigned blocks, hipStream_t stream, const lrd::DScene *device_scene,
                                                                const lrd::RenderArgs *args) {
-    hipLaunchKernelGGL(lrd::LR_KERNEL<LR_VARIANT>, dim3(blocks), dim3(lrd::kBlockThreads), 0, stream, *scene, *args);
+    hipLaunchKernelGGL(lrd::LR_KERNEL<LR_VARIANT>, dim3(blocks), dim3(lrd::kBlockThreads), 0, stream,
+                       (lrd::DScenePtr)device_scene, *args);
     return hipGetLastError();
 }
 

@@ -173,7 +173,8 @@ enum : uint32_t { kVptBegin = 0u, kVptMain, kVptWalkMedium, kVptWalkSurface, kVp
 constexpr uint32_t kVptMaxCrossings = 64u;
 
 template<uint32_t F>
-__global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScene scene, RenderArgs args) {
+__global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr scene_ptr, RenderArgs args) {
+    const DScene &scene = *(const DScene *)scene_ptr;
     constexpr bool COUNT = (F & 1u) != 0u, PCG = (F & 2u) != 0u;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];
