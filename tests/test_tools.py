@@ -1,0 +1,31 @@
+"""tools/ that the design decisions lean on must keep building: tools/bvh_sim.cpp is the CPU model of the kernel's BVH walk
+ that the host builder's choices were compared with."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from luisarender_amd import _ffi
+from luisarender_amd.scenes import cornell_box
+
+
+def test_bvh_sim_builds_and_counts(tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("no C++ compiler")
+    _ffi.host_lib()
+    exe = tmp_path / "bvh_sim"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(_ffi.REPO_ROOT, "include"), os.path.join(_ffi.REPO_ROOT, "tools", "bvh_sim.cpp"),
+                           "-L", _ffi.LIB_DIR, "-llrhost", f"-Wl,-rpath,{_ffi.LIB_DIR}", "-o", str(exe)])
+    scene = tmp_path / "c.luisa"
+    scene.write_text(cornell_box(resolution=64, spp=1))
+    out = {}
+    for knobs in ({}, {"LR_BVH_SWEEP": "0", "LR_BVH_COLLAPSE": "0", "LR_BVH_REINSERT": "0"}):
+        r = subprocess.run([str(exe), str(scene), "48", "4"], capture_output=True, text=True, timeout=120, env={**os.environ, **knobs})
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"nodes (\d+), tris (\d+) \| closest: rays (\d+) nodes/ray ([\d.]+) tris/ray ([\d.]+)", r.stdout)
+        assert m, r.stdout
+        out[bool(knobs)] = (int(m.group(1)), int(m.group(2)), float(m.group(4)))
+    # 32 triangles, every ray of the closed box hits something; the default builder is never worse than the round-1b one here
+    assert out[False][1] == 32 and out[True][1] == 32 and out[False][2] <= out[True][2] * 1.05
