@@ -74,12 +74,110 @@ LR_D void layer_stack(const HeavyCtx &cx, LayerStack &layers) {// LayeredSurface
     layers.max_depth = c.x[2], layers.samples = c.x[3];
 }
 
+// ---- Mix trees.  The reference's Mix closure holds two arbitrary child closures (mix.cpp:82-212), Mix surfaces included.
+// Device code has no unbounded recursion, so a Mix tree is interpreted by functions templated on the nesting depth still
+// allowed below them (kMixMaxDepth levels under the root: the host loader rejects deeper trees); the leaves go through two
+// out-of-line functions so that each level adds a loop, not another copy of the closure interpreter.
+#ifndef LR_MIX_DEPTH
+#define LR_MIX_DEPTH 3
+#endif
+constexpr int kMixMaxDepth = LR_MIX_DEPTH;
+
+LR_HEAVY BsdfEval mix_leaf_evaluate(const HeavyCtx *cx, const DClosure *c, const Frame *fr, f3 wi) {
+    return closure_evaluate<true>(*c, *fr, cx->ng, cx->wo, wi);
+}
+LR_HEAVY BsdfSample mix_leaf_sample(const HeavyCtx *cx, const DClosure *c, const Frame *fr, float u_lobe, f2 u) {
+    return closure_sample<true>(*c, *fr, cx->ng, cx->wo, u_lobe, u);
+}
+
+// MixSurfaceClosure::_evaluate (mix.cpp:169-177) + the public wrapper's side validation (surface.cpp:45-56)
+template<int DEPTH>
+LR_D BsdfEval mix_evaluate(const HeavyCtx &cx, const DClosure &node, const Frame &frame, f3 wi) {
+    BsdfEval e[2];
+#pragma nounroll
+    for (auto k = 0u; k < 2u; k++) {
+        DClosure child;
+        Frame fr;
+        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[k], frame, child, fr);
+        if constexpr (DEPTH > 0) {
+            if (child.kind == LR_SURFACE_MIX) {
+                e[k] = mix_evaluate<DEPTH - 1>(cx, child, fr, wi);
+                continue;
+            }
+        }
+        e[k] = mix_leaf_evaluate(&cx, &child, &fr, wi);
+    }
+    auto eval = mix_blend(e[0], e[1], node.s0);
+    if (!valid_sides(cx.ng, frame.n, cx.wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
+    return eval;
+}
+
+// MixSurfaceClosure::eta (mix.cpp:148-157) of the tree below `node`
+template<int DEPTH>
+LR_D bool mix_eta(const HeavyCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
+    bool has[2];
+    float e[2] = {1.f, 1.f};
+#pragma nounroll
+    for (auto k = 0u; k < 2u; k++) {
+        auto &rec = cx.tb.closures[node.x[k]];// (eta never comes from an image texture: the static record has it)
+        has[k] = closure_eta(rec, e[k]);
+        if constexpr (DEPTH > 0) {
+            if (rec.kind == LR_SURFACE_MIX) {
+                DClosure child;
+                Frame fr;
+                load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[k], frame, child, fr);// (its ratio may be textured)
+                has[k] = mix_eta<DEPTH - 1>(cx, child, fr, e[k]);
+            }
+        }
+    }
+    eta = !has[0] ? e[1] : (!has[1] ? e[0] : lerp(e[1], e[0], node.s0));
+    return has[0] || has[1];
+}
+
+// MixSurfaceClosure::_sample (mix.cpp:178-196); the "sample b" branch samples A and evaluates B (reference quirk, kept), so
+// sampling always walks down the chain of first children
+template<int DEPTH>
+LR_D BsdfSample mix_sample(const HeavyCtx &cx, const DClosure &node, const Frame &frame, float u_lobe, f2 u_bsdf) {
+    const auto ratio = node.s0;
+    const auto first = u_lobe < ratio;
+    const auto u_child = first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio);
+    DClosure child;
+    Frame fr;
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[0], frame, child, fr);
+    BsdfSample bs;
+    auto nested = false;
+    if constexpr (DEPTH > 0) {
+        if (child.kind == LR_SURFACE_MIX) {
+            bs = mix_sample<DEPTH - 1>(cx, child, fr, u_child, u_bsdf);
+            nested = true;
+        }
+    }
+    if (!nested) { bs = mix_leaf_sample(&cx, &child, &fr, u_child, u_bsdf); }
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[1], frame, child, fr);
+    BsdfEval eb;
+    nested = false;
+    if constexpr (DEPTH > 0) {
+        if (child.kind == LR_SURFACE_MIX) {
+            eb = mix_evaluate<DEPTH - 1>(cx, child, fr, bs.wi);
+            nested = true;
+        }
+    }
+    if (!nested) { eb = mix_leaf_evaluate(&cx, &child, &fr, bs.wi); }
+    auto m = first ? mix_blend(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_blend(eb, BsdfEval{bs.f, bs.pdf}, ratio);
+    bs.f = m.f, bs.pdf = m.pdf;
+    if (!valid_sides(cx.ng, frame.n, cx.wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
+    return bs;
+}
+
 // evaluate of a Disney / Mix / Layered surface (MIX / LAYERED: which interpreters this kernel variant holds)
 template<bool MIX, bool LAYERED>
 LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     auto &cx = *cxp;
     auto &c = cx.closure;
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:169-177
+        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth>(cx, c, cx.shading, wi); }// a tree: the general interpreter
+        // the common case, two non-Mix children, keeps the closure interpreter inline (the out-of-line leaves of the
+        // general path cost C5 3 %)
         BsdfEval e[2];
 #pragma nounroll
         for (auto k = 0u; k < 2u; k++) {
@@ -106,6 +204,11 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
     auto &c = cx.closure;
     HeavySample r;
     r.eta = 1.f, r.has_eta = 0u;
+    if (MIX && c.kind == LR_SURFACE_MIX && c.x[2] != 0u) {// a Mix tree
+        r.bs = mix_sample<kMixMaxDepth>(cx, c, cx.shading, u_lobe, u_bsdf);
+        r.has_eta = mix_eta<kMixMaxDepth>(cx, c, cx.shading, r.eta) ? 1u : 0u;
+        return r;
+    }
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
         const auto ratio = c.s0;
         DClosure ca, cb;

@@ -450,7 +450,7 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
         }
         case LR_SURFACE_MIX: {// mix.cpp:198-212
             c.s0 = s.tex[0] >= 0 ? clampf(tex(s.tex[0]).x, 0.f, 1.f) : 0.5f;
-            c.x[0] = s.u[0], c.x[1] = s.u[1];
+            c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = s.u[2];// children, nesting depth below this node
             break;
         }
         default: c.kind = LR_SURFACE_NULL; break;
@@ -561,8 +561,19 @@ LR_D float surface_opacity(const DScene &scene, uint32_t tag, f2 uv) {
         auto alpha_tex = scene.surfaces[t].alpha_tex;
         return alpha_tex >= 0 ? texture_eval(scene, alpha_tex, uv).x : 1.f;
     };
-    auto &s = scene.surfaces[tag];
-    return s.kind == LR_SURFACE_MIX ? one(s.u[0]) * one(s.u[1]) : one(tag);
+    if (scene.surfaces[tag].kind != LR_SURFACE_MIX) { return one(tag); }
+    // a Mix tree (children may be Mix surfaces, at most 3 levels below the root): the product over its leaves, multiplied in
+    // the order the recursion a.opacity * b.opacity visits them
+    uint32_t stack[8];
+    auto sp = 0u;
+    stack[sp++] = tag;
+    auto opacity = 1.f;
+    while (sp > 0u) {
+        auto &s = scene.surfaces[stack[--sp]];
+        if (s.kind == LR_SURFACE_MIX && sp + 2u <= 8u) { stack[sp++] = s.u[1], stack[sp++] = s.u[0]; }
+        else { opacity *= one(static_cast<uint32_t>(&s - scene.surfaces)); }
+    }
+    return opacity;
 }
 
 // Geometry::_alpha_skip, geometry.cpp:165-192: a candidate hit is skipped when

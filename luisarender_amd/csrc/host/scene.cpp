@@ -631,9 +631,10 @@ public:
                 throw Error{"Mix surface with a null child is not supported. [" + d->location() + "]"};
             }
             children = {register_surface(a), register_surface(b)};
-            if (_out.surfaces[children[0]].kind == LR_SURFACE_MIX || _out.surfaces[children[1]].kind == LR_SURFACE_MIX) {
-                throw Error{"Nested Mix surfaces are not supported by the megakernel. [" + d->location() + "]"};
-            }
+            // nested Mix surfaces: the kernel interprets up to 3 levels below the root (dev_heavy.h: kMixMaxDepth); u[2] = depth
+            auto depth_of = [&](uint32_t c) { return _out.surfaces[c].kind == LR_SURFACE_MIX ? 1u + _out.surfaces[c].u[2] : 0u; };
+            s.u[2] = std::max(depth_of(children[0]), depth_of(children[1]));
+            if (s.u[2] > 3u) { throw Error{"Mix surfaces nested more than 3 levels deep are not supported by the megakernel. [" + d->location() + "]"}; }
             if (_out.surfaces[children[0]].kind == LR_SURFACE_LAYERED || _out.surfaces[children[1]].kind == LR_SURFACE_LAYERED) {
                 throw Error{"Layered children of a Mix surface are not supported by the megakernel. [" + d->location() + "]"};
             }

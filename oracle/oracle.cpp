@@ -262,7 +262,8 @@ struct oracle_ctx {
             return alpha_tex >= 0 ? texture_evaluate(*scene, alpha_tex, uv).x : 1.f;
         };
         auto &s = scene->surfaces[tag];
-        return s.kind == LR_SURFACE_MIX ? one(s.u[0]) * one(s.u[1]) : one(tag);
+        if (s.kind != LR_SURFACE_MIX) { return one(tag); }
+        return surface_opacity(s.u[0], uv) * surface_opacity(s.u[1], uv);// (Mix children may be Mix surfaces themselves)
     }
     // Geometry::_alpha_skip, geometry.cpp:165-192
     bool alpha_skip(uint32_t inst_id, uint32_t prim, float u, float v) const {

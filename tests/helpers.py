@@ -23,6 +23,13 @@ MATERIALS = {
     "mix_glass": "Surface mg_a : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.5 } } } "
                  "Surface mg_b : Disney { color : Constant { v { 0.5, 0.6, 0.7 } } roughness : Constant { v { 0.5 } } } "
                  "Surface m : Mix { a { @mg_a } b { @mg_b } ratio : Constant { v { 0.6 } } }",
+    "mix_nested": "Surface mn_a : Matte { Kd : Constant { v { 0.7, 0.2, 0.2 } } } "
+                  "Surface mn_b : Mirror { color : Constant { v { 0.9, 0.9, 0.9 } } roughness : Constant { v { 0.3 } } } "
+                  "Surface mn_c : Plastic { Kd : Constant { v { 0.2, 0.3, 0.8 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.5 } } } "
+                  "Surface mn_d : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.5 } } } "
+                  "Surface mn_in : Mix { a { @mn_a } b { @mn_b } ratio : Constant { v { 0.25 } } } "
+                  "Surface mn_in2 : Mix { a { @mn_d } b { @mn_in } ratio : Constant { v { 0.5 } } } "
+                  "Surface m : Mix { a { @mn_in2 } b { @mn_c } ratio : Constant { v { 0.6 } } }",
     "layered": "Surface lay_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.15 } } eta : Constant { v { 1.5 } } } "
                "Surface lay_b : Matte { Kd : Constant { v { 0.7, 0.5, 0.3 } } } "
                "Surface m : Layered { top { @lay_t } bottom { @lay_b } thickness : Constant { v { 0.05 } } }",
