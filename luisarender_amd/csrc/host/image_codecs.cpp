@@ -52,7 +52,7 @@ struct HuffmanTable {
     uint16_t first_code[17]{};
     uint8_t symbols[256]{};
     uint8_t fast_symbol[512]{}, fast_length[512]{};// 9-bit look-ahead
-    void build(const uint8_t counts[16], const uint8_t *syms, uint32_t n) {
+    bool build(const uint8_t counts[16], const uint8_t *syms, uint32_t n) {// false: the lengths do not form a prefix code
         std::memcpy(symbols, syms, n);
         std::memset(fast_length, 0, sizeof(fast_length));
         uint32_t code = 0u, k = 0u;
@@ -60,6 +60,7 @@ struct HuffmanTable {
             first_index[l] = static_cast<int32_t>(k) - static_cast<int32_t>(code);
             first_code[l] = static_cast<uint16_t>(code);
             for (auto i = 0u; i < counts[l - 1]; i++, k++, code++) {
+                if (code >= (1u << l)) { return false; }// over-subscribed (corrupt table)
                 if (l <= 9) {
                     auto lo = code << (9 - l);
                     for (auto f = 0u; f < (1u << (9 - l)); f++) { fast_symbol[lo + f] = symbols[k], fast_length[lo + f] = static_cast<uint8_t>(l); }
@@ -71,6 +72,7 @@ struct HuffmanTable {
         }
         max_code[17] = 0x7fffffff;
         defined = true;
+        return true;
     }
 };
 
@@ -336,7 +338,7 @@ class JpegDecoder {
             auto n = 0u;
             for (auto &c : counts) { c = u8(), n += c; }
             if (n > 256u || _pos + n > _d.size()) { fail("bad Huffman table"); }
-            (tc ? _ac : _dc)[th].build(counts, _d.data() + _pos, n);
+            if (!(tc ? _ac : _dc)[th].build(counts, _d.data() + _pos, n)) { fail("bad Huffman table"); }
             _pos += n;
         }
     }
@@ -346,6 +348,7 @@ class JpegDecoder {
         if (u8() != 8u) { fail("only 8-bit precision is supported"); }
         _height = u16(), _width = u16();
         if (_width == 0u || _height == 0u) { fail("empty image"); }
+        if (static_cast<uint64_t>(_width) * _height > (1ull << 28u)) { fail("image too large"); }
         auto n = u8();
         if (n != 1u && n != 3u) { fail(n == 4u ? "CMYK / YCCK images are not supported" : "bad component count"); }
         _comp.resize(n);
@@ -582,6 +585,7 @@ LoadedImage read_bmp_data(const std::vector<uint8_t> &d, const std::string &name
     auto top_down = h < 0;
     h = std::abs(h);
     if (w <= 0 || h == 0) { return fail("empty image"); }
+    if (w > 32768 || h > 32768) { return fail("image too large"); }
     if (!((compression == 0u && (bpp == 8u || bpp == 24u || bpp == 32u)) || (compression == 3u && bpp == 32u))) {
         return fail("only uncompressed 8-bit palette, 24-bit and 32-bit images are supported");
     }
@@ -595,6 +599,7 @@ LoadedImage read_bmp_data(const std::vector<uint8_t> &d, const std::string &name
     auto palette = 14u + header;
     auto row_bytes = ((static_cast<size_t>(w) * bpp + 31u) / 32u) * 4u;
     if (offset + row_bytes * static_cast<size_t>(h) > d.size()) { return fail("truncated pixel data"); }
+    if (bpp == 8u && static_cast<size_t>(palette) + 256u * 4u > d.size()) { return fail("truncated palette"); }
     auto img = make_image(static_cast<uint32_t>(w), static_cast<uint32_t>(h), channels);
     auto field = [](uint32_t v, uint32_t m) {// a masked field scaled to 8 bits
         if (m == 0u) { return 255u; }

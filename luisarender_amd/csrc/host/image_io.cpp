@@ -215,7 +215,15 @@ LoadedImage read_exr(const fs::path &path) {
     if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
     std::string data{std::istreambuf_iterator<char>{f}, std::istreambuf_iterator<char>{}};
     size_t p = 0;
-    auto rd32 = [&](size_t at) { uint32_t v; std::memcpy(&v, data.data() + at, 4); return v; };
+    auto truncated = [&]() -> Error { return Error{"Truncated or corrupt EXR image '" + path.string() + "'."}; };
+    auto need = [&](size_t at, size_t n) { if (at > data.size() || n > data.size() - at) { throw truncated(); } };
+    auto rd32 = [&](size_t at) { need(at, 4u); uint32_t v; std::memcpy(&v, data.data() + at, 4); return v; };
+    auto cstr = [&](size_t at) {// a NUL-terminated string that ends inside the file
+        need(at, 1u);
+        auto end = data.find('\0', at);
+        if (end == std::string::npos) { throw truncated(); }
+        return std::string{data.data() + at, end - at};
+    };
     if (data.size() < 8u || rd32(0) != 20000630u) { throw Error{"Invalid EXR image '" + path.string() + "'."}; }
     if ((rd32(4) & 0x1e00u) != 0u) { throw Error{"Only single-part scanline EXR is supported: '" + path.string() + "'."}; }
     p = 8;
@@ -224,31 +232,38 @@ LoadedImage read_exr(const fs::path &path) {
     int32_t xmin = 0, ymin = 0, xmax = -1, ymax = -1;
     uint8_t compression = 0;
     while (p < data.size() && data[p] != '\0') {
-        std::string name{data.c_str() + p};
+        auto name = cstr(p);
         p += name.size() + 1u;
-        std::string type{data.c_str() + p};
+        auto type = cstr(p);
         p += type.size() + 1u;
         auto size = rd32(p);
         p += 4;
+        need(p, size);
         if (name == "channels") {
             auto q = p;
-            while (data[q] != '\0') {
+            while (q < p + size && data[q] != '\0') {
                 Channel c;
-                c.name = data.c_str() + q;
+                c.name = cstr(q);
                 q += c.name.size() + 1u;
                 c.type = rd32(q);
+                if (c.type > 2u) { throw truncated(); }
                 q += 16u;
                 channels.emplace_back(c);
             }
         } else if (name == "dataWindow") {
+            need(p, 16u);
             std::memcpy(&xmin, data.data() + p, 4), std::memcpy(&ymin, data.data() + p + 4, 4);
             std::memcpy(&xmax, data.data() + p + 8, 4), std::memcpy(&ymax, data.data() + p + 12, 4);
         } else if (name == "compression") {
+            need(p, 1u);
             compression = static_cast<uint8_t>(data[p]);
         }
         p += size;
     }
     p++;
+    if (channels.empty() || xmax < xmin || ymax < ymin || static_cast<int64_t>(xmax) - xmin >= 65536 || static_cast<int64_t>(ymax) - ymin >= 65536) {
+        throw Error{"Invalid EXR header (channels / dataWindow) in '" + path.string() + "'."};
+    }
     // NO_COMPRESSION (0), ZIPS (2: one scanline per chunk), ZIP (3: 16 scanlines per chunk); the deflate streams go
     // through zlib (the reference reads EXR with tinyexr + miniz, src/util/imageio.cpp:419-538)
     // and RLE (1: one scanline per chunk; signed run bytes, then the same predictor + byte de-interleave as ZIP)
@@ -276,18 +291,21 @@ LoadedImage read_exr(const fs::path &path) {
     std::vector<uint8_t> raw, tmp;
     for (uint32_t chunk = 0; chunk < chunk_count; chunk++) {
         uint64_t off;
+        need(table + static_cast<size_t>(chunk) * 8u, 8u);
         std::memcpy(&off, data.data() + table + static_cast<size_t>(chunk) * 8u, 8);
-        if (off + 8u > data.size()) { throw Error{"Truncated EXR image '" + path.string() + "'."}; }
+        if (off > data.size() || data.size() - off < 8u) { throw truncated(); }
         int32_t yy;
         uint32_t packed;
         std::memcpy(&yy, data.data() + off, 4);
         std::memcpy(&packed, data.data() + off + 4u, 4);
+        if (yy < ymin || yy > ymax) { throw truncated(); }
         auto first_row = static_cast<uint32_t>(yy - ymin);
         auto rows = std::min(lines_per_chunk, h - first_row);
         auto expect = line_bytes * rows;
         auto src = reinterpret_cast<const uint8_t *>(data.data()) + off + 8u;
-        if (off + 8u + packed > data.size()) { throw Error{"Truncated EXR image '" + path.string() + "'."}; }
+        if (packed > data.size() - off - 8u) { throw truncated(); }
         if (compression == 0u || packed == expect) {// stored
+            if (packed < expect) { throw truncated(); }
             raw.assign(src, src + expect);
         } else {
             tmp.resize(expect);
@@ -369,8 +387,9 @@ LoadedImage read_png(const fs::path &path) {
         auto len = be32(p);
         std::string type{data.data() + p + 4u, 4u};
         auto body = reinterpret_cast<const uint8_t *>(data.data()) + p + 8u;
-        if (p + 12u + len > data.size()) { throw Error{"Truncated PNG image '" + path.string() + "'."}; }
+        if (len > data.size() || p + 12u + len > data.size()) { throw Error{"Truncated PNG image '" + path.string() + "'."}; }
         if (type == "IHDR") {
+            if (len < 13u) { throw Error{"Corrupt PNG header '" + path.string() + "'."}; }
             w = be32(p + 8u), h = be32(p + 12u);
             depth = body[8], color = body[9], interlace = body[12];
         } else if (type == "PLTE") {
@@ -383,6 +402,10 @@ LoadedImage read_png(const fs::path &path) {
             break;
         }
         p += 12u + len;
+    }
+    if (w > 32768u || h > 32768u || (color != 0u && color != 2u && color != 3u && color != 4u && color != 6u) ||
+        (color == 3u && depth != 1u && depth != 2u && depth != 4u && depth != 8u)) {
+        throw Error{"Corrupt PNG header '" + path.string() + "'."};
     }
     if (w == 0u || h == 0u || interlace != 0u || (depth != 8u && depth != 16u && !(color == 3u && depth <= 8u))) {
         throw Error{"Unsupported PNG variant (interlaced or sub-byte samples) '" + path.string() + "'."};

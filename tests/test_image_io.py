@@ -262,3 +262,18 @@ def test_unsupported_formats_fail_loudly(tmp_path):
     q.write_bytes(b"GIF89a")
     with pytest.raises(HostError):
         load_image(str(q))
+
+
+def test_corrupt_files_fail_with_an_error_not_a_crash():
+    """regression corpus of an AddressSanitizer fuzzing pass over the readers (mutated / truncated files that used to read or
+    write out of bounds): every one must come back as a HostError or as a finite image"""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fuzz", "*")))
+    assert len(files) >= 7
+    for f in files:
+        try:
+            img, _ = load_image(f)
+            assert np.isfinite(img).all(), f
+        except HostError:
+            pass
