@@ -103,6 +103,13 @@ int lrhip_synchronize(lrhip_ctx *ctx);
  * converted == 0: the raw (sum r, sum g, sum b, n) film.  Synchronises.              */
 int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted);
 
+/* The path's only collective: sum-reduce of the per-rank films to rank `root` over RCCL / xGMI, in place on the film
+ * this context accumulates into, in stream order behind the renders.  `nccl_comm` is the caller's ncclComm_t (one per process /
+ * GPU, created by the caller: ncclCommInitRank); librccl.so is loaded on first use, so the library has no link-time dependency
+ * on it.  Every pixel is owned by exactly one rank under tile sharding and the others hold exact zeros there, so the reduced
+ * film is bit-identical to the 1-GPU film.  The reference has no multi-device path (src/apps/cli.cpp:172,181).              */
+int lrhip_film_reduce(lrhip_ctx *ctx, void *nccl_comm, int root);
+
 int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out); /* summed since upload; synchronises */
 /* HIP-event time of the megakernel launches of the last lrhip_render call, in ms; synchronises */
 double lrhip_last_render_ms(lrhip_ctx *ctx);

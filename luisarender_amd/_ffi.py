@@ -234,6 +234,7 @@ def hip_lib() -> C.CDLL:
         lib.lrhip_destroy.argtypes = [C.c_void_p]
         lib.lrhip_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
         lib.lrhip_update_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
+        lib.lrhip_film_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.lrhip_bind_film.argtypes = [C.c_void_p, C.c_void_p]
         lib.lrhip_film_clear.argtypes = [C.c_void_p]
         lib.lrhip_render.argtypes = [C.c_void_p, C.POINTER(RenderParams)]

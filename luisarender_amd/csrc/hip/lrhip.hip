@@ -5,6 +5,7 @@
 #include "../../../include/lrhip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -654,6 +655,25 @@ int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted) {
     }
     LR_HIP_CHECK(hipMemcpyAsync(rgba, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return LRHIP_OK;
+}
+
+int lrhip_film_reduce(lrhip_ctx *ctx, void *nccl_comm, int root) {
+    if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_reduce: no scene uploaded"); }
+    if (nccl_comm == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_reduce: communicator is NULL"); }
+    // ncclReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, root, comm, stream), rccl.h
+    using reduce_fn = int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
+    static reduce_fn reduce = [] {
+        auto lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib == nullptr) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); }
+        return lib != nullptr ? reinterpret_cast<reduce_fn>(dlsym(lib, "ncclReduce")) : nullptr;
+    }();
+    if (reduce == nullptr) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_film_reduce: librccl.so (ncclReduce) could not be loaded"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    auto count = static_cast<size_t>(ctx->width) * ctx->height * 4u;
+    if (auto rc = reduce(ctx->film, ctx->film, count, 7, 0, root, nccl_comm, ctx->stream); rc != 0) {
+        return fail(LRHIP_ERROR_DEVICE, "lrhip_film_reduce: ncclReduce failed with code " + std::to_string(rc));
+    }
     return LRHIP_OK;
 }
 

@@ -541,3 +541,39 @@ render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : Me
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
     assert np.array_equal(gpu[..., 3], cpu[..., 3]) and abs(gc["closest_rays"] - cc["closest_rays"]) <= 4
     assert _rel_l1(gpu, cpu) < 2e-3 and gpu[..., :3].mean() > 0.01
+
+
+def test_film_reduce_through_rccl_single_rank(renderer):
+    """lrhip_film_reduce (the C-level twin of bench.py's torch.distributed reduce): with a one-rank communicator the sum-reduce
+    must leave the film exactly as it was; the call goes through librccl's ncclReduce on the context's stream"""
+    import ctypes as C
+    from luisarender_amd import _ffi
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        pytest.skip("librccl.so not found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    if rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        pytest.skip("ncclGetUniqueId failed")
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    if rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) != 0:
+        pytest.skip("ncclCommInitRank failed on this box")
+    try:
+        sc = Scene.from_string(cornell_box(resolution=32, spp=4))
+        renderer.upload(sc)
+        renderer.render(0, 4, sync=True)
+        before = renderer.download(converted=False)
+        lib = _ffi.hip_lib()
+        assert lib.lrhip_film_reduce(renderer._ctx, comm, 0) == 0, lib.lrhip_last_error()
+        renderer.synchronize()
+        after = renderer.download(converted=False)
+        assert np.array_equal(before, after) and before[..., 3].min() == 4
+        assert lib.lrhip_film_reduce(renderer._ctx, None, 0) < 0  # NULL communicator: error code, no crash
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
