@@ -167,3 +167,31 @@ def test_device_motion_blur_matches_oracle():
     rel = float(np.abs(gpu[..., :3] - cpu[..., :3]).sum() / np.abs(cpu[..., :3]).sum())
     assert np.array_equal(gpu[..., 3], cpu[..., 3]) and rel < 1e-4, rel
     r.close()
+
+
+def test_animated_camera_and_environment_follow_the_time():
+    """Pipeline::update re-evaluates EVERY registered animated transform (pipeline.cpp:101-113): cameras and the environment too"""
+    text = """
+Shape floor : InlineMesh { positions { -5,0,-5, 5,0,-5, 5,0,5, -5,0,5 } indices { 0,2,1, 0,3,2 } surface : Matte { } }
+Camera cam : Pinhole { spp { 4 } film : Color { resolution { 8, 8 } } shutter_span { 0, 2 } shutter_samples { 2 }
+  transform : Lerp { time_points { 0, 2 } transforms { View { position { 0, 1, 4 } front { 0, 0, -1 } }, View { position { 2, 1, 4 } front { 0, 0, -1 } } } } }
+render { cameras { @cam } shapes { @floor } integrator : MegaPath { }
+  environment : Directional { emission : Constant { v { 5 } } angle { 5 }
+    transform : Lerp { time_points { 0, 2 } transforms { SRT { rotate { 0, 0, 1, 0 } }, SRT { rotate { 0, 0, 1, 90 } } } } } }
+"""
+    sc = Scene.from_string(text)
+    assert sc.set_time(1.0)
+    v = sc.view()
+    c2w = np.array(v.camera.camera_to_world[:], np.float32).reshape(4, 4).T
+    assert np.allclose(c2w[:3, 3], [1, 1, 4], atol=1e-6)  # half way between the two key positions
+    e2w = np.array(v.environment.env_to_world[:], np.float32).reshape(3, 3).T
+    c = np.cos(np.pi / 4)
+    assert np.allclose(e2w, [[c, -c, 0], [c, c, 0], [0, 0, 1]], atol=1e-5)  # 45 degrees about z
+    assert np.allclose(np.array(v.environment.world_to_env[:]).reshape(3, 3).T, e2w.T, atol=1e-6)
+    sc.set_time(0.0)
+    assert np.allclose(np.array(sc.view().environment.env_to_world[:]).reshape(3, 3), np.eye(3), atol=1e-6)
+    # the frame renders (two shutter samples, camera and light moved in between) and differs from the static frame at t = 0
+    film, _ = Oracle.render_frame(sc)
+    static = Scene.from_string(text.replace("shutter_span { 0, 2 } shutter_samples { 2 }", "shutter_span { 0 }"))
+    ref, _ = Oracle.render_frame(static)
+    assert np.all(film[..., 3] == 4) and np.isfinite(film).all() and not np.allclose(film[..., :3], ref[..., :3])
