@@ -85,9 +85,11 @@ int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream);
 /* scene->accel must be built (lrhost_scene_build_accel) */
 int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *scene);
 
-/* Pipeline::update (src/base/pipeline.cpp:101-113) for the next shutter sample of a motion-blurred frame: like lrhip_upload_scene
- * with the tables moved to the sample's time (lrhost_scene_set_time), but the film, its binding and the counters carry on;
- * the resolution must not change.  (Everything is uploaded again; only the instance, camera and BVH tables differ.) */
+/* Pipeline::update (src/base/pipeline.cpp:101-113) for the next shutter sample of a motion-blurred frame: `scene` must be the
+ * uploaded scene moved to another time (lrhost_scene_set_time).  Only what moves is copied again, over the same device buffers
+ * and in stream order — instance matrices, the re-baked triangles and their shading records, the refitted BVH packets, camera and
+ * environment transforms — while textures, environment tables, materials, the film, its binding and the counters stay.  Table
+ * sizes and BVH topology are checked against the upload; anything else that differs is the caller's error.                      */
 int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *scene);
 
 /* optional: accumulate into a caller-owned device buffer float4[W*H] (e.g. a torch tensor that

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -100,6 +101,7 @@ struct lrhip_ctx {
     uint32_t grid_blocks{0};
     uint32_t cu_count{0};
     uint32_t bvh_depth{0};
+    uint32_t update_counts[7]{};// table sizes of the uploaded scene: what lrhip_update_scene checks its argument against
     uint32_t last_variant{0u};// feature mask of the kernel the last lrhip_render launched
     uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
@@ -216,6 +218,69 @@ uint32_t bvh_depth(const lr_accel &accel) {
     return depth;
 }
 
+// ---- the tables that depend on the scene time (Pipeline::update / Geometry::update): built once per upload and again per
+// lrhip_update_scene, which copies them over the existing device buffers
+std::vector<lrd::DNodeQ> build_packed_nodes(const lr_scene *s) {
+    std::vector<lrd::DNodeQ> packed(s->accel.node_count);
+    for (uint32_t i = 0; i < s->accel.node_count; i++) { packed[i] = quantise_node(s->accel.nodes[i]); }
+    return packed;
+}
+
+std::vector<lrd::DInstance> build_instances(const lr_scene *s) {// one 128-byte line each
+    std::vector<lrd::DInstance> instances(s->instance_count);
+    for (uint32_t i = 0; i < s->instance_count; i++) {
+        auto &src = s->instances[i];
+        auto &dst = instances[i];
+        std::memset(&dst, 0, sizeof(dst));
+        dst.handle[0] = src.handle.x, dst.handle[1] = src.handle.y, dst.handle[2] = src.handle.z, dst.handle[3] = src.handle.w;
+        auto m = src.object_to_world;
+        for (auto r = 0; r < 3; r++) { dst.c0[r] = m[r], dst.c1[r] = m[4 + r], dst.c2[r] = m[8 + r], dst.t[r] = m[12 + r]; }
+        float nm[9];
+        normal_matrix(m, nm);
+        for (auto r = 0; r < 3; r++) { dst.n0[r] = nm[r], dst.n1[r] = nm[3 + r], dst.n2[r] = nm[6 + r]; }
+        auto &mesh = s->meshes[src.handle.x >> 10u];
+        dst.vertex_offset = mesh.vertex_offset;
+        dst.triangle_offset = mesh.triangle_offset;
+    }
+    return instances;
+}
+
+// shading records of the baked triangles (dev_scene.h: DShadeTri), in BVH triangle order; empty + error text on bad references
+std::vector<lrd::DShadeTri> build_shade_tris(const lr_scene *s, const std::vector<lrd::DInstance> &instances, std::string &error) {
+    std::vector<lrd::DShadeTri> shade(s->accel.triangle_count);
+    for (uint32_t i = 0; i < s->accel.triangle_count; i++) {
+        auto &bt = s->accel.triangles[i];
+        if (bt.inst >= s->instance_count) { error = "BVH triangle references an unknown instance"; return {}; }
+        auto &inst = s->instances[bt.inst];
+        auto &di = instances[bt.inst];
+        auto &mesh = s->meshes[inst.handle.x >> 10u];
+        if (bt.prim >= mesh.triangle_count) { error = "BVH triangle references an unknown primitive"; return {}; }
+        auto tri = s->triangles[mesh.triangle_offset + bt.prim];
+        const lr_vertex *v[3] = {s->vertices + mesh.vertex_offset + tri.i0, s->vertices + mesh.vertex_offset + tri.i1, s->vertices + mesh.vertex_offset + tri.i2};
+        auto &r = shade[i];
+        std::memset(&r, 0, sizeof(r));
+        for (auto c = 0; c < 3; c++) { r.p0[c] = bt.v0[c], r.e1[c] = bt.e1[c], r.e2[c] = bt.e2[c]; }
+        float *n[3] = {r.n0, r.n1, r.n2};
+        for (auto k = 0; k < 3; k++) {
+            for (auto c = 0; c < 3; c++) { n[k][c] = di.n0[c] * v[k]->nx + di.n1[c] * v[k]->ny + di.n2[c] * v[k]->nz; }
+        }
+        r.uv0x = v[0]->u, r.uv0y = v[0]->v, r.uv1x = v[1]->u, r.uv1y = v[1]->v, r.uv2x = v[2]->u, r.uv2y = v[2]->v;
+        r.flags = inst.handle.x & 1023u, r.tags = inst.handle.y, r.offset_bits = inst.handle.w;
+        r.tri_pdf = s->tri_pdf[mesh.triangle_offset + bt.prim];
+        r.inst = bt.inst, r.prim = bt.prim, r.tri_offset = mesh.triangle_offset;
+    }
+    return shade;
+}
+
+void set_camera(lrd::DScene &d, const lr_scene *s) {
+    auto &cam = d.camera;
+    cam.kind = s->camera.kind, cam.width = s->camera.width, cam.height = s->camera.height;
+    std::memcpy(cam.c2w, s->camera.camera_to_world, sizeof(cam.c2w));
+    cam.tan_half_fov = s->camera.tan_half_fov, cam.focus_distance = s->camera.focus_distance;
+    cam.lens_radius = s->camera.lens_radius, cam.projected_pixel_size = s->camera.projected_pixel_size;
+    cam.ortho_scale = s->camera.ortho_scale, cam.clip_near = s->camera.clip_near, cam.clip_far = s->camera.clip_far;
+}
+
 }// namespace
 
 extern "C" {
@@ -276,21 +341,53 @@ int lrhip_set_stream(lrhip_ctx *ctx, void *hip_stream) {
     return LRHIP_OK;
 }
 
-static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film);
-
-int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) { return upload_scene_impl(ctx, s, false); }
 
 int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: no scene uploaded"); }
     if (s == nullptr || s->camera.width != ctx->width || s->camera.height != ctx->height) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: the film resolution must not change");
     }
-    return upload_scene_impl(ctx, s, true);
+    // Only what Pipeline::update / Geometry::update move is copied again (instance matrices, the baked triangles and their
+    // shading records, the refitted BVH packets, camera and environment transforms), over the SAME device buffers: a frame with
+    // 256 shutter samples must not push its textures and environment tables through PCIe 256 times.  Everything else must be
+    // the scene that was uploaded; the table sizes are the part of that contract that can be checked.
+    if (s->accel.nodes == nullptr || s->accel.node_count != ctx->update_counts[0] || s->accel.triangle_count != ctx->update_counts[1] ||
+        s->instance_count != ctx->update_counts[2] || s->triangle_count != ctx->update_counts[3] || s->texture_count != ctx->update_counts[4] ||
+        s->surface_count != ctx->update_counts[5] || s->environment.kind != ctx->update_counts[6]) {
+        return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: not the uploaded scene at another time (table sizes differ); use lrhip_upload_scene");
+    }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    if (bvh_depth(s->accel) != ctx->bvh_depth) { return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: the BVH topology changed; use lrhip_upload_scene"); }
+    auto &d = ctx->scene;
+    auto copy = [&](const void *device, const void *host, size_t bytes) {// stream-ordered behind the renders that still read the old tables
+        return bytes == 0u ? hipSuccess : hipMemcpyAsync(const_cast<void *>(device), host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    };
+    auto packed = build_packed_nodes(s);
+    auto instances = build_instances(s);
+    std::string error;
+    auto shade = build_shade_tris(s, instances, error);
+    if (!error.empty()) { return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: " + error); }
+    LR_HIP_CHECK(copy(d.nodes, packed.data(), packed.size() * sizeof(packed[0])));
+    LR_HIP_CHECK(copy(d.bvh_tris, s->accel.triangles, static_cast<size_t>(s->accel.triangle_count) * sizeof(lr_bvh_triangle)));
+    LR_HIP_CHECK(copy(d.instances, instances.data(), instances.size() * sizeof(instances[0])));
+    LR_HIP_CHECK(copy(d.shade_tris, shade.data(), shade.size() * sizeof(shade[0])));
+    LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));// the host vectors above go out of scope
+    set_camera(d, s);
+    if (d.env_kind == lrd::kEnvConstant) {
+        std::memcpy(d.env_to_world, s->environment.env_to_world, sizeof(d.env_to_world));
+    } else if (d.env != nullptr && s->environment.kind != LR_ENV_COMBINED) {// (animated Combined environments are rejected by the host loader)
+        // the record's two matrices lead the struct: overwrite them in place
+        float m[18];
+        std::memcpy(m, s->environment.world_to_env, sizeof(float) * 9u);
+        std::memcpy(m + 9, s->environment.env_to_world, sizeof(float) * 9u);
+        static_assert(offsetof(lrd::DEnvironment, world_to_env) == 0u && offsetof(lrd::DEnvironment, env_to_world) == sizeof(float) * 9u, "DEnvironment layout");
+        LR_HIP_CHECK(hipMemcpy(const_cast<lrd::DEnvironment *>(d.env), m, sizeof(m), hipMemcpyHostToDevice));
+    }
+    return LRHIP_OK;
 }
 
-static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) {
+int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (ctx == nullptr || s == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: NULL argument"); }
-    auto bound_film = ctx->film;
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
     }
@@ -316,8 +413,7 @@ static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) 
         return rc;                                    \
     }
     {
-        std::vector<lrd::DNodeQ> packed(s->accel.node_count);
-        for (uint32_t i = 0; i < s->accel.node_count; i++) { packed[i] = quantise_node(s->accel.nodes[i]); }
+        auto packed = build_packed_nodes(s);
         LR_UP(upload(ctx, packed.data(), packed.size(), &d.nodes));
     }
     LR_UP(upload(ctx, s->accel.triangles, s->accel.triangle_count, &d.bvh_tris));
@@ -330,46 +426,12 @@ static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) 
     LR_UP(upload(ctx, s->textures, s->texture_count, &d.textures));
     LR_UP(upload(ctx, s->texels, s->texel_count * 4u, &d.texels));
     LR_UP(upload(ctx, &s->filter, 1u, &d.filter));
-    // instances: one 128-byte line each
-    std::vector<lrd::DInstance> instances(s->instance_count);
-    for (uint32_t i = 0; i < s->instance_count; i++) {
-        auto &src = s->instances[i];
-        auto &dst = instances[i];
-        std::memset(&dst, 0, sizeof(dst));
-        dst.handle[0] = src.handle.x, dst.handle[1] = src.handle.y, dst.handle[2] = src.handle.z, dst.handle[3] = src.handle.w;
-        auto m = src.object_to_world;
-        for (auto r = 0; r < 3; r++) { dst.c0[r] = m[r], dst.c1[r] = m[4 + r], dst.c2[r] = m[8 + r], dst.t[r] = m[12 + r]; }
-        float nm[9];
-        normal_matrix(m, nm);
-        for (auto r = 0; r < 3; r++) { dst.n0[r] = nm[r], dst.n1[r] = nm[3 + r], dst.n2[r] = nm[6 + r]; }
-        auto &mesh = s->meshes[src.handle.x >> 10u];
-        dst.vertex_offset = mesh.vertex_offset;
-        dst.triangle_offset = mesh.triangle_offset;
-    }
+    auto instances = build_instances(s);
     LR_UP(upload(ctx, instances.data(), instances.size(), &d.instances));
-    {// shading records of the baked triangles (dev_scene.h: DShadeTri), in BVH triangle order
-        std::vector<lrd::DShadeTri> shade(s->accel.triangle_count);
-        for (uint32_t i = 0; i < s->accel.triangle_count; i++) {
-            auto &bt = s->accel.triangles[i];
-            if (bt.inst >= s->instance_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: BVH triangle references an unknown instance"); }
-            auto &inst = s->instances[bt.inst];
-            auto &di = instances[bt.inst];
-            auto &mesh = s->meshes[inst.handle.x >> 10u];
-            if (bt.prim >= mesh.triangle_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: BVH triangle references an unknown primitive"); }
-            auto tri = s->triangles[mesh.triangle_offset + bt.prim];
-            const lr_vertex *v[3] = {s->vertices + mesh.vertex_offset + tri.i0, s->vertices + mesh.vertex_offset + tri.i1, s->vertices + mesh.vertex_offset + tri.i2};
-            auto &r = shade[i];
-            std::memset(&r, 0, sizeof(r));
-            for (auto c = 0; c < 3; c++) { r.p0[c] = bt.v0[c], r.e1[c] = bt.e1[c], r.e2[c] = bt.e2[c]; }
-            float *n[3] = {r.n0, r.n1, r.n2};
-            for (auto k = 0; k < 3; k++) {
-                for (auto c = 0; c < 3; c++) { n[k][c] = di.n0[c] * v[k]->nx + di.n1[c] * v[k]->ny + di.n2[c] * v[k]->nz; }
-            }
-            r.uv0x = v[0]->u, r.uv0y = v[0]->v, r.uv1x = v[1]->u, r.uv1y = v[1]->v, r.uv2x = v[2]->u, r.uv2y = v[2]->v;
-            r.flags = inst.handle.x & 1023u, r.tags = inst.handle.y, r.offset_bits = inst.handle.w;
-            r.tri_pdf = s->tri_pdf[mesh.triangle_offset + bt.prim];
-            r.inst = bt.inst, r.prim = bt.prim, r.tri_offset = mesh.triangle_offset;
-        }
+    {
+        std::string error;
+        auto shade = build_shade_tris(s, instances, error);
+        if (!error.empty()) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: " + error); }
         LR_UP(upload(ctx, shade.data(), shade.size(), &d.shade_tris));
     }
     // closures: fold constant textures on the host (same arithmetic as the per-hit device path)
@@ -415,12 +477,7 @@ static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) 
     }
     LR_UP(upload(ctx, lights.data(), lights.size(), &d.lights));
 #undef LR_UP
-    auto &cam = d.camera;
-    cam.kind = s->camera.kind, cam.width = s->camera.width, cam.height = s->camera.height;
-    std::memcpy(cam.c2w, s->camera.camera_to_world, sizeof(cam.c2w));
-    cam.tan_half_fov = s->camera.tan_half_fov, cam.focus_distance = s->camera.focus_distance;
-    cam.lens_radius = s->camera.lens_radius, cam.projected_pixel_size = s->camera.projected_pixel_size;
-    cam.ortho_scale = s->camera.ortho_scale, cam.clip_near = s->camera.clip_near, cam.clip_far = s->camera.clip_far;
+    set_camera(d, s);
     d.env_kind = lrd::kEnvNone;
     d.env = nullptr;
     if (s->environment.kind != LR_ENV_NONE) {
@@ -526,19 +583,18 @@ static int upload_scene_impl(lrhip_ctx *ctx, const lr_scene *s, bool keep_film) 
     if (auto r = ensure(ctx->converted, film_bytes); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->counters, sizeof(lrd::DCounters)); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->work_counter, 256u); r != LRHIP_OK) { return r; }
-    if (keep_film) {// the next shutter sample of the same frame: film, binding and counters carry on
-        ctx->film = bound_film;
-    } else {
-        LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
-        ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
-        LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
-    }
+    LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
+    ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
+    LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
     // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
     // traversal-stack overflow area is sized for the densest variant
     for (auto &b : ctx->variant_blocks) { b = -1; }
     ctx->grid_blocks = ctx->cu_count * kMaxBlocksPerCu;
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
     if (auto r = ensure(ctx->spill, total_threads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    ctx->update_counts[0] = s->accel.node_count, ctx->update_counts[1] = s->accel.triangle_count, ctx->update_counts[2] = s->instance_count;
+    ctx->update_counts[3] = static_cast<uint32_t>(s->triangle_count), ctx->update_counts[4] = s->texture_count, ctx->update_counts[5] = s->surface_count;
+    ctx->update_counts[6] = s->environment.kind;
     ctx->scene_ready = true;
     return LRHIP_OK;
 }
