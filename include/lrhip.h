@@ -15,6 +15,7 @@
  *                                  render(sample_id, time, weight).dispatch(resolution), i.e.
  *                                  Li() + film accumulate                 src/integrators/mega_path.cpp:49-156
  *   lrhip_film_download            ColorFilmInstance::download            src/films/color.cpp:99-105
+ *   lrhip_film_reduce              (no reference equivalent: the one collective of the multi-GPU path)
  *   lrhip_get_counters             (no reference equivalent; roofline accounting)
  *
  * Conventions: 0 = OK, negative = error (text via lrhip_last_error, thread-local); nothing
