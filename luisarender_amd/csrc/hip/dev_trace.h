@@ -91,6 +91,9 @@ struct TraversalStack {
 #ifndef LR_PUSH_UNSORTED
 #define LR_PUSH_UNSORTED 0
 #endif
+#ifndef LR_TRI_STRIDE
+#define LR_TRI_STRIDE 48u// bytes between baked BVH triangles on the device (64: one cache line each)
+#endif
 #ifndef LR_LDS_DIRECT
 #define LR_LDS_DIRECT 1
 #endif
@@ -295,7 +298,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
             auto found = false;
             {
-                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
+                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * (LR_TRI_STRIDE / 16u);
                 auto a = tb[0], b = tb[1], c = tb[2];
                 if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF

@@ -226,6 +226,12 @@ std::vector<lrd::DNodeQ> build_packed_nodes(const lr_scene *s) {
     return packed;
 }
 
+std::vector<uint8_t> build_padded_triangles(const lr_scene *s) {// the baked triangles at the device stride (dev_trace.h: LR_TRI_STRIDE)
+    std::vector<uint8_t> out(static_cast<size_t>(s->accel.triangle_count) * LR_TRI_STRIDE, 0u);
+    for (uint32_t i = 0; i < s->accel.triangle_count; i++) { std::memcpy(out.data() + static_cast<size_t>(i) * LR_TRI_STRIDE, s->accel.triangles + i, sizeof(lr_bvh_triangle)); }
+    return out;
+}
+
 std::vector<lrd::DInstance> build_instances(const lr_scene *s) {// one 128-byte line each
     std::vector<lrd::DInstance> instances(s->instance_count);
     for (uint32_t i = 0; i < s->instance_count; i++) {
@@ -368,7 +374,8 @@ int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
     auto shade = build_shade_tris(s, instances, error);
     if (!error.empty()) { return fail(LRHIP_ERROR_INVALID, "lrhip_update_scene: " + error); }
     LR_HIP_CHECK(copy(d.nodes, packed.data(), packed.size() * sizeof(packed[0])));
-    LR_HIP_CHECK(copy(d.bvh_tris, s->accel.triangles, static_cast<size_t>(s->accel.triangle_count) * sizeof(lr_bvh_triangle)));
+    auto padded = build_padded_triangles(s);
+    LR_HIP_CHECK(copy(d.bvh_tris, padded.data(), padded.size()));
     LR_HIP_CHECK(copy(d.instances, instances.data(), instances.size() * sizeof(instances[0])));
     LR_HIP_CHECK(copy(d.shade_tris, shade.data(), shade.size() * sizeof(shade[0])));
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));// the host vectors above go out of scope
@@ -416,7 +423,12 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         auto packed = build_packed_nodes(s);
         LR_UP(upload(ctx, packed.data(), packed.size(), &d.nodes));
     }
-    LR_UP(upload(ctx, s->accel.triangles, s->accel.triangle_count, &d.bvh_tris));
+    {
+        auto padded = build_padded_triangles(s);
+        const uint8_t *dev = nullptr;
+        LR_UP(upload(ctx, padded.data(), padded.size(), &dev));
+        d.bvh_tris = reinterpret_cast<const lr_bvh_triangle *>(dev);
+    }
     LR_UP(upload(ctx, s->vertices, s->vertex_count, &d.vertices));
     LR_UP(upload(ctx, s->triangles, s->triangle_count, &d.triangles));
     LR_UP(upload(ctx, s->tri_alias, s->triangle_count, &d.tri_alias));
