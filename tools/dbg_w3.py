@@ -1,3 +1,6 @@
+"""Diagnose a kernel build variant on the Layered parity scenes (GPU box): LRHIP_LIB=<variant .so> python tools/dbg_w3.py
+prints how many samples the film rejected (NaN / Inf) against the oracle and where — this is how the 3-waves-per-SIMD build of the
+Layered variants was found to be miscompiled."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
