@@ -29,3 +29,22 @@ def test_bvh_sim_builds_and_counts(tmp_path):
         out[bool(knobs)] = (int(m.group(1)), int(m.group(2)), float(m.group(4)))
     # 32 triangles, every ray of the closed box hits something; the default builder is never worse than the round-1b one here
     assert out[False][1] == 32 and out[True][1] == 32 and out[False][2] <= out[True][2] * 1.05
+
+
+def test_default_builder_beats_the_round1b_builder_on_a_room(tmp_path):
+    """regression guard for DESIGN.md §4.4: on a (small) bathroom-class room the default builder (exact sweep + reinsertion +
+    optimal collapse) visits clearly fewer nodes per ray than 16-bin SAH + greedy collapse"""
+    from luisarender_amd.scenes import generate_room_scene
+    if shutil.which("g++") is None:
+        pytest.skip("no C++ compiler")
+    _ffi.host_lib()
+    exe = tmp_path / "bvh_sim"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(_ffi.REPO_ROOT, "include"), os.path.join(_ffi.REPO_ROOT, "tools", "bvh_sim.cpp"),
+                           "-L", _ffi.LIB_DIR, "-llrhost", f"-Wl,-rpath,{_ffi.LIB_DIR}", "-o", str(exe)])
+    scene = generate_room_scene(str(tmp_path), target_triangles=40_000, resolution=(64, 64), spp=1)
+    steps = {}
+    for name, knobs in (("default", {}), ("round1b", {"LR_BVH_SWEEP": "0", "LR_BVH_COLLAPSE": "0", "LR_BVH_REINSERT": "0"})):
+        r = subprocess.run([str(exe), scene, "64", "5"], capture_output=True, text=True, timeout=300, env={**os.environ, **knobs})
+        assert r.returncode == 0, r.stderr
+        steps[name] = float(re.search(r"total steps/ray ([\d.]+)", r.stdout).group(1))
+    assert steps["default"] < 0.92 * steps["round1b"], steps
