@@ -51,7 +51,8 @@ constexpr auto bin_count = 16u;
 //     the sweep everywhere; 32 / 64 / 128 bins: 18.2 / 18.0 / 17.2; C5 17.6 -> 16.4, C3 19.6 -> 19.2);
 //   * SAH-optimal BVH2 -> BVH4 collapse instead of "open the largest child" (20 % fewer nodes in memory, -1 % steps per ray);
 //   * insertion-based optimisation of the BVH2 before the collapse (Reinserter below): 16.7 -> 14.7 steps per ray after one
-//     pass over all inner nodes (2 / 4 passes: 14.6 / 14.5), +4 s of build time for 600 k triangles;
+//     pass over all inner nodes (2 / 4 passes: 14.6 / 14.5), +4 s of build time for 600 k triangles; the worse half of the
+//     nodes (by area x imbalance) carries most of it: fraction 0.5 -> 14.77 in half the time (0.25: 14.84);
 //   * node order in memory: breadth-first, or depth-first over sibling groups (a subtree's nodes are contiguous; measured
 //     on the device: no difference).
 // Measured on the device (C2 at 256 spp, tools/gpu_call_bvh.sh): binned + greedy 554, sweep + optimal collapse 597,
@@ -406,6 +407,9 @@ void build_accel(SceneData &scene) {
         builder.build(0u, ref_count);
         nodes2.resize(builder.node_count());
     }
+    // the concurrent build hands out node slots in whatever order its tasks run: renumber first, so that the optimiser (whose
+    // tie-breaks go by index) and everything after it see the same tree in every run and on every rank
+    relinearise(nodes2, indices);
     if (reinsertion_passes > 0u && nodes2.size() > 7u) {
         Reinserter opt{nodes2};
         auto before = opt.total_area();

@@ -207,3 +207,19 @@ render { cameras { @cam } shapes { @quad } environment : Spherical { emission : 
     t = [v.textures[i] for i in range(v.texture_count) if v.textures[i].kind == 0 and v.textures[i].channels == 2]
     assert any(np.allclose(x.v[:2], [0.3, 0.2]) for x in t)  # evaluate_static: (z, y) of the constant
     assert np.allclose(folded, [0.3, 0.2, 1.0], rtol=0.03)  # two channels extend to (x, y, 1)
+
+
+def test_bvh_build_is_deterministic(tmp_path):
+    """the sweep build runs its big subtrees as concurrent tasks; the tree that comes out (topology, node order, triangle
+    order) must not depend on how they were scheduled: every rank of a multi-GPU render builds its own copy"""
+    import ctypes as C
+    from luisarender_amd.scenes import generate_room_scene
+    path = generate_room_scene(str(tmp_path), target_triangles=60_000, resolution=(32, 32), spp=1)
+    blobs = []
+    for _ in range(3):
+        sc = Scene.load(path)
+        v = sc.view()
+        nodes = C.string_at(C.addressof(v.accel.nodes.contents), v.accel.node_count * 128)
+        tris = C.string_at(C.addressof(v.accel.triangles.contents), v.accel.triangle_count * 48)
+        blobs.append((v.accel.node_count, nodes, tris))
+    assert blobs[0] == blobs[1] == blobs[2]
