@@ -1,5 +1,5 @@
 // bvh_sim.cpp — CPU model of the megakernel's BVH4 walk (dev_trace.h: ordered near->far, one-triangle leaves,
-// quantised boxes are NOT modelled) used to compare host BVH builders offline: node visits / triangle tests per ray
+// fp32 child boxes, or the packets' 8-bit planes with BVH_SIM_QUANTISED=1) used to compare host BVH builders offline: node visits / triangle tests per ray
 // for camera rays, diffuse bounces and shadow rays of a seeded stand-in path workload.
 //   g++ -O2 -std=c++17 -Iinclude tools/bvh_sim.cpp -Lluisarender_amd/lib -llrhost -Wl,-rpath,$PWD/luisarender_amd/lib -o /tmp/bvh_sim
 //   /tmp/bvh_sim scene.luisa [pixels_per_axis=192] [bounces=6]
@@ -25,6 +25,28 @@ static V norm(V a) { return a * (1.f / std::sqrt(dot(a, a))); }
 struct Stats { uint64_t rays{0}, nodes{0}, tris{0}, empty{0}, max_stack{0}; };
 
 struct Hit { float t; uint32_t tri; float u, v; };
+
+// optional model of the device's 64-byte packets: child boxes snapped outwards to the 8-bit grid of their node's own box
+// (lrhip.hip: quantise_node); BVH_SIM_QUANTISED=1
+static bool g_quantised = false;
+static std::vector<lr_bvh4_node> g_qnodes;
+static void quantise(const lr_accel &acc) {
+    g_qnodes.assign(acc.nodes, acc.nodes + acc.node_count);
+    for (auto &n : g_qnodes) {
+        float *lo[3] = {n.lo_x, n.lo_y, n.lo_z}, *hi[3] = {n.hi_x, n.hi_y, n.hi_z};
+        for (int a = 0; a < 3; a++) {
+            float mn = 3e38f, mx = -3e38f;
+            for (int c = 0; c < 4; c++) { if (n.child[c] != ~0u) { mn = std::min(mn, lo[a][c]), mx = std::max(mx, hi[a][c]); } }
+            auto sc = (mx - mn) / 255.f;
+            if (!(sc > 0.f)) { continue; }
+            for (int c = 0; c < 4; c++) {
+                if (n.child[c] == ~0u) { continue; }
+                lo[a][c] = mn + std::floor((lo[a][c] - mn) / sc) * sc;
+                hi[a][c] = mn + std::ceil((hi[a][c] - mn) / sc) * sc;
+            }
+        }
+    }
+}
 
 static bool trace(const lr_accel &acc, V o, V d, float t_min, float t_max, bool any, Hit &hit, Stats &st) {
     V inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
@@ -53,7 +75,7 @@ static bool trace(const lr_accel &acc, V o, V d, float t_min, float t_max, bool 
             cur = sp ? stack[--sp] : ~0u;
             continue;
         }
-        auto &n = acc.nodes[cur];
+        auto &n = g_quantised ? g_qnodes[cur] : acc.nodes[cur];
         st.nodes++;
         uint32_t key[4];
         for (int i = 0; i < 4; i++) {
@@ -105,6 +127,7 @@ int main(int argc, char **argv) {
         for (uint32_t i = 0; i < s.light_instance_count; i++) { is_light[s.light_instances[i].instance_id] = 1; }
         for (uint32_t i = 0; i < acc.triangle_count; i++) { if (is_light[acc.triangles[i].inst]) { light_tris.push_back(i); } }
     }
+    if (auto e = std::getenv("BVH_SIM_QUANTISED"); e != nullptr && std::atoi(e) != 0) { g_quantised = true, quantise(acc); }
     Stats closest, shadow;
     auto &cam = s.camera;
     auto m = cam.camera_to_world;
