@@ -223,3 +223,44 @@ def test_bvh_build_is_deterministic(tmp_path):
         tris = C.string_at(C.addressof(v.accel.triangles.contents), v.accel.triangle_count * 48)
         blobs.append((v.accel.node_count, nodes, tris))
     assert blobs[0] == blobs[1] == blobs[2]
+
+
+def test_bvh4_is_a_valid_tree_over_every_triangle(tmp_path):
+    """structural check of what lrhip_upload_scene receives: every baked triangle sits in exactly one leaf, every child box
+    encloses its child (the triangle, or the child node's boxes), child indices are larger than their parent's (refit and the
+    collapse rely on it), depth within the traversal stack's bound"""
+    from luisarender_amd.scenes import generate_room_scene
+    sc = Scene.load(generate_room_scene(str(tmp_path), target_triangles=30_000, resolution=(32, 32), spp=1))
+    v = sc.view()
+    n_nodes, n_tris = v.accel.node_count, v.accel.triangle_count
+    import ctypes as C
+    raw = np.frombuffer(C.string_at(C.addressof(v.accel.nodes.contents), n_nodes * 128), np.uint8).reshape(n_nodes, 128)
+    boxes = raw[:, :96].copy().view(np.float32).reshape(n_nodes, 6, 4)   # lo_x lo_y lo_z hi_x hi_y hi_z, 4 children each
+    child = raw[:, 96:112].copy().view(np.uint32).reshape(n_nodes, 4)
+    tri = np.frombuffer(C.string_at(C.addressof(v.accel.triangles.contents), n_tris * 48), np.float32).reshape(n_tris, 12)
+    p0, e1, e2 = tri[:, 0:3], tri[:, 4:7], tri[:, 8:11]
+    tlo = np.minimum(np.minimum(p0, p0 + e1), p0 + e2)
+    thi = np.maximum(np.maximum(p0, p0 + e1), p0 + e2)
+    valid = child != 0xFFFFFFFF
+    leaf = valid & ((child & 0x80000000) != 0)
+    inner = valid & ~leaf
+    # leaves: each triangle exactly once, inside its box
+    refs = (child[leaf] & 0x7FFFFFF).astype(np.int64)
+    assert np.array_equal(np.sort(refs), np.arange(n_tris))
+    node_of, slot_of = np.nonzero(leaf)
+    lo = boxes[node_of, 0:3, slot_of]
+    hi = boxes[node_of, 3:6, slot_of]
+    assert (tlo[refs] >= lo - 1e-6).all() and (thi[refs] <= hi + 1e-6).all()
+    # inner children: larger index than the parent, box encloses the child's boxes, every node except the root referenced once
+    node_of, slot_of = np.nonzero(inner)
+    kids = child[inner].astype(np.int64)
+    assert (kids > node_of).all() and np.array_equal(np.sort(kids), np.arange(1, n_nodes))
+    big = 3e38
+    klo = np.where(valid[kids][:, None, :], boxes[kids, 0:3, :], big).min(axis=2)
+    khi = np.where(valid[kids][:, None, :], boxes[kids, 3:6, :], -big).max(axis=2)
+    assert (klo >= boxes[node_of, 0:3, slot_of] - 1e-6).all() and (khi <= boxes[node_of, 3:6, slot_of] + 1e-6).all()
+    depth = np.zeros(n_nodes, np.int64)
+    depth[0] = 1
+    for parent, kid in sorted(zip(node_of.tolist(), kids.tolist())):
+        depth[kid] = depth[parent] + 1
+    assert depth.max() * 3 <= 16 + 88  # lrhip_upload_scene's bound: kStackLds + kSpillEntries
