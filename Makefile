@@ -25,8 +25,13 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean hip-variant variant-lib
+.PHONY: all host hip oracle cli clean hip-variant variant-lib ref
 all: host oracle hip cli
+
+# oracle/_ref: the reference's OWN sources compiled in place against the scalar LuisaCompute stand-in of oracle/ref_shim
+# (test infrastructure: pins oracle/ to the reference; needs /root/reference, so only where the reference tree exists)
+ref:
+	$(MAKE) -f oracle/Makefile.ref ref
 
 host: $(LIBDIR)/liblrhost.so
 $(LIBDIR)/liblrhost.so: $(HOST_SRC) $(HOST_HDR) Makefile

@@ -1,0 +1,2 @@
+#pragma once
+#include "../lc_runtime.h"

@@ -1,0 +1,3 @@
+// stand-in for luisa/runtime/rtx/triangle.h (oracle/ref_shim, TEST INFRASTRUCTURE ONLY): see lc_runtime.h
+#pragma once
+#include "../../lc_runtime.h"
