@@ -779,7 +779,9 @@ struct LightPick {
     f3 L;
     float pdf;
 };
-template<bool ENV>
+// NULL_SHAPE: `it` is Interaction{p} of a medium point (interaction.h:77-78): its Shape::Handle is default-constructed, the
+// intersection-offset factor is 0 and p_robust() returns p itself (pinned against the reference's own code, oracle/_ref).
+template<bool ENV, bool NULL_SHAPE = false>
 LR_D LightPick sample_one_light(const DScene &scene, const SurfacePoint &it, float u_light_selection, f2 u_light_surface) {
     LightPick out;
     out.L = mk3(0.f), out.pdf = 0.f;
@@ -812,7 +814,7 @@ LR_D LightPick sample_one_light(const DScene &scene, const SurfacePoint &it, flo
             out.L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
             out.pdf = (kInvPi * 0.25f) * prob;
         }
-        out.shadow.o = robust_origin(it, wi);
+        out.shadow.o = NULL_SHAPE ? it.p : robust_origin(it, wi);
         out.shadow.d = wi;
         out.shadow.t_min = 0.f, out.shadow.t_max = kFloatMax;
     } else {// _sample_area, uniform.cpp:107-123
@@ -830,7 +832,7 @@ LR_D LightPick sample_one_light(const DScene &scene, const SurfacePoint &it, flo
         lp.back_facing = dot(lp.ng, it.p - lp.p) < 0.f;
         light_evaluate(scene, lp, pick.index, it.p, out.L, out.pdf);
         out.pdf *= prob;
-        auto p_from = robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
+        auto p_from = NULL_SHAPE ? it.p : robust_origin(it, lp.p - it.p);// spawn_ray_to, interaction.cpp:25-30
         auto Lv = lp.p - p_from;
         auto dist = length(Lv);
         out.shadow.o = p_from;

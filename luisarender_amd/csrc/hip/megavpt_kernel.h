@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
                                 mp.shading.s = mk3(1.f, 0.f, 0.f), mp.shading.t = mk3(0.f, 1.f, 0.f), mp.shading.n = mk3(0.f, 0.f, 1.f);
                                 mp.offset_bits = 0u;
                                 if (COUNT) { local.nee_samples++; }
-                                pick = sample_one_light<true>(scene, mp, u_light_selection, u_light_surface);
+                                pick = sample_one_light<true, true>(scene, mp, u_light_selection, u_light_surface);
                                 start_walk(kVptWalkMedium);
                                 break;
                             }

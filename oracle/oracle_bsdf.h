@@ -271,6 +271,10 @@ struct Interaction {// src/base/interaction.h
     uint32_t surface_tag() const { return (handle.y >> 12u) & 4095u; }
     uint32_t mesh_index() const { return handle.x >> 10u; }
     float intersection_offset_factor() const {// Shape::Handle::decode, shape.cpp:88-93
+        // An interaction without a shape (Interaction{p} of a medium point, interaction.h:77-78) keeps the DEFAULT-constructed
+        // Shape::Handle, whose DSL members are zero: factor 0, p_robust() returns p itself (pinned by oracle/_ref: the reference's
+        // own code gives exactly that; round 1 had decoded a zero handle word to factor 1 here).
+        if (!valid()) { return 0.f; }
         auto x = static_cast<float>(handle.w & 0xffffu) * (1.0f / 65536.f);
         return clampf(x * 255.f + 1.f, 1.f, 256.f);
     }

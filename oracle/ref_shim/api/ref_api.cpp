@@ -18,6 +18,8 @@
 #include <base/integrator.h>
 
 #include <map>
+#include <csignal>
+#include <execinfo.h>
 
 namespace libref {
 std::map<std::string, std::vector<float>> &saved_images() noexcept;// ref_imageio.cpp
@@ -52,10 +54,30 @@ struct RefScene {
 
 }// namespace
 
+// Heap objects start zeroed, as DSL variables do (see oracle/Makefile.ref on -ftrivial-auto-var-init=zero).  libref.so and its
+// plugins resolve operator new here; nothing else in the process does (the library is test infrastructure, loaded by ctypes).
+void *operator new(std::size_t n) {
+    if (auto p = std::calloc(1u, n == 0u ? 1u : n)) { return p; }
+    throw std::bad_alloc{};
+}
+void *operator new[](std::size_t n) { return ::operator new(n); }
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+
+static void libref_abort_handler(int) {// LUISA_ERROR / assert -> abort: say where, the reference's code is not ours to read blind
+    void *frames[48];
+    auto n = backtrace(frames, 48);
+    backtrace_symbols_fd(frames, n, 2);
+    std::_Exit(134);
+}
+
 extern "C" {
 
 // ---- scene ------------------------------------------------------------------------------------------------------------------
 void *ref_scene_load(const char *scene_file, const char *plugin_dir) {
+    if (std::getenv("LIBREF_BACKTRACE") != nullptr) { std::signal(SIGABRT, libref_abort_handler); }
     auto s = new RefScene{Context{std::filesystem::path{plugin_dir}}};
     SceneParser::MacroMap macros;
     s->desc = SceneParser::parse(scene_file, macros);

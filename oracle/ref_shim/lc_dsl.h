@@ -34,21 +34,8 @@ struct StructVar : public detail::StructExtension<S> {
     [[nodiscard]] const StructVar *operator->() const noexcept { return this; }
 };
 
-namespace detail {
-template<typename T, bool value = is_value_type_v<T>>
-struct var_of { using type = T; };
-template<typename T>
-struct var_of<T, false> { using type = StructVar<T>; };
-}// namespace detail
-
-template<typename T>
-using Var = typename detail::var_of<T>::type;
-template<typename T>
-using VarOf = Var<T>;
-
 template<typename T>
 struct Expr;
-
 template<typename T>
     requires std::is_arithmetic_v<T>
 struct Expr<T> {
@@ -66,6 +53,18 @@ struct Expr<T> {
     constexpr operator T() const noexcept { return _v; }
 };
 
+namespace detail {
+template<typename T, bool value = is_value_type_v<T>>
+struct var_of { using type = T; };// scalars, vectors and matrices ARE their values
+template<typename T>
+struct var_of<T, false> { using type = StructVar<T>; };
+}// namespace detail
+
+template<typename T>
+using Var = typename detail::var_of<T>::type;
+template<typename T>
+using VarOf = Var<T>;
+
 template<typename T>
     requires std::is_class_v<T>
 struct Expr<T> : public Var<T> {
@@ -78,6 +77,7 @@ Expr(StructVar<T>) -> Expr<T>;
 
 template<typename T>
 Expr(T) -> Expr<T>;
+
 template<typename T>
 Expr(Expr<T>) -> Expr<T>;
 
@@ -85,9 +85,14 @@ template<typename T>
 struct expr_value { using type = T; };
 template<typename T>
 struct expr_value<Expr<T>> { using type = T; };
+
 template<typename T>
 using expr_value_t = typename expr_value<std::remove_cvref_t<T>>::type;
 
+// DSL scalar variables are plain C++ scalars.  The DSL zero-initialises a default-constructed variable (the render code relies
+// on it: the default Shape::Handle of Interaction{p} has intersection-offset factor 0, src/base/interaction.h:77-78); here
+// that comes from the build: -ftrivial-auto-var-init=zero for automatic objects and a zeroing operator new (ref_api.cpp) for
+// heap objects -- see oracle/Makefile.ref.
 using Bool = bool;
 using Float = float;
 using Int = int;
@@ -125,7 +130,8 @@ template<typename T>
 template<typename T, typename... Args>
 [[nodiscard]] constexpr Var<T> def(Args &&...args) noexcept {
     if constexpr (detail::is_value_type_v<T>) {
-        if constexpr (sizeof...(Args) == 1u) { return T(static_cast<T>(args)...); }
+        if constexpr (sizeof...(Args) == 0u) { return T{}; }
+        else if constexpr (sizeof...(Args) == 1u) { return T(static_cast<T>(args)...); }
         else { return T{std::forward<Args>(args)...}; }
     } else {
         Var<T> v{};

@@ -407,7 +407,7 @@ class BindlessBuffer {
 public:
     BindlessBuffer(const void *data, size_t bytes) noexcept : _data{static_cast<const T *>(data)}, _size{bytes / sizeof(T)} {}
     [[nodiscard]] VarOf<T> read(size_t i) const noexcept {
-        assert(i < _size);
+        if (i >= _size) { LUISA_ERROR("libref: bindless buffer read out of range: index {} of {} elements of {} bytes", i, _size, sizeof(T)); }
         if constexpr (detail::is_value_type_v<T>) { return _data[i]; }
         else { VarOf<T> v; static_cast<T &>(v) = _data[i]; return v; }
     }
@@ -957,7 +957,16 @@ Kernel2D(F) -> Kernel2D<F>;
 template<typename F>
 Kernel3D(F) -> Kernel3D<F>;
 
-class Printer {
+class Printer {// the DSL's device-side printf; here it prints at once when LIBREF_PRINTER is set (a free trace of the reference)
+    static bool _enabled() noexcept {
+        static bool e = std::getenv("LIBREF_PRINTER") != nullptr;
+        return e;
+    }
+    template<typename... A>
+    static void _print(std::string_view f, const A &...a) noexcept {
+        if (_enabled()) { std::fprintf(stderr, "[ref] %s\n", fmt::format(f, a...).c_str()); }
+    }
+
 public:
     template<typename D>
     explicit Printer(D &) noexcept {}
@@ -965,21 +974,21 @@ public:
     ShimCommand retrieve() noexcept { return {}; }
     [[nodiscard]] bool empty() const noexcept { return true; }
     template<typename... A>
-    void info(A &&...) noexcept {}
+    void info(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void verbose(A &&...) noexcept {}
+    void verbose(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void error(A &&...) noexcept {}
+    void error(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void info_with_location(A &&...) noexcept {}
+    void warning(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void verbose_with_location(A &&...) noexcept {}
+    void info_with_location(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void warning(A &&...) noexcept {}
+    void verbose_with_location(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void warning_with_location(A &&...) noexcept {}
+    void warning_with_location(std::string_view f, const A &...a) noexcept { _print(f, a...); }
     template<typename... A>
-    void error_with_location(A &&...) noexcept {}
+    void error_with_location(std::string_view f, const A &...a) noexcept { _print(f, a...); }
 };
 
 // =============================================================================================================================
@@ -1091,9 +1100,8 @@ public:
     template<typename Impl, typename... A>
     uint create(A &&...a) noexcept { return emplace(luisa::make_unique<Impl>(std::forward<A>(a)...)); }
     template<typename F>
-    void dispatch(uint tag, F &&f) const noexcept {
-        assert(tag < _impl.size());
-        std::forward<F>(f)(impl(tag));
+    void dispatch(uint tag, F &&f) const noexcept {// a DSL switch over the tags: no case, no effect
+        if (tag < _impl.size()) { std::forward<F>(f)(impl(tag)); }
     }
     template<typename F>
     void dispatch_range(uint tag, uint lo, uint hi, F &&f) const noexcept {
