@@ -66,7 +66,7 @@ def build_scene(workload: str, tmpdir: str, spp_override: int | None):
 
 def cpu_baseline(scene, res, budget_s: float):
     """Oracle on all host cores over a bounded sample: whole frame at 1..n spp until ~budget_s."""
-    from luisarender_amd.oracle_check import Oracle, algorithmic_bytes
+    from oracle.check import Oracle, algorithmic_bytes
     cores = os.cpu_count() or 1
     oracle = Oracle(scene)
     # calibrate on a strip, then size the sample

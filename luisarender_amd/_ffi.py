@@ -134,14 +134,6 @@ STRUCTS = {"lr_scene": Scene, "lr_vertex": Vertex, "lr_triangle": Triangle, "lr_
            "lr_bvh_triangle": BvhTriangle, "lr_accel": Accel, "lr_light_handle": LightHandle, "lr_medium": Medium}
 
 
-class OracleCounters(C.Structure):
-    _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
-                                   "surface_hits", "nee_samples", "path_length_sum")]
-
-    def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
-
-
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
@@ -185,41 +177,6 @@ def host_lib() -> C.CDLL:
         lib.lrhost_scene_camera_file.argtypes = [C.c_void_p, C.c_int]
         lib.lrhost_scene_has_lighting.argtypes = [C.c_void_p]
         lib.lrhost_save_image.argtypes = [C.c_char_p, C.c_void_p, u32, u32]
-        lib._lr_ready = True
-    return lib
-
-
-def oracle_lib() -> C.CDLL:
-    """The CPU checker.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg call this."""
-    lib = _load(os.path.join(REPO_ROOT, "oracle", "liboracle.so"))
-    if not getattr(lib, "_lr_ready", False):
-        lib.oracle_create.restype = C.c_void_p
-        lib.oracle_create.argtypes = [C.POINTER(Scene)]
-        lib.oracle_destroy.argtypes = [C.c_void_p]
-        lib.oracle_set_shutter_weight.argtypes = [C.c_void_p, f32]
-        lib.oracle_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u32, C.c_int, C.c_void_p,
-                                      C.POINTER(OracleCounters)]
-        lib.oracle_film_convert.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p]
-        lib.oracle_li.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p]
-        lib.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
-        lib.oracle_camera_ray.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p]
-        for name, n in (("oracle_xxhash32_1", 1), ("oracle_xxhash32_2", 2), ("oracle_xxhash32_3", 3), ("oracle_xxhash32_4", 4)):
-            fn = getattr(lib, name)
-            fn.restype = u32
-            fn.argtypes = [u32] * n
-        lib.oracle_sampler_stream.argtypes = [C.POINTER(Scene), u32, u32, u32, u32, C.c_void_p]
-        lib.oracle_lcg.restype = f32
-        lib.oracle_lcg.argtypes = [C.POINTER(u32)]
-        lib.oracle_pcg32_next.restype = u32
-        lib.oracle_pcg32_next.argtypes = [C.POINTER(u64), C.POINTER(u64)]
-        lib.oracle_pcg32_seed.argtypes = [u64, C.POINTER(u64), C.POINTER(u64)]
-        lib.oracle_create_alias_table.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
-        lib.oracle_sample_alias_table.argtypes = [C.c_void_p, u32, f32, C.POINTER(u32), C.POINTER(f32)]
-        lib.oracle_filter_sample.argtypes = [C.POINTER(Filter), f32, f32, C.c_void_p]
-        lib.oracle_encode_handle.argtypes = [u32] * 6 + [f32, f32, C.c_void_p]
-        lib.oracle_offset_ray_origin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.oracle_surface_evaluate.argtypes = [C.POINTER(Scene), u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.oracle_surface_sample.argtypes = [C.POINTER(Scene), u32, C.c_void_p, C.c_void_p, f32, f32, f32, C.c_void_p]
         lib._lr_ready = True
     return lib
 

@@ -1,7 +1,8 @@
-"""Python handle on the CPU oracle (oracle/liboracle.so).
+"""Python handle on the CPU oracle (oracle/liboracle.so): ctypes prototypes + the Oracle class.
 
-CHECKER ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-Nothing in the product path (render.py, csrc/) imports this module."""
+TEST INFRASTRUCTURE ONLY, like everything under oracle/: imported by tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg
+and the debugging scripts under tools/ -- never by the product package luisarender_amd (which only lends it its ctypes mirror of
+include/lr_scene.h, the structs both sides read)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,13 +10,60 @@ import os
 
 import numpy as np
 
-from . import _ffi
-from .scene import Scene
+from luisarender_amd import _ffi
+from luisarender_amd.scene import Scene
+
+u32, u64, f32 = C.c_uint32, C.c_uint64, C.c_float
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
+                                   "surface_hits", "nee_samples", "path_length_sum")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+
+def oracle_lib() -> C.CDLL:
+    """The CPU checker.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg call this."""
+    lib = _ffi._load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle.so"))
+    if not getattr(lib, "_lr_ready", False):
+        lib.oracle_create.restype = C.c_void_p
+        lib.oracle_create.argtypes = [C.POINTER(_ffi.Scene)]
+        lib.oracle_destroy.argtypes = [C.c_void_p]
+        lib.oracle_set_shutter_weight.argtypes = [C.c_void_p, f32]
+        lib.oracle_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u32, C.c_int, C.c_void_p,
+                                      C.POINTER(OracleCounters)]
+        lib.oracle_film_convert.argtypes = [C.POINTER(_ffi.Scene), C.c_void_p, C.c_void_p]
+        lib.oracle_li.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p]
+        lib.oracle_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p]
+        lib.oracle_camera_ray.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p]
+        for name, n in (("oracle_xxhash32_1", 1), ("oracle_xxhash32_2", 2), ("oracle_xxhash32_3", 3), ("oracle_xxhash32_4", 4)):
+            fn = getattr(lib, name)
+            fn.restype = u32
+            fn.argtypes = [u32] * n
+        lib.oracle_sampler_stream.argtypes = [C.POINTER(_ffi.Scene), u32, u32, u32, u32, C.c_void_p]
+        lib.oracle_lcg.restype = f32
+        lib.oracle_lcg.argtypes = [C.POINTER(u32)]
+        lib.oracle_pcg32_next.restype = u32
+        lib.oracle_pcg32_next.argtypes = [C.POINTER(u64), C.POINTER(u64)]
+        lib.oracle_pcg32_seed.argtypes = [u64, C.POINTER(u64), C.POINTER(u64)]
+        lib.oracle_create_alias_table.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
+        lib.oracle_sample_alias_table.argtypes = [C.c_void_p, u32, f32, C.POINTER(u32), C.POINTER(f32)]
+        lib.oracle_filter_sample.argtypes = [C.POINTER(_ffi.Filter), f32, f32, C.c_void_p]
+        lib.oracle_encode_handle.argtypes = [u32] * 6 + [f32, f32, C.c_void_p]
+        lib.oracle_offset_ray_origin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_surface_evaluate.argtypes = [C.POINTER(_ffi.Scene), u32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_surface_sample.argtypes = [C.POINTER(_ffi.Scene), u32, C.c_void_p, C.c_void_p, f32, f32, f32, C.c_void_p]
+        lib._lr_ready = True
+    return lib
+
 
 
 class Oracle:
     def __init__(self, scene: Scene, camera: int = 0):
-        self._lib = _ffi.oracle_lib()
+        self._lib = oracle_lib()
         self._scene = scene
         self._view = scene.view(camera)
         self._ctx = self._lib.oracle_create(C.byref(self._view))
@@ -26,7 +74,7 @@ class Oracle:
         x0, y0, x1, y1 = rect if rect else (0, 0, self.width, self.height)
         if film is None:
             film = np.zeros((self.height, self.width, 4), np.float32)
-        cnt = _ffi.OracleCounters()
+        cnt = OracleCounters()
         threads = threads or os.cpu_count() or 1
         rc = self._lib.oracle_render(self._ctx, spp_begin, spp_end, x0, y0, x1, y1, threads, film.ctypes.data, C.byref(cnt))
         if rc != 0:

@@ -199,16 +199,22 @@ inline void assume(A &&...) noexcept {}
 
 // ---- arrays ----------------------------------------------------------------------------------------------------------------
 template<typename T>
-class Local {
-    mutable std::vector<Var<T>> _data;// a DSL array is a handle: element access through a const Local still yields an lvalue
+class Local {// a DSL array is a handle: element access through a const Local still yields an lvalue
+    static constexpr size_t inline_capacity = 4u;// spectra have 1, 3 or 4 samples: no heap traffic for them
+    mutable std::array<Var<T>, inline_capacity> _inline{};
+    mutable std::vector<Var<T>> _heap;
+    size_t _size{0u};
+    [[nodiscard]] Var<T> *_ptr() const noexcept { return _size <= inline_capacity ? _inline.data() : _heap.data(); }
 
 public:
     Local() noexcept = default;
-    explicit Local(size_t n) noexcept : _data(n) {}
-    [[nodiscard]] auto size() const noexcept { return _data.size(); }
-    [[nodiscard]] Var<T> &operator[](size_t i) const noexcept { return _data[i]; }
-    [[nodiscard]] Var<T> read(size_t i) const noexcept { return _data[i]; }
-    void write(size_t i, const Var<T> &v) const noexcept { _data[i] = v; }
+    explicit Local(size_t n) noexcept : _size{n} {
+        if (n > inline_capacity) { _heap.resize(n); }
+    }
+    [[nodiscard]] auto size() const noexcept { return _size; }
+    [[nodiscard]] Var<T> &operator[](size_t i) const noexcept { return _ptr()[i]; }
+    [[nodiscard]] Var<T> read(size_t i) const noexcept { return _ptr()[i]; }
+    void write(size_t i, const Var<T> &v) const noexcept { _ptr()[i] = v; }
     [[nodiscard]] Local *operator->() noexcept { return this; }
     [[nodiscard]] const Local *operator->() const noexcept { return this; }
 };

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from luisarender_amd import Scene  # noqa: E402
-from luisarender_amd.oracle_check import Oracle  # noqa: E402
+from oracle.check import Oracle  # noqa: E402
 from luisarender_amd.scenes import cornell_box  # noqa: E402
 
 

@@ -3,6 +3,7 @@ import ctypes as C
 import numpy as np
 
 from luisarender_amd import Scene, _ffi
+from oracle.check import oracle_lib
 
 MATERIALS = {
     "matte": "Surface m : Matte { Kd : Constant { v { 0.6, 0.5, 0.4 } } }",
@@ -61,7 +62,7 @@ class SurfaceProbe:
     """evaluate/sample of the patch surface on a flat patch (ng = +z) through the oracle hooks"""
 
     def __init__(self, scene, ns=(0.0, 0.0, 1.0)):
-        self.o = _ffi.oracle_lib()
+        self.o = oracle_lib()
         self.scene = scene
         self.view = scene.view()
         self.ns = np.array(ns, np.float32)

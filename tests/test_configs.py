@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
 
 SMALL = dict(target_triangles=60_000, resolution=(64, 36), spp=2)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene, _ffi
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scene import save_image
 
 W, H = 2048, 1024  # Spherical::sample_map_size

@@ -5,6 +5,7 @@ import os
 import re
 
 from luisarender_amd import _ffi
+from oracle.check import oracle_lib
 
 
 def _declared(header, prefix):
@@ -38,7 +39,7 @@ def test_hip_library_exports_header_symbols():
 
 
 def test_oracle_exports():
-    lib = _ffi.oracle_lib()
+    lib = oracle_lib()
     for n in _declared("../oracle/oracle.h", "oracle"):
         assert hasattr(lib, n), n
 

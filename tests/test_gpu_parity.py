@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import (cornell_box, generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene,
                                     generate_room_scene)
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 
 # an emissive strip of width 0.5 sweeps from x = -2 to x = 2 in front of a black backdrop while the shutter is open;
 # the orthographic camera looks down -z

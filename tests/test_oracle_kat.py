@@ -16,9 +16,10 @@ import pytest
 import xxhash
 
 from luisarender_amd import Scene, _ffi
+from oracle.check import oracle_lib
 from luisarender_amd.scenes import cornell_box
 
-O = _ffi.oracle_lib()
+O = oracle_lib()
 
 
 def _xxh32_words(words, seed):

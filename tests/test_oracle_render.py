@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")

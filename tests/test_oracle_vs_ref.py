@@ -1,0 +1,443 @@
+"""oracle/ held against the REFERENCE'S OWN CODE.
+
+oracle/_ref/libref.so is /root/reference/src/{util,sdl,base}/*.cpp plus its plugins (surfaces, lights, samplers, cameras, filters,
+environments, integrators ...), compiled WHERE THEY LIE by oracle/Makefile.ref against the scalar LuisaCompute stand-in of
+oracle/ref_shim.  Every test below runs the same input through the reference's code and through oracle/ and compares:
+
+* unit level  -- hashes, LCG, PCG32, alias tables, warps, Fresnel terms, GGX, frames, handle packing: bit for bit;
+* table level -- what the reference's host code BUILDS from the node descriptions (filter LUT + alias tables, instance handles)
+  against what liblrhost flattened for the oracle and the device: bit for bit (this is the check of the flattening itself);
+* closure level -- Surface::Closure::evaluate / sample of every surface plugin through the reference's own parser, plugin loader,
+  populate_closure and PolymorphicCall: bit for bit (Layered: <= 2e-6, its walk sums in a compiler-dependent order);
+* sample level -- the integrator's Li(pixel, sample) of MegaPath / Direct / Normal / MegaVPTNaive over a corpus of scenes
+  (every closure, image + directional + combined environments with their importance tables, textures, normal maps, alpha
+  test, thin lens / ortho cameras, Sobol samplers, instancing, subdivision shapes, participating media): bit for bit;
+* frame level -- the reference's whole frame loop (render kernel, film clamp + accumulate, convert, save_image).
+
+What is NOT the reference's in libref: the LuisaCompute builtins, the ray-tracing unit, bilinear texture filtering and image file
+IO (oracle/ref_shim).  A constant Spherical environment is excluded: the reference dereferences an empty optional there
+(src/environments/spherical.cpp:97-105), which is undefined behaviour in its own build as well.
+
+CPU-only; skipped where libref.so has not been built (it needs /root/reference: `make ref`)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ref_helpers as R
+from helpers import MATERIALS, _PATCH, SurfaceProbe, material_scene
+from luisarender_amd import Scene, _ffi
+from oracle.check import Oracle, oracle_lib
+from luisarender_amd.scenes.cornell import cornell_box
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref.so not built (make ref; needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def O():
+    return oracle_lib()
+
+
+@pytest.fixture(scope="module")
+def L():
+    return R.lib()
+
+
+def _f32(*v):
+    return np.ascontiguousarray(np.array(v, np.float32).ravel())
+
+
+def _same_bits(a, b):
+    """bit-for-bit equality; a NaN equals a NaN whatever its sign / payload bits (they are not defined by IEEE arithmetic)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | both_nan))
+
+
+# ---------------------------------------------------------------------------------------------------------------- unit level
+def test_hashes_and_generators_bit_exact(O, L):
+    rng = np.random.default_rng(7)
+    for x, y, z, w in rng.integers(0, 2 ** 32, size=(2000, 4), dtype=np.uint64):
+        x, y, z, w = int(x), int(y), int(z), int(w)
+        assert O.oracle_xxhash32_1(x) == L.ref_xxhash32_1(x)
+        assert O.oracle_xxhash32_2(x, y) == L.ref_xxhash32_2(x, y)
+        assert O.oracle_xxhash32_3(x, y, z) == L.ref_xxhash32_3(x, y, z)
+        assert O.oracle_xxhash32_4(x, y, z, w) == L.ref_xxhash32_4(x, y, z, w)
+    for seed in rng.integers(0, 2 ** 32, size=64, dtype=np.uint64):
+        a, b = C.c_uint32(int(seed)), np.array([int(seed)], np.uint32)
+        for _ in range(50):
+            va = O.oracle_lcg(C.byref(a))
+            vb = L.ref_lcg(b.ctypes.data)
+            assert va == vb and a.value == int(b[0]) and 0.0 <= va < 1.0
+    for seq in [0, 1, 42, 2 ** 32 - 1, 2 ** 40 + 12345, 2 ** 63 + 99]:
+        so, io = C.c_uint64(), C.c_uint64()
+        O.oracle_pcg32_seed(seq, C.byref(so), C.byref(io))
+        sr, ir = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        L.ref_pcg32_seed(seq, sr.ctypes.data, ir.ctypes.data)  # the reference's U64 emulation (src/util/u64.h)
+        assert so.value == int(sr[0]) and io.value == int(ir[0])
+        for _ in range(100):
+            assert O.oracle_pcg32_next(C.byref(so), C.byref(io)) == L.ref_pcg32_next(sr.ctypes.data, ir.ctypes.data)
+            assert so.value == int(sr[0])
+
+
+def test_alias_tables_bit_exact(O, L):
+    rng = np.random.default_rng(11)
+    for n in [1, 2, 3, 7, 63, 64, 500, 2048]:
+        for kind in range(3):
+            v = rng.random(n).astype(np.float32)
+            if kind == 1:
+                v[rng.random(n) < 0.4] = 0.0  # empty bins
+            if kind == 2:
+                v = (v ** 8 * 1000).astype(np.float32)  # a few dominant bins
+            if not v.any():
+                v[0] = 1.0
+            table = np.zeros(n, dtype=[("prob", np.float32), ("alias", np.uint32)])
+            pdf_o = np.zeros(n, np.float32)
+            O.oracle_create_alias_table(v.ctypes.data, n, table.ctypes.data, pdf_o.ctypes.data)
+            prob, alias, pdf_r = np.zeros(n, np.float32), np.zeros(n, np.uint32), np.zeros(n, np.float32)
+            L.ref_create_alias_table(v.ctypes.data, n, prob.ctypes.data, alias.ctypes.data, pdf_r.ctypes.data)
+            assert np.array_equal(table["prob"].view(np.uint32), prob.view(np.uint32)), (n, kind)
+            assert np.array_equal(table["alias"], alias) and np.array_equal(pdf_o.view(np.uint32), pdf_r.view(np.uint32))
+            for u in rng.random(200).astype(np.float32):
+                io, uo = C.c_uint32(), C.c_float()
+                O.oracle_sample_alias_table(table.ctypes.data, n, float(u), C.byref(io), C.byref(uo))
+                ir, ur = np.zeros(1, np.uint32), np.zeros(1, np.float32)
+                L.ref_sample_alias_table(prob.ctypes.data, alias.ctypes.data, n, float(u), ir.ctypes.data, ur.ctypes.data)
+                assert io.value == int(ir[0]) and np.float32(uo.value).view(np.uint32) == ur.view(np.uint32)[0]
+    # all-zero weights: uniform pdf (src/util/sampling.cpp:43-45)
+    v = np.zeros(5, np.float32)
+    prob, alias, pdf_r = np.zeros(5, np.float32), np.zeros(5, np.uint32), np.zeros(5, np.float32)
+    L.ref_create_alias_table(v.ctypes.data, 5, prob.ctypes.data, alias.ctypes.data, pdf_r.ctypes.data)
+    table, pdf_o = np.zeros(5, dtype=[("prob", np.float32), ("alias", np.uint32)]), np.zeros(5, np.float32)
+    O.oracle_create_alias_table(v.ctypes.data, 5, table.ctypes.data, pdf_o.ctypes.data)
+    assert np.array_equal(pdf_o, pdf_r) and np.allclose(pdf_r, 0.2)
+
+
+def test_handle_packing_bit_exact(O, L):
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        base, flags = int(rng.integers(0, 2 ** 22)), int(rng.integers(0, 64))
+        st, lt, mt, tc = int(rng.integers(0, 4096)), int(rng.integers(0, 4096)), int(rng.integers(0, 256)), int(rng.integers(0, 2 ** 31))
+        sh, io = float(rng.random()), float(rng.choice([0.0, 1.0, rng.random()]))
+        a, b = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+        O.oracle_encode_handle(base, flags, st, lt, mt, tc, sh, io, a.ctypes.data)
+        L.ref_encode_handle(base, flags, st, lt, mt, tc, sh, io, b.ctypes.data)
+        assert np.array_equal(a, b)
+
+
+# the oracle's scalar helpers are header-inline: reach them through the closure hooks below; here the reference functions are
+# checked against the closed forms the oracle's own tests (tests/test_oracle_bsdf.py) already pin the oracle to
+def test_reference_warps_and_fresnel_closed_forms(L):
+    rng = np.random.default_rng(5)
+    out = np.zeros(3, np.float32)
+    for ux, uy in rng.random((500, 2)).astype(np.float32):
+        L.ref_sample_uniform_triangle(float(ux), float(uy), out.ctypes.data)
+        assert abs(out.sum() - 1.0) < 1e-6 and (out >= -1e-7).all()
+        L.ref_sample_cosine_hemisphere(float(ux), float(uy), out.ctypes.data)
+        assert abs(np.linalg.norm(out) - 1.0) < 1e-5 and out[2] >= 0.0
+        L.ref_sample_uniform_sphere(float(ux), float(uy), out.ctypes.data)
+        assert abs(np.linalg.norm(out) - 1.0) < 1e-5 and abs(out[2] - (1.0 - 2.0 * ux)) < 1e-6
+    assert L.ref_fresnel_dielectric(1.0, 1.0, 1.5) == pytest.approx(0.04, rel=1e-6)
+    assert L.ref_fresnel_dielectric(0.1, 1.5, 1.0) == 1.0  # total internal reflection
+    assert L.ref_balance_heuristic(0.0, 0.0) == 0.0 and L.ref_balance_heuristic(3.0, 1.0) == 0.75
+    assert L.ref_power_heuristic(3.0, 1.0) == pytest.approx(0.9)
+
+
+# --------------------------------------------------------------------------------------------------------------- table level
+@pytest.mark.parametrize("filt", ["Box { radius { 0.5 } }", "Gaussian { radius { 1 } }", "Gaussian { radius { 1.5 } sigma { 0.4 } }",
+                                  "Triangle { radius { 1.2 } }", "Mitchell { radius { 2 } }", "Mitchell { radius { 2 } b { 0.2 } c { 0.6 } }",
+                                  "LanczosSinc { radius { 3 } }", "LanczosSinc { radius { 2 } tau { 2 } }", "Box { radius { 0.5 } shift { 0.25, -0.125 } }"])
+def test_filter_tables_and_sampling_bit_exact(O, filt):
+    """src/base/filter.cpp:24-64 run by the reference's own Filter plugins vs csrc/host/scene.cpp build_filter + oracle filter_sample"""
+    src = cornell_box(resolution=8, spp=1).replace("filter : Box { radius { 0.5 } }", "filter : " + filt)
+    assert filt in src
+    rs = R.RefScene(src)
+    view = Scene.from_string(src, build_accel=False).view()
+    lut, pdf, prob, idx = rs.filter_tables()
+    f = view.filter
+    assert np.array_equal(np.frombuffer(f.lut, np.float32).view(np.uint32), lut.view(np.uint32))
+    assert np.array_equal(np.frombuffer(f.pdf, np.float32).view(np.uint32), pdf.view(np.uint32))
+    assert np.array_equal(np.frombuffer(f.alias_prob, np.float32).view(np.uint32), prob.view(np.uint32))
+    assert np.array_equal(np.frombuffer(f.alias_index, np.uint32), idx)
+    rng = np.random.default_rng(2)
+    out = np.zeros(3, np.float32)
+    for ux, uy in rng.random((400, 2)).astype(np.float32):
+        O.oracle_filter_sample(C.byref(f), float(ux), float(uy), out.ctypes.data)
+        assert np.array_equal(out.view(np.uint32), rs.filter_sample(float(ux), float(uy)).view(np.uint32))
+
+
+INSTANCING = """
+Surface s : Matte { Kd : Constant { v { 0.5, 0.6, 0.7 } } }
+Shape cube : InlineMesh {
+  positions { -1,0,-1, 1,0,-1, 1,2,-1, -1,2,-1, -1,0,1, 1,0,1, 1,2,1, -1,2,1 }
+  indices { 0,2,1, 0,3,2,  4,5,6, 4,6,7,  0,1,5, 0,5,4,  3,6,2, 3,7,6,  0,7,3, 0,4,7,  1,2,6, 1,6,5 } }
+Shape a : Instance { shape { @cube } surface { @s } transform : SRT { scale { 0.5, 1.5, 0.5 } rotate { 0, 1, 0, 30 } translate { -2, 0, 0 } } }
+Shape b : Instance { shape { @cube } surface : Mirror { roughness : Constant { v { 0.2 } } } intersection_offset { 0.3 }
+  transform : Matrix { m { 1,0,0,2, 0,1,0,0, 0,0,1,0.5, 0,0,0,1 } } }
+Shape g : Group { shapes { @a, @b } transform : Stack { transforms { SRT { rotate { 0, 1, 0, 15 } }, SRT { translate { 0, 0, -1 } } } } }
+Shape floor : InlineMesh { positions { -6,0,-6, 6,0,-6, 6,0,6, -6,0,6 } indices { 0,2,1, 0,3,2 } surface { @s } }
+Shape lamp : InlineMesh { positions { -1,5,-1, 1,5,-1, 1,5,1, -1,5,1 } indices { 0,1,2, 0,2,3 } light : Diffuse { emission : Constant { v { 12, 11, 10 } } scale { 2 } } }
+Camera cam : Pinhole { fov { 45 } spp { 4 } film : Color { resolution { 24, 16 } } position { 0, 3, 9 } look_at { 0, 0.8, 0 } }
+render { cameras { @cam } shapes { @g, @floor, @lamp } integrator : MegaPath { depth { 6 } rr_depth { 2 } } }
+"""
+
+
+def test_instance_handles_as_the_reference_packs_them():
+    """Geometry::_process_shape (src/base/geometry.cpp:29-163): traversal order, override rules, tags, flags, fixed-point offsets.
+    The bindless base differs by construction (the reference registers 3 CIE curves first, 4 buffers per mesh after that);
+    everything else of the uint4 must be the word the host flattening wrote."""
+    rs = R.RefScene(INSTANCING)
+    view = Scene.from_string(INSTANCING).view()
+    ref = rs.instance_handles()
+    assert len(ref) == view.instance_count == 4
+    for i in range(len(ref)):
+        h = view.instances[i].handle
+        mine = np.array([h.x, h.y, h.z, h.w], np.uint32)
+        assert mine[0] & 1023 == ref[i][0] & 1023, i  # property flags
+        assert (ref[i][0] >> 10) == 3 + 4 * (mine[0] >> 10)  # bindless base <-> mesh index
+        assert np.array_equal(mine[1:], ref[i][1:]), i  # tags, triangle count, shadow-terminator | intersection offset
+
+
+# ------------------------------------------------------------------------------------------------------------- closure level
+def _rdir(rng):
+    v = rng.normal(size=3).astype(np.float32)
+    return v / np.linalg.norm(v)
+
+
+@pytest.mark.parametrize("material", list(MATERIALS))
+def test_closures_match_the_reference_plugins(material):
+    """Surface::Closure::evaluate / sample (src/base/surface.cpp:45-68) of src/surfaces/<plugin>.cpp, reached the reference's
+    way (parser -> Scene::load_node -> dlopen'ed plugin -> Pipeline::register_surface -> populate_closure -> PolymorphicCall)."""
+    rs = R.RefScene(_PATCH.format(surface=MATERIALS[material]))
+    sc = material_scene(material)
+    layered = material.startswith("layered")
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for ns in [(0.0, 0.0, 1.0), (0.2, -0.1, 0.9), (-0.5, 0.3, 0.6)]:
+        probe = SurfaceProbe(sc, ns)
+        for k in range(150):
+            wo, wi = _rdir(rng), _rdir(rng)
+            if k % 10 == 0:
+                wi = -wo  # wh = 0
+            if k % 10 == 1:
+                wo = _f32(0, 0, 1 if k % 20 == 1 else -1)  # normal incidence
+            a = rs.surface_evaluate(0, ns, wo, wi)
+            f, pdf = probe.evaluate(wo, wi)
+            b = np.array([*f, pdf], np.float32)
+            u = rng.random(3).astype(np.float32)
+            sa = rs.surface_sample(0, ns, wo, float(u[0]), float(u[1]), float(u[2]))
+            f, pdf, w, ev = probe.sample(wo, float(u[0]), float(u[1]), float(u[2]))
+            sb = np.array([*f, pdf, *w, ev], np.float32)
+            if not layered:
+                assert _same_bits(a, b), (material, ns, wo, wi, a, b)
+                assert _same_bits(sa, sb), (material, ns, wo, u, sa, sb)
+            else:
+                worst = max(worst, np.abs(a - b).max() / max(1e-6, np.abs(a).max()), np.abs(sa - sb).max() / max(1.0, np.abs(sa[:4]).max()))
+    assert worst < 2e-6
+
+
+# -------------------------------------------------------------------------------------------------------------- sample level
+def _write_pfm(path, img):
+    img = np.asarray(img, np.float32)
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(img[::-1, :, :3].tobytes())
+
+
+def _compare_li(src, directory=None, stride=2, spp=3, tol=0.0):
+    rs = R.RefScene(src, directory)
+    sc = Scene.from_string(src, virtual_path=os.path.join(directory, "scene.luisa") if directory else "")
+    o = Oracle(sc)
+    assert (rs.width, rs.height) == (o.width, o.height)
+    lit = 0
+    for py in range(0, o.height, stride):
+        for px in range(0, o.width, stride):
+            for s in range(spp):
+                a, b = rs.li(px, py, s), o.li(px, py, s)
+                lit += bool(a.any())
+                if tol == 0.0:
+                    assert _same_bits(a, b), (px, py, s, a, b)
+                else:
+                    assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(a).max()), (px, py, s, a, b)
+    assert lit > 5  # the comparison is not of black images
+
+
+def _mat_scene(material, **kw):
+    extra = MATERIALS[material].replace("Surface m ", f"Surface {material} ") + "\n"
+    return cornell_box(resolution=20, spp=3, short_box_surface=material, tall_box_surface=material, extra_surfaces=extra, **kw)
+
+
+@pytest.mark.parametrize("material", ["matte", "oren", "mirror", "glass", "plastic", "metal", "disney", "disney_trans", "disney_thin",
+                                      "mix", "mix_glass", "mix_nested"])
+def test_li_each_closure_bit_exact(material):
+    _compare_li(_mat_scene(material))
+
+
+@pytest.mark.parametrize("material", ["layered", "layered_medium"])
+def test_li_layered(material):
+    _compare_li(_mat_scene(material), tol=2e-6)
+
+
+@pytest.mark.parametrize("variant", ["gaussian_rr", "sobol", "padded_sobol", "thin_lens", "ortho_clip", "depth1"])
+def test_li_cameras_samplers_filters_bit_exact(variant):
+    src = {"gaussian_rr": cornell_box(resolution=20, spp=3, filter_impl="Gaussian", filter_radius=1.0, rr_depth=2),
+           "sobol": cornell_box(resolution=(24, 16), spp=3, sampler="Sobol"),
+           "padded_sobol": cornell_box(resolution=(24, 16), spp=3, sampler="PaddedSobol", seed=7),
+           "thin_lens": cornell_box(resolution=20, spp=3).replace("Camera cam : Pinhole {", "Camera cam : ThinLens {\n  aperture { 1.4 } focal_length { 50 } focus_distance { 900 }"),
+           "ortho_clip": cornell_box(resolution=20, spp=3).replace("Camera cam : Pinhole {\n  fov { 39.3 }", "Camera cam : Ortho {\n  zoom { -8.2 } clip { 100, 1300 }"),
+           "depth1": cornell_box(resolution=20, spp=3, depth=1)}[variant]
+    if variant == "ortho_clip":
+        assert "Ortho" in src
+    _compare_li(src)
+
+
+ENV_SCENE = """
+Surface ground : Matte {{ Kd : Constant {{ v {{ 0.5, 0.5, 0.5 }} }} }}
+Surface shiny : Plastic {{ Kd : Constant {{ v {{ 0.7, 0.2, 0.1 }} }} roughness : Constant {{ v {{ 0.15 }} }} }}
+Shape quad : InlineMesh {{ positions {{ -20,0,-20, 20,0,-20, 20,0,20, -20,0,20 }} indices {{ 0,2,1, 0,3,2 }} surface {{ @ground }} }}
+Shape cube : InlineMesh {{
+  positions {{ -1,0,-1, 1,0,-1, 1,2,-1, -1,2,-1, -1,0,1, 1,0,1, 1,2,1, -1,2,1 }}
+  indices {{ 0,2,1, 0,3,2,  4,5,6, 4,6,7,  0,1,5, 0,5,4,  3,6,2, 3,7,6,  0,7,3, 0,4,7,  1,2,6, 1,6,5 }}
+  surface {{ @shiny }} transform : SRT {{ rotate {{ 0, 1, 0, 30 }} }} }}
+Camera cam : Pinhole {{ fov {{ 40 }} spp {{ 3 }} film : Color {{ resolution {{ 24, 18 }} clamp {{ 64 }} }}
+  position {{ 0, 4, 9 }} look_at {{ 0, 1, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @quad, @cube }}
+  environment : {env}
+  integrator : MegaPath {{ depth {{ 6 }} rr_depth {{ 2 }} }} }}
+"""
+
+
+@pytest.mark.parametrize("kind", ["image_rotated", "directional", "directional_hidden", "combined"])
+def test_li_environments_bit_exact(kind, tmp_path):
+    """Spherical::build (src/environments/spherical.cpp:144-235: the 2048x1024 scale map, MIS compensation, per-row + marginal
+    alias tables, pdf table) is run by the REFERENCE here and by csrc/host/environment.cpp for the oracle: the two only agree
+    sample for sample if the tables agree entry for entry."""
+    from test_environment import sky_image
+    _write_pfm(tmp_path / "sky.pfm", sky_image())
+    img = 'Image { file { "sky.pfm" } encoding { "linear" } }'
+    env = {"image": f"Spherical {{ emission : {img} }}",
+           "image_rotated": f"Spherical {{ emission : {img} scale {{ 2 }} compensate_mis {{ false }} transform : SRT {{ rotate {{ 0.2, 1, 0.1, 130 }} }} }}",
+           "directional": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 6 } direction { 0.4, 1, 0.3 } }",
+           "directional_hidden": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 25 } direction { -0.5, 1, 0.2 } visible { false } normalize { false } scale { 4 } }",
+           "combined": f"Combined {{ a : Spherical {{ emission : {img} transform : SRT {{ rotate {{ 1, 0, 0, 20 }} }} }} "
+                       "b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } } scale_a { 0.7 } scale_b { 1.5 } "
+                       "transform : SRT { rotate { 0, 1, 0, 60 } } }"}[kind]
+    _compare_li(ENV_SCENE.format(env=env), str(tmp_path))
+
+
+def test_li_textures_normal_map_shapes_bit_exact(tmp_path):
+    """Sphere + LoopSubdiv meshes generated by the reference's own src/util/loop_subdiv.cpp / shapes/sphere.cpp vs
+    csrc/host/subdiv.cpp; Image (sRGB decode, uv transform), Swizzle and Checkerboard textures; the NormalMap wrapper."""
+    y, x = np.mgrid[0:64, 0:64]
+    pic = np.stack([128 + 100 * np.sin(x / 5.0), 128 + 100 * np.cos(y / 7.0), 4 * x], axis=-1).clip(0, 255).astype(np.float32) / 255
+    _write_pfm(tmp_path / "tex.pfm", pic)
+    nm = np.stack([0.5 + 0.2 * np.sin(x / 3.0), 0.5 + 0.2 * np.cos(y / 4.0), np.full(x.shape, 0.9)], axis=-1).astype(np.float32)
+    _write_pfm(tmp_path / "nm.pfm", nm)
+    src = """
+Texture chk : Checkerboard { on : Constant { v { 0.8, 0.3, 0.2 } } off : Constant { v { 0.2, 0.5, 0.8 } } scale { 4 } }
+Shape ball : Sphere { subdivision { 2 } surface : Plastic { Kd { @chk } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.5 } } }
+  transform : SRT { translate { -1.2, 1, 0 } } }
+Shape tetra : InlineMesh { positions { 1,1,1, -1,-1,1, -1,1,-1, 1,-1,-1 } indices { 0,1,2, 0,3,1, 0,2,3, 1,3,2 } }
+Shape blob : LoopSubdiv { mesh { @tetra } level { 2 } surface : Metal { eta { "Cu" } roughness : Constant { v { 0.25 } } } transform : SRT { translate { 1.2, 1, 0 } } }
+Shape floor : InlineMesh { positions { -4,0,-4, 4,0,-4, 4,0,4, -4,0,4 } indices { 0,2,1, 0,3,2 } uvs { 0,0, 1,0, 1,1, 0,1 }
+  surface : Matte { Kd : Swizzle { base : Image { file { "tex.pfm" } encoding { "sRGB" } uv_scale { 2, 3 } uv_offset { 0.1, 0.2 } } swizzle { "bgr" } }
+                    normal_map : Image { file { "nm.pfm" } encoding { "linear" } } normal_map_strength { 0.7 } } }
+Shape lamp : InlineMesh { positions { -1,4,-1, 1,4,-1, 1,4,1, -1,4,1 } indices { 0,1,2, 0,2,3 } light : Diffuse { emission : Constant { v { 12, 11, 10 } } } }
+Camera cam : Pinhole { fov { 45 } spp { 3 } film : Color { resolution { 24, 16 } } position { 0, 2.5, 7 } look_at { 0, 0.8, 0 } }
+render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : MegaPath { depth { 6 } } }
+"""
+    _compare_li(src, str(tmp_path))
+
+
+def test_li_alpha_test_textured_closures_instancing():
+    extra = """
+Texture holes : Checkerboard { on : Constant { v { 1 } } off : Constant { v { 0.2 } } scale { 3 } }
+Surface cutout : Matte { Kd : Constant { v { 0.7, 0.6, 0.2 } } alpha { @holes } }
+Surface veil_a : Mirror { color : Constant { v { 0.9 } } roughness : Constant { v { 0.3 } } alpha : Constant { v { 0.5 } } }
+Surface veil_b : Matte { Kd : Constant { v { 0.2, 0.3, 0.8 } } }
+Surface veil : Mix { a { @veil_a } b { @veil_b } ratio : Constant { v { 0.5 } } }
+"""
+    # Geometry::_alpha_skip (src/base/geometry.cpp:165-192) hashes the candidate's barycentric BITS: equal here because the
+    # stand-in's ray-tracing unit and the oracle's intersect the same way (object space, Moeller-Trumbore)
+    _compare_li(cornell_box(resolution=20, spp=3, short_box_surface="cutout", tall_box_surface="veil", extra_surfaces=extra))
+    extra = """
+Texture chk : Checkerboard { on : Constant { v { 0.8, 0.3, 0.2 } } off : Constant { v { 0.2, 0.5, 0.8 } } scale { 4 } }
+Texture chk1 : Checkerboard { on : Constant { v { 0.9 } } off : Constant { v { 0.1 } } scale { 3 } }
+Surface dis : Disney { color { @chk } metallic { @chk1 } roughness : Constant { v { 0.3 } } clearcoat : Constant { v { 0.5 } } eta : Constant { v { 1.5 } } }
+Surface ma : Matte { Kd { @chk } }
+Surface mb : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } }
+Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
+"""
+    _compare_li(cornell_box(resolution=20, spp=3, short_box_surface="dis", tall_box_surface="mx", extra_surfaces=extra))
+    _compare_li(INSTANCING, tol=2e-6)  # a scaled + rotated instance: the inverse instance matrix is the stand-in's, 1 ulp apart
+
+
+@pytest.mark.parametrize("integrator", ['Direct { importance_sampling { "both" }', 'Direct { importance_sampling { "light" }',
+                                        'Direct { importance_sampling { "surface" }', "Normal {", "Normal { remap { false } shading { false }"])
+def test_li_sibling_integrators_bit_exact(integrator):
+    """src/integrators/direct.cpp:66-200 and normal.cpp:36-70"""
+    extra = MATERIALS["glass"].replace("Surface m ", "Surface probe ") + "\n"
+    src = cornell_box(resolution=20, spp=3, short_box_surface="probe", extra_surfaces=extra).replace("integrator : MegaPath {", "integrator : " + integrator)
+    src = src.replace("render {", "render {\n  environment : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 40 } direction { 0.1, 0.2, -1 } }")
+    _compare_li(src)
+
+
+FOG = """
+Medium fog : Homogeneous { sigma_a : Constant { v { 0.0001, 0.0002, 0.0003 } } sigma_s : Constant { v { 0.0006 } } eta { 1 }
+  phasefunction : HenyeyGreenstein { g { 0.4 } } }
+Medium inner : Homogeneous { sigma_a : Constant { v { 0.004, 0.002, 0.001 } } sigma_s : Constant { v { 0.003 } } eta { 1.3 } priority { 0 }
+  phasefunction : HenyeyGreenstein { g { -0.3 } } }
+Surface skin : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.05 } } eta : Constant { v { 1.3 } } }
+"""
+
+
+@pytest.mark.parametrize("case", ["vacuum", "fog_lamp", "fog_lamp_and_medium_box", "fog_directional_env"])
+def test_li_volumetric_integrator_bit_exact(case):
+    """src/integrators/mega_vpt_naive.cpp:68-483 with src/media/homogeneous.cpp, phasefunctions/henyey_greenstein.cpp and
+    util/medium_tracker.cpp.  Round 1 called the lamp-lit cases a "rounding lottery"; held against the reference's code the
+    cause was a restatement error (the offset factor of a medium point, oracle_bsdf.h Interaction) -- fixed, they are exact."""
+    extra = "" if case == "vacuum" else FOG
+    boxed = case == "fog_lamp_and_medium_box"
+    src = cornell_box(resolution=20, spp=3, depth=8, extra_surfaces=extra, short_box_surface="skin" if boxed else "white")
+    src = src.replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
+    if case != "vacuum":
+        src = src.replace("render {", "render {\n  environment_medium { @fog }")
+    if boxed:
+        assert "surface { @skin }" in src
+        src = src.replace("surface { @skin }", "surface { @skin } medium { @inner }")
+    if case == "fog_directional_env":
+        src = src.replace("render {", "render {\n  environment : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 30 } direction { 0, 0.3, -1 } }")
+    _compare_li(src)
+
+
+# --------------------------------------------------------------------------------------------------------------- frame level
+def test_whole_frame_through_the_reference_render_loop():
+    """ProgressiveIntegrator::Instance::render (src/base/integrator.cpp:34-113): one kernel launch per sample over the frame,
+    ColorFilmInstance::_accumulate (clamp, NaN rejection) and the convert kernel (src/films/color.cpp:80-130), save_image."""
+    src = cornell_box(resolution=(24, 20), spp=6).replace("resolution { 24, 20 }", "resolution { 24, 20 } exposure { 1, 0, -1 } clamp { 4 }")
+    assert "exposure" in src
+    rs = R.RefScene(src)
+    ref = rs.render()
+    sc = Scene.from_string(src)
+    o = Oracle(sc)
+    film, _ = o.render(0, 6, threads=1)
+    mine = o.convert(film)
+    assert np.array_equal(ref.view(np.uint32), mine.view(np.uint32))
+    assert ref[..., :3].max() > 0.5 and (ref[..., 3] == 1.0).all()
+
+
+def test_camera_rays_and_sampler_streams_bit_exact():
+    for sampler in ["Independent", "Sobol", "PaddedSobol"]:
+        src = cornell_box(resolution=(40, 24), spp=4, sampler=sampler, filter_impl="Gaussian", filter_radius=1.0)
+        src = src.replace("Camera cam : Pinhole {", "Camera cam : ThinLens {\n  aperture { 2 } focal_length { 35 } focus_distance { 800 }")
+        rs = R.RefScene(src)
+        sc = Scene.from_string(src, build_accel=True)
+        o = Oracle(sc)
+        view = sc.view()
+        out = np.zeros(22, np.float32)
+        for px, py, s in [(0, 0, 0), (39, 23, 3), (17, 5, 1), (3, 20, 2)]:
+            assert np.array_equal(rs.camera_ray(px, py, s).view(np.uint32), o.camera_ray(px, py, s).view(np.uint32)), sampler
+            oracle_lib().oracle_sampler_stream(C.byref(view), px, py, s, 20, out.ctypes.data)
+            assert np.array_equal(rs.sampler_stream(px, py, s, 20).view(np.uint32), out.view(np.uint32)), sampler

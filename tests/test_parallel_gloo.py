@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from luisarender_amd import Scene
-    from luisarender_amd.oracle_check import Oracle
+    from oracle.check import Oracle
     from luisarender_amd.parallel import owned_tiles, reduce_film, tile_rect
     from luisarender_amd.scenes import cornell_box
     sc = Scene.from_string(cornell_box(resolution=(28, 20), spp=3))
@@ -48,7 +48,7 @@ def test_tile_shard_and_film_reduce_world2(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     sys.path.insert(0, ROOT)
     from luisarender_amd import Scene
-    from luisarender_amd.oracle_check import Oracle
+    from oracle.check import Oracle
     from luisarender_amd.scenes import cornell_box
     sc = Scene.from_string(cornell_box(resolution=(28, 20), spp=3))
     full, _ = Oracle(sc).render(0, 3)

@@ -17,10 +17,11 @@ import pytest
 
 from luisarender_amd import Scene, _ffi
 from luisarender_amd.scenes import cornell_box
+from oracle.check import oracle_lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-O = _ffi.oracle_lib()
+O = oracle_lib()
 
 
 def _load_committed():
@@ -100,7 +101,7 @@ def test_padded_sobol_streams():
 
 
 def test_sobol_render_converges_to_the_independent_estimate():
-    from luisarender_amd.oracle_check import Oracle
+    from oracle.check import Oracle
     imgs = {}
     for sampler in ("Independent", "Sobol", "PaddedSobol"):
         sc = Scene.from_string(cornell_box(resolution=24, spp=64, sampler=sampler))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 spec = importlib.util.spec_from_file_location("tungsten2luisa", os.path.join(ROOT, "tools", "tungsten2luisa.py"))

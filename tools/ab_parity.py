@@ -3,7 +3,7 @@ import sys, tempfile, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box, generate_room_scene
 from golden.make_golden import cornell_materials_text
 r = MegaPathRenderer(0)

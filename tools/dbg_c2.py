@@ -2,7 +2,7 @@ import sys, tempfile, numpy as np
 sys.path.insert(0, '.')
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import generate_room_scene
 with tempfile.TemporaryDirectory() as tmp:
     sc = Scene.load(generate_room_scene(tmp, resolution=(1024, 1024), spp=8))

@@ -4,7 +4,7 @@ import numpy as np
 from helpers import MATERIALS
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box
 r = MegaPathRenderer(0)
 for material in sys.argv[1:]:

@@ -5,7 +5,7 @@ import numpy as np
 from helpers import MATERIALS
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box
 MATERIALS = dict(MATERIALS)
 def mixof(a, b, ratio):

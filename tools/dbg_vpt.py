@@ -4,7 +4,7 @@ import numpy as np
 from test_gpu_parity import FOG
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box
 text = cornell_box(resolution=64, spp=1, depth=8, extra_surfaces=FOG).replace("integrator : MegaPath {", "integrator : MegaVPTNaive {").replace("render {", "render {\n  environment_medium { @fog }")
 shapes = re.search(r"shapes \{ (.*?) \}\n  integrator", text, re.S).group(1)

@@ -2,7 +2,7 @@ import sys, time, numpy as np
 sys.path.insert(0, '.')
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
-from luisarender_amd.oracle_check import Oracle
+from oracle.check import Oracle
 from luisarender_amd.scenes import cornell_box
 sc = Scene.from_string(cornell_box(resolution=128, spp=16))
 r = MegaPathRenderer(0)

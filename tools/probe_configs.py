@@ -5,7 +5,7 @@ import sys, tempfile, time
 import numpy as np
 sys.path.insert(0, ".")
 from luisarender_amd import Scene
-from luisarender_amd.oracle_check import Oracle, algorithmic_bytes
+from oracle.check import Oracle, algorithmic_bytes
 from luisarender_amd.render import MegaPathRenderer
 from luisarender_amd.scenes import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene, generate_room_scene
 
