@@ -76,4 +76,12 @@ def scenes(directory):
     vpt = cornell_box(resolution=32, spp=8, depth=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
     vpt = vpt.replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }")
     out["vpt_fog_medium_box"] = (vpt, 8)
+    # the same without an area light to run into: lit through the open front by a Directional + image environment.  No emitter
+    # is ever evaluated from a ray origin lying IN its surface (mega_vpt_naive.cpp:331 after homogeneous.cpp:64), which is what
+    # makes the lamp-lit case above chaotic in the last bit
+    lamp = "\n  light : Diffuse { emission : Constant { v { 17, 12, 4 } } }"
+    assert lamp in vpt
+    env = (f"Combined {{ a : Spherical {{ emission : {img} }} b : Directional {{ emission : Constant {{ v {{ 30, 25, 20 }} }} angle {{ 30 }} "
+           "direction { 0, 0.3, -1 } } scale_a { 0.5 } scale_b { 1 } }")
+    out["vpt_fog_env_medium_box"] = (vpt.replace(lamp, "").replace("render {", "render {\n  environment : " + env), 8)
     return out
