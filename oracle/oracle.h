@@ -5,12 +5,16 @@
  * flattened tables of include/lr_scene.h.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load it; it is the checker, never the product.
  *
- * PARITY UNPINNED by the reference: the reference tree holds no golden images, KATs or
- * fixtures for this path and its own binary cannot be built here
- * (LuisaCompute submodule absent).  The oracle is pinned instead by: bit-exact KATs of the
- * hash/RNG functions against independent implementations (python xxhash, published PCG32
- * vectors), alias-table frequency tests, BSDF energy/reciprocity/pdf-vs-histogram tests and
- * closed-form furnace scenes — all under tests/.
+ * PARITY PINNED TO THE REFERENCE (round 2).  The reference's own binary still cannot be built (LuisaCompute, LLVM, Embree are
+ * absent), but its own RENDER CODE can: oracle/Makefile.ref compiles /root/reference/src/{util,sdl,base}/*.cpp and its plugins
+ * where they lie, against a scalar stand-in for the LuisaCompute DSL (oracle/ref_shim), into oracle/_ref/libref.so.
+ * tests/test_oracle_vs_ref.py holds this oracle against it -- hashes, generators, alias tables, filter tables, instance handles,
+ * every closure's evaluate / sample, the per-sample Li of MegaPath / Direct / Normal / MegaVPTNaive over a scene corpus and whole
+ * frames: bit for bit (Layered: to 2e-6) -- and tests/golden/ref_*.npz are frames the reference's code rendered, which
+ * tests/test_ref_golden.py compares with this oracle (bit for bit, CPU) and with the HIP path (GPU box).  What libref cannot
+ * pin is what LuisaCompute itself supplies (builtins, the ray-tracing unit, texture filtering): stated in oracle/ref_shim.
+ * The older pins stay: bit-exact KATs against independent implementations (python xxhash, published PCG32 vectors), alias-table
+ * frequency tests, BSDF energy / reciprocity tests and closed-form furnace scenes -- all under tests/.
  */
 #ifndef ORACLE_H
 #define ORACLE_H

@@ -3,8 +3,8 @@
 // TEST INFRASTRUCTURE ONLY: everything under oracle/ is a CPU restatement of the reference
 // algorithm used as the parity checker (tests/, __graft_entry__.smoke(), bench.py's
 // cpu_baseline leg).  The product path (luisarender_amd/csrc/hip) never includes, links or
-// calls it.  PARITY UNPINNED by reference tests: the reference ships no golden vectors for the
-// renderer; pins are the KATs/analytic tests under tests/.
+// calls it.  Pinned to the reference's own code compiled in place (oracle/_ref, tests/test_oracle_vs_ref.py);
+// the builtins below are the ones oracle/ref_shim/lc_types.h gives that code, operation for operation.
 //
 // Semantics follow the LuisaCompute DSL builtins the reference is written in (absent
 // submodule; restated): sign(x) = copysign(1, x) (the published branch-free ONB of

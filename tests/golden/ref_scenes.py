@@ -76,6 +76,16 @@ def scenes(directory):
     vpt = cornell_box(resolution=32, spp=8, depth=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
     vpt = vpt.replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }")
     out["vpt_fog_medium_box"] = (vpt, 8)
+    # the remaining precompiled kernel variants (csrc/hip/variants.h): Disney alone (16), environment + Disney (20), Layered (124)
+    # and the generic-sampler twin of the lean kernel (2)
+    dis = "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in ("disney", "disney_trans"))
+    out["disney"] = (cornell_box(resolution=32, spp=8, short_box_surface="disney", tall_box_surface="disney_trans", extra_surfaces=dis), 8)
+    out["env_disney"] = (ENV.format(spp=8, env=f"Spherical {{ emission : {img} }}").replace(
+        "Surface shiny : Plastic { Kd : Constant { v { 0.7, 0.2, 0.1 } } roughness : Constant { v { 0.15 } } }",
+        MATERIALS["disney"].replace("Surface m ", "Surface shiny ")), 8)
+    out["cornell_sobol"] = (cornell_box(resolution=(40, 24), spp=8, sampler="Sobol"), 8)
+    lay = MATERIALS["layered"].replace("Surface m ", "Surface layered ") + "\n"
+    out["layered"] = (cornell_box(resolution=32, spp=256, short_box_surface="layered", tall_box_surface="layered", extra_surfaces=lay), 256)
     # the same without an area light to run into: lit through the open front by a Directional + image environment.  No emitter
     # is ever evaluated from a ray origin lying IN its surface (mega_vpt_naive.cpp:331 after homogeneous.cpp:64), which is what
     # makes the lamp-lit case above chaotic in the last bit

@@ -21,13 +21,15 @@ from ref_scenes import scenes  # noqa: E402
 from luisarender_amd import Scene  # noqa: E402
 
 NAMES = ["cornell", "materials", "disney_mix_sobol", "thin_lens_plastic", "env_image", "env_combined", "direct_both", "vpt_fog_medium_box",
-         "vpt_fog_env_medium_box"]
+         "vpt_fog_env_medium_box", "disney", "env_disney", "cornell_sobol", "layered"]
 # rel-L1 bound of the device image against the reference's; specular chains amplify a rounding flip into a different path
 DEVICE_TOL = {"cornell": 1e-4, "materials": 3e-3, "disney_mix_sobol": 3e-3, "thin_lens_plastic": 3e-3, "env_image": 1e-3,
-              "env_combined": 1e-3, "direct_both": 1e-3, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 5e-3}
+              "env_combined": 1e-3, "direct_both": 1e-3, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 5e-3,
+              "disney": 3e-3, "env_disney": 3e-3, "cornell_sobol": 1e-4, "layered": "blocks"}
 # the smallest precompiled kernel variant each scene needs (lrhip.h LRHIP_FEAT_*; bit 0 = counters must be OFF here)
 VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {60}, "thin_lens_plastic": {0}, "env_image": {4},
-           "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256}}
+           "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256},
+           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {124}}
 
 
 def _fixture(name):
@@ -48,6 +50,9 @@ def test_oracle_reproduces_the_reference_frame_bit_for_bit(name, tmp_path):
     mine = o.convert(film)
     ref = _fixture(name)
     assert mine.shape == ref.shape and ref[..., :3].mean() > 0.01
+    if name == "layered":  # its walk sums in an order the C++ of the reference leaves to the compiler: ulps (test_oracle_vs_ref.py)
+        assert np.abs(mine - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(mine - ref).max()
+        return
     assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (name, np.abs(mine - ref).max())
 
 
@@ -66,13 +71,23 @@ def test_device_matches_the_reference_frame(renderer, name, tmp_path):
     renderer.upload(sc)
     renderer.render(0, spp, counters=False, sync=True)
     variant = renderer.last_variant()
-    assert variant & 1 == 0 and (variant & ~2) in VARIANT[name], (name, variant)  # the shipped binary, not its COUNT twin
+    assert variant & 1 == 0 and (variant & ~2) in VARIANT[name], (name, variant)
+    assert (variant & 2 != 0) == ("sobol" in name)  # the generic-sampler twins (| 2) for Sobol / PaddedSobol  # the shipped binary, not its COUNT twin
     gpu = renderer.download(converted=True)
     ref = _fixture(name)
     err = float(np.abs(gpu[..., :3] - ref[..., :3]).sum() / np.abs(ref[..., :3]).sum())
     bias = abs(float(gpu[..., :3].mean()) - float(ref[..., :3].mean())) / float(ref[..., :3].mean())
     print(f"{name}: variant {variant}, rel-L1 vs the reference's frame {err:.2e}, mean {bias:.2e}")
     assert np.isfinite(gpu).all() and (gpu[..., 3] == 1.0).all()
+    if DEVICE_TOL[name] == "blocks":
+        # Layered (src/surfaces/layered.cpp:195-470) seeds its random walk from the BITS of the hit position and direction
+        # (:271,416); the device's positions differ from the reference's in the last bits (fp contraction), so the two draw
+        # different, equally valid walks: agreement in the mean, 8x8-pixel block means at 256 spp
+        b = lambda f: f[..., :3].reshape(4, 8, 4, 8, 3).mean(axis=(1, 3))
+        berr = float(np.abs(b(gpu) - b(ref)).sum() / np.abs(b(ref)).sum())
+        print(f"{name}: block rel-L1 {berr:.3e}")
+        assert berr < 5e-2 and bias < 1.5e-2, (name, berr, bias)
+        return
     if DEVICE_TOL[name] is None:
         # Lamp-lit fog: chaotic in the reference's own algorithm.  After a medium "hit surface" event the ray origin lies IN the
         # surface it reached (src/media/homogeneous.cpp:64); when that surface is the lamp, the emitter is evaluated from a point
