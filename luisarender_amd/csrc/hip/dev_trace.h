@@ -124,7 +124,7 @@ LR_D float ubyte_to_float(uint32_t v, int byte) {// v_cvt_f32_ubyteN
 // "dynamic fetch" scheme, inside one megakernel.
 enum : uint32_t { kPhaseIdle = 0u, kPhaseShadow = 1u, kPhaseClosest = 2u };
 struct TravState {
-    f3 o, d, inv;
+    f3 o, d;// (1 / d is recomputed on entry to trace_steps: three v_rcp per call instead of three registers live across shading)
     float t_min, t_max;
     uint32_t cur, sp;
     uint32_t phase;
@@ -133,7 +133,7 @@ struct TravState {
 };
 
 LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
-    tr.o = r.o, tr.d = r.d, tr.inv = safe_inverse(r.d);
+    tr.o = r.o, tr.d = r.d;
     tr.t_min = r.t_min, tr.t_max = r.t_max;
     tr.cur = 0u, tr.sp = 0u;// root
     tr.phase = phase;
@@ -159,6 +159,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
     const auto owner0 = lane >> 2u;
     const auto my_swz = (lane >> 2u) & 3u;
     auto idle_at_entry = tr.phase == kPhaseIdle;
+    auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
         auto live = tr.phase != kPhaseIdle;
@@ -218,8 +219,8 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
 #endif
                 // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
                 //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
-                auto ax = q0.w * tr.inv.x, ay = q2.z * tr.inv.y, az = q2.w * tr.inv.z;
-                auto bx = (q0.x - tr.o.x) * tr.inv.x, by = (q0.y - tr.o.y) * tr.inv.y, bz = (q0.z - tr.o.z) * tr.inv.z;
+                auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
+                auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
                 auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
                 auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
                 uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
@@ -227,9 +228,9 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
 #if LR_SLAB_SIGN
                 // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis,
                 // and the 24 plane FMAs go out as 12 v_pk_fma_f32 over child pairs
-                auto nx = tr.inv.x < 0.f ? hix : lox, fx = tr.inv.x < 0.f ? lox : hix;
-                auto ny = tr.inv.y < 0.f ? hiy : loy, fy = tr.inv.y < 0.f ? loy : hiy;
-                auto nz = tr.inv.z < 0.f ? hiz : loz, fz = tr.inv.z < 0.f ? loz : hiz;
+                auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
+                auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
+                auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
                 v2f a_x = {ax, ax}, a_y = {ay, ay}, a_z = {az, az}, b_x = {bx, bx}, b_y = {by, by}, b_z = {bz, bz};
 #pragma unroll
                 for (auto p = 0; p < 4; p += 2) {
@@ -341,6 +342,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         if (live && tr.cur == kInvalid) {
             if (tr.phase == kPhaseShadow && has_next) {
                 trav_begin(tr, next_closest, kPhaseClosest);
+                inv = safe_inverse(tr.d);
             } else {
                 tr.phase = kPhaseIdle;
             }

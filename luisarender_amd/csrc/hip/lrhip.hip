@@ -594,7 +594,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (auto r = ensure(ctx->film_own, film_bytes); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->converted, film_bytes); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->counters, sizeof(lrd::DCounters)); r != LRHIP_OK) { return r; }
-    if (auto r = ensure(ctx->work_counter, 256u); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->work_counter, 1024u); r != LRHIP_OK) { return r; }
     LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
     ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
     LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
@@ -668,7 +668,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
         if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
         args.partial = static_cast<float4 *>(ctx->partial.ptr);
     }
-    LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 4u, ctx->stream));
+    LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
     auto vi = pick_variant(ctx->features, count, generic);
