@@ -11,10 +11,17 @@ used).  For N > 1 the same frame is sharded by screen tile over the ranks (stron
 the float4 film is sum-reduced to rank 0 over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line with the driver's contract plus
-  "roofline":     algorithmic bytes per launch (oracle's canonical-BVH2 counters) divided
-                  by the megakernel's HIP-event duration, against the 8 TB/s HBM3E peak;
-  "cpu_baseline": the CPU oracle ("port": reference-faithful restatement, not the reference binary)
-                  timed on the host cores on a bounded sample of the same workload.
+  "roofline":     against the 8 TB/s HBM3E peak.  `traffic` = HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 +
+                  WRITE_SIZE, MI355X_MICROARCH.md), collected LIVE by this run: two short rocprofv3 --pmc passes of this same
+                  script on the same workload at 64 spp (bytes per sample are spp-invariant), scaled to the timed launch;
+                  `achieved` = traffic / kernel duration and `frac` = achieved / peak -- the MEASURED HBM fraction (round 1
+                  reported the algorithmic figure here, which exceeds the peak for this kernel: most of the canonical-BVH2
+                  bytes are served by L2 / LDS).  The algorithmic figure of SURVEY 8(d) stays, under its own name:
+                  `algorithmic_gbps` = algorithmic bytes per launch / kernel duration.  `valu` holds the third PMC pass
+                  (wave-level VALU instructions) against the issue rates calibrated on the box by tools/valu_peak.hip.
+  "cpu_baseline": the CPU oracle ("port": reference-faithful restatement, not the reference binary; it is pinned to the
+                  reference's own code, tests/test_oracle_vs_ref.py) timed on the host cores on a bounded sample of the workload.
+  "extra_configs": short runs of the other BASELINE configs (C1 with its full CPU leg = configs[0], C3, C5) in the same line.
 """
 from __future__ import annotations
 
@@ -44,7 +51,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per sample (SURVEY §8d formula on the oracle's canonical-BVH2 counters).  Measured live by
 # the cpu_baseline leg at N = 1 (and reported from that measurement); at N > 1 no oracle runs, so the N = 1
 # value of the same seeded workload is used (profiles/r01_bench_c2_1gpu.json).
-ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 2500.0, "c3": 15000.0, "c4": 15000.0, "c5": 15000.0}
+# (all five measured by the cpu_baseline leg of profiles/r01d_bench_c*_1gpu.json)
+ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 3909.0, "c3": 11125.0, "c4": 8323.0, "c5": 13974.0}
+# VALU issue rates calibrated on the box (tools/valu_peak.hip -> profiles/r02_valu_peak.json): cycles a SIMD needs per wave64
+# instruction with >= 2 waves resident: v_fma_f32 / v_add_u32 2.3-2.6, v_max_f32 / v_cvt_f32_ubyte / v_pk_fma_f32 4.1-4.3
+VALU_CYCLES_PER_WAVE_INSTR = (2.4, 4.2)
+SHADER_CLOCK_HZ = 2.4e9
 METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
@@ -64,8 +76,8 @@ def build_scene(workload: str, tmpdir: str, spp_override: int | None):
     return scene, desc, res, spp
 
 
-def cpu_baseline(scene, res, budget_s: float):
-    """Oracle on all host cores over a bounded sample: whole frame at 1..n spp until ~budget_s."""
+def cpu_baseline(scene, res, budget_s: float, full_spp: int | None = None):
+    """Oracle on all host cores over a bounded sample: whole frame at 1..n spp until ~budget_s (full_spp: the whole configuration)."""
     from oracle.check import Oracle, algorithmic_bytes
     cores = os.cpu_count() or 1
     oracle = Oracle(scene)
@@ -73,7 +85,7 @@ def cpu_baseline(scene, res, budget_s: float):
     t0 = time.perf_counter()
     _, c0 = oracle.render(0, 1, rect=(0, res[1] // 2 - 16, res[0], res[1] // 2 + 16), threads=cores)
     rate = c0["paths"] / max(time.perf_counter() - t0, 1e-6)
-    spp = int(max(1, min(16, budget_s * rate / (res[0] * res[1]))))
+    spp = int(max(1, min(full_spp or 16, budget_s * rate / (res[0] * res[1]))))
     t0 = time.perf_counter()
     _, counters = oracle.render(0, spp, threads=cores)
     dt = time.perf_counter() - t0
@@ -82,6 +94,98 @@ def cpu_baseline(scene, res, budget_s: float):
         "sample": f"CPU oracle (reference-faithful restatement, not the reference binary), full frame {res[0]}x{res[1]} at {spp} spp "
                   f"= {counters['paths']} paths in {dt:.1f} s",
     }, algorithmic_bytes(counters) / counters["paths"], counters
+
+
+def source_hash() -> str:
+    """identifies the build a profile belongs to: the device + BVH-builder sources (there is no .git on the GPU box)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "luisarender_amd", "csrc", "hip", "*")) + [os.path.join(ROOT, "luisarender_amd", "csrc", "host", "accel.cpp"), os.path.join(ROOT, "Makefile")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
+    """HBM traffic + VALU instruction count per sample of the workload's megakernel, measured NOW: three rocprofv3 --pmc passes
+    (counters only, with --kernel-trace, as the pool allows) of this script on the same workload at `spp` samples per pixel."""
+    import shutil
+    import sqlite3
+    import subprocess
+    if shutil.which("rocprofv3") is None:
+        return None
+    desc, res, _, _ = WORKLOADS[workload]
+    samples = res[0] * res[1] * spp
+    out = {"spp": spp, "samples_per_launch": samples, "tool": "rocprofv3 --pmc (separate passes) --kernel-trace"}
+    counters = {}
+    with tempfile.TemporaryDirectory(prefix="lr_pmc_") as d:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"])):
+            cmd = ["rocprofv3", "--pmc", *pmc, "--kernel-trace", "-d", os.path.join(d, name), "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-extra"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+                dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(d, name)) for f in fs if f.endswith(".db")]
+                db = sqlite3.connect(dbs[0])
+                for cname, value in db.execute("select counter_name, avg(value) from counters_collection where kernel_name like '%mega%_kernel%' group by counter_name"):
+                    counters[cname] = value
+            except Exception as e:  # no profiler on this box / a refused counter: report what was measured
+                out.setdefault("errors", []).append(f"{name}: {type(e).__name__}")
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 (MI355X_MICROARCH.md, HBM section)
+        out["hbm_bytes_per_sample"] = (counters["FETCH_SIZE"] * 2048.0 + counters["WRITE_SIZE"] * 1024.0) / samples
+        out["hbm_read_bytes_per_sample"] = counters["FETCH_SIZE"] * 2048.0 / samples
+        out["hbm_write_bytes_per_sample"] = counters["WRITE_SIZE"] * 1024.0 / samples
+    if "SQ_INSTS_VALU" in counters:
+        out["valu_wave_instr_per_sample"] = counters["SQ_INSTS_VALU"] / samples
+    out["counters"] = counters
+    return out
+
+
+def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None):
+    """times `steps` frames of one workload -> (value Msamples/s, ms_per_step, kernel_ms, variant, scene, res, spp, desc)"""
+    import torch
+    import torch.distributed as dist
+    from luisarender_amd.parallel import reduce_film
+    from luisarender_amd.render import MegaPathRenderer
+    scene, desc, res, spp = build_scene(workload, tmp, spp_override)
+    renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
+    renderer.upload(scene)
+    film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    renderer.bind_film(film.data_ptr())
+    torch.cuda.synchronize()
+
+    def step():
+        film.zero_()
+        torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
+        renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
+        renderer.synchronize()
+        if world > 1:
+            reduce_film(film, dst=0)
+            torch.cuda.synchronize()
+        return renderer.last_render_ms()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = [step() for _ in range(steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mean_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    if world > 1:
+        t = torch.tensor([elapsed, mean_kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, mean_kernel_ms = float(t[0]), float(t[1])
+    variant = renderer.last_variant()
+    renderer.close()
+    value = res[0] * res[1] * spp * steps / elapsed / 1e6
+    return value, elapsed / steps * 1e3, mean_kernel_ms, variant, scene, res, spp, desc
 
 
 def main():
@@ -93,6 +197,8 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override the workload's spp (invalidates the headline number)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic from profiles/ or null)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configs")
     args = ap.parse_args()
 
     import torch
@@ -109,49 +215,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from luisarender_amd.parallel import reduce_film
-    from luisarender_amd.render import MegaPathRenderer
-
     with tempfile.TemporaryDirectory(prefix="lr_bench_") as tmp:
-        scene, desc, res, spp = build_scene(args.workload, tmp, args.spp)
-        renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
-        renderer.upload(scene)
-        film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        renderer.bind_film(film.data_ptr())
-        torch.cuda.synchronize()
-
-        def step():
-            film.zero_()
-            torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
-            renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
-            renderer.synchronize()
-            if world > 1:
-                reduce_film(film, dst=0)
-                torch.cuda.synchronize()
-            return renderer.last_render_ms()
-
-        def barrier():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        kernel_ms = [step() for _ in range(args.steps)]
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, mean_kernel_ms = float(t[0]), float(t[1])
-        else:
-            mean_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        value, ms_per_step, mean_kernel_ms, variant, scene, res, spp, desc = run_workload(
+            args.workload, args, rank, world, local_rank, tmp, args.steps, args.warmup, args.spp)
+        elapsed = ms_per_step * args.steps * 1e-3
 
         if rank == 0:
             samples_per_step = res[0] * res[1] * spp
-            value = samples_per_step * args.steps / elapsed / 1e6
             out = {
                 "metric": METRIC, "value": value, "unit": "Msamples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -168,25 +238,54 @@ def main():
                 cpu, bytes_per_sample, _ = cpu_baseline(scene, res, args.cpu_seconds)
                 out["cpu_baseline"] = cpu
             # one launch renders this rank's shard: samples_per_step / world samples
-            launch_bytes = bytes_per_sample * samples_per_step / world
-            achieved = launch_bytes / (mean_kernel_ms * 1e-3) / 1e9
-            traffic = None
-            prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-            if world == 1 and args.spp is None and os.path.exists(prof):
-                try:
-                    traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            launch_samples = samples_per_step / world
+            algorithmic_gbps = bytes_per_sample * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
+            pmc, pmc_source = None, None
+            if world == 1 and not args.no_pmc:
+                pmc, pmc_source = live_pmc(args.workload), "live: rocprofv3 --pmc passes of this run, same workload at 64 spp, scaled per sample"
+            if pmc is None or "hbm_bytes_per_sample" not in pmc:
+                prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+                if os.path.exists(prof):
+                    try:
+                        p = json.load(open(prof))
+                        if p.get("source_hash") == source_hash() and p.get("hbm_bytes_per_sample"):  # a profile of another build is not evidence
+                            pmc, pmc_source = p, f"profiles/pmc_{args.workload}.json (same source hash)"
+                    except Exception:
+                        pass
+            traffic = pmc["hbm_bytes_per_sample"] * launch_samples if pmc and pmc.get("hbm_bytes_per_sample") else None
+            achieved = traffic / (mean_kernel_ms * 1e-3) / 1e9 if traffic else None
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "kernel": f"lrd::megapath_kernel<{renderer.last_variant()}u>", "kernel_ms": mean_kernel_ms,
-                "algorithmic_bytes_per_sample": bytes_per_sample,
-                "note": "algorithmic bytes = canonical BVH2 walk of the oracle (SURVEY 8d); the quantised BVH4 + L2/LDS reuse "
-                        "serve most of them on chip, so `achieved` may exceed the HBM peak while `traffic` (PMC, per launch) "
-                        "stays far below it; the kernel is VALU-issue/latency bound (DESIGN.md section 5)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic, "traffic_source": pmc_source,
+                "kernel": f"lrd::megapath_kernel<{variant}u>", "kernel_ms": mean_kernel_ms,
+                "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_gbps": algorithmic_gbps,
+                "algorithmic_frac_of_hbm_peak": algorithmic_gbps / HBM_PEAK_GBPS,
+                "note": "achieved / frac = MEASURED HBM traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE) over the kernel's HIP-event duration; "
+                        "algorithmic_* = the canonical-BVH2 byte count of SURVEY 8(d), most of which L2 / LDS serve on chip (it may exceed "
+                        "the HBM peak and is not a traffic figure); the kernel is bound by VALU issue + memory latency, see `valu` and DESIGN.md 5",
             }
+            if pmc and pmc.get("valu_wave_instr_per_sample"):
+                instr = pmc["valu_wave_instr_per_sample"] * launch_samples
+                import torch
+                simds = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
+                simd_cycles = simds * mean_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
+                out["roofline"]["valu"] = {
+                    "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"],
+                    "issue_frac_if_all_full_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[0] / simd_cycles,
+                    "issue_frac_if_all_quarter_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[1] / simd_cycles,
+                    "calibration": "profiles/r02_valu_peak.json (tools/valu_peak.hip): 2.4 cycles per wave64 v_fma / v_add, 4.2 per v_max / v_cvt_ubyte / v_pk_fma; the kernel's mix lies between",
+                }
+            if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None:
+                extra = []
+                for w, steps, spp_o, with_cpu in (("c1", 3, None, True), ("c3", 2, 1024, False), ("c5", 1, 512, False)):
+                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o)
+                    e = {"workload": d, "spp_timed": sp, "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms, "kernel": f"lrd::megapath_kernel<{var}u>",
+                         "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
+                    if with_cpu:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration
+                        e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _ = cpu_baseline(sc, r, 30.0, full_spp=sp)
+                    extra.append(e)
+                out["extra_configs"] = extra
             print(json.dumps(out), flush=True)
-        renderer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
