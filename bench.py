@@ -146,23 +146,23 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
     """times `steps` frames of one workload -> (value Msamples/s, ms_per_step, kernel_ms, variant, scene, res, spp, desc)"""
     import torch
     import torch.distributed as dist
-    from luisarender_amd.parallel import reduce_film
+    from luisarender_amd.parallel import FilmReducer
     from luisarender_amd.render import MegaPathRenderer
     scene, desc, res, spp = build_scene(workload, tmp, spp_override)
     renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     renderer.upload(scene)
     film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     renderer.bind_film(film.data_ptr())
+    reducer = FilmReducer(renderer, rank, world)  # communicator through the C ABI: the timed collective is lrhip_film_reduce
     torch.cuda.synchronize()
 
     def step():
         film.zero_()
         torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
         renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
-        renderer.synchronize()
         if world > 1:
-            reduce_film(film, dst=0)
-            torch.cuda.synchronize()
+            reducer.reduce(0)  # ncclReduce on the renderer's stream, behind the megakernel
+        renderer.synchronize()
         return renderer.last_render_ms()
 
     def barrier():
@@ -183,6 +183,7 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, mean_kernel_ms = float(t[0]), float(t[1])
     variant = renderer.last_variant()
+    reducer.close()
     renderer.close()
     value = res[0] * res[1] * spp * steps / elapsed / 1e6
     return value, elapsed / steps * 1e3, mean_kernel_ms, variant, scene, res, spp, desc

@@ -41,9 +41,12 @@ typedef struct lrhip_ctx lrhip_ctx;
 #define LRHIP_ERROR_UNSUPPORTED (-3)
 
 /* Work of one lrhip_render call: samples [spp_begin, spp_end) of every pixel of the screen tiles
- * {tile_begin + k * tile_stride : tile_begin + k * tile_stride < tile_end}.  Tiles are 8x8 pixels,
- * numbered row-major over ceil(W/8) x ceil(H/8).  (0, tile_count, 1) renders the whole frame;
- * (rank, tile_count, world) is the round-robin screen-tile shard of one GPU.      */
+ * {tile_begin + k * tile_stride : tile_begin + k * tile_stride < tile_end}.  Tiles are 8x8 pixels; tile number
+ * t = ty * tiles_x + j names the tile in row ty whose column is (j + ty) mod tiles_x (tiles_x = ceil(W/8)): every row is
+ * rotated by its index, so that a strided shard (rank, tile_count, world) is a set of DIAGONALS of the frame, never a set
+ * of columns (tiles_x is a multiple of the world size for every power-of-two frame).  Every tile has exactly one number,
+ * so any partition of [0, tile_count) partitions the frame.  (0, tile_count, 1) renders the whole frame; (rank, tile_count,
+ * world) is the interleaved screen-tile shard of one GPU; tile_begin >= tile_end is an empty shard (no error). */
 typedef struct lrhip_render_params {
     uint32_t spp_begin, spp_end;
     uint32_t tile_begin, tile_end, tile_stride;
@@ -64,7 +67,7 @@ typedef struct lrhip_render_params {
 
 typedef struct lrhip_counters {
     uint64_t paths, closest_rays, shadow_rays;
-    uint64_t nodes_visited;  /* BVH4 nodes fetched (128 B each)              */
+    uint64_t nodes_visited;  /* quantised BVH4 packets fetched (64 B each)   */
     uint64_t tris_tested;    /* triangle tests (48 B each)                   */
     uint64_t surface_hits, nee_samples, path_length_sum;
     /* SIMD-occupancy diagnostics: lane-iterations of the traversal loop (all lanes of every wave) and the
@@ -112,6 +115,20 @@ int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted);
  * on it.  Every pixel is owned by exactly one rank under tile sharding and the others hold exact zeros there, so the reduced
  * film is bit-identical to the 1-GPU film.  The reference has no multi-device path (src/apps/cli.cpp:172,181).              */
 int lrhip_film_reduce(lrhip_ctx *ctx, void *nccl_comm, int root);
+/* the same for several contexts driven by ONE host thread (one process, one context + communicator per GPU): a single RCCL group */
+int lrhip_film_reduce_group(int count, lrhip_ctx *const *ctxs, void *const *comms, int root);
+
+/* Communicators for lrhip_film_reduce, so that a host needs no RCCL headers of its own (librccl.so is loaded on first use):
+ *   one process per GPU:  rank 0 calls lrhip_comm_unique_id, ships the 128 bytes to the other ranks by its own means (MPI, a
+ *                         file, torch.distributed), every rank calls lrhip_comm_init_rank on its context         (ncclCommInitRank)
+ *   one process, N GPUs:  lrhip_comm_init_all(N, device ordinals, comms)                                        (ncclCommInitAll)
+ * lrhip_comm_destroy releases one communicator.  lrhip_device_count = hipGetDeviceCount.                                      */
+#define LRHIP_COMM_ID_BYTES 128
+int lrhip_device_count(int *count);
+int lrhip_comm_unique_id(unsigned char id[LRHIP_COMM_ID_BYTES]);
+int lrhip_comm_init_rank(lrhip_ctx *ctx, int world, int rank, const unsigned char id[LRHIP_COMM_ID_BYTES], void **comm);
+int lrhip_comm_init_all(int count, const int *devices, void **comms);
+int lrhip_comm_destroy(void *comm);
 
 int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out); /* summed since upload; synchronises */
 /* HIP-event time of the megakernel launches of the last lrhip_render call, in ms; synchronises */

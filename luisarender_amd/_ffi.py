@@ -192,6 +192,11 @@ def hip_lib() -> C.CDLL:
         lib.lrhip_upload_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
         lib.lrhip_update_scene.argtypes = [C.c_void_p, C.POINTER(Scene)]
         lib.lrhip_film_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.lrhip_comm_unique_id.argtypes = [C.c_void_p]
+        lib.lrhip_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.lrhip_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        lib.lrhip_comm_destroy.argtypes = [C.c_void_p]
+        lib.lrhip_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.lrhip_bind_film.argtypes = [C.c_void_p, C.c_void_p]
         lib.lrhip_film_clear.argtypes = [C.c_void_p]
         lib.lrhip_render.argtypes = [C.c_void_p, C.POINTER(RenderParams)]

@@ -12,7 +12,8 @@ __global__ void resolve_partial_kernel(float4 *film, const float4 *partial, uint
     auto i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pixel_count) { return; }
     auto px = i % width, py = i / width;
-    auto tile = (py / 8u) * tiles_x + px / 8u;
+    auto ty = py / 8u, tcol = px / 8u;
+    auto tile = ty * tiles_x + (tcol + tiles_x - ty % tiles_x) % tiles_x;// the tile NUMBER of column tcol in the rotated row (lrhip.h)
     if (tile < tile_begin || tile >= tile_end || (tile - tile_begin) % tile_stride != 0u) { return; }
     auto v = film[i];
     for (auto c = 0u; c < chunk_count; c++) {

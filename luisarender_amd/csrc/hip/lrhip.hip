@@ -98,6 +98,8 @@ struct lrhip_ctx {
     DeviceBuffer film_own, converted, partial, spill, counters, work_counter;
     DeviceBuffer scene_record;// lrd::DScene in device memory: the kernels read it through scalar loads (dev_scene.h: DScenePtr)
     float4 *film{nullptr};// bound film (own or external)
+    float4 *film_external{nullptr};// lrhip_bind_film's buffer; kept across uploads of the same resolution
+    uint32_t film_external_w{0}, film_external_h{0};
     uint32_t grid_blocks{0};
     uint32_t cu_count{0};
     uint32_t bvh_depth{0};
@@ -393,6 +395,47 @@ int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
     return LRHIP_OK;
 }
 
+// Every index one table holds into another, checked once: the caller may be a third party, and nothing may read out of bounds
+// on either side of the boundary (lrhip.h: "nothing throws or aborts across the boundary").
+static std::string validate_indices(const lr_scene *s) {
+    auto tex_ok = [&](int32_t id) { return id < 0 || static_cast<uint32_t>(id) < s->texture_count; };
+    for (uint32_t i = 0; i < s->texture_count; i++) {
+        auto &t = s->textures[i];
+        if (t.kind == LR_TEX_CHECKERBOARD && (!tex_ok(t.child[0]) || !tex_ok(t.child[1]))) { return "texture " + std::to_string(i) + ": child texture out of range"; }
+    }
+    for (uint32_t i = 0; i < s->surface_count; i++) {
+        auto &f = s->surfaces[i];
+        for (auto t : f.tex) { if (!tex_ok(t)) { return "surface " + std::to_string(i) + ": texture id out of range"; } }
+        if (!tex_ok(f.normal_tex) || !tex_ok(f.alpha_tex)) { return "surface " + std::to_string(i) + ": normal / alpha texture id out of range"; }
+        if ((f.kind == LR_SURFACE_MIX || f.kind == LR_SURFACE_LAYERED) && (f.u[0] >= s->surface_count || f.u[1] >= s->surface_count)) {
+            return "surface " + std::to_string(i) + ": child surface out of range";
+        }
+    }
+    for (uint32_t i = 0; i < s->light_count; i++) {
+        auto e = s->lights[i].emission_tex;
+        if (e < 0 || static_cast<uint32_t>(e) >= s->texture_count) { return "light " + std::to_string(i) + ": emission texture out of range"; }
+    }
+    for (uint32_t i = 0; i < s->instance_count; i++) {
+        auto &h = s->instances[i].handle;
+        if ((h.x >> 10u) >= s->mesh_count) { return "instance " + std::to_string(i) + ": mesh index out of range"; }
+        auto flags = h.x & 1023u;
+        if ((flags & LR_SHAPE_HAS_SURFACE) && ((h.y >> 12u) & 4095u) >= s->surface_count) { return "instance " + std::to_string(i) + ": surface tag out of range"; }
+        if ((flags & LR_SHAPE_HAS_LIGHT) && (h.y & 4095u) >= s->light_count) { return "instance " + std::to_string(i) + ": light tag out of range"; }
+    }
+    for (uint32_t i = 0; i < s->light_instance_count; i++) {
+        if (s->light_instances[i].instance_id >= s->instance_count) { return "light instance " + std::to_string(i) + ": instance id out of range"; }
+    }
+    if (s->environment.kind == LR_ENV_COMBINED) {
+        for (uint32_t i = 0; i < s->environment_child_count; i++) {
+            auto &c = s->environment_children[i];
+            if (c.kind != LR_ENV_NONE && c.kind != LR_ENV_COMBINED && (c.emission_tex < 0 || static_cast<uint32_t>(c.emission_tex) >= s->texture_count)) {
+                return "environment child " + std::to_string(i) + ": emission texture out of range";
+            }
+        }
+    }
+    return {};
+}
+
 int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (ctx == nullptr || s == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: NULL argument"); }
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
@@ -401,6 +444,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->environment.kind > LR_ENV_COMBINED || (s->environment.kind == LR_ENV_COMBINED && (s->environment_child_count != 2u || s->environment_children == nullptr))) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
     }
+    if (auto bad = validate_indices(s); !bad.empty()) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: " + bad); }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
     LR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     release_scene(ctx);
@@ -596,7 +640,14 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (auto r = ensure(ctx->counters, sizeof(lrd::DCounters)); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->work_counter, 1024u); r != LRHIP_OK) { return r; }
     LR_HIP_CHECK(hipMemset(ctx->counters.ptr, 0, sizeof(lrd::DCounters)));
-    ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
+    // a caller-owned film (lrhip_bind_film) stays bound across uploads of the same resolution (MegaPathRenderer.render_frame
+    // uploads per shutter sample); a resolution change unbinds it -- its size is no longer the frame's
+    if (ctx->film_external != nullptr && ctx->film_external_w == ctx->width && ctx->film_external_h == ctx->height) {
+        ctx->film = ctx->film_external;
+    } else {
+        ctx->film_external = nullptr;
+        ctx->film = static_cast<float4 *>(ctx->film_own.ptr);
+    }
     LR_HIP_CHECK(hipMemset(ctx->film, 0, film_bytes));
     // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
     // traversal-stack overflow area is sized for the densest variant
@@ -613,6 +664,8 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
 
 int lrhip_bind_film(lrhip_ctx *ctx, void *device_float4_film) {
     if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_bind_film: no scene uploaded"); }
+    ctx->film_external = static_cast<float4 *>(device_float4_film);
+    ctx->film_external_w = ctx->width, ctx->film_external_h = ctx->height;
     ctx->film = device_float4_film != nullptr ? static_cast<float4 *>(device_float4_film) : static_cast<float4 *>(ctx->film_own.ptr);
     return LRHIP_OK;
 }
@@ -628,12 +681,12 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (ctx == nullptr || p == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_render: no scene uploaded"); }
     auto tiles_x = (ctx->width + 7u) / 8u, tiles_y = (ctx->height + 7u) / 8u;
     auto tile_count = tiles_x * tiles_y;
-    if (p->spp_end < p->spp_begin || p->tile_stride == 0u || p->tile_end > tile_count || p->tile_begin > p->tile_end) {
+    if (p->spp_end < p->spp_begin || p->tile_stride == 0u || p->tile_end > tile_count) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_render: invalid spp/tile range");
     }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
     ctx->timed = false;
-    if (p->spp_end == p->spp_begin || p->tile_begin == p->tile_end) { return LRHIP_OK; }
+    if (p->spp_end == p->spp_begin || p->tile_begin >= p->tile_end) { return LRHIP_OK; }// (rank >= tile count: an empty shard)
     // MegakernelPathTracingInstance::_render_one_camera (mega_path.cpp:40-47): no lights -> nothing rendered
     // (the normal visualiser needs no light: normal.cpp has no such check)
     if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone && ctx->scene.integrator_kind != LR_INTEGRATOR_NORMAL) { return LRHIP_OK; }
@@ -726,23 +779,101 @@ int lrhip_film_download(lrhip_ctx *ctx, float *rgba, int converted) {
     return LRHIP_OK;
 }
 
+namespace {
+// librccl.so is loaded on first use (no link-time dependency): the handful of entry points the multi-GPU path needs
+struct Rccl {
+    using unique_id = struct { char internal[128]; };
+    int (*get_unique_id)(unique_id *){nullptr};
+    int (*comm_init_rank)(void **, int, unique_id, int){nullptr};
+    int (*comm_init_all)(void **, int, const int *){nullptr};
+    int (*comm_destroy)(void *){nullptr};
+    int (*reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t){nullptr};
+    int (*group_start)(){nullptr};
+    int (*group_end)(){nullptr};
+    bool ok{false};
+    Rccl() {
+        auto lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib == nullptr) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); }
+        if (lib == nullptr) { return; }
+        get_unique_id = reinterpret_cast<decltype(get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+        comm_init_rank = reinterpret_cast<decltype(comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+        comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(lib, "ncclCommInitAll"));
+        comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
+        group_start = reinterpret_cast<decltype(group_start)>(dlsym(lib, "ncclGroupStart"));
+        group_end = reinterpret_cast<decltype(group_end)>(dlsym(lib, "ncclGroupEnd"));
+        ok = get_unique_id && comm_init_rank && comm_init_all && comm_destroy && reduce && group_start && group_end;
+    }
+};
+const Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+}// namespace
+
+int lrhip_device_count(int *count) {
+    if (count == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_device_count: NULL argument"); }
+    LR_HIP_CHECK(hipGetDeviceCount(count));
+    return LRHIP_OK;
+}
+
+int lrhip_comm_unique_id(unsigned char id[LRHIP_COMM_ID_BYTES]) {
+    if (id == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_comm_unique_id: NULL argument"); }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_unique_id: librccl.so could not be loaded"); }
+    Rccl::unique_id u{};
+    static_assert(sizeof(u) == LRHIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (auto rc = rccl().get_unique_id(&u); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclGetUniqueId failed with code " + std::to_string(rc)); }
+    std::memcpy(id, &u, sizeof(u));
+    return LRHIP_OK;
+}
+
+int lrhip_comm_init_rank(lrhip_ctx *ctx, int world, int rank, const unsigned char id[LRHIP_COMM_ID_BYTES], void **comm) {
+    if (ctx == nullptr || id == nullptr || comm == nullptr || world < 1 || rank < 0 || rank >= world) { return fail(LRHIP_ERROR_INVALID, "lrhip_comm_init_rank: invalid argument"); }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_init_rank: librccl.so could not be loaded"); }
+    LR_HIP_CHECK(hipSetDevice(ctx->device));
+    Rccl::unique_id u{};
+    std::memcpy(&u, id, sizeof(u));
+    if (auto rc = rccl().comm_init_rank(comm, world, u, rank); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+    return LRHIP_OK;
+}
+
+int lrhip_comm_init_all(int count, const int *devices, void **comms) {
+    if (count < 1 || devices == nullptr || comms == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_comm_init_all: invalid argument"); }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_init_all: librccl.so could not be loaded"); }
+    if (auto rc = rccl().comm_init_all(comms, count, devices); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommInitAll failed with code " + std::to_string(rc)); }
+    return LRHIP_OK;
+}
+
+int lrhip_comm_destroy(void *comm) {
+    if (comm == nullptr) { return LRHIP_OK; }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_destroy: librccl.so could not be loaded"); }
+    if (auto rc = rccl().comm_destroy(comm); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommDestroy failed with code " + std::to_string(rc)); }
+    return LRHIP_OK;
+}
+
 int lrhip_film_reduce(lrhip_ctx *ctx, void *nccl_comm, int root) {
     if (ctx == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_reduce: no scene uploaded"); }
     if (nccl_comm == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_reduce: communicator is NULL"); }
-    // ncclReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, root, comm, stream), rccl.h
-    using reduce_fn = int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t);
-    static reduce_fn reduce = [] {
-        auto lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (lib == nullptr) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); }
-        return lib != nullptr ? reinterpret_cast<reduce_fn>(dlsym(lib, "ncclReduce")) : nullptr;
-    }();
-    if (reduce == nullptr) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_film_reduce: librccl.so (ncclReduce) could not be loaded"); }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_film_reduce: librccl.so (ncclReduce) could not be loaded"); }
     LR_HIP_CHECK(hipSetDevice(ctx->device));
     auto count = static_cast<size_t>(ctx->width) * ctx->height * 4u;
-    if (auto rc = reduce(ctx->film, ctx->film, count, 7, 0, root, nccl_comm, ctx->stream); rc != 0) {
+    // ncclReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, root, comm, stream), rccl.h
+    if (auto rc = rccl().reduce(ctx->film, ctx->film, count, 7, 0, root, nccl_comm, ctx->stream); rc != 0) {
         return fail(LRHIP_ERROR_DEVICE, "lrhip_film_reduce: ncclReduce failed with code " + std::to_string(rc));
     }
     return LRHIP_OK;
+}
+
+// One host thread drives several contexts of one process (the C++ host's multi-GPU path): the reduces of all of them go out as
+// ONE group, as RCCL requires of a single thread that owns several communicators.
+int lrhip_film_reduce_group(int count, lrhip_ctx *const *ctxs, void *const *comms, int root) {
+    if (count < 1 || ctxs == nullptr || comms == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_film_reduce_group: invalid argument"); }
+    if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_film_reduce_group: librccl.so could not be loaded"); }
+    if (auto rc = rccl().group_start(); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclGroupStart failed with code " + std::to_string(rc)); }
+    auto status = LRHIP_OK;
+    for (auto i = 0; i < count && status == LRHIP_OK; i++) { status = lrhip_film_reduce(ctxs[i], comms[i], root); }
+    if (auto rc = rccl().group_end(); rc != 0 && status == LRHIP_OK) { return fail(LRHIP_ERROR_DEVICE, "ncclGroupEnd failed with code " + std::to_string(rc)); }
+    return status;
 }
 
 int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out) {

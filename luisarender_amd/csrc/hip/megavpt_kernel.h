@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
         const auto tile_index = item / args.chunk_count;
         const auto chunk = item - tile_index * args.chunk_count;
         const auto tile = args.tile_begin + tile_index * args.tile_stride;
-        const auto tx = tile % args.tiles_x, ty = tile / args.tiles_x;
+        const auto ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
         const auto spp_total = args.spp_end - args.spp_begin;
         const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
         const auto s_begin = args.spp_begin + chunk * per_chunk;

@@ -22,7 +22,7 @@ namespace {
 void print_help() {
     std::cout << "Usage:\n  luisa-render-cli [OPTION...] <file>\n\n"
                  "  -b, --backend <backend>    Compute backend name (hip)\n"
-                 "  -d, --device <index>       Compute device index (default: -1)\n"
+                 "  -d, --device <index>       Compute device index (default: -1); a list `0,1,2,3` (or LR_DEVICES) shards the frame over several GPUs\n"
                  "      --scene <file>         Path to scene description file\n"
                  "  -D, --define <key>=<value> Parameter definitions to override scene description macros.\n"
                  "  -h, --help                 Display this help message\n";
@@ -43,6 +43,7 @@ int main(int argc, char *argv[]) {
     lr::MacroMap macros;
     std::string backend, scene_file;
     auto device_index = -1;
+    std::string device_list;// `-d 2` as in the reference, or `-d 0,1,2,3`: one frame sharded over several GPUs
     std::vector<std::string> unknown;
     auto parse_macro = [&](std::string_view d) {
         auto p = d.find('=');
@@ -68,9 +69,9 @@ int main(int argc, char *argv[]) {
         } else if (arg.rfind("--backend=", 0) == 0) {
             backend = arg.substr(10);
         } else if (arg == "-d" || arg == "--device") {
-            if (auto v = next()) { device_index = std::atoi(v); }
+            if (auto v = next()) { device_list = v; }
         } else if (arg.rfind("--device=", 0) == 0) {
-            device_index = std::atoi(std::string{arg.substr(9)}.c_str());
+            device_list = std::string{arg.substr(9)};
         } else if (arg == "--scene") {
             if (auto v = next()) { scene_file = v; }
         } else if (arg == "-h" || arg == "--help") {
@@ -102,7 +103,18 @@ int main(int argc, char *argv[]) {
         lr::log_warning("Backend '" + backend + "' is not available in this build; using 'hip' (MI355X / gfx950).");
     }
     try {
-        luisa::compute::Device device{"hip", device_index};
+        if (device_list.empty()) {
+            if (auto env = std::getenv("LR_DEVICES")) { device_list = env; }
+        }
+        std::vector<int> devices;
+        for (size_t b = 0; b < device_list.size();) {
+            auto e = device_list.find(',', b);
+            if (e == std::string::npos) { e = device_list.size(); }
+            if (e > b) { devices.emplace_back(std::atoi(device_list.substr(b, e - b).c_str())); }
+            b = e + 1;
+        }
+        if (!devices.empty()) { device_index = devices.front(); }
+        luisa::compute::Device device{"hip", device_index, devices.size() > 1u ? devices : std::vector<int>{}};
         auto t0 = std::chrono::steady_clock::now();
         auto desc = lr::parse_scene_file(scene_file, macros);
         auto parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

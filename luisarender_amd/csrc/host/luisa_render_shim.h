@@ -7,6 +7,7 @@
 //   Integrator / Instance            src/base/integrator.h:19-79
 //   Pipeline::create / render        src/base/pipeline.cpp:44-99,115-117
 #pragma once
+#include <vector>
 #include <filesystem>
 #include <memory>
 #include <string>
@@ -20,6 +21,9 @@ namespace luisa::compute {
 struct Device {
     std::string backend;
     int index{0};
+    // multi-GPU extension of `-d` (the reference drives one device, src/apps/cli.cpp:172): `-d 0,1,2,3` / LR_DEVICES=0,1,2,3 shards
+    // the frame by screen tile over these HIP devices; empty = the single device `index`
+    std::vector<int> indices;
 };
 struct Stream {
     Device *device{nullptr};

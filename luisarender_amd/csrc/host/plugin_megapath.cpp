@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <thread>
+
 #include "../../../include/lrhip.h"
 #include "luisa_render_shim.h"
 
@@ -40,6 +42,10 @@ struct HipApi {
     decltype(&lrhip_synchronize) synchronize{};
     decltype(&lrhip_film_download) film_download{};
     decltype(&lrhip_last_error) last_error{};
+    // multi-GPU: only looked up when the frame is sharded
+    decltype(&lrhip_comm_init_all) comm_init_all{};
+    decltype(&lrhip_comm_destroy) comm_destroy{};
+    decltype(&lrhip_film_reduce_group) film_reduce_group{};
 
     bool load(const std::filesystem::path &runtime_dir) {
         for (auto &dir : {runtime_dir, runtime_dir / ".." / "lib"}) {
@@ -57,6 +63,9 @@ struct HipApi {
         LR_SYM(synchronize, "lrhip_synchronize");
         LR_SYM(film_download, "lrhip_film_download");
         LR_SYM(last_error, "lrhip_last_error");
+        LR_SYM(comm_init_all, "lrhip_comm_init_all");
+        LR_SYM(comm_destroy, "lrhip_comm_destroy");
+        LR_SYM(film_reduce_group, "lrhip_film_reduce_group");
 #undef LR_SYM
         return create && destroy && upload_scene && update_scene && film_clear && render && synchronize && film_download && last_error;
     }
@@ -93,12 +102,45 @@ public:
             std::fprintf(stderr, "[error] Failed to load liblrhip.so (the gfx950 megakernel library): %s\n", dlerror());
             std::abort();// LUISA_ERROR semantics: log + abort
         }
-        lrhip_ctx *ctx = nullptr;
-        auto device_index = stream.device != nullptr ? std::max(stream.device->index, 0) : 0;
-        if (api.create(device_index, &ctx) != LRHIP_OK) {
-            std::fprintf(stderr, "[error] lrhip_create: %s\n", api.last_error());
-            std::abort();
+        // One lrhip_ctx per GPU.  `-d 0,1,2,3` / LR_DEVICES shards every frame by screen tile over the listed devices:
+        // this process flattens the scene and builds the BVH ONCE, one host thread per GPU uploads the same host tables and renders
+        // the tiles {r, r + W, ...} (lrhip.h: diagonals of the frame) with balance_shards = W, and ONE collective -- lrhip_film_reduce
+        // = ncclReduce over xGMI, communicators from ncclCommInitAll -- sums the films on the first device, which converts and saves.
+        // Every pixel is owned by one GPU and the others hold exact zeros there, so the image is the 1-GPU image bit for bit.
+        std::vector<int> devices;
+        if (stream.device != nullptr && stream.device->indices.size() > 1u) { devices = stream.device->indices; }
+        else { devices = {stream.device != nullptr ? std::max(stream.device->index, 0) : 0}; }
+        const auto world = static_cast<uint32_t>(devices.size());
+        std::vector<lrhip_ctx *> ctxs(world, nullptr);
+        std::vector<void *> comms(world, nullptr);
+        for (auto r = 0u; r < world; r++) {
+            if (api.create(devices[r], &ctxs[r]) != LRHIP_OK) {
+                std::fprintf(stderr, "[error] lrhip_create(device %d): %s\n", devices[r], api.last_error());
+                std::abort();
+            }
         }
+        if (world > 1u) {
+            if (api.comm_init_all == nullptr || api.film_reduce_group == nullptr || api.comm_init_all(static_cast<int>(world), devices.data(), comms.data()) != LRHIP_OK) {
+                std::fprintf(stderr, "[error] lrhip_comm_init_all: %s\n", api.last_error());
+                std::abort();
+            }
+        }
+        auto ctx = ctxs[0];
+        auto device_index = devices[0];
+        // runs f(rank) on one host thread per GPU (the calling thread takes rank 0) and joins; a context is driven by one thread at a time
+        auto on_every_gpu = [&](auto &&f) {
+            std::vector<std::thread> threads;
+            std::vector<std::string> errors(world);
+            for (auto r = 1u; r < world; r++) { threads.emplace_back([&, r] { errors[r] = f(r); }); }
+            errors[0] = f(0u);
+            for (auto &t : threads) { t.join(); }
+            for (auto r = 0u; r < world; r++) {
+                if (!errors[r].empty()) {
+                    std::fprintf(stderr, "[error] HIP device %d: %s\n", devices[r], errors[r].c_str());
+                    std::abort();
+                }
+            }
+        };
         for (size_t i = 0; i < data.cameras.size(); i++) {
             auto &camera = data.cameras[i];
             auto width = camera.camera.width, height = camera.camera.height;
@@ -117,26 +159,31 @@ public:
                 auto &shutter = camera.shutter_samples;
                 for (auto &s : shutter) {
                     auto moved = lr::set_scene_time(data, s.time);
-                    if (first || moved) {
-                        auto view = data.view(i);
-                        if ((first ? api.upload_scene(ctx, &view) : api.update_scene(ctx, &view)) != LRHIP_OK) {
-                            std::fprintf(stderr, "[error] lrhip_upload_scene: %s\n", api.last_error());
-                            std::abort();
-                        }
-                    }
-                    if (first) { api.film_clear(ctx); }
+                    auto view = data.view(i);// the host tables of this shutter sample: read-only while the GPUs upload them
+                    const auto upload = first || moved;
+                    const auto was_first = first;
+                    const auto begin = sample_id;
+                    on_every_gpu([&](uint32_t r) -> std::string {
+                        if (upload && (was_first ? api.upload_scene(ctxs[r], &view) : api.update_scene(ctxs[r], &view)) != LRHIP_OK) { return std::string{"lrhip_upload_scene: "} + api.last_error(); }
+                        if (was_first && api.film_clear(ctxs[r]) != LRHIP_OK) { return std::string{"lrhip_film_clear: "} + api.last_error(); }
+                        lrhip_render_params params{begin, begin + s.spp, r, tiles, world, shutter.size() > 1u ? LRHIP_RENDER_SHUTTER_WEIGHT : 0u, world, s.weight};
+                        if (api.render(ctxs[r], &params) != LRHIP_OK || api.synchronize(ctxs[r]) != LRHIP_OK) { return std::string{"lrhip_render: "} + api.last_error(); }
+                        return {};
+                    });
                     first = false;
-                    lrhip_render_params params{sample_id, sample_id + s.spp, 0u, tiles, 1u, shutter.size() > 1u ? LRHIP_RENDER_SHUTTER_WEIGHT : 0u, 1u, s.weight};
                     sample_id += s.spp;
-                    if (api.render(ctx, &params) != LRHIP_OK || api.synchronize(ctx) != LRHIP_OK) {
-                        std::fprintf(stderr, "[error] lrhip_render: %s\n", api.last_error());
+                }
+                if (world > 1u) {// the path's one collective: per-GPU films -> devices[0]
+                    if (api.film_reduce_group(static_cast<int>(world), ctxs.data(), comms.data(), 0) != LRHIP_OK) {
+                        std::fprintf(stderr, "[error] lrhip_film_reduce: %s\n", api.last_error());
                         std::abort();
                     }
+                    on_every_gpu([&](uint32_t r) -> std::string { return api.synchronize(ctxs[r]) != LRHIP_OK ? std::string{"lrhip_synchronize: "} + api.last_error() : std::string{}; });
                 }
                 auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 std::fprintf(stderr, "[info] Rendering finished in %g ms.\n", ms);
                 auto samples = static_cast<double>(width) * height * camera.camera.spp;
-                std::fprintf(stderr, "[info] %.2f Msamples/s on HIP device %d.\n", samples / ms * 1e-3, device_index);
+                std::fprintf(stderr, "[info] %.2f Msamples/s on %u HIP device(s), first %d.\n", samples / ms * 1e-3, world, device_index);
                 if (api.film_download(ctx, pixels.data(), 1) != LRHIP_OK) {
                     std::fprintf(stderr, "[error] lrhip_film_download: %s\n", api.last_error());
                     std::abort();
@@ -144,7 +191,10 @@ public:
             }
             lr::save_image(camera.file, pixels.data(), width, height);
         }
-        api.destroy(ctx);
+        for (auto r = 0u; r < world; r++) {
+            if (comms[r] != nullptr) { api.comm_destroy(comms[r]); }
+            api.destroy(ctxs[r]);
+        }
     }
 };
 

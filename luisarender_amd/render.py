@@ -57,7 +57,8 @@ class MegaPathRenderer:
         p = _ffi.RenderParams()
         p.balance_shards = balance_shards
         p.spp_begin, p.spp_end = spp_begin, spp_end
-        p.tile_begin, p.tile_end, p.tile_stride = rank, tile_count(self.width, self.height), world
+        tiles = tile_count(self.width, self.height)
+        p.tile_begin, p.tile_end, p.tile_stride = min(rank, tiles), tiles, world  # rank >= tiles: an empty shard
         p.flags = 1 if counters else 0
         if shutter_weight is not None:  # Camera::ShutterSample weight of these samples (integrator.cpp:74)
             p.flags |= 2
@@ -88,6 +89,24 @@ class MegaPathRenderer:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._check(self._lib.lrhip_film_download(self._ctx, out.ctypes.data, 1 if converted else 0))
         return out
+
+    # ---- the one collective of the multi-GPU path, through the C ABI
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_ubyte * 128)()
+        self._check(self._lib.lrhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, world: int, rank: int, unique_id: bytes) -> C.c_void_p:
+        comm = C.c_void_p()
+        self._check(self._lib.lrhip_comm_init_rank(self._ctx, world, rank, (C.c_ubyte * 128).from_buffer_copy(unique_id), C.byref(comm)))
+        return comm
+
+    def film_reduce(self, comm, root: int = 0) -> None:
+        """sum-reduce of the bound film to `root` over RCCL, in stream order behind the renders (lrhip_film_reduce)"""
+        self._check(self._lib.lrhip_film_reduce(self._ctx, comm, root))
+
+    def comm_destroy(self, comm) -> None:
+        self._check(self._lib.lrhip_comm_destroy(comm))
 
     def counters(self) -> dict:
         c = _ffi.HipCounters()

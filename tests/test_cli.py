@@ -76,3 +76,34 @@ def test_cli_renders_motion_blur_like_the_c_abi(tmp_path):
     renderer.close()
     assert np.array_equal(img, ref)
     assert (img[..., 0] > 0.01).mean() > 0.3  # the streak of the moving strip
+
+
+@pytest.mark.gpu
+def test_cli_shards_a_frame_over_several_gpus(tmp_path):
+    """The C++ host's multi-GPU path (plugin_megapath.cpp: one host thread + one lrhip_ctx per GPU, ncclCommInitAll, the tiles
+    {r, r + W, ...}, lrhip_film_reduce to the first device) against the same frame rendered on one GPU with the same work-item
+    sizing: bit for bit.  With a single visible GPU the list `-d 0` / LR_DEVICES=0 still goes through the threaded path
+    (world 1); world 2 runs when the box has two GPUs (the driver's multi-GPU node; a 1-GPU box skips that half)."""
+    import ctypes as C
+    from luisarender_amd import _ffi
+    from luisarender_amd.render import MegaPathRenderer
+    from luisarender_amd.scene import load_image
+    text = cornell_box(resolution=(96, 64), spp=8, file="out.exr")
+    scene_file = tmp_path / "cornell.luisa"
+    scene_file.write_text(text)
+    n = C.c_int()
+    assert _ffi.hip_lib().lrhip_device_count(C.byref(n)) == 0 and n.value >= 1
+    sc = Scene.load(str(scene_file))
+    for world in (1, 2):
+        if world > n.value:
+            pytest.skip(f"{n.value} GPU(s) visible: the world-{world} half needs {world}")
+        env = dict(os.environ, LR_DEVICES=",".join(str(d) for d in range(world)))
+        r = subprocess.run([CLI, "-b", "hip", str(scene_file)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and f"on {world} HIP device(s)" in r.stderr, r.stderr
+        img, _ = load_image(str(tmp_path / "out.exr"))
+        one = MegaPathRenderer(0)
+        one.upload(sc)
+        one.render(0, 8, balance_shards=world, sync=True)
+        ref = one.download(converted=True)
+        one.close()
+        assert np.array_equal(img.reshape(ref.shape), ref), world

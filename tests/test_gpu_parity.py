@@ -543,37 +543,64 @@ render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : Me
     assert _rel_l1(gpu, cpu) < 2e-3 and gpu[..., :3].mean() > 0.01
 
 
-def test_film_reduce_through_rccl_single_rank(renderer):
-    """lrhip_film_reduce (the C-level twin of bench.py's torch.distributed reduce): with a one-rank communicator the sum-reduce
-    must leave the film exactly as it was; the call goes through librccl's ncclReduce on the context's stream"""
-    import ctypes as C
+def test_film_reduce_through_the_c_abi_single_rank(renderer):
+    """The product's collective end to end through include/lrhip.h: lrhip_comm_unique_id -> lrhip_comm_init_rank (world 1) ->
+    lrhip_film_reduce (ncclReduce on the context's stream) -> lrhip_comm_destroy.  With one rank the sum-reduce must leave the
+    film exactly as it was.  (World > 1 needs > 1 GPU: bench.py --gpus N runs exactly these calls, test_cli.py the C++ host.)"""
     from luisarender_amd import _ffi
+    from luisarender_amd.parallel import FilmReducer
+    sc = Scene.from_string(cornell_box(resolution=32, spp=4))
+    renderer.upload(sc)
+    renderer.render(0, 4, sync=True)
+    before = renderer.download(converted=False)
+    comm = renderer.comm_init_rank(1, 0, renderer.comm_unique_id())
     try:
-        rccl = C.CDLL("librccl.so")
-    except OSError:
-        pytest.skip("librccl.so not found")
-
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-
-    uid = UniqueId()
-    if rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-        pytest.skip("ncclGetUniqueId failed")
-    comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    if rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) != 0:
-        pytest.skip("ncclCommInitRank failed on this box")
-    try:
-        sc = Scene.from_string(cornell_box(resolution=32, spp=4))
-        renderer.upload(sc)
-        renderer.render(0, 4, sync=True)
-        before = renderer.download(converted=False)
-        lib = _ffi.hip_lib()
-        assert lib.lrhip_film_reduce(renderer._ctx, comm, 0) == 0, lib.lrhip_last_error()
+        renderer.film_reduce(comm, 0)
         renderer.synchronize()
         after = renderer.download(converted=False)
         assert np.array_equal(before, after) and before[..., 3].min() == 4
+        lib = _ffi.hip_lib()
         assert lib.lrhip_film_reduce(renderer._ctx, None, 0) < 0  # NULL communicator: error code, no crash
     finally:
-        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-        rccl.ncclCommDestroy(comm)
+        renderer.comm_destroy(comm)
+    assert FilmReducer(renderer, 0, 1).comm is None  # one rank: no communicator, reduce() is a no-op
+
+
+def test_strided_shards_are_diagonals_and_empty_shards_are_legal(renderer):
+    """include/lrhip.h: tile numbers rotate every row by its index, so a strided shard is a set of diagonals (not of column stripes,
+    which tile % world gives whenever the tile-row length is a multiple of the world size); rank >= tile count is an empty shard."""
+    from luisarender_amd.parallel import owner_mask
+    sc = Scene.from_string(cornell_box(resolution=64, spp=2))
+    renderer.upload(sc)
+    for world in (2, 4, 8):
+        for rank in (0, world - 1):
+            renderer.clear()
+            renderer.render(0, 2, rank=rank, world=world, sync=True)
+            owned = renderer.download(converted=False)[..., 3] == 2
+            assert np.array_equal(owned, owner_mask(64, 64, rank, world)), (rank, world)
+            cols = owned.any(axis=0)
+            assert cols.all()  # every pixel column holds tiles of this rank: no stripes
+    tiny = Scene.from_string(cornell_box(resolution=8, spp=1))  # one tile
+    renderer.upload(tiny)
+    renderer.render(0, 1, rank=5, world=8, sync=True)  # more ranks than tiles: nothing to do, no error
+    assert not renderer.download(converted=False).any()
+
+
+def test_bound_film_survives_an_upload(renderer):
+    """lrhip_bind_film + MegaPathRenderer.render_frame (which uploads per shutter sample): the caller's buffer stays bound across
+    uploads of the same resolution (round-1 advisor finding: it was silently dropped, the tensor stayed zero)"""
+    import torch
+    sc = Scene.from_string(cornell_box(resolution=32, spp=4))
+    renderer.upload(sc)
+    film = torch.zeros((32, 32, 4), dtype=torch.float32, device="cuda:0")
+    renderer.bind_film(film.data_ptr())
+    renderer.render_frame(sc)  # uploads again
+    renderer.synchronize()
+    torch.cuda.synchronize()
+    got = film.cpu().numpy()
+    assert (got[..., 3] == 4).all() and got[..., :3].sum() > 0
+    assert np.array_equal(got, renderer.download(converted=False))
+    renderer.bind_film(None)
+    renderer.upload(Scene.from_string(cornell_box(resolution=16, spp=1)))  # another resolution: back to the library's film
+    renderer.render(0, 1, sync=True)
+    assert renderer.download(converted=False).shape == (16, 16, 4)

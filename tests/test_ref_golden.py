@@ -23,9 +23,12 @@ from luisarender_amd import Scene  # noqa: E402
 NAMES = ["cornell", "materials", "disney_mix_sobol", "thin_lens_plastic", "env_image", "env_combined", "direct_both", "vpt_fog_medium_box",
          "vpt_fog_env_medium_box", "disney", "env_disney", "cornell_sobol", "layered"]
 # rel-L1 bound of the device image against the reference's; specular chains amplify a rounding flip into a different path
-DEVICE_TOL = {"cornell": 1e-4, "materials": 3e-3, "disney_mix_sobol": 3e-3, "thin_lens_plastic": 3e-3, "env_image": 1e-3,
-              "env_combined": 1e-3, "direct_both": 1e-3, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 5e-3,
-              "disney": 3e-3, "env_disney": 3e-3, "cornell_sobol": 1e-4, "layered": "blocks"}
+# (measured on the MI355X, round 2: cornell 1e-7, materials 8e-6, disney_mix_sobol 2e-6, thin_lens_plastic 6e-6, env_image 5e-7,
+#  env_combined 2e-7, direct_both 7e-8, vpt_fog_env_medium_box 4e-8, disney 4e-7, env_disney 1e-7, cornell_sobol 1e-7; the bars
+#  leave room for a flipped lobe choice or two, not for a wrong formula)
+DEVICE_TOL = {"cornell": 1e-5, "materials": 5e-4, "disney_mix_sobol": 5e-4, "thin_lens_plastic": 5e-4, "env_image": 1e-4,
+              "env_combined": 1e-4, "direct_both": 1e-4, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 1e-4,
+              "disney": 5e-4, "env_disney": 5e-4, "cornell_sobol": 1e-5, "layered": "blocks"}
 # the smallest precompiled kernel variant each scene needs (lrhip.h LRHIP_FEAT_*; bit 0 = counters must be OFF here)
 VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {60}, "thin_lens_plastic": {0}, "env_image": {4},
            "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256},
@@ -99,6 +102,6 @@ def test_device_matches_the_reference_frame(renderer, name, tmp_path):
         # The env-lit twin of this scene (next fixture) has no such event and takes the tight bar.
         same = np.abs(gpu[..., :3] - ref[..., :3]).max(axis=-1) <= 1e-3 * np.abs(ref[..., :3]).max(axis=-1) + 1e-6
         print(f"{name}: {same.mean():.4f} of the pixels equal the reference's")
-        assert same.mean() > 0.85 and abs(np.median(gpu[..., :3]) / np.median(ref[..., :3]) - 1) < 1e-3
+        assert same.mean() > 0.85 and abs(np.median(gpu[..., :3]) / np.median(ref[..., :3]) - 1) < 1e-2
         return
-    assert err < DEVICE_TOL[name] and bias < max(DEVICE_TOL[name] / 3, 1e-4), (name, err, bias)
+    assert err < DEVICE_TOL[name] and bias < max(DEVICE_TOL[name] / 3, 1e-5), (name, err, bias)
