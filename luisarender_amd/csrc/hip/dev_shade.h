@@ -594,6 +594,42 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
     return xi > surface_opacity(scene, (h.y >> 12u) & 4095u, uv);
 }
 
+// The alpha test of the candidates the traversal loop parked (dev_trace.h kPhasePendingAlpha): commit the hit or skip it, then
+// move on to the next stack entry exactly as the leaf step would have.
+LR_D void resolve_pending_alpha(const DScene &scene, const TraversalStack &stack, TravState &tr) {
+    if ((tr.phase & kPhasePendingAlpha) != 0u) {
+        const auto phase = tr.phase & ~kPhasePendingAlpha;
+        const auto tri_index = tr.cur & ((1u << 27u) - 1u);
+        const auto tb = reinterpret_cast<const float4 *>(scene.bvh_tris) + static_cast<size_t>(tri_index) * (LR_TRI_STRIDE / 16u);
+        const auto inst = __float_as_uint(tb[0].w), prim = __float_as_uint(tb[1].w);
+        if (!alpha_skip(scene, inst, prim, tr.pend_u, tr.pend_v)) {
+            tr.t_max = tr.pend_t;
+            if (phase == kPhaseClosest) {
+                tr.hit.inst = inst, tr.hit.prim = prim, tr.hit.u = tr.pend_u, tr.hit.v = tr.pend_v, tr.hit.tri = tri_index;
+            } else {
+                tr.occluded = true;
+                tr.sp = 0u;// any-hit: drop the rest of the stack
+            }
+        }
+        tr.cur = tr.sp > 0u ? stack.pop(--tr.sp) : kInvalid;
+        tr.phase = phase;
+    }
+}
+
+// Runs the wave's traversal until `refill` lanes have results to shade (or nothing is in flight), resolving parked alpha
+// candidates in between: the shading block is only entered for the reasons it was entered before.
+template<bool COUNT, bool ALPHA>
+LR_D void trace_until_refill(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next, const Ray &next_closest,
+                             int refill, TraceStats &stats) {
+    const auto idle_at_entry = tr.phase == kPhaseIdle;
+    for (;;) {
+        trace_steps<COUNT, ALPHA>(scene, stack, tr, has_next, next_closest, refill, stats, idle_at_entry);
+        if (!ALPHA) { break; }
+        if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        resolve_pending_alpha(scene, stack, tr);
+    }
+}
+
 // LuisaCompute `offset_ray_origin` (Ray Tracing Gems ch. 6), restated from the published algorithm
 LR_D f3 offset_ray_origin(f3 p, f3 n) {
     constexpr auto origin = 1.0f / 32.0f;

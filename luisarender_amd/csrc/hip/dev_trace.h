@@ -122,7 +122,10 @@ LR_D float ubyte_to_float(uint32_t v, int byte) {// v_cvt_f32_ubyteN
 // traversal loop as soon as enough lanes have finished their rays (they go and shade / spawn new
 // rays) while the remaining lanes keep cur/sp/stack and continue afterwards — the persistent-threads
 // "dynamic fetch" scheme, inside one megakernel.
-enum : uint32_t { kPhaseIdle = 0u, kPhaseShadow = 1u, kPhaseClosest = 2u };
+// kPhasePendingAlpha (a flag on top of Shadow / Closest, ALPHA kernels only): the lane stands at a leaf whose triangle it hit, on
+// an instance that may be non-opaque; the candidate (pend_t, pend_u, pend_v) waits for the stochastic alpha test, which runs
+// OUTSIDE the traversal loop (resolve_pending_alpha, dev_shade.h) -- see trace_steps.
+enum : uint32_t { kPhaseIdle = 0u, kPhaseShadow = 1u, kPhaseClosest = 2u, kPhasePendingAlpha = 4u };
 struct TravState {
     f3 o, d;// (1 / d is recomputed on entry to trace_steps: three v_rcp per call instead of three registers live across shading)
     float t_min, t_max;
@@ -130,6 +133,7 @@ struct TravState {
     uint32_t phase;
     HitRecord hit;
     bool occluded;
+    float pend_t, pend_u, pend_v;// ALPHA kernels: the candidate hit awaiting its alpha test (dead registers elsewhere)
 };
 
 LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
@@ -147,10 +151,14 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
 // (if has_next) without leaving the loop.  Must be called by all 64 lanes.
 // ALPHA: candidate hits on maybe-non-opaque instances (triangle flag bit 1 clear) pass through the
 // stochastic alpha test before they are committed, for closest-hit and any-hit rays alike
-// (Geometry::trace_closest / trace_any ray-query branch, geometry.cpp:248-279).
+// (Geometry::trace_closest / trace_any ray-query branch, geometry.cpp:248-279).  The test (uv interpolation, a hash, a texture
+// lookup) is NOT in this loop: a lane with such a candidate parks it (kPhasePendingAlpha), the wave leaves the loop, the caller
+// resolves the parked candidates (resolve_pending_alpha) and calls again with the same `idle_at_entry`.  Round 2: with the test
+// inlined here the loop of the ALPHA variants carried the texture code's registers and calls, and a scene with 2 % alpha-tested
+// triangles ran at 390 instead of 519 Msamples/s (tools/c5_ablation.py).
 template<bool COUNT, bool ALPHA>
 LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next,
-                      const Ray &next_closest, int refill, TraceStats &stats) {
+                      const Ray &next_closest, int refill, TraceStats &stats, bool idle_at_entry) {
     const auto lane = threadIdx.x & 63u;
     const auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
     const auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
@@ -158,11 +166,10 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
     const auto part = lane & 3u;
     const auto owner0 = lane >> 2u;
     const auto my_swz = (lane >> 2u) & 3u;
-    auto idle_at_entry = tr.phase == kPhaseIdle;
     auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
-        auto live = tr.phase != kPhaseIdle;
+        auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
         auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
         if (__any(is_inner)) {
             // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS -> 4 ds_read_b128 per lane
@@ -321,7 +328,11 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 auto v = dot(tr.d, qvec) * inv_det;
                 auto t = dot(e2, qvec) * inv_det;
                 auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
-                if (ALPHA && ok && (flags & 2u) == 0u) { ok = !alpha_skip(scene, __float_as_uint(a.w), __float_as_uint(b.w), u, v); }
+                if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
+                    tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
+                    tr.phase |= kPhasePendingAlpha;
+                    ok = false;
+                }
                 if (ok) {
                     tr.t_max = t;
                     found = true;
@@ -336,7 +347,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 tr.occluded = true;
                 tr.sp = 0u;// any-hit: drop the rest of the stack
             }
-            tr.cur = tr.sp > 0u ? stack.pop(--tr.sp) : kInvalid;
+            if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = tr.sp > 0u ? stack.pop(--tr.sp) : kInvalid; }// (a parked lane stays at its leaf)
         }
         // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
         if (live && tr.cur == kInvalid) {
@@ -349,6 +360,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         }
         auto in_flight = __ballot(tr.phase != kPhaseIdle);
         if (in_flight == 0ull) { break; }
+        if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
         auto finished = __ballot(tr.phase == kPhaseIdle && !idle_at_entry);
         if (__popcll(finished) >= refill) { break; }
     }

@@ -71,6 +71,8 @@ enum : uint32_t {
 constexpr uint32_t kSceneVariants[] = {
     0u,
     kFeatEnv,
+    kFeatAlpha,
+    kFeatEnv | kFeatAlpha,
     kFeatDisney,
     kFeatEnv | kFeatDisney,
     kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
             // ==== (B) traverse until `refill` lanes have results to shade
             TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
             const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
-            trace_steps<COUNT, ALPHA>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
+            trace_until_refill<COUNT, ALPHA>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
                 if (lane == 0u) { local.shade_cycles += t_trace - t_shade, local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
                 local.nodes_visited += ts.nodes, local.tris_tested += ts.tris, local.nodes_empty += ts.nodes_empty;

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
                 if (!__any(tr.phase != kPhaseIdle)) { break; }
                 // ==== trace every pending ray of the wave to completion
                 TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
-                trace_steps<COUNT, true>(scene, stack, tr, false, ray, 65, ts);
+                trace_until_refill<COUNT, true>(scene, stack, tr, false, ray, 65, ts);
                 if (COUNT) {
                     local.nodes_visited += ts.nodes, local.tris_tested += ts.tris;
                     local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy;

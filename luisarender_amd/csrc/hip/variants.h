@@ -5,6 +5,8 @@
 #define LR_VARIANT_LIST(X)                                                                  \
     X(0) X(1) X(2) X(3)         /* lean: Matte / Mirror / Glass / Plastic / Metal, lights */  \
     X(4) X(5) X(6) X(7)         /* + image / directional / combined environment */           \
+    X(8) X(9) X(10) X(11)       /* lean + alpha-tested traversal (round 2: such a scene ran 25 % slower on <60>) */ \
+    X(12) X(13) X(14) X(15)     /* + environment + alpha test */                             \
     X(16) X(17) X(18) X(19)     /* + Disney */                                               \
     X(20) X(21) X(22) X(23)     /* + environment + Disney */                                 \
     X(60) X(61) X(62) X(63)     /* + environment + alpha test + Disney + Mix */              \

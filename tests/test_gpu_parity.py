@@ -311,6 +311,11 @@ def test_kernel_variant_selection(renderer):
     assert variant(None, sampler="Sobol") == 2
     assert variant("glass") == 0 and variant("metal") == 0
     assert variant("disney") == 16 and variant("disney_thin") == 16
+    cut = "Surface probe : Matte { Kd : Constant { v { 0.7 } } alpha : Constant { v { 0.5 } } }\n"
+    sc = Scene.from_string(cornell_box(resolution=16, spp=1, short_box_surface="probe", extra_surfaces=cut))
+    renderer.upload(sc)
+    renderer.render(0, 1, sync=True)
+    assert renderer.last_variant() == 8  # alpha-tested traversal on the lean kernel
     assert variant("mix") == 60          # no <Mix only> variant is precompiled: next superset
     assert variant("layered") == 124
 
@@ -418,7 +423,7 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
         assert _rel_l1(a, b) < 2e-2 and abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 2e-3
 
 
-@pytest.mark.parametrize("case", ["lean", "environment", "disney", "env_disney", "mix_alpha", "layered", "direct", "vpt", "sobol"])
+@pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "direct", "vpt", "sobol"])
 def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
     """Every parity test above drives the COUNT twin of a kernel variant (it needs the ray counters); bench.py and the CLI launch
     the twin without counters.  The two are the same template with `if (COUNT)` blocks, but they are different BINARIES (round 1
@@ -440,6 +445,8 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
     text, variant = {
         "lean": (cornell_box(resolution=64, spp=8, short_box_surface="glass", tall_box_surface="metal", extra_surfaces=mat("glass", "metal")), 0),
         "environment": (cornell_box(resolution=64, spp=8).replace("render {", env), 4),
+        "alpha": (cornell_box(resolution=64, spp=8, short_box_surface="cutout", tall_box_surface="glass", extra_surfaces=mat("glass") + alpha), 8),
+        "env_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="cutout", extra_surfaces=alpha).replace("render {", env), 12),
         "disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", tall_box_surface="disney_thin", extra_surfaces=mat("disney", "disney_thin")), 16),
         "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), 20),
         "mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha), 60),

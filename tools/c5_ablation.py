@@ -1,0 +1,49 @@
+"""Where does the kitchen-class (C5) frame spend its time?  Renders the stand-in with the expensive closure families replaced by
+Matte, one family at a time (same geometry, same kernel variant <124> unless LEAN=1), and prints Msamples/s + shading share."""
+import os, re, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from luisarender_amd import Scene
+from luisarender_amd.render import MegaPathRenderer
+from luisarender_amd.scenes.configs import generate_kitchen_scene
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+MATTE = "Matte { Kd : Constant { v { 0.5, 0.5, 0.5 } } }"
+
+
+def replace(text, names):
+    for n in names:
+        text = re.sub(r"Surface %s : [^\n]*\n" % n, f"Surface {n} : {MATTE}\n", text)
+    return text
+
+
+with tempfile.TemporaryDirectory() as tmp:
+    path = generate_kitchen_scene(tmp, resolution=(1280, 720), spp=spp)
+    base = open(path).read()
+    cases = {
+        "full": base,
+        "no_layered": replace(base, ["layered0", "layered1"]),
+        "no_layered_mix": replace(base, ["layered0", "layered1", "mix0", "mix1"]),
+        "no_layered_mix_disney": replace(base, ["layered0", "layered1", "mix0", "mix1", "disney0", "disney1", "disney2"]),
+    }
+    heavy = ["layered0", "layered1", "mix0", "mix1", "disney0", "disney1", "disney2"]
+    cases["basic_no_alpha"] = replace(base, heavy + ["lace"])
+    cases["basic_no_alpha_no_nmap"] = replace(base, heavy + ["lace", "bumpy"])
+    cases["basic_no_alpha_no_nmap_no_images"] = replace(base, heavy + ["lace", "bumpy", "oren", "plastic0", "floor_s"])
+    cases["alpha_only"] = replace(base, heavy + ["bumpy", "oren", "plastic0", "floor_s"])
+    if len(sys.argv) > 2:
+        cases = {k: v for k, v in cases.items() if k in sys.argv[2:]}
+    r = MegaPathRenderer(0)
+    for name, text in cases.items():
+        p = os.path.join(tmp, name + ".luisa")
+        open(p, "w").write(text)
+        sc = Scene.load(p)
+        r.upload(sc)
+        r.render(0, spp, counters=False, sync=True)
+        ms = r.last_render_ms()
+        v = r.last_variant()
+        r.upload(sc)
+        r.render(0, spp, counters=True, sync=True)
+        c = r.counters()
+        print(f"{name:24s} variant {v:3d}: {1280 * 720 * spp / ms / 1e3:7.1f} Msamples/s ({ms:7.1f} ms)   shade share {c['shade_cycles'] / c['wave_cycles']:.2f} "
+              f"trace share {c['trace_cycles'] / c['wave_cycles']:.2f}  cycles/shade call {c['shade_cycles'] / (c['shade_calls'] / 64):8.0f}  shade lanes {c['shade_busy'] / max(c['shade_calls'], 1):.2f}  "
+              f"trace lanes {c['trace_steps_busy'] / max(c['trace_steps'], 1):.2f}")
