@@ -15,7 +15,7 @@
 // in the lean ones the call overhead costs more than it saves (measured inline vs call: C2 +2 %, C3 +1.4 %, C4 +7 %).
 // Every variant is its own translation unit (megapath_variant.hip defines LR_VARIANT), so this is a preprocessor choice.
 #ifndef LR_CALL
-#if defined(LR_VARIANT) && ((LR_VARIANT) & (96 | 256))
+#if defined(LR_VARIANT) && ((LR_VARIANT) & (96 | 256)) && !defined(LR_CALL_INLINE)
 #define LR_CALL __device__ __noinline__
 #else
 #define LR_CALL __device__ __forceinline__

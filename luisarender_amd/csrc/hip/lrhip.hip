@@ -724,7 +724,9 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
-    auto vi = pick_variant(ctx->features, count, generic);
+    auto features = ctx->features;
+    if (auto force = std::getenv("LRHIP_FORCE_FEATURES")) { features |= static_cast<uint32_t>(std::atoi(force)) & lrd::kFeatSceneMask; }// tools/ only: A/B of a variant on a scene that does not need it
+    auto vi = pick_variant(features, count, generic);
     if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +
                                                  " was compiled into this library");
@@ -805,7 +807,7 @@ struct Rccl {
         ok = get_unique_id && comm_init_rank && comm_init_all && comm_destroy && reduce && group_start && group_end;
     }
 };
-const Rccl &rccl() {
+extern "C++" const Rccl &rccl() {
     static Rccl r;
     return r;
 }

@@ -91,7 +91,13 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #ifndef LR_WAVES_LAYERED
 #define LR_WAVES_LAYERED 2
 #endif
-constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : LR_MIN_WAVES; }
+#ifndef LR_HEAVY_BATCH
+#define LR_HEAVY_BATCH 12// parked heavy hits that trigger the out-of-line closures (1 = never park).  Kitchen stand-in, 64 spp: 181 / 193 (6, 3 waves) / 203 (12) / 196 (24) / 166 (40) Msamples/s
+#endif
+#ifndef LR_WAVES_MIX
+#define LR_WAVES_MIX LR_MIN_WAVES
+#endif
+constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : (f & kFeatMix) ? LR_WAVES_MIX : LR_MIN_WAVES; }
 
 // Work distribution, XCD-aware: MI355X is 8 XCDs with an L2 each, and workgroups are dealt to the XCDs round-robin
 // (blockIdx.x & 7).  The item space (tiles x sample-chunks, tile-major) is cut into 8 contiguous ranges with a counter each
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
                    LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u;
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
+    constexpr bool PARK_HEAVY = (MIX || LAYERED) && !AUX && LR_HEAVY_BATCH > 1;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
     const auto tid = threadIdx.x;
@@ -178,7 +185,32 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
             auto want_shadow = false, want_closest = false;
             Ray shadow{};
             const auto t_shade = COUNT ? __builtin_readcyclecounter() : 0ull;
-            if (tr.phase == kPhaseIdle) {
+            // ---- heavy hits wait for company.  In a variant with out-of-line closures (Mix / Layered present) a hit on a
+            // Disney / Mix / Layered surface costs the WAVE the whole heavy call, however few lanes take it -- and with ~8 % heavy
+            // hits nearly every shading round has one or two.  Such a lane stays parked (idle, hit and shadow result kept in its
+            // state, exactly like a lane that has not been shaded yet) until LR_HEAVY_BATCH lanes are parked or the wave has
+            // nothing else to do; then they are shaded together.  A sample's value does not depend on when it is shaded.
+            auto parked = false;
+            if (PARK_HEAVY) {
+                const auto ready = tr.phase == kPhaseIdle && traced_closest;
+                auto heavy_hit = false;
+                if (ready && tr.hit.inst != kInvalid) {
+#if LR_BAKED_SHADING
+                    const auto rec = reinterpret_cast<const float4 *>(scene.shade_tris + tr.hit.tri);
+                    const auto flags = __float_as_uint(rec[0].w), tags = __float_as_uint(rec[1].w);
+#else
+                    const auto h = reinterpret_cast<const uint4 *>(scene.instances + tr.hit.inst)[0];
+                    const auto flags = h.x & 1023u, tags = h.y;
+#endif
+                    heavy_hit = (flags & LR_SHAPE_HAS_SURFACE) != 0u && scene.closures[(tags >> 12u) & 4095u].kind >= LR_SURFACE_DISNEY;
+                }
+                const auto heavy_lanes = __popcll(__ballot(heavy_hit));
+                if (heavy_lanes > 0 && heavy_lanes < LR_HEAVY_BATCH) {
+                    const auto others = __any(tr.phase != kPhaseIdle || (ready && !heavy_hit) || (tr.phase == kPhaseIdle && !path_open && q_next < q_total));
+                    parked = heavy_hit && others;
+                }
+            }
+            if (tr.phase == kPhaseIdle && !parked) {
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
                     if (!tr.occluded) { Li += nee; }
                     traced_shadow = false;
@@ -369,7 +401,10 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
                 }
             }
-            if (!__any(tr.phase != kPhaseIdle)) { break; }// every lane of the tile is out of samples
+            if (!__any(tr.phase != kPhaseIdle)) {
+                if (PARK_HEAVY && __any(parked)) { continue; }// only parked lanes are left: shade them now
+                break;// every lane of the tile is out of samples
+            }
             // ==== (B) traverse until `refill` lanes have results to shade
             TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
             const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
