@@ -91,6 +91,11 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #ifndef LR_WAVES_LAYERED
 #define LR_WAVES_LAYERED 2
 #endif
+// MEASURED AND NOT KEPT (round 2, profiles/r02d_heavy_parking.txt): (1) the traversal as a real call in these variants, so that it
+// gets a register allocation of its own (its loops then hold no spills): kitchen stand-in 202 -> 129 Msamples/s at 2 waves, 165 at
+// 4 -- the state crosses the call through scratch and the loop loses its software pipelining across calls; (2) <60> at 3 waves per
+// SIMD: +9 % without parking, nothing with it; (3) texture / environment code inlined in the heavy variants: basic hits 335 -> 391
+// but Disney/Mix hits 248 -> 216.
 #ifndef LR_HEAVY_BATCH
 #define LR_HEAVY_BATCH 12// parked heavy hits that trigger the out-of-line closures (1 = never park).  Kitchen stand-in, 64 spp: 181 / 193 (6, 3 waves) / 203 (12) / 196 (24) / 166 (40) Msamples/s
 #endif
