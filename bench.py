@@ -286,6 +286,7 @@ def main():
                         e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _ = cpu_baseline(sc, r, 30.0, full_spp=sp)
                     extra.append(e)
                 out["extra_configs"] = extra
+            out["source_hash"] = source_hash()  # the kernel + BVH-builder sources this line was measured on (profiles/*.json carry the same)
             print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

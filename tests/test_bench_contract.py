@@ -24,7 +24,7 @@ def test_metric_is_the_baseline_metric():
 
 
 def test_committed_headline_line_follows_the_contract():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02c_bench_c2_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02e_bench_c2_1gpu.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], typ), key
@@ -50,3 +50,23 @@ def test_committed_headline_line_follows_the_contract():
     assert set(extra) == {"Cornell Box", "Bedroom-class", "Kitchen-class"}
     c1 = extra["Cornell Box"]
     assert c1["spp_timed"] == 64 and "512x512 at 64 spp" in c1["cpu_baseline"]["sample"] and c1["value"] > 100 * c1["cpu_baseline"]["value"]
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is the checker: nothing under luisarender_amd/ (Python or C++/HIP) may import, include, link or dlopen it."""
+    import re
+    pkg = os.path.join(ROOT, "luisarender_amd")
+    bad = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".h", ".hip", ".inl")):
+                continue
+            text = open(os.path.join(base, f), errors="replace").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b|#include\s*[\"<][^\">]*oracle|liboracle|libref\.so|dlopen\([^)]*oracle", text, re.M):
+                bad.append(os.path.join(base, f))
+    assert not bad, bad
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    # the product libraries' link lines never name the oracle
+    for line in mk.splitlines():
+        if ("liblrhip.so" in line or "liblrhost.so" in line) and "-o" in line:
+            assert "oracle" not in line, line

@@ -16,6 +16,12 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     samples = float(sys.argv[3]) if len(sys.argv) > 3 else None
     out = {"source": src, "tool": "rocprofv3 --kernel-trace --stats / --pmc (separate passes)", "kernel": None}
+    try:  # the state of the kernel sources this profile belongs to (the same hash bench.py puts into its line)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["source_hash"] = bench.source_hash()
+    except Exception as e:  # noqa: BLE001
+        out["source_hash"] = f"unavailable: {e}"
     db = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
     rows = list(db.execute("select name, (end-start)/1e6, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
                            "from kernels where name like ? order by start", (KERNEL,)))
