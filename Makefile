@@ -45,7 +45,7 @@ oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h
 # The megakernel is precompiled for a curated set of feature masks (csrc/hip/variants.h), one object per mask so
 # that they build in parallel (make -j).  VARIANT_MASKS may be narrowed for experiments (a missing variant is a
 # run-time error of lrhip_render, never a fallback).
-VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 252 253 254 255 256 257 258 259
+VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 636 637 638 639 252 253 254 255 256 257 258 259
 OBJDIR := $(LIBDIR)/obj
 VARIANT_OBJ := $(foreach m,$(VARIANT_MASKS),$(OBJDIR)/variant_$(m).o)
 

@@ -144,6 +144,9 @@ double lrhip_last_render_ms(lrhip_ctx *ctx);
 #define LRHIP_FEAT_DISNEY 16u
 #define LRHIP_FEAT_MIX 32u
 #define LRHIP_FEAT_LAYERED 64u
+#define LRHIP_FEAT_AUX_INTEGRATORS 128u
+#define LRHIP_FEAT_VOLUMETRIC 256u
+#define LRHIP_FEAT_NESTED 512u /* Mix trees with Layered leaves / Layered surfaces with Mix interfaces */
 uint32_t lrhip_last_variant(lrhip_ctx *ctx);
 
 const char *lrhip_last_error(void);

@@ -15,13 +15,6 @@
 
 namespace lrd {
 
-struct LobeTables {// the scene tables closure loading reads
-    const DClosure *closures;
-    const lr_surface *surfaces;
-    const lr_texture *textures;
-    const float *texels;
-};
-
 // closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
 // per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
 LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
@@ -62,112 +55,167 @@ LR_D BsdfEval mix_blend(const BsdfEval &a, const BsdfEval &b, float r) {// MixSu
     return BsdfEval{a.f + t * (b.f - a.f), lerp(a.pdf, b.pdf, t)};
 }
 
-LR_D void layer_stack(const HeavyCtx &cx, LayerStack &layers) {// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500
-    auto &c = cx.closure;
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[0], cx.shading, layers.top, layers.f_top);
-    float eta_top = 1.f;
-    closure_eta(layers.top, eta_top);
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, c.x[1], cx.shading, layers.bottom, layers.f_bottom, eta_top);
-    layers.own = cx.shading, layers.ng = cx.ng, layers.p = cx.p;
-    layers.thickness = c.s0, layers.g = c.s1;
-    layers.albedo = mk3(c.c0[0], c.c0[1], c.c0[2]);
-    layers.max_depth = c.x[2], layers.samples = c.x[3];
-}
+// what the closures below a Mix / Layered node are populated from (populate_closure's arguments, mix.cpp:198-212)
+struct MixCtx {
+    LobeTables tb;
+    f2 uv;
+    f3 ng, p, wo_pop;// wo_pop: the hit's wo (normal-map clamping of the children); the evaluated direction is a parameter
+    float eta_i;
+};
+LR_D MixCtx mix_ctx_of(const HeavyCtx &cx) { return MixCtx{cx.tb, cx.uv, cx.ng, cx.p, cx.wo, 1.f}; }
 
-// ---- Mix trees.  The reference's Mix closure holds two arbitrary child closures (mix.cpp:82-212), Mix surfaces included.
-// Device code has no unbounded recursion, so a Mix tree is interpreted by functions templated on the nesting depth still
-// allowed below them (kMixMaxDepth levels under the root: the host loader rejects deeper trees); the leaves go through two
-// out-of-line functions so that each level adds a loop, not another copy of the closure interpreter.
+// ---- Mix trees.  The reference's Mix closure holds two arbitrary child closures (mix.cpp:82-212), Mix and Layered surfaces
+// included, and a Layered surface holds two arbitrary interfaces (layered.cpp:195-253).  Device code has no unbounded
+// recursion, so a Mix tree is interpreted by functions templated on the nesting depth still allowed below them
+// (kMixMaxDepth levels under the root: the host loader rejects deeper trees); the leaves go through two out-of-line
+// functions so that each level adds a loop, not another copy of the closure interpreter.  LEAVES: a leaf may be a Layered
+// surface (true for a tree hit by a ray; false for a tree that IS an interface of a Layered surface -- the loader rejects
+// Layered inside Layered, which bounds the call graph: mix<true> -> layered -> mix<false> -> basic / Disney).
 #ifndef LR_MIX_DEPTH
 #define LR_MIX_DEPTH 3
 #endif
 constexpr int kMixMaxDepth = LR_MIX_DEPTH;
 
-LR_HEAVY BsdfEval mix_leaf_evaluate(const HeavyCtx *cx, const DClosure *c, const Frame *fr, f3 wi) {
-    return closure_evaluate<true>(*c, *fr, cx->ng, cx->wo, wi);
+template<int DEPTH>
+LR_D bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta);
+
+// eta of the closure with record `rec` (tag `tag`): Surface::Closure::eta of a basic closure, MixSurfaceClosure::eta
+// (mix.cpp:148-157), LayeredSurfaceClosure::eta = its bottom's (layered.cpp:252)
+template<int DEPTH>
+LR_D bool node_eta(const MixCtx &cx, uint32_t tag, const Frame &frame, float &eta) {
+    auto rec = &cx.tb.closures[tag];// (eta never comes from an image texture: the static record has it)
+    if (rec->kind == LR_SURFACE_LAYERED) { tag = rec->x[1], rec = &cx.tb.closures[tag]; }// (its bottom is never a Layered surface)
+    if constexpr (DEPTH > 0) {
+        if (rec->kind == LR_SURFACE_MIX) {
+            DClosure child;
+            Frame fr;
+            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, tag, frame, child, fr, cx.eta_i);// (its ratio may be textured)
+            return mix_eta<DEPTH - 1>(cx, child, fr, eta);
+        }
+    }
+    return closure_eta(*rec, eta);
 }
-LR_HEAVY BsdfSample mix_leaf_sample(const HeavyCtx *cx, const DClosure *c, const Frame *fr, float u_lobe, f2 u) {
-    return closure_sample<true>(*c, *fr, cx->ng, cx->wo, u_lobe, u);
+template<int DEPTH>
+LR_D bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
+    bool has[2];
+    float e[2] = {1.f, 1.f};
+#pragma nounroll
+    for (auto k = 0u; k < 2u; k++) { has[k] = node_eta<DEPTH>(cx, node.x[k], frame, e[k]); }
+    eta = !has[0] ? e[1] : (!has[1] ? e[0] : lerp(e[1], e[0], node.s0));
+    return has[0] || has[1];
+}
+
+// LayeredSurfaceInstance::populate_closure, layered.cpp:478-500, of the Layered record `c` with frame `own`
+LR_D void layer_stack(const MixCtx &cx, const DClosure &c, const Frame &own, LayerStack &layers) {
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, c.x[0], own, layers.top, layers.f_top, cx.eta_i);
+    float eta_top = 1.f;
+#if LR_NEST
+    if (!node_eta<kMixMaxDepth>(cx, c.x[0], own, eta_top)) { eta_top = 1.f; }
+#else
+    closure_eta(layers.top, eta_top);
+#endif
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, c.x[1], own, layers.bottom, layers.f_bottom, eta_top);
+    layers.own = own, layers.ng = cx.ng, layers.p = cx.p;
+    layers.thickness = c.s0, layers.g = c.s1;
+    layers.albedo = mk3(c.c0[0], c.c0[1], c.c0[2]);
+    layers.max_depth = c.x[2], layers.samples = c.x[3];
+#if LR_NEST
+    layers.tb = cx.tb, layers.uv = cx.uv, layers.wo_pop = cx.wo_pop, layers.eta_i = cx.eta_i, layers.eta_bottom = eta_top;
+#endif
+}
+
+template<bool LEAVES>
+LR_HEAVY BsdfEval mix_leaf_evaluate(const MixCtx *cx, const DClosure *c, const Frame *fr, f3 wo, f3 wi, bool importance) {
+    if constexpr (LEAVES) {
+        if (c->kind == LR_SURFACE_LAYERED) {
+            LayerStack layers;
+            layer_stack(*cx, *c, *fr, layers);
+            return layered_evaluate(layers, wo, wi);
+        }
+    }
+    return closure_evaluate<true>(*c, *fr, cx->ng, wo, wi, importance);
+}
+template<bool LEAVES>
+LR_HEAVY BsdfSample mix_leaf_sample(const MixCtx *cx, const DClosure *c, const Frame *fr, f3 wo, float u_lobe, f2 u, bool importance) {
+    if constexpr (LEAVES) {
+        if (c->kind == LR_SURFACE_LAYERED) {
+            LayerStack layers;
+            layer_stack(*cx, *c, *fr, layers);
+            return layered_sample(layers, wo, u_lobe, u);
+        }
+    }
+    return closure_sample<true>(*c, *fr, cx->ng, wo, u_lobe, u, importance);
 }
 
 // MixSurfaceClosure::_evaluate (mix.cpp:169-177) + the public wrapper's side validation (surface.cpp:45-56)
-template<int DEPTH>
-LR_D BsdfEval mix_evaluate(const HeavyCtx &cx, const DClosure &node, const Frame &frame, f3 wi) {
+template<int DEPTH, bool LEAVES>
+LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, f3 wi, bool importance) {
     BsdfEval e[2];
 #pragma nounroll
     for (auto k = 0u; k < 2u; k++) {
         DClosure child;
         Frame fr;
-        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[k], frame, child, fr);
+        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[k], frame, child, fr, cx.eta_i);
         if constexpr (DEPTH > 0) {
             if (child.kind == LR_SURFACE_MIX) {
-                e[k] = mix_evaluate<DEPTH - 1>(cx, child, fr, wi);
+                e[k] = mix_evaluate<DEPTH - 1, LEAVES>(cx, child, fr, wo, wi, importance);
                 continue;
             }
         }
-        e[k] = mix_leaf_evaluate(&cx, &child, &fr, wi);
+        e[k] = mix_leaf_evaluate<LEAVES>(&cx, &child, &fr, wo, wi, importance);
     }
     auto eval = mix_blend(e[0], e[1], node.s0);
-    if (!valid_sides(cx.ng, frame.n, cx.wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
+    if (!valid_sides(cx.ng, frame.n, wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
     return eval;
-}
-
-// MixSurfaceClosure::eta (mix.cpp:148-157) of the tree below `node`
-template<int DEPTH>
-LR_D bool mix_eta(const HeavyCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
-    bool has[2];
-    float e[2] = {1.f, 1.f};
-#pragma nounroll
-    for (auto k = 0u; k < 2u; k++) {
-        auto &rec = cx.tb.closures[node.x[k]];// (eta never comes from an image texture: the static record has it)
-        has[k] = closure_eta(rec, e[k]);
-        if constexpr (DEPTH > 0) {
-            if (rec.kind == LR_SURFACE_MIX) {
-                DClosure child;
-                Frame fr;
-                load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[k], frame, child, fr);// (its ratio may be textured)
-                has[k] = mix_eta<DEPTH - 1>(cx, child, fr, e[k]);
-            }
-        }
-    }
-    eta = !has[0] ? e[1] : (!has[1] ? e[0] : lerp(e[1], e[0], node.s0));
-    return has[0] || has[1];
 }
 
 // MixSurfaceClosure::_sample (mix.cpp:178-196); the "sample b" branch samples A and evaluates B (reference quirk, kept), so
 // sampling always walks down the chain of first children
-template<int DEPTH>
-LR_D BsdfSample mix_sample(const HeavyCtx &cx, const DClosure &node, const Frame &frame, float u_lobe, f2 u_bsdf) {
+template<int DEPTH, bool LEAVES>
+LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, float u_lobe, f2 u_bsdf, bool importance) {
     const auto ratio = node.s0;
     const auto first = u_lobe < ratio;
     const auto u_child = first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio);
     DClosure child;
     Frame fr;
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[0], frame, child, fr);
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[0], frame, child, fr, cx.eta_i);
     BsdfSample bs;
     auto nested = false;
     if constexpr (DEPTH > 0) {
         if (child.kind == LR_SURFACE_MIX) {
-            bs = mix_sample<DEPTH - 1>(cx, child, fr, u_child, u_bsdf);
+            bs = mix_sample<DEPTH - 1, LEAVES>(cx, child, fr, wo, u_child, u_bsdf, importance);
             nested = true;
         }
     }
-    if (!nested) { bs = mix_leaf_sample(&cx, &child, &fr, u_child, u_bsdf); }
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo, node.x[1], frame, child, fr);
+    if (!nested) { bs = mix_leaf_sample<LEAVES>(&cx, &child, &fr, wo, u_child, u_bsdf, importance); }
+    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[1], frame, child, fr, cx.eta_i);
     BsdfEval eb;
     nested = false;
     if constexpr (DEPTH > 0) {
         if (child.kind == LR_SURFACE_MIX) {
-            eb = mix_evaluate<DEPTH - 1>(cx, child, fr, bs.wi);
+            eb = mix_evaluate<DEPTH - 1, LEAVES>(cx, child, fr, wo, bs.wi, importance);
             nested = true;
         }
     }
-    if (!nested) { eb = mix_leaf_evaluate(&cx, &child, &fr, bs.wi); }
+    if (!nested) { eb = mix_leaf_evaluate<LEAVES>(&cx, &child, &fr, wo, bs.wi, importance); }
     auto m = first ? mix_blend(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_blend(eb, BsdfEval{bs.f, bs.pdf}, ratio);
     bs.f = m.f, bs.pdf = m.pdf;
-    if (!valid_sides(cx.ng, frame.n, cx.wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
+    if (!valid_sides(cx.ng, frame.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
     return bs;
 }
+
+#if LR_NEST
+// a Mix tree as an interface of a Layered surface (dev_layered.h: layer_eval / layer_sample); its children are populated with
+// the interface's eta_i (mix.cpp:210-211)
+__device__ __noinline__ BsdfEval layer_mix_evaluate(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance) {
+    const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
+    return mix_evaluate<kMixMaxDepth, false>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, wi, importance);
+}
+__device__ __noinline__ BsdfSample layer_mix_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance) {
+    const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
+    return mix_sample<kMixMaxDepth, false>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, uc, u, importance);
+}
+#endif
 
 // evaluate of a Disney / Mix / Layered surface (MIX / LAYERED: which interpreters this kernel variant holds)
 template<bool MIX, bool LAYERED>
@@ -175,8 +223,8 @@ LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     auto &cx = *cxp;
     auto &c = cx.closure;
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:169-177
-        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth>(cx, c, cx.shading, wi); }// a tree: the general interpreter
-        // the common case, two non-Mix children, keeps the closure interpreter inline (the out-of-line leaves of the
+        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth, LAYERED && LR_NEST>(mix_ctx_of(cx), c, cx.shading, cx.wo, wi, false); }// a tree: the general interpreter
+        // the common case, two basic / Disney children, keeps the closure interpreter inline (the out-of-line leaves of the
         // general path cost C5 3 %)
         BsdfEval e[2];
 #pragma nounroll
@@ -192,7 +240,7 @@ LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     }
     if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
         LayerStack layers;
-        layer_stack(cx, layers);
+        layer_stack(mix_ctx_of(cx), c, cx.shading, layers);
         return layered_evaluate(layers, cx.wo, wi);
     }
     return closure_evaluate<true>(c, cx.shading, cx.ng, cx.wo, wi);// Disney
@@ -205,8 +253,9 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
     HeavySample r;
     r.eta = 1.f, r.has_eta = 0u;
     if (MIX && c.kind == LR_SURFACE_MIX && c.x[2] != 0u) {// a Mix tree
-        r.bs = mix_sample<kMixMaxDepth>(cx, c, cx.shading, u_lobe, u_bsdf);
-        r.has_eta = mix_eta<kMixMaxDepth>(cx, c, cx.shading, r.eta) ? 1u : 0u;
+        const auto mx = mix_ctx_of(cx);
+        r.bs = mix_sample<kMixMaxDepth, LAYERED && LR_NEST>(mx, c, cx.shading, cx.wo, u_lobe, u_bsdf, false);
+        r.has_eta = mix_eta<kMixMaxDepth>(mx, c, cx.shading, r.eta) ? 1u : 0u;
         return r;
     }
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
@@ -229,10 +278,15 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
         return r;
     }
     if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
+        const auto mx = mix_ctx_of(cx);
         LayerStack layers;
-        layer_stack(cx, layers);
+        layer_stack(mx, c, cx.shading, layers);
         r.bs = layered_sample(layers, cx.wo, u_lobe, u_bsdf);
+#if LR_NEST
+        r.has_eta = node_eta<kMixMaxDepth>(mx, c.x[1], cx.shading, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
+#else
         r.has_eta = closure_eta(layers.bottom, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
+#endif
         return r;
     }
     r.bs = closure_sample<true>(c, cx.shading, cx.ng, cx.wo, u_lobe, u_bsdf);// Disney

@@ -25,6 +25,21 @@ LR_HD uint32_t xxhash32_3(uint32_t x, uint32_t y, uint32_t z) {// rng.cpp:38-51
     return h ^ (h >> 16u);
 }
 
+#ifndef LR_NEST// free Mix / Layered composition: only in the variants that carry kFeatNest (512), one translation unit per variant
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 512) && !((LR_VARIANT) & 256)
+#define LR_NEST 1
+#else
+#define LR_NEST 0
+#endif
+#endif
+
+struct LobeTables {// the scene tables closure loading reads (dev_heavy.h: load_lobe)
+    const DClosure *closures;
+    const lr_surface *surfaces;
+    const lr_texture *textures;
+    const float *texels;
+};
+
 struct LayerStack {
     DClosure top, bottom;
     Frame f_top, f_bottom;// the children's own (possibly normal-mapped) shading frames
@@ -33,7 +48,19 @@ struct LayerStack {
     float thickness, g;
     f3 albedo;
     uint32_t max_depth, samples;
+#if LR_NEST
+    // an interface may be a Mix tree (round 2): its children are loaded per call, which needs what populate_closure had
+    LobeTables tb;
+    f2 uv;
+    f3 wo_pop;              // the hit's wo the closures were populated with (clamp_shading_normal of normal-mapped children)
+    float eta_i, eta_bottom;// eta_i the top / the bottom (and their children) were populated with, layered.cpp:497-499
+#endif
 };
+#if LR_NEST
+// Mix interfaces (dev_heavy.h: the Mix interpreter with basic / Disney leaves; a Layered surface never sits inside a Layered one)
+__device__ BsdfEval layer_mix_evaluate(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance);
+__device__ BsdfSample layer_mix_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance);
+#endif
 
 struct LayerRng {
     uint32_t state;
@@ -68,10 +95,16 @@ LR_D bool is_black(f3 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
 // TopOrBottom (layered.cpp:54-102): `is_top` picks the interface
 // (not inlined: the random walk has ~20 call sites and each inlined copy would carry the whole closure interpreter)
 __device__ __noinline__ BsdfEval layer_eval(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance) {
+#if LR_NEST
+    if ((is_top ? L.top.kind : L.bottom.kind) == LR_SURFACE_MIX) { return layer_mix_evaluate(L, is_top, wo, wi, importance); }
+#endif
     return is_top ? closure_evaluate<true>(L.top, L.f_top, L.ng, wo, wi, importance) :
                     closure_evaluate<true>(L.bottom, L.f_bottom, L.ng, wo, wi, importance);
 }
 __device__ __noinline__ BsdfSample layer_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance) {
+#if LR_NEST
+    if ((is_top ? L.top.kind : L.bottom.kind) == LR_SURFACE_MIX) { return layer_mix_sample(L, is_top, wo, uc, u, importance); }
+#endif
     return is_top ? closure_sample<true>(L.top, L.f_top, L.ng, wo, uc, u, importance) :
                     closure_sample<true>(L.bottom, L.f_bottom, L.ng, wo, uc, u, importance);
 }

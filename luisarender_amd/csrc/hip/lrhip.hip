@@ -498,6 +498,16 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         if (surf.kind == LR_SURFACE_DISNEY) { ctx->features |= lrd::kFeatDisney; }
         if (surf.kind == LR_SURFACE_MIX) { ctx->features |= lrd::kFeatMix; }
         if (surf.kind == LR_SURFACE_LAYERED) { ctx->features |= lrd::kFeatLayered | lrd::kFeatDisney; }
+        if (surf.kind == LR_SURFACE_MIX || surf.kind == LR_SURFACE_LAYERED) {// composition of the two (validate_scene checked the child indices)
+            for (auto k = 0u; k < 2u; k++) {
+                auto child = s->surfaces[surf.u[k]].kind;
+                if (child == LR_SURFACE_LAYERED && surf.kind == LR_SURFACE_LAYERED) {
+                    release_scene(ctx);
+                    return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: a Layered surface as an interface of a Layered surface is not supported");
+                }
+                if ((surf.kind == LR_SURFACE_MIX && child == LR_SURFACE_LAYERED) || (surf.kind == LR_SURFACE_LAYERED && child == LR_SURFACE_MIX)) { ctx->features |= lrd::kFeatNest; }
+            }
+        }
         auto dynamic = surf.normal_tex >= 0;
         for (auto t : surf.tex) { dynamic = dynamic || !is_constant(t); }
         lrd::DClosure c{};
@@ -598,6 +608,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     d.integrator_kind = s->integrator.kind, d.integrator_flags = s->integrator.flags;
     if (s->integrator.kind > LR_INTEGRATOR_VPT_NAIVE) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: unknown integrator kind"); }
     d.env_medium_tag = s->integrator.environment_medium_tag;
+    const auto nested = (ctx->features & lrd::kFeatNest) != 0u;
     if (s->integrator.kind == LR_INTEGRATOR_VPT_NAIVE) {// the volumetric megakernel is one kernel with everything in it
         for (uint32_t i = 0; i < s->instance_count; i++) {
             if ((s->instances[i].handle.x & LR_SHAPE_HAS_MEDIUM) && (s->instances[i].handle.y >> 24u) >= s->medium_count) {
@@ -608,7 +619,9 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         if (d.env_medium_tag != LR_INVALID_ID && d.env_medium_tag >= s->medium_count) { release_scene(ctx); return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: invalid environment medium tag"); }
         if (auto r = upload(ctx, s->media, s->medium_count, &d.media); r != LRHIP_OK) { release_scene(ctx); return r; }
         ctx->features = lrd::kFeatVpt;
+        if (nested) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Mix / Layered surfaces nested in each other are supported by the MegaPath integrator only"); }
     } else if (s->integrator.kind != LR_INTEGRATOR_MEGAPATH) {
+        if (nested) { release_scene(ctx); return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: Mix / Layered surfaces nested in each other are supported by the MegaPath integrator only"); }
         // the sibling integrators (Direct / Normal) live in the all-features variant only
         ctx->features |= lrd::kFeatSceneMask | lrd::kFeatAux;
     }

@@ -58,6 +58,8 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 //   kFeatDisney   Disney closure (thick + thin)
 //   kFeatMix      Mix closure (children: any non-Mix closure the mask holds)
 //   kFeatLayered  Layered closure (random walk over two nested closures; implies the Disney interpreter)
+//   kFeatNest     free composition of Mix and Layered (round 2): Mix trees with Layered leaves, Layered surfaces whose interfaces are
+//                 Mix trees.  Its own variant: the larger call graph cost the everything-variant 9 % on a scene that does not nest
 //   kFeatAux      the sibling integrators that reuse this kernel's pieces: DirectLighting
 //                 (src/integrators/direct.cpp:66-200) and NormalVisualizer (normal.cpp:36-70), selected at run time by
 //                 scene.integrator_kind; debug / AOV views, so they only exist on top of the all-features variant
@@ -65,6 +67,7 @@ enum : uint32_t {
     kFeatCount = 1u, kFeatGeneric = 2u, kFeatEnv = 4u, kFeatAlpha = 8u, kFeatDisney = 16u, kFeatMix = 32u, kFeatLayered = 64u,
     kFeatAux = 128u,
     kFeatVpt = 256u,// the volumetric megakernel (megavpt_kernel.h): a different kernel, same launch interface
+    kFeatNest = 512u,
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 // the precompiled scene-feature sets, smallest first (each also exists x {Count} x {Generic}); csrc/hip/variants/*.hip
@@ -77,6 +80,7 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatEnv | kFeatDisney,
     kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
     kFeatSceneMask,
+    kFeatSceneMask | kFeatNest,
     kFeatSceneMask | kFeatAux,
     kFeatVpt,
 };

@@ -11,5 +11,6 @@
     X(20) X(21) X(22) X(23)     /* + environment + Disney */                                 \
     X(60) X(61) X(62) X(63)     /* + environment + alpha test + Disney + Mix */              \
     X(124) X(125) X(126) X(127) /* everything (+ Layered) */                                 \
+    X(636) X(637) X(638) X(639) /* everything + Mix / Layered nested in each other (kFeatNest) */ \
     X(252) X(253) X(254) X(255) /* everything + the sibling integrators Direct / Normal */ \
     X(256) X(257) X(258) X(259) /* the volumetric megakernel MegaVPTNaive (megavpt_kernel.h) */

@@ -631,13 +631,15 @@ public:
                 throw Error{"Mix surface with a null child is not supported. [" + d->location() + "]"};
             }
             children = {register_surface(a), register_surface(b)};
-            // nested Mix surfaces: the kernel interprets up to 3 levels below the root (dev_heavy.h: kMixMaxDepth); u[2] = depth
-            auto depth_of = [&](uint32_t c) { return _out.surfaces[c].kind == LR_SURFACE_MIX ? 1u + _out.surfaces[c].u[2] : 0u; };
+            // nested Mix surfaces: the kernel interprets up to 3 levels below the root (dev_heavy.h: kMixMaxDepth); u[2] = depth.
+            // A Layered child is a leaf of the tree (its own interfaces may be Mix trees again, counted from zero); it sends the
+            // Mix through the general interpreter (u[2] != 0), whose leaves know the Layered closure.
+            auto depth_of = [&](uint32_t c) {
+                auto &cs = _out.surfaces[c];
+                return cs.kind == LR_SURFACE_MIX ? 1u + cs.u[2] : (cs.kind == LR_SURFACE_LAYERED ? 1u : 0u);
+            };
             s.u[2] = std::max(depth_of(children[0]), depth_of(children[1]));
             if (s.u[2] > 3u) { throw Error{"Mix surfaces nested more than 3 levels deep are not supported by the megakernel. [" + d->location() + "]"}; }
-            if (_out.surfaces[children[0]].kind == LR_SURFACE_LAYERED || _out.surfaces[children[1]].kind == LR_SURFACE_LAYERED) {
-                throw Error{"Layered children of a Mix surface are not supported by the megakernel. [" + d->location() + "]"};
-            }
             s.u[0] = children[0], s.u[1] = children[1];
             s.tex[0] = tex("ratio");
             wrappers = false;// NormalMapWrapper<MixSurface> only (mix.cpp:214-215)
@@ -648,10 +650,9 @@ public:
             auto top = d->node("top"), bottom = d->node("bottom");
             if (surface_is_null(top) || surface_is_null(bottom)) { throw Error{"Creating closure for null LayeredSurface. [" + d->location() + "]"}; }
             children = {register_surface(top), register_surface(bottom)};
-            for (auto c : children) {
-                auto k = _out.surfaces[c].kind;
-                if (k == LR_SURFACE_MIX || k == LR_SURFACE_LAYERED) {
-                    throw Error{"Mix / Layered children of a Layered surface are not supported by the megakernel. [" + d->location() + "]"};
+            for (auto c : children) {// interfaces: basic closures, Disney, or Mix trees of those (dev_heavy.h: layer_mix_evaluate)
+                if (surface_contains_layered(c)) {
+                    throw Error{"A Layered surface inside a Layered surface is not supported by the megakernel. [" + d->location() + "]"};
                 }
             }
             s.u[0] = children[0], s.u[1] = children[1];
@@ -674,6 +675,12 @@ public:
         _out.surfaces.emplace_back(s);
         _surface_tags.emplace(d, tag);
         return tag;
+    }
+
+    bool surface_contains_layered(uint32_t tag) const {
+        auto &s = _out.surfaces[tag];
+        if (s.kind == LR_SURFACE_LAYERED) { return true; }
+        return s.kind == LR_SURFACE_MIX && (surface_contains_layered(s.u[0]) || surface_contains_layered(s.u[1]));
     }
 
     bool surface_maybe_non_opaque(uint32_t tag) const {// OpacitySurfaceWrapper::maybe_non_opaque

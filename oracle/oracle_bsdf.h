@@ -1047,8 +1047,9 @@ struct Closure {
             }
             case LR_SURFACE_LAYERED: return layered_evaluate(wo, wi);
             case LR_SURFACE_MIX: {// mix.cpp:169-177: children through their public evaluate (side validation included)
-                auto ea = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
-                auto eb = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi);
+                // (the transport mode goes down to the children: a Mix can be an interface of a Layered surface)
+                auto ea = populate_tag(*mix_scene, mix_a, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi, importance);
+                auto eb = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i).evaluate(wo, wi, importance);
                 return mix(ea, eb, s0);
             }
             default: return {};
@@ -1147,13 +1148,13 @@ struct Closure {
                 auto b = populate_tag(*mix_scene, mix_b, mix_it, mix_wo, mix_eta_i);
                 auto ratio = s0;
                 if (u_lobe < ratio) {
-                    auto sa = a.sample(wo, u_lobe / ratio, u);
-                    auto eb = b.evaluate(wo, sa.wi);
+                    auto sa = a.sample(wo, u_lobe / ratio, u, importance);
+                    auto eb = b.evaluate(wo, sa.wi, importance);
                     out.eval = mix(sa.eval, eb, ratio);
                     out.wi = sa.wi, out.event = sa.event;
                 } else {
-                    auto sb = a.sample(wo, (u_lobe - ratio) / (1.f - ratio), u);
-                    auto ea = b.evaluate(wo, sb.wi);
+                    auto sb = a.sample(wo, (u_lobe - ratio) / (1.f - ratio), u, importance);
+                    auto ea = b.evaluate(wo, sb.wi, importance);
                     out.eval = mix(ea, sb.eval, ratio);
                     out.wi = sb.wi, out.event = sb.event;
                 }

@@ -86,6 +86,9 @@ def scenes(directory):
     out["cornell_sobol"] = (cornell_box(resolution=(40, 24), spp=8, sampler="Sobol"), 8)
     lay = MATERIALS["layered"].replace("Surface m ", "Surface layered ") + "\n"
     out["layered"] = (cornell_box(resolution=32, spp=256, short_box_surface="layered", tall_box_surface="layered", extra_surfaces=lay), 256)
+    # Mix and Layered nested in each other (kernel variant 636): a Mix with a Layered leaf, a Layered surface with Mix interfaces
+    nest = "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in ("mix_layered", "layered_mix"))
+    out["nested"] = (cornell_box(resolution=32, spp=256, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=nest), 256)
     # the same without an area light to run into: lit through the open front by a Directional + image environment.  No emitter
     # is ever evaluated from a ray origin lying IN its surface (mega_vpt_naive.cpp:331 after homogeneous.cpp:64), which is what
     # makes the lamp-lit case above chaotic in the last bit

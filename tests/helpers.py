@@ -38,8 +38,28 @@ MATERIALS = {
                       "Surface lm_b : Metal { eta { \"Au\" } roughness : Constant { v { 0.3 } } } "
                       "Surface m : Layered { top { @lm_t } bottom { @lm_b } thickness : Constant { v { 0.3 } } g : Constant { v { 0.4 } } "
                       "albedo : Constant { v { 0.8, 0.6, 0.4 } } max_depth { 12 } samples { 2 } two_sided { true } }",
+    # free composition of Mix and Layered (mix.cpp:82-212 and layered.cpp:195-500 hold arbitrary child closures)
+    "mix_layered": "Surface ml_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.15 } } eta : Constant { v { 1.5 } } } "
+                   "Surface ml_b : Matte { Kd : Constant { v { 0.3, 0.5, 0.7 } } } "
+                   "Surface ml_l : Layered { top { @ml_t } bottom { @ml_b } thickness : Constant { v { 0.05 } } } "
+                   "Surface ml_p : Plastic { Kd : Constant { v { 0.6, 0.3, 0.2 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.5 } } } "
+                   "Surface m : Mix { a { @ml_l } b { @ml_p } ratio : Constant { v { 0.6 } } }",
+    "layered_mix": "Surface lx_g1 : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } } "
+                   "Surface lx_g2 : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9, 0.95, 1 } } roughness : Constant { v { 0.4 } } eta : Constant { v { 1.5 } } } "
+                   "Surface lx_top : Mix { a { @lx_g1 } b { @lx_g2 } ratio : Constant { v { 0.5 } } } "
+                   "Surface lx_m : Matte { Kd : Constant { v { 0.7, 0.5, 0.3 } } } "
+                   "Surface lx_c : Metal { eta { \"Cu\" } roughness : Constant { v { 0.3 } } } "
+                   "Surface lx_bot : Mix { a { @lx_m } b { @lx_c } ratio : Constant { v { 0.7 } } } "
+                   "Surface m : Layered { top { @lx_top } bottom { @lx_bot } thickness : Constant { v { 0.1 } } }",
     "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
 }
+
+# rejected by the loader with a clear error (the megakernel bounds its call graph: no Layered inside Layered)
+LAYERED_IN_LAYERED = ("Surface ll_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } } "
+                       "Surface ll_t2 : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1, 0.8, 0.6 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.3 } } } "
+                       "Surface ll_b : Matte { Kd : Constant { v { 0.6, 0.6, 0.6 } } } "
+                       "Surface ll_in : Layered { top { @ll_t2 } bottom { @ll_b } thickness : Constant { v { 0.05 } } } "
+                       "Surface m : Layered { top { @ll_t } bottom { @ll_in } thickness : Constant { v { 0.02 } } g : Constant { v { 0.2 } } albedo : Constant { v { 0.5, 0.6, 0.7 } } }")
 
 _PATCH = """
 {surface}

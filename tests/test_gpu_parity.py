@@ -109,7 +109,7 @@ Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
-@pytest.mark.parametrize("material", ["layered", "layered_medium"])
+@pytest.mark.parametrize("material", ["layered", "layered_medium", "mix_layered", "layered_mix"])
 def test_layered_closure(renderer, material):
     """Row a14, Layered (layered.cpp:195-470): its random walk is seeded from the BITS of the hit position and direction
     (:271,416), which fp contraction changes between the device and the oracle, so parity is statistical (8x8 block means),
@@ -127,7 +127,7 @@ def test_layered_closure(renderer, material):
     assert err < 3e-2 and bias < 8e-3
     assert abs(gc["closest_rays"] - cc["closest_rays"]) < 5e-3 * cc["closest_rays"]
     # and it is not the bare substrate: rendering the bottom closure alone is far outside that tolerance
-    bare = "lay_b" if material == "layered" else "lm_b"
+    bare = {"layered": "lay_b", "layered_medium": "lm_b", "mix_layered": "ml_p", "layered_mix": "lx_m"}[material]
     sc2 = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface=bare, tall_box_surface=bare, extra_surfaces=extra))
     renderer.upload(sc2)
     renderer.render(0, spp, sync=True)
@@ -423,7 +423,7 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
         assert _rel_l1(a, b) < 2e-2 and abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 2e-3
 
 
-@pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "direct", "vpt", "sobol"])
+@pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "nested", "direct", "vpt", "sobol"])
 def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
     """Every parity test above drives the COUNT twin of a kernel variant (it needs the ray counters); bench.py and the CLI launch
     the twin without counters.  The two are the same template with `if (COUNT)` blocks, but they are different BINARIES (round 1
@@ -451,6 +451,7 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), 20),
         "mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha), 60),
         "layered": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium")), 124),
+        "nested": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix")), 636),
         "direct": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass")).replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 252),
         "vpt": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                 .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 256),
@@ -465,7 +466,7 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         films.append(renderer.download(converted=False))
     a, b = films
     assert a[..., :3].sum() > 0 and np.isfinite(b).all() and np.array_equal(a[..., 3], b[..., 3]), case
-    if case == "layered":
+    if case in ("layered", "nested"):
         g, c = _blocks(b), _blocks(a)
         err, bias = np.abs(g - c).sum() / np.abs(c).sum(), abs(g.mean() - c.mean()) / c.mean()
         print(f"{case}: block rel-L1 {err:.3e}, mean {bias:.2e}")
@@ -693,3 +694,17 @@ def test_bound_film_survives_an_upload(renderer):
     renderer.upload(Scene.from_string(cornell_box(resolution=16, spp=1)))  # another resolution: back to the library's film
     renderer.render(0, 1, sync=True)
     assert renderer.download(converted=False).shape == (16, 16, 4)
+
+
+def test_nested_mix_layered_only_in_megapath(renderer):
+    """Mix / Layered nested in each other live in their own kernel variant (636); the sibling and volumetric kernels refuse them."""
+    from helpers import MATERIALS
+    from luisarender_amd.render import DeviceError
+    extra = MATERIALS["mix_layered"].replace("Surface m ", "Surface mix_layered ") + "\n"
+    text = cornell_box(resolution=32, spp=4, short_box_surface="mix_layered", extra_surfaces=extra)
+    renderer.upload(Scene.from_string(text))
+    renderer.render(0, 4, sync=True)
+    assert renderer.last_variant() == 636
+    for integrator in ('Direct { importance_sampling { "both" }', "MegaVPTNaive {"):
+        with pytest.raises(DeviceError, match="MegaPath integrator only"):
+            renderer.upload(Scene.from_string(text.replace("integrator : MegaPath {", "integrator : " + integrator)))
