@@ -271,6 +271,14 @@ LoadedImage read_exr(const fs::path &path) {
         throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP are): '" + path.string() + "'."};
     }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
+    // nothing is allocated on the word of the header alone: at most 2^28 pixels (the JPEG reader's cap), and the file must be
+    // long enough for the chunk-offset table and the 8-byte header of every chunk the data window promises
+    {
+        auto chunks = (static_cast<uint64_t>(h) + (compression == 3u ? 15u : 0u)) / (compression == 3u ? 16u : 1u);
+        if (static_cast<uint64_t>(w) * h > (1ull << 28u) || p > data.size() || (data.size() - p) / 16u < chunks) {
+            throw Error{"EXR data window " + std::to_string(w) + "x" + std::to_string(h) + " is too large for the file (or beyond 2^28 pixels): '" + path.string() + "'."};
+        }
+    }
     LoadedImage img;
     img.width = w, img.height = h, img.is_hdr = true;
     img.pixels.assign(static_cast<size_t>(w) * h * 4u, 0.f);

@@ -277,3 +277,25 @@ def test_corrupt_files_fail_with_an_error_not_a_crash():
             assert np.isfinite(img).all(), f
         except HostError:
             pass
+
+
+def test_exr_header_cannot_make_the_reader_allocate_gigabytes(tmp_path):
+    """A few-hundred-byte file whose dataWindow claims 60000 x 60000 pixels (54 GB of float4) is refused before anything is allocated."""
+    import struct
+    good = tmp_path / "good.exr"
+    save_image(str(good), np.full((4, 6, 4), 0.5, np.float32))
+    raw = bytearray(good.read_bytes())
+    at = raw.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    assert struct.unpack_from("<4i", raw, at) == (0, 0, 5, 3)
+    struct.pack_into("<4i", raw, at, 0, 0, 59999, 59999)
+    bad = tmp_path / "bad.exr"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(HostError, match="too large"):
+        load_image(str(bad))
+    # tall but narrow: the pixel count is small, the offset table the header promises is longer than the file
+    struct.pack_into("<4i", raw, at, 0, 0, 5, 59999)
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(HostError, match="too large"):
+        load_image(str(bad))
+    got, _ = load_image(str(good))
+    assert got.shape == (4, 6, 4) and np.allclose(got[..., :3], 0.5)
