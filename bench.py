@@ -153,16 +153,34 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
     renderer.upload(scene)
     film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     renderer.bind_film(film.data_ptr())
-    reducer = FilmReducer(renderer, rank, world)  # communicator through the C ABI: the timed collective is lrhip_film_reduce
+    # communicator through the C ABI: the timed collective is the product's lrhip_film_reduce.  LR_BENCH_FORCE_COLLECTIVE=1 runs
+    # the same code with one rank (1-GPU boxes).  Should the C-ABI communicator fail on a node this was never run on, the same
+    # RCCL reduce goes through torch.distributed instead and the line says so (config.collective) -- a bench that dies has no line.
+    force = os.environ.get("LR_BENCH_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
+    collective = "none (single GPU)"
+    reducer = None
+    if world > 1 or force:
+        try:
+            reducer = FilmReducer(renderer, rank, world, force=force)
+            collective = "lrhip_film_reduce (ncclReduce through the C ABI, on the render stream)"
+        except Exception as e:  # noqa: BLE001
+            collective = f"torch.distributed.reduce (C-ABI communicator failed: {e})"
+    run_workload.collective = collective
     torch.cuda.synchronize()
 
     def step():
         film.zero_()
         torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
         renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
-        if world > 1:
+        if reducer is not None:
             reducer.reduce(0)  # ncclReduce on the renderer's stream, behind the megakernel
-        renderer.synchronize()
+            renderer.synchronize()
+        elif world > 1:
+            renderer.synchronize()
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        else:
+            renderer.synchronize()
         return renderer.last_render_ms()
 
     def barrier():
@@ -183,7 +201,8 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, mean_kernel_ms = float(t[0]), float(t[1])
     variant = renderer.last_variant()
-    reducer.close()
+    if reducer is not None:
+        reducer.close()
     renderer.close()
     value = res[0] * res[1] * spp * steps / elapsed / 1e6
     return value, elapsed / steps * 1e3, mean_kernel_ms, variant, scene, res, spp, desc
@@ -212,7 +231,7 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (os.environ.get("LR_BENCH_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -228,7 +247,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)",
-                           "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU"},
+                           "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
+                           "collective": getattr(run_workload, "collective", None)},
             }
             if args.spp is not None:
                 out["config"]["note"] = "spp overridden: not the headline configuration"
@@ -288,7 +308,7 @@ def main():
                 out["extra_configs"] = extra
             out["source_hash"] = source_hash()  # the kernel + BVH-builder sources this line was measured on (profiles/*.json carry the same)
             print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -183,6 +183,15 @@ def host_lib() -> C.CDLL:
 
 def hip_lib() -> C.CDLL:
     """The product's device library.  Fails loudly when the HIP extension is missing."""
+    # One HIP runtime and one RCCL per process: PyTorch-ROCm bundles its own libamdhip64 / librccl (same sonames as /opt/rocm's,
+    # older versions), and whichever is loaded first serves both.  A Python host shares device pointers and streams with torch
+    # (bench.py's film tensor, torch.distributed's process group), so torch's copies must be the ones: import it BEFORE the
+    # library pulls /opt/rocm's through its RUNPATH.  (Loaded the other way round, torch ran on a HIP runtime it was not built
+    # for and the process died in a double free at exit.)  C / C++ hosts have no torch and use /opt/rocm's alone.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     # LRHIP_LIB selects an experimental build variant (tools/ only); the default is the shipped library
     lib = _load(os.environ.get("LRHIP_LIB") or os.path.join(LIB_DIR, "liblrhip.so"))
     if not getattr(lib, "_lr_ready", False):

@@ -43,11 +43,11 @@ class FilmReducer:
     (lrhip_comm_unique_id on rank 0, the 128 bytes broadcast over the process group the launcher already made,
     lrhip_comm_init_rank on every rank) and lrhip_film_reduce on the renderer's own stream.  bench.py times THIS."""
 
-    def __init__(self, renderer, rank: int, world: int):
+    def __init__(self, renderer, rank: int, world: int, force: bool = False):
         import torch
         import torch.distributed as dist
         self.renderer, self.comm = renderer, None
-        if world <= 1:
+        if world <= 1 and not force:  # (force: a one-rank communicator, to run this very code on a 1-GPU box)
             return
         uid = torch.tensor(list(renderer.comm_unique_id()) if rank == 0 else [0] * 128, dtype=torch.uint8, device=f"cuda:{torch.cuda.current_device()}")
         dist.broadcast(uid, src=0)
