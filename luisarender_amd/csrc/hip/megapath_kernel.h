@@ -87,13 +87,16 @@ constexpr uint32_t kSceneVariants[] = {
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
 // waves per SIMD requested from the register allocator (512 VGPRs / waves).  Measured (Msamples/s at 2 / 3 / 4 waves):
-// lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 174 / 192 / 149
-// (with the heavy closures out of line; 165 / 141 / 104 when they were inlined into the shading block).  3 waves
-// (168 VGPRs) is NOT used for the Layered variants although it is the fastest: that build is miscompiled — NaN samples
-// all over tests/test_gpu_parity.py::test_layered_closure — by the compiler's SGPR-to-VGPR-lane spilling around the
-// out-of-line calls (with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 it is bit-identical to the 2-wave build, and slow).
+// lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 174 / 192 / 149 in round 1
+// (with the heavy closures out of line; 165 / 141 / 104 when they were inlined into the shading block).
+// Round 1 could NOT use 3 waves (168 VGPRs) for the Layered variants: that build was miscompiled -- NaN samples all over
+// tests/test_gpu_parity.py::test_layered_closure -- by the compiler's SGPR-to-VGPR-lane spilling around the out-of-line calls
+// (with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 it was bit-identical to the 2-wave build, and slow).  Round 2, after the shading
+// block changed around those calls (parked heavy hits, deferred alpha test, MixCtx): the 3-wave build passes every Layered /
+// kitchen / golden / twin test and runs the kitchen stand-in at 237 instead of 201 Msamples/s.  3 it is; the tests named above
+// are the guard, -DLR_WAVES_LAYERED=2 the way back.
 #ifndef LR_WAVES_LAYERED
-#define LR_WAVES_LAYERED 2
+#define LR_WAVES_LAYERED 3
 #endif
 // MEASURED AND NOT KEPT (round 2, profiles/r02d_heavy_parking.txt): (1) the traversal as a real call in these variants, so that it
 // gets a register allocation of its own (its loops then hold no spills): kitchen stand-in 202 -> 129 Msamples/s at 2 waves, 165 at
@@ -101,7 +104,9 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 // SIMD: +9 % without parking, nothing with it; (3) texture / environment code inlined in the heavy variants: basic hits 335 -> 391
 // but Disney/Mix hits 248 -> 216.
 #ifndef LR_HEAVY_BATCH
-#define LR_HEAVY_BATCH 12// parked heavy hits that trigger the out-of-line closures (1 = never park).  Kitchen stand-in, 64 spp: 181 / 193 (6, 3 waves) / 203 (12) / 196 (24) / 166 (40) Msamples/s
+#define LR_HEAVY_BATCH 12// parked heavy hits that trigger the out-of-line closures (1 = never park).  Kitchen stand-in, 64 spp, Layered at 2 waves:
+// 181 (never) / 193 (6) / 203 (12) / 196 (24) / 166 (40) Msamples/s; Layered at 3 waves: 228 (8) / 238 (12) / 244 (16) / 239 (24)
+#define LR_HEAVY_BATCH_LAYERED 16
 #endif
 #ifndef LR_WAVES_MIX
 #define LR_WAVES_MIX LR_MIN_WAVES
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
                    LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u;
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
-    constexpr bool PARK_HEAVY = (MIX || LAYERED) && !AUX && LR_HEAVY_BATCH > 1;
+    constexpr int HEAVY_BATCH = LAYERED ? LR_HEAVY_BATCH_LAYERED : LR_HEAVY_BATCH;
+    constexpr bool PARK_HEAVY = (MIX || LAYERED) && !AUX && HEAVY_BATCH > 1;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
     const auto tid = threadIdx.x;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     heavy_hit = (flags & LR_SHAPE_HAS_SURFACE) != 0u && scene.closures[(tags >> 12u) & 4095u].kind >= LR_SURFACE_DISNEY;
                 }
                 const auto heavy_lanes = __popcll(__ballot(heavy_hit));
-                if (heavy_lanes > 0 && heavy_lanes < LR_HEAVY_BATCH) {
+                if (heavy_lanes > 0 && heavy_lanes < HEAVY_BATCH) {
                     const auto others = __any(tr.phase != kPhaseIdle || (ready && !heavy_hit) || (tr.phase == kPhaseIdle && !path_open && q_next < q_total));
                     parked = heavy_hit && others;
                 }
