@@ -19,7 +19,7 @@ BINDIR := luisarender_amd/bin
 HOSTDIR := luisarender_amd/csrc/host
 HIPDIR := luisarender_amd/csrc/hip
 
-HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/subdiv.cpp $(HOSTDIR)/image_io.cpp $(HOSTDIR)/image_codecs.cpp $(HOSTDIR)/environment.cpp \
+HOST_SRC := $(HOSTDIR)/sdl.cpp $(HOSTDIR)/scene.cpp $(HOSTDIR)/mesh_io.cpp $(HOSTDIR)/subdiv.cpp $(HOSTDIR)/catmull_clark.cpp $(HOSTDIR)/image_io.cpp $(HOSTDIR)/image_codecs.cpp $(HOSTDIR)/environment.cpp \
             $(HOSTDIR)/accel.cpp $(HOSTDIR)/host_api.cpp $(HOSTDIR)/luisa_render_shim.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip

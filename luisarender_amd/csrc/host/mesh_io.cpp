@@ -1,6 +1,7 @@
 // mesh_io.cpp — Wavefront OBJ reader standing in for assimp in the reference's Mesh shape.
 // Reproduces the observable effect of the import flags at src/shapes/mesh.cpp:46-69:
-//   * polygons are fan-triangulated (aiProcess_Triangulate), lines/points dropped;
+//   * polygons are fan-triangulated (aiProcess_Triangulate), lines/points dropped; with `subdivision` > 0 they are kept and
+//     subdivided instead (mesh.cpp:69,86-93; catmull_clark.cpp);
 //   * identical (position, normal, uv) corners are merged (aiProcess_JoinIdenticalVertices);
 //   * V is flipped (v -> 1 - v) unless `flip_uv` (the reference passes aiProcess_FlipUVs when
 //     flip_uv is *false*, mesh.cpp:61);
@@ -35,7 +36,7 @@ int resolve_index(int idx, size_t count) {
 
 }// namespace
 
-LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv) {
+LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv, uint32_t subdivision) {
     std::ifstream file{path};
     if (!file) { throw Error{"Failed to load mesh '" + path + "'."}; }
     auto ext_pos = path.find_last_of('.');
@@ -46,7 +47,7 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
     }
     std::vector<float3> positions, normals;
     std::vector<float2> uvs;
-    std::vector<std::array<Corner, 3>> faces;
+    std::vector<std::vector<Corner>> faces;// triangles (fan) unless the mesh is to be subdivided: then the polygons as they are
     std::string line;
     while (std::getline(file, line)) {
         if (line.size() < 2u) { continue; }
@@ -89,8 +90,10 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
                 }
                 corners.emplace_back(corner);
             }
-            for (size_t i = 2; i < corners.size(); i++) {
-                faces.push_back({corners[0], corners[i - 1u], corners[i]});
+            if (subdivision != 0u) {
+                if (corners.size() >= 3u) { faces.emplace_back(std::move(corners)); }
+            } else {
+                for (size_t i = 2; i < corners.size(); i++) { faces.push_back({corners[0], corners[i - 1u], corners[i]}); }
             }
         }
     }
@@ -106,15 +109,16 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
     }
 
     // smooth-normal generation with a 45 degree limit when the file has no normals
-    std::vector<std::array<float3, 3>> generated;
+    std::vector<std::vector<float3>> generated;
     auto generate = !drop_normal && !has_file_normals;
     if (generate) {
         std::vector<float3> face_normals(faces.size());
         std::vector<std::vector<uint32_t>> incident(positions.size());
         for (size_t i = 0; i < faces.size(); i++) {
             auto &f = faces[i];
+            // (a polygon's normal from its first, second and LAST corner, as assimp's normal generation does; a triangle's as before)
             auto n = cross(positions[static_cast<size_t>(f[1].p)] - positions[static_cast<size_t>(f[0].p)],
-                           positions[static_cast<size_t>(f[2].p)] - positions[static_cast<size_t>(f[0].p)]);
+                           positions[static_cast<size_t>(f.back().p)] - positions[static_cast<size_t>(f[0].p)]);
             auto len = length(n);
             face_normals[i] = len > 0.f ? n / len : float3{0.f, 0.f, 0.f};
             for (auto &c : f) { incident[static_cast<size_t>(c.p)].emplace_back(static_cast<uint32_t>(i)); }
@@ -122,7 +126,8 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
         auto limit = std::cos(radians(45.f));
         generated.resize(faces.size());
         for (size_t i = 0; i < faces.size(); i++) {
-            for (auto k = 0u; k < 3u; k++) {
+            generated[i].resize(faces[i].size());
+            for (size_t k = 0; k < faces[i].size(); k++) {
                 float3 sum{0.f, 0.f, 0.f};
                 for (auto j : incident[static_cast<size_t>(faces[i][k].p)]) {
                     if (dot(face_normals[j], face_normals[i]) >= limit) { sum = sum + face_normals[j]; }
@@ -143,9 +148,11 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
         std::memcpy(&i, &f, sizeof(i));
         return i;
     };
+    PolygonMesh polygons;
+    polygons.face_offsets.emplace_back(0u);
     for (size_t i = 0; i < faces.size(); i++) {
-        uint32_t idx[3];
-        for (auto k = 0u; k < 3u; k++) {
+        std::vector<uint32_t> idx(faces[i].size());
+        for (size_t k = 0; k < faces[i].size(); k++) {
             auto &c = faces[i][k];
             lr_vertex v{};
             auto p = positions[static_cast<size_t>(c.p)];
@@ -166,7 +173,19 @@ LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal
             }
             idx[k] = it->second;
         }
-        mesh.triangles.push_back({idx[0], idx[1], idx[2]});
+        if (subdivision == 0u) { mesh.triangles.push_back({idx[0], idx[1], idx[2]}); }
+        else {
+            polygons.indices.insert(polygons.indices.end(), idx.begin(), idx.end());
+            polygons.face_offsets.emplace_back(static_cast<uint32_t>(polygons.indices.size()));
+        }
+    }
+    if (subdivision != 0u) {// mesh.cpp:86-93: Assimp::Subdivider::Create(CATMULL_CLARKE)->Subdivide(mesh, out, level, true)
+        polygons.vertices = std::move(mesh.vertices);
+        auto polygon_count = polygons.face_offsets.size() - 1u;
+        mesh = catmull_clark_subdivide(polygons, subdivision, mesh.properties);
+        log_info("Subdivided '" + path + "' (Catmull-Clark, " + std::to_string(subdivision) + " levels): " + std::to_string(polygon_count) +
+                 " polygons -> " + std::to_string(mesh.triangles.size()) + " triangles.");
+        return mesh;
     }
     log_info("Loaded triangle mesh '" + path + "': " + std::to_string(mesh.vertices.size()) + " vertices, " +
              std::to_string(mesh.triangles.size()) + " triangles.");

@@ -827,10 +827,9 @@ public:
         } else if (impl == "mesh") {// mesh.cpp:151-157
             auto path = d->path_or("file");
             if (path.empty()) { throw Error{"No valid values given for property 'file'. [" + d->location() + "]"}; }
-            if (d->uint_or("subdivision", 0u) != 0u) {
-                throw Error{"Mesh subdivision is not supported (SURVEY §2 row 17). [" + d->location() + "]"};
-            }
-            mesh = load_obj_mesh(path, d->bool_or("flip_uv", false), d->bool_or("drop_normal", false), d->bool_or("drop_uv", false));
+            auto subdivision = d->uint_or("subdivision", 0u);// mesh.cpp:155: Catmull-Clark levels
+            if (subdivision > 8u) { throw Error{"Mesh subdivision level " + std::to_string(subdivision) + " is out of range (at most 8: 4^8 quads per face). [" + d->location() + "]"}; }
+            mesh = load_obj_mesh(path, d->bool_or("flip_uv", false), d->bool_or("drop_normal", false), d->bool_or("drop_uv", false), subdivision);
         } else if (impl == "sphere") {// sphere.cpp:113-117
             mesh = make_sphere_mesh(std::min(d->uint_or("subdivision", 0u), 8u));
         } else if (impl == "loopsubdiv") {// loop_subdiv.cpp:24-58

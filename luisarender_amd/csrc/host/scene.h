@@ -124,7 +124,16 @@ struct LoadedMesh {
     std::vector<lr_triangle> triangles;
     uint32_t properties{0u};
 };
-LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv);
+// subdivision > 0: the polygons are kept (no aiProcess_Triangulate, mesh.cpp:69) and go through that many levels of Catmull-Clark
+LoadedMesh load_obj_mesh(const std::string &path, bool flip_uv, bool drop_normal, bool drop_uv, uint32_t subdivision = 0u);
+// catmull_clark.cpp: the Mesh shape's `subdivision` (assimp's Subdivider in the reference; restated, parity unpinned)
+struct PolygonMesh {
+    std::vector<lr_vertex> vertices;
+    std::vector<uint32_t> indices;     // corners of all faces, face after face
+    std::vector<uint32_t> face_offsets;// face f = indices[face_offsets[f] .. face_offsets[f + 1])
+};
+PolygonMesh catmull_clark_level(const PolygonMesh &in);
+LoadedMesh catmull_clark_subdivide(const PolygonMesh &base, uint32_t levels, uint32_t properties);
 // subdiv.cpp: Loop subdivision (src/util/loop_subdiv.cpp) and the icosphere of the Sphere shape (src/shapes/sphere.cpp)
 LoadedMesh loop_subdivide(const std::vector<lr_vertex> &vertices, const std::vector<lr_triangle> &triangles, uint32_t levels);
 LoadedMesh make_sphere_mesh(uint32_t subdivision);

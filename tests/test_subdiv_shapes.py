@@ -91,3 +91,106 @@ def test_sphere_renders_like_a_ball_under_a_white_sky():
     # the ball of radius 2 at distance 9 subtends asin(2/9); the 40 degree fov spans 32 px
     r_px = np.tan(np.arcsin(2 / 9)) / np.tan(np.radians(20)) * 16
     assert covered == pytest.approx(np.pi * r_px ** 2 / 32 ** 2, rel=0.12)
+
+
+# ------------------------------------------------------------------ Mesh { subdivision }: Catmull-Clark (csrc/host/catmull_clark.cpp)
+CUBE_OBJ = """
+v -1 -1 -1
+v  1 -1 -1
+v  1  1 -1
+v -1  1 -1
+v -1 -1  1
+v  1 -1  1
+v  1  1  1
+v -1  1  1
+f 1 4 3 2
+f 5 6 7 8
+f 1 2 6 5
+f 2 3 7 6
+f 3 4 8 7
+f 4 1 5 8
+"""
+MESH = """
+Shape m : Mesh {{ file {{ "{file}" }} subdivision {{ {level} }} {flags} surface : Matte {{ Kd : Constant {{ v {{ 0.8 }} }} }} }}
+Camera cam : Pinhole {{ fov {{ 40 }} spp {{ 16 }} film : Color {{ resolution {{ 32, 32 }} }} position {{ 0, 0, 9 }} look_at {{ 0, 0, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @m }} environment : Spherical {{ emission : Constant {{ v {{ 1 }} }} }} integrator : MegaPath {{ depth {{ 6 }} }} }}
+"""
+
+
+def _cc(tmp_path, obj, level, flags="drop_normal { true } drop_uv { true }"):
+    path = tmp_path / "m.obj"
+    path.write_text(obj)
+    return Scene.from_string(MESH.format(file=str(path), level=level, flags=flags), build_accel=False)
+
+
+def test_catmull_clark_first_level_of_a_cube(tmp_path):
+    """closed form: 6 face points at the face centres, 12 edge points (2 end points + 2 face points) / 4 = 3/4 of the edge midpoint,
+    8 vertex points (F + 2 R + (3 - 3) P) / 3 with F = 1/3 P-ish ... = 5/9 of the corner; 24 quads = 48 triangles"""
+    verts, tris = _mesh(_cc(tmp_path, CUBE_OBJ, 1))
+    p = verts[:, :3]
+    assert len(tris) == 48 and len(verts) == 26  # V - E + F = 26 - 48 + 24 = 2, shared vertices
+    kinds = {round(float(np.abs(q).sum()), 5): 0 for q in p}
+    for q in p:
+        kinds[round(float(np.abs(q).sum()), 5)] += 1
+    # face points (+-1, 0, 0): |.|_1 = 1; edge points (+-3/4, +-3/4, 0): 1.5; vertex points 5/9 (+-1, +-1, +-1): 5/3
+    assert kinds == {1.0: 6, 1.5: 12, round(5 / 3, 5): 8}, kinds
+    e = _edges(tris)
+    directed = {(a, b) for a, b in e.tolist()}
+    assert len(directed) == len(e)  # consistently oriented
+    fn = np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]])
+    assert (np.einsum("ij,ij->i", fn, p[tris].mean(axis=1)) > 0).all()  # outward, like the input faces
+
+
+def test_catmull_clark_converges_to_the_limit_surface_of_the_cube(tmp_path):
+    areas, radii = [], []
+    for level in (1, 2, 3, 4):
+        verts, tris = _mesh(_cc(tmp_path, CUBE_OBJ, level))
+        p = verts[:, :3]
+        assert len(tris) == 12 * 4 ** level and len(verts) == 6 * 4 ** level + 2
+        fn = np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]])
+        areas.append(0.5 * np.linalg.norm(fn, axis=1).sum())
+        r = np.linalg.norm(p, axis=1)
+        radii.append((r.min(), r.max()))
+    # the control mesh shrinks onto a rounded, nearly spherical limit surface: areas decrease and settle, the cubic symmetry stays
+    assert all(a > b for a, b in zip(areas, areas[1:])) and areas[-2] - areas[-1] < 0.02 * areas[-1]
+    assert radii[-1][1] / radii[-1][0] < 1.05 and 0.8 < radii[-1][0] < radii[-1][1] < 0.9  # a slightly cubic ball of radius ~0.85
+    verts, _ = _mesh(_cc(tmp_path, CUBE_OBJ, 3))
+    q = np.abs(verts[:, :3])
+    assert np.allclose(np.sort(q, axis=1)[np.lexsort(np.sort(q, axis=1).T)], np.sort(q[:, [1, 2, 0]], axis=1)[np.lexsort(np.sort(q[:, [1, 2, 0]], axis=1).T)], atol=1e-6)
+
+
+def test_catmull_clark_open_grid_keeps_its_plane_boundary_and_uvs(tmp_path):
+    """a flat 2 x 2 grid of quads with uvs = xy / 2: stays flat, boundary vertices stay, uv stays the same affine function of the
+    position (every attribute goes through the same weights), normals stay the plane normal"""
+    lines = [f"v {x} {y} 0" for y in range(3) for x in range(3)] + [f"vt {x / 2} {y / 2}" for y in range(3) for x in range(3)]
+    for y in range(2):
+        for x in range(2):
+            a, b, c, d = y * 3 + x + 1, y * 3 + x + 2, (y + 1) * 3 + x + 2, (y + 1) * 3 + x + 1
+            lines.append(f"f {a}/{a} {b}/{b} {c}/{c} {d}/{d}")
+    verts, tris = _mesh(_cc(tmp_path, "\n".join(lines), 2, flags="flip_uv { true }"))
+    p, n, uv = verts[:, :3], verts[:, 3:6], verts[:, 6:]
+    assert len(tris) == 4 * 16 * 2
+    assert np.allclose(p[:, 2], 0) and np.allclose(n, [0, 0, 1], atol=1e-6)
+    assert p[:, :2].min() == 0 and p[:, :2].max() == 2  # the four corners did not move
+    assert np.allclose(uv, p[:, :2] / 2, atol=1e-6)
+    area = 0.5 * np.linalg.norm(np.cross(p[tris[:, 1]] - p[tris[:, 0]], p[tris[:, 2]] - p[tris[:, 0]]), axis=1).sum()
+    assert area <= 4.0 + 1e-5  # inside the original square
+
+
+def test_catmull_clark_handles_triangles_and_ngons_and_renders(tmp_path):
+    """a tetrahedron (triangles -> 3 quads each) and a render through the oracle: the subdivided solid is lit and closed"""
+    tet = "v 1 1 1\nv -1 -1 1\nv -1 1 -1\nv 1 -1 -1\nf 1 2 3\nf 1 4 2\nf 1 3 4\nf 2 4 3\n"
+    sc = _cc(tmp_path, tet, 2, flags="")
+    verts, tris = _mesh(sc)
+    assert len(tris) == 4 * 3 * 4 * 2 and np.allclose(np.linalg.norm(verts[:, 3:6], axis=1), 1, atol=1e-5)
+    e = _edges(tris)
+    directed = {(a, b) for a, b in e.tolist()}
+    assert all((b, a) in directed for a, b in directed)  # watertight
+    path = tmp_path / "m.obj"
+    sc = Scene.from_string(MESH.format(file=str(path), level=2, flags=""))
+    o = Oracle(sc)
+    film, _ = o.render(0, 16)
+    img = o.convert(film)[..., :3]
+    assert img[12:20, 12:20].mean() < 0.95 * img[0:4, 0:4].mean() and np.isfinite(img).all()  # the solid shades, the sky is 1
+    with pytest.raises(Exception, match="out of range"):
+        _cc(tmp_path, tet, 9)
