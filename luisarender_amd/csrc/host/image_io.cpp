@@ -210,6 +210,222 @@ LoadedImage read_hdr(const fs::path &path) {
     return img;
 }
 
+// ---- OpenEXR PIZ (compression 4): per chunk of 32 scanlines, the 16-bit words of all channels (channel after channel) go
+// through a value-compaction LUT, a 2-D Haar-like wavelet per channel plane and a canonical Huffman coder with a run-length
+// symbol.  The reference reads it through tinyexr (src/util/imageio.cpp:419-538; tinyexr is an empty submodule in the snapshot);
+// restated from the published OpenEXR format (ImfPizCompressor / ImfHuf / ImfWav) -- PARITY UNPINNED AGAINST REAL FILES: no PIZ
+// file and no other decoder exist on this machine; tests/test_image_io.py holds it against an independent Python ENCODER of
+// the same format description (round trips over the 14- and 16-bit wavelet paths, odd sizes, run-length symbols).
+namespace piz {
+
+struct Error {};// any inconsistency: the caller reports a corrupt chunk
+
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t c{0u};
+    int lc{0};
+    uint32_t get(int n) {// most significant bit first
+        while (lc < n) {
+            if (p >= end) { throw Error{}; }
+            c = (c << 8u) | *p++;
+            lc += 8;
+        }
+        lc -= n;
+        return static_cast<uint32_t>((c >> lc) & ((1ull << n) - 1ull));
+    }
+};
+
+constexpr uint32_t kEncSize = (1u << 16u) + 1u;// 65536 values + the run-length symbol
+constexpr uint32_t kShortZeroRun = 59u, kLongZeroRun = 63u, kShortestLongRun = 2u + kLongZeroRun - kShortZeroRun;
+
+// hufUncompress: header (min symbol, max symbol = run-length symbol, table bytes, data bits, reserved), 6-bit code lengths with
+// zero runs, canonical codes (longest codes hold the numerically smallest values), data bits
+void huffman_decode(const uint8_t *src, size_t size, uint16_t *out, size_t count) {
+    if (size < 20u) { if (count != 0u) { throw Error{}; } return; }
+    auto rd = [&](size_t at) { uint32_t v; std::memcpy(&v, src + at, 4); return v; };
+    auto im = rd(0), iM = rd(4), n_bits = rd(12);
+    if (im >= kEncSize || iM >= kEncSize || im > iM) { throw Error{}; }
+    std::vector<uint8_t> length(kEncSize, 0u);
+    BitReader table{src + 20u, src + size};
+    for (auto i = im; i <= iM; i++) {
+        auto l = table.get(6);
+        if (l == kLongZeroRun || l >= kShortZeroRun) {
+            auto run = l == kLongZeroRun ? table.get(8) + kShortestLongRun : l - kShortZeroRun + 2u;
+            if (i + run > iM + 1u) { throw Error{}; }
+            i += run - 1u;// (the lengths are zero already)
+        } else {
+            length[i] = static_cast<uint8_t>(l);
+        }
+    }
+    const uint8_t *data = table.p;// the data starts at the next byte
+    if (static_cast<uint64_t>(n_bits) > 8ull * static_cast<uint64_t>(src + size - data)) { throw Error{}; }
+    // canonical codes: count per length, first code per length from the longest down, symbols in increasing order inside a length
+    uint64_t count_of[59] = {}, first[59] = {};
+    for (auto i = im; i <= iM; i++) { count_of[length[i]]++; }
+    {
+        uint64_t c = 0u;
+        for (auto l = 58; l > 0; l--) {
+            auto next = (c + count_of[l]) >> 1u;
+            first[l] = c;
+            c = next;
+        }
+    }
+    std::vector<uint32_t> offset(60, 0u), symbols;
+    for (auto l = 1; l <= 58; l++) { offset[l + 1] = offset[l] + static_cast<uint32_t>(count_of[l]); }
+    symbols.resize(offset[59]);
+    {
+        auto fill = offset;
+        for (auto i = im; i <= iM; i++) { if (length[i] != 0u) { symbols[fill[length[i]]++] = i; } }
+    }
+    BitReader bits{data, src + size};
+    uint64_t used = 0u;
+    size_t produced = 0u;
+    const auto rlc = iM;
+    while (used < n_bits) {
+        uint64_t code = 0u;
+        auto found = false;
+        for (auto l = 1; l <= 58 && used < n_bits; l++) {
+            code = (code << 1u) | bits.get(1);
+            used++;
+            if (count_of[l] != 0u && code >= first[l] && code - first[l] < count_of[l]) {
+                auto symbol = symbols[offset[l] + static_cast<uint32_t>(code - first[l])];
+                if (symbol == rlc) {
+                    if (used + 8u > n_bits || produced == 0u) { throw Error{}; }
+                    auto run = bits.get(8);
+                    used += 8u;
+                    if (produced + run > count) { throw Error{}; }
+                    for (auto k = 0u; k < run; k++) { out[produced + k] = out[produced - 1u]; }
+                    produced += run;
+                } else {
+                    if (produced >= count) { throw Error{}; }
+                    out[produced++] = static_cast<uint16_t>(symbol);
+                }
+                found = true;
+                break;
+            }
+        }
+        if (!found) { throw Error{}; }
+    }
+    if (produced != count) { throw Error{}; }
+}
+
+inline void wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    auto ls = static_cast<int16_t>(l), hs = static_cast<int16_t>(h);
+    int hi = hs, ai = ls + (hi & 1) + (hi >> 1);
+    a = static_cast<uint16_t>(static_cast<int16_t>(ai));
+    b = static_cast<uint16_t>(static_cast<int16_t>(ai - hi));
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    int m = l, d = h;
+    auto bb = (m - (d >> 1)) & 0xffff;
+    auto aa = (d + bb - 0x8000) & 0xffff;
+    b = static_cast<uint16_t>(bb), a = static_cast<uint16_t>(aa);
+}
+
+// wav2Decode: the inverse 2-D wavelet of one plane (nx x ny words, strides ox / oy), coarsest level first
+void wavelet_decode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t max_value) {
+    const auto w14 = max_value < (1u << 14u);
+    auto n = std::min(nx, ny);
+    auto p = 1;
+    while (p <= n) { p <<= 1; }
+    p >>= 1;
+    auto p2 = p;
+    p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) { w14 ? wdec14(l, h, a, b) : wdec16(l, h, a, b); };
+    while (p >= 1) {
+        auto py = in;
+        auto ey = in + static_cast<ptrdiff_t>(oy) * (ny - p2);
+        auto oy1 = static_cast<ptrdiff_t>(oy) * p, oy2 = static_cast<ptrdiff_t>(oy) * p2;
+        auto ox1 = static_cast<ptrdiff_t>(ox) * p, ox2 = static_cast<ptrdiff_t>(ox) * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            auto px = py;
+            auto ex = py + static_cast<ptrdiff_t>(ox) * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                auto p01 = px + ox1, p10 = px + oy1, p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {
+                auto p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            auto px = py;
+            auto ex = py + static_cast<ptrdiff_t>(ox) * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                auto p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p;
+        p >>= 1;
+    }
+}
+
+// one chunk -> the scanline layout of an uncompressed chunk (row after row, channel after channel inside a row).
+// `words[c]`: 16-bit words per pixel of channel c (1 = HALF, 2 = FLOAT / UINT)
+void decode_chunk(const uint8_t *src, size_t size, const std::vector<uint32_t> &words, uint32_t width, uint32_t rows, std::vector<uint8_t> &out) {
+    size_t total = 0u;
+    for (auto w : words) { total += static_cast<size_t>(w) * width * rows; }
+    if (size < 4u) { throw Error{}; }
+    uint16_t min_nz, max_nz;
+    std::memcpy(&min_nz, src, 2), std::memcpy(&max_nz, src + 2, 2);
+    constexpr size_t kBitmap = 8192u;
+    if (max_nz >= kBitmap) { throw Error{}; }
+    std::vector<uint8_t> bitmap(kBitmap, 0u);
+    size_t at = 4u;
+    if (min_nz <= max_nz) {
+        auto n = static_cast<size_t>(max_nz - min_nz) + 1u;
+        if (size - at < n) { throw Error{}; }
+        std::memcpy(bitmap.data() + min_nz, src + at, n);
+        at += n;
+    }
+    std::vector<uint16_t> lut(1u << 16u, 0u);
+    uint32_t k = 0u;
+    for (uint32_t i = 0u; i < (1u << 16u); i++) {// reverseLutFromBitmap: zero is always a value
+        if (i == 0u || (bitmap[i >> 3u] & (1u << (i & 7u)))) { lut[k++] = static_cast<uint16_t>(i); }
+    }
+    const auto max_value = static_cast<uint16_t>(k - 1u);
+    if (size - at < 4u) { throw Error{}; }
+    int32_t length;
+    std::memcpy(&length, src + at, 4);
+    at += 4u;
+    if (length < 0 || static_cast<size_t>(length) > size - at) { throw Error{}; }
+    std::vector<uint16_t> buffer(total);
+    huffman_decode(src + at, static_cast<size_t>(length), buffer.data(), total);
+    size_t start = 0u;
+    for (auto w : words) {
+        for (auto j = 0u; j < w; j++) {
+            wavelet_decode(buffer.data() + start + j, static_cast<int>(width), static_cast<int>(w), static_cast<int>(rows), static_cast<int>(width * w), max_value);
+        }
+        start += static_cast<size_t>(w) * width * rows;
+    }
+    for (auto &v : buffer) { v = lut[v]; }
+    out.resize(total * 2u);
+    std::vector<size_t> cursor(words.size());
+    start = 0u;
+    for (size_t c = 0; c < words.size(); c++) {
+        cursor[c] = start;
+        start += static_cast<size_t>(words[c]) * width * rows;
+    }
+    size_t q = 0u;
+    for (uint32_t r = 0; r < rows; r++) {
+        for (size_t c = 0; c < words.size(); c++) {
+            auto n = static_cast<size_t>(words[c]) * width;
+            std::memcpy(out.data() + q, buffer.data() + cursor[c], n * 2u);
+            q += n * 2u, cursor[c] += n;
+        }
+    }
+}
+
+}// namespace piz
+
 LoadedImage read_exr(const fs::path &path) {
     std::ifstream f{path, std::ios::binary};
     if (!f) { throw Error{"Failed to load image '" + path.string() + "'."}; }
@@ -267,14 +483,16 @@ LoadedImage read_exr(const fs::path &path) {
     // NO_COMPRESSION (0), ZIPS (2: one scanline per chunk), ZIP (3: 16 scanlines per chunk); the deflate streams go
     // through zlib (the reference reads EXR with tinyexr + miniz, src/util/imageio.cpp:419-538)
     // and RLE (1: one scanline per chunk; signed run bytes, then the same predictor + byte de-interleave as ZIP)
-    if (compression > 3u) {
-        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP are): '" + path.string() + "'."};
+    // and PIZ (4: 32 scanlines per chunk; namespace piz above)
+    if (compression > 4u) {
+        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP / PIZ are): '" + path.string() + "'."};
     }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
     // nothing is allocated on the word of the header alone: at most 2^28 pixels (the JPEG reader's cap), and the file must be
     // long enough for the chunk-offset table and the 8-byte header of every chunk the data window promises
     {
-        auto chunks = (static_cast<uint64_t>(h) + (compression == 3u ? 15u : 0u)) / (compression == 3u ? 16u : 1u);
+        const auto per_chunk = compression == 3u ? 16u : (compression == 4u ? 32u : 1u);
+        auto chunks = (static_cast<uint64_t>(h) + per_chunk - 1u) / per_chunk;
         if (static_cast<uint64_t>(w) * h > (1ull << 28u) || p > data.size() || (data.size() - p) / 16u < chunks) {
             throw Error{"EXR data window " + std::to_string(w) + "x" + std::to_string(h) + " is too large for the file (or beyond 2^28 pixels): '" + path.string() + "'."};
         }
@@ -293,7 +511,7 @@ LoadedImage read_exr(const fs::path &path) {
     if (!has_alpha) {
         for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) { img.pixels[i * 4u + 3u] = 1.f; }
     }
-    auto lines_per_chunk = compression == 3u ? 16u : 1u;
+    auto lines_per_chunk = compression == 3u ? 16u : (compression == 4u ? 32u : 1u);
     auto chunk_count = (h + lines_per_chunk - 1u) / lines_per_chunk;
     auto table = p;
     std::vector<uint8_t> raw, tmp;
@@ -316,6 +534,16 @@ LoadedImage read_exr(const fs::path &path) {
             if (packed < expect) { throw truncated(); }
             raw.assign(src, src + expect);
         } else {
+            if (compression == 4u) {
+                std::vector<uint32_t> words;
+                for (auto &c : channels) { words.emplace_back(c.type == 1u ? 1u : 2u); }
+                try {
+                    piz::decode_chunk(src, packed, words, w, rows, raw);
+                } catch (const piz::Error &) {
+                    throw Error{"Corrupt PIZ chunk in EXR image '" + path.string() + "'."};
+                }
+                if (raw.size() != expect) { throw truncated(); }
+            } else {
             tmp.resize(expect);
             if (compression == 1u) {// a count byte n: n >= 0 -> the next byte n + 1 times; n < 0 -> -n literal bytes
                 size_t in = 0u, out = 0u;
@@ -344,6 +572,7 @@ LoadedImage read_exr(const fs::path &path) {
             raw.resize(expect);
             auto half = (expect + 1u) / 2u;// de-interleave: first half = even bytes, second half = odd bytes
             for (size_t i = 0; i < expect; i++) { raw[i] = (i & 1u) ? tmp[half + i / 2u] : tmp[i / 2u]; }
+            }
         }
         size_t q = 0u;
         for (uint32_t r = 0; r < rows; r++) {

@@ -299,3 +299,64 @@ def test_exr_header_cannot_make_the_reader_allocate_gigabytes(tmp_path):
         load_image(str(bad))
     got, _ = load_image(str(good))
     assert got.shape == (4, 6, 4) and np.allclose(got[..., :3], 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------- EXR PIZ
+@pytest.mark.parametrize("case", ["half_smooth", "half_noise", "float_rgba", "constant", "odd_sizes", "many_values", "tall"])
+def test_exr_piz_reader_against_an_independent_encoder(tmp_path, case):
+    """csrc/host/image_io.cpp namespace piz (bitmap LUT, inverse wavelet, canonical Huffman + run-length symbol) reads what
+    tests/exr_piz_encoder.py -- written separately from the same published format -- produces, exactly.  (No PIZ file and no
+    other EXR codec exist on this machine: the reader is NOT pinned against a real OpenEXR file; DESIGN.md says so.)"""
+    from exr_piz_encoder import write_exr_piz
+    rng = np.random.default_rng(5)
+    half, channels = True, "RGB"
+    if case == "half_smooth":  # few distinct values: the 14-bit wavelet, long runs
+        y, x = np.mgrid[0:40, 0:52]
+        img = np.stack([x / 52, y / 40, (x + y) / 92], -1).astype(np.float32)
+        img = np.round(img * 16) / 16
+    elif case == "half_noise":  # > 2^14 distinct half values: the 16-bit wavelet
+        img = rng.normal(0, 30, (70, 300, 3)).astype(np.float32)
+    elif case == "float_rgba":
+        img, half, channels = rng.random((33, 17, 4)).astype(np.float32) * 10 - 2, False, "RGBA"
+    elif case == "constant":  # one value: bitmap of one bit, a two-symbol code
+        img = np.full((5, 9, 3), 0.25, np.float32)
+    elif case == "odd_sizes":
+        img = rng.random((37, 13, 3)).astype(np.float32)
+    elif case == "many_values":
+        img, half = (rng.random((64, 64, 3)) * 1000).astype(np.float32), False
+    else:  # several 32-line chunks, the last one short, width 1
+        img = rng.random((71, 1, 3)).astype(np.float32)
+    path = tmp_path / "piz.exr"
+    coded = write_exr_piz(str(path), img, half=half, channels=channels)
+    assert coded == (img.shape[0] + 31) // 32  # every chunk went through the coder
+    assert path.read_bytes().find(b"compression\0compression\0\x01\0\0\0\x04") > 0
+    got, ch = load_image(str(path))
+    want = img.astype(np.float16).astype(np.float32) if half else img
+    assert got.shape == (img.shape[0], img.shape[1], 4) and ch == len(channels)
+    assert np.array_equal(got[..., :len(channels)], want)
+    if len(channels) == 3:
+        assert (got[..., 3] == 1).all()
+
+
+def test_exr_piz_corrupt_chunks_fail_with_an_error(tmp_path):
+    from exr_piz_encoder import write_exr_piz
+    img = np.random.default_rng(1).random((40, 24, 3)).astype(np.float32)
+    path = tmp_path / "piz.exr"
+    assert write_exr_piz(str(path), img) == 2
+    raw = bytearray(path.read_bytes())
+    rng = np.random.default_rng(2)
+    failures = 0
+    for trial in range(300):
+        bad = bytearray(raw)
+        at = int(rng.integers(len(raw) // 4, len(raw)))
+        bad[at] ^= 1 << int(rng.integers(8))
+        (tmp_path / "bad.exr").write_bytes(bytes(bad))
+        try:
+            got, _ = load_image(str(tmp_path / "bad.exr"))
+            assert got.shape == (40, 24, 4)
+        except HostError:
+            failures += 1
+    assert failures > 10  # symbol and bit counts are checked exactly; a flip that keeps both decodes to other pixels, never crashes
+    (tmp_path / "bad.exr").write_bytes(bytes(raw[:len(raw) - 20]))
+    with pytest.raises(HostError):
+        load_image(str(tmp_path / "bad.exr"))
