@@ -12,7 +12,12 @@ ORACLE_FLAGS ?= -std=c++17 -O3 -march=x86-64-v3 -ffp-contract=off -fPIC -Wall -W
 # around every v_rcp / v_sqrt / v_rsq (-18 % VALU instructions in the kernel, +5 % throughput) without touching
 # the denormal mode.  Denormal flushing itself was measured and REJECTED: it moved the C2 image mean by 0.8 %
 # against the oracle (tools/dbg_c2.py); these flags do not (tests/test_gpu_parity.py bias checks).
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -fno-hip-fp32-correctly-rounded-divide-sqrt -fapprox-func
+# -fno-slp-vectorize (round 2): the SLP vectorizer pairs scalar fp32 operations into v_pk_* instructions.  On gfx950 a wave64
+# v_pk_fma_f32 issues in ~4.2 cycles against ~2.4 for a v_fma_f32 (tools/valu_peak.hip), so a pair gains little, and the packing
+# costs v_mov shuffles into consecutive registers plus register pressure.  Off: C2 689 -> 774 Msamples/s (+12 %), C3 651 -> 758,
+# C4 683 -> 747, C5 255 -> 276 at the A/B sizes (profiles/r02f_ab_compiler_flags.txt).  The slab test's hand-written v2f FMAs stay.
+# Same arithmetic per lane.  -fno-vectorize (loop vectorizer), -O2, -fno-unroll-loops, relaxed-occupancy scheduling: no change.
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -fno-hip-fp32-correctly-rounded-divide-sqrt -fapprox-func -fno-slp-vectorize
 
 LIBDIR := luisarender_amd/lib
 BINDIR := luisarender_amd/bin
@@ -57,7 +62,7 @@ hip: $(LIBDIR)/liblrhip.so
 # good.  With the arithmetic of the reference-pinned oracle the device takes the same decisions (tests/test_ref_golden.py,
 # test_gpu_parity.py::test_volumetric_megakernel); with contraction it renders the lamp-lit fog scenes 30 % darker than the
 # reference's own code does (measured, round 2).  It is a feature row, not the benchmarked path.
-VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize
 variant_flags = $(if $(filter 256 257 258 259,$(1)),$(VPT_HIPFLAGS),$(HIPFLAGS))
 $(OBJDIR)/variant_%.o: $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
 	@mkdir -p $(OBJDIR)

@@ -89,14 +89,15 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 // waves per SIMD requested from the register allocator (512 VGPRs / waves).  Measured (Msamples/s at 2 / 3 / 4 waves):
 // lean C2 -- / 487 / 536; environment + Disney (C4) 442 / 563 / 578; everything incl. Layered (C5) 174 / 192 / 149 in round 1
 // (with the heavy closures out of line; 165 / 141 / 104 when they were inlined into the shading block).
-// Round 1 could NOT use 3 waves (168 VGPRs) for the Layered variants: that build was miscompiled -- NaN samples all over
-// tests/test_gpu_parity.py::test_layered_closure -- by the compiler's SGPR-to-VGPR-lane spilling around the out-of-line calls
-// (with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 it was bit-identical to the 2-wave build, and slow).  Round 2, after the shading
-// block changed around those calls (parked heavy hits, deferred alpha test, MixCtx): the 3-wave build passes every Layered /
-// kitchen / golden / twin test and runs the kitchen stand-in at 237 instead of 201 Msamples/s.  3 it is; the tests named above
-// are the guard, -DLR_WAVES_LAYERED=2 the way back.
+// 3 waves (168 VGPRs) is a trap for the Layered variants: that build comes out MISCOMPILED or not depending on unrelated code
+// and flags -- NaN samples all over tests/test_gpu_parity.py::test_layered_closure in round 1; fine after round 2's changes to
+// the shading block (238 Msamples/s on the kitchen stand-in against 201 at 2 waves); NaN samples again once the SLP vectorizer
+// was switched off (Makefile).  It is the compiler's SGPR-to-VGPR-lane spilling around the out-of-line calls: with
+// -mllvm -amdgpu-spill-sgpr-to-vgpr=0 the 3-wave build is bit-identical to the 2- and 4-wave builds.  Without the SLP
+// vectorizer the register pressure is low enough for 4 waves (128 VGPRs): kitchen stand-in 212 (2 waves) / 262 (3, SGPR spills to
+// memory) / 274 (4), all three with identical images.  4 it is; test_layered_closure and the golden / twin tests are the guard.
 #ifndef LR_WAVES_LAYERED
-#define LR_WAVES_LAYERED 3
+#define LR_WAVES_LAYERED 4
 #endif
 // MEASURED AND NOT KEPT (round 2, profiles/r02d_heavy_parking.txt): (1) the traversal as a real call in these variants, so that it
 // gets a register allocation of its own (its loops then hold no spills): kitchen stand-in 202 -> 129 Msamples/s at 2 waves, 165 at
@@ -106,6 +107,8 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #ifndef LR_HEAVY_BATCH
 #define LR_HEAVY_BATCH 12// parked heavy hits that trigger the out-of-line closures (1 = never park).  Kitchen stand-in, 64 spp, Layered at 2 waves:
 // 181 (never) / 193 (6) / 203 (12) / 196 (24) / 166 (40) Msamples/s; Layered at 3 waves: 228 (8) / 238 (12) / 244 (16) / 239 (24)
+#endif
+#ifndef LR_HEAVY_BATCH_LAYERED
 #define LR_HEAVY_BATCH_LAYERED 16
 #endif
 #ifndef LR_WAVES_MIX
