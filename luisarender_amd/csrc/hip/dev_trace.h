@@ -88,6 +88,9 @@ struct TraversalStack {
 #ifndef LR_SLAB_SIGN
 #define LR_SLAB_SIGN 1
 #endif
+#ifndef LR_SLAB_PACKED
+#define LR_SLAB_PACKED 0// 1: the 24 plane FMAs as 12 v_pk_fma_f32 (round 1); 0: 24 v_fma_f32 -- +2.2 % once the SLP vectorizer is off (775 -> 792 on C2 at 256 spp): a v_pk_fma_f32 issues in 4.2 cycles against 2 x 2.4 and needs its operands in register pairs
+#endif
 #ifndef LR_PUSH_UNSORTED
 #define LR_PUSH_UNSORTED 0
 #endif
@@ -238,6 +241,17 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
                 auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
                 auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
+#if !LR_SLAB_PACKED
+#pragma unroll
+                for (auto i = 0; i < 4; i++) {// the same with 24 scalar v_fma_f32
+                    auto tn = fmaxf(fmaxf(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by)),
+                                    fmaxf(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
+                    auto tf = fminf(fminf(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by)),
+                                    fminf(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
+                    auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
+                    key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
+                }
+#else
                 v2f a_x = {ax, ax}, a_y = {ay, ay}, a_z = {az, az}, b_x = {bx, bx}, b_y = {by, by}, b_z = {bz, bz};
 #pragma unroll
                 for (auto p = 0; p < 4; p += 2) {
@@ -256,6 +270,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                         key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
                     }
                 }
+#endif
 #else
 #pragma unroll
                 for (auto i = 0; i < 4; i++) {
