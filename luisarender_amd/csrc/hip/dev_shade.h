@@ -55,6 +55,10 @@ struct PathSampler<false> {
         return u;
     }
     LR_D f2 next_pixel_2d() { return next_2d(); }// Sampler::Instance::generate_pixel_2d default, sampler.h:48
+    // the stream position of a path that leaves its lane (megapath_kernel.h: deferred heavy hits)
+    static constexpr uint32_t kSavedWords = 1u;
+    LR_D uint32_t save(uint32_t *w) const { w[0] = state; return kSavedWords; }
+    LR_D void restore(const DScene &, const uint32_t *w) { state = w[0]; }
 };
 
 LR_HD uint32_t xxhash32_2(uint32_t x, uint32_t y) {// rng.cpp:25-36
@@ -123,6 +127,17 @@ struct PathSampler<true> {
             i ^= i >> 5u;
         } while (i >= l);
         return (i + p) % l;
+    }
+    static constexpr uint32_t kSavedWords = 8u;// (megapath_kernel.h: deferred heavy hits)
+    LR_D uint32_t save(uint32_t *w) const {
+        w[0] = static_cast<uint32_t>(a), w[1] = static_cast<uint32_t>(a >> 32u), w[2] = static_cast<uint32_t>(b), w[3] = static_cast<uint32_t>(b >> 32u);
+        w[4] = px, w[5] = py, w[6] = sample_index, w[7] = dimension;
+        return kSavedWords;
+    }
+    LR_D void restore(const DScene &s, const uint32_t *w) {
+        scene = &s;
+        a = w[0] | (static_cast<uint64_t>(w[1]) << 32u), b = w[2] | (static_cast<uint64_t>(w[3]) << 32u);
+        px = w[4], py = w[5], sample_index = w[6], dimension = w[7];
     }
     LR_D void start(const DScene &s, uint32_t x, uint32_t y, uint32_t index) {
         scene = &s;

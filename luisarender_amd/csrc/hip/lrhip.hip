@@ -95,7 +95,7 @@ struct lrhip_ctx {
     bool scene_ready{false};
     uint32_t width{0}, height{0};
     float film_scale[3]{1.f, 1.f, 1.f};
-    DeviceBuffer film_own, converted, partial, spill, counters, work_counter;
+    DeviceBuffer film_own, converted, partial, spill, counters, work_counter, heavy_queue;
     DeviceBuffer scene_record;// lrd::DScene in device memory: the kernels read it through scalar loads (dev_scene.h: DScenePtr)
     float4 *film{nullptr};// bound film (own or external)
     float4 *film_external{nullptr};// lrhip_bind_film's buffer; kept across uploads of the same resolution
@@ -327,7 +327,7 @@ void lrhip_destroy(lrhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     release_scene(ctx);
     ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
-    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
+    ctx->spill.release(), ctx->heavy_queue.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -751,6 +751,17 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
+    // deferred heavy hits (megapath_kernel.h): a queue per resident wave in the variants with out-of-line closures.  2048 entries
+    // x 120 B x 4096 waves = 1 GB of the 288; LRHIP_HEAVY_QUEUE=<entries per wave> resizes it, 0 = park in the lane instead
+    if ((kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u && (kVariants[vi].mask & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        auto capacity = 2048u;
+        if (auto e = std::getenv("LRHIP_HEAVY_QUEUE")) { capacity = static_cast<uint32_t>(std::max(0, std::atoi(e))); }
+        if (capacity != 0u) {
+            auto waves = static_cast<size_t>(args.total_threads / 64u);
+            if (auto r = ensure(ctx->heavy_queue, waves * capacity * lrd::kHeavyQueueWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+            args.heavy_queue = static_cast<uint32_t *>(ctx->heavy_queue.ptr), args.heavy_capacity = capacity;
+        }
+    }
     auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns

@@ -423,7 +423,8 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
         assert _rel_l1(a, b) < 2e-2 and abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 2e-3
 
 
-@pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "nested", "direct", "vpt", "sobol"])
+@pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "nested", "direct", "vpt", "sobol",
+                                  "mix_sobol", "layered_pcg", "nested_sobol", "direct_pcg", "vpt_pcg"])
 def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
     """Every parity test above drives the COUNT twin of a kernel variant (it needs the ray counters); bench.py and the CLI launch
     the twin without counters.  The two are the same template with `if (COUNT)` blocks, but they are different BINARIES (round 1
@@ -456,6 +457,14 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         "vpt": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                 .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 256),
         "sobol": (cornell_box(resolution=(96, 64), spp=8, sampler="Sobol"), 2),
+        # the generic-sampler twins (| 2) of the variants that make real calls: every shipped binary of that kind is held to its
+        # counting twin (they are the ones a compiler mishap has hit, Makefile: CALL_SAFE_FLAGS)
+        "mix_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha, sampler="Sobol"), 62),
+        "layered_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium"), sampler="PCG32"), 126),
+        "nested_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix"), sampler="PaddedSobol"), 638),
+        "direct_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PCG32").replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 254),
+        "vpt_pcg": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin", sampler="PCG32").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
+                    .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 258),
     }[case]
     sc = Scene.from_string(text)
     films = []
@@ -466,7 +475,10 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         films.append(renderer.download(converted=False))
     a, b = films
     assert a[..., :3].sum() > 0 and np.isfinite(b).all() and np.array_equal(a[..., 3], b[..., 3]), case
-    if case in ("layered", "nested"):
+    renderer.upload(sc)  # and the shipped binary is deterministic (a miscompiled <124> once was not: lost samples, another sum every run)
+    renderer.render(0, 8, counters=False, sync=True)
+    assert np.array_equal(renderer.download(converted=False), b), case
+    if case in ("layered", "nested", "layered_pcg", "nested_sobol"):
         g, c = _blocks(b), _blocks(a)
         err, bias = np.abs(g - c).sum() / np.abs(c).sum(), abs(g.mean() - c.mean()) / c.mean()
         print(f"{case}: block rel-L1 {err:.3e}, mean {bias:.2e}")
