@@ -714,7 +714,9 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // declares it (balance_shards), so that every shard of a frame — and the unsharded frame rendered with the same
     // hint — uses the same chunking.
     auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
-    auto s_item = std::sqrt(1.25 * spp * shard_tiles / kNominalWaves);
+    auto item_scale = 1.25;
+    if (auto e = std::getenv("LRHIP_ITEM_SCALE")) { item_scale *= std::max(0.01, std::atof(e)); }// tools/ only: sweep of the loss model's constant
+    auto s_item = std::sqrt(item_scale * spp * shard_tiles / kNominalWaves);
     auto chunk_count = static_cast<uint32_t>(std::lround(spp / std::max(s_item, 1.0)));
     chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
     lrd::RenderArgs args{};
