@@ -753,10 +753,11 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
-    // deferred heavy hits (megapath_kernel.h): a queue per resident wave in the variants with out-of-line closures.  2048 entries
-    // x 120 B x 4096 waves = 1 GB of the 288; LRHIP_HEAVY_QUEUE=<entries per wave> resizes it, 0 = park in the lane instead
+    // deferred heavy hits (megapath_kernel.h, -DLR_HEAVY_QUEUE=1 builds only -- measured and off in the shipped library): a queue
+    // per resident wave in the variants with out-of-line closures, LRHIP_HEAVY_QUEUE=<entries per wave> (2048 entries x 120 B x
+    // 4096 waves = 1 GB of the 288).  Unset: nothing is allocated and such a build parks in the lane like the shipped one.
     if ((kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u && (kVariants[vi].mask & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        auto capacity = 2048u;
+        auto capacity = 0u;
         if (auto e = std::getenv("LRHIP_HEAVY_QUEUE")) { capacity = static_cast<uint32_t>(std::max(0, std::atoi(e))); }
         if (capacity != 0u) {
             auto waves = static_cast<size_t>(args.total_threads / 64u);

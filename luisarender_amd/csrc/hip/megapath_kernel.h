@@ -123,7 +123,8 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 // are shaded on the spot.
 // MEASURED, OFF BY DEFAULT: kitchen stand-in 274 -> 300 Msamples/s with the default SGPR spilling -- and 256 -> 246 with the
 // spill-to-memory flag the call-making variants are built with (Makefile: CALL_SAFE_FLAGS), under which its extra wave-uniform
-// state costs more than the full batches give back.  -DLR_HEAVY_QUEUE=1 (+ LRHIP_HEAVY_QUEUE=<entries>) brings it back.
+// state costs more than the full batches give back.  -DLR_HEAVY_QUEUE=1 with LRHIP_HEAVY_QUEUE=<entries per wave> at run time
+// brings it back (tools/ only; the shipped library allocates nothing for it).
 #ifndef LR_HEAVY_QUEUE
 #define LR_HEAVY_QUEUE 0
 #endif

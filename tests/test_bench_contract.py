@@ -24,7 +24,7 @@ def test_metric_is_the_baseline_metric():
 
 
 def test_committed_headline_line_follows_the_contract():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02i_bench_c2_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02j_bench_c2_1gpu.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], typ), key
