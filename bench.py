@@ -21,7 +21,8 @@ Rank 0 prints ONE JSON line with the driver's contract plus
                   (wave-level VALU instructions) against the issue rates calibrated on the box by tools/valu_peak.hip.
   "cpu_baseline": the CPU oracle ("port": reference-faithful restatement, not the reference binary; it is pinned to the
                   reference's own code, tests/test_oracle_vs_ref.py) timed on the host cores on a bounded sample of the workload.
-  "extra_configs": short runs of the other BASELINE configs (C1 with its full CPU leg = configs[0], C3, C5) in the same line.
+  "extra_configs": short runs of the other BASELINE configs (C1 with its full CPU leg = configs[0], C3, C5) in the same line; C1 also
+  carries "cpu_reference": the reference's OWN MegaPath code (oracle/_ref) timed on one host thread over a bounded sample.
 """
 from __future__ import annotations
 
@@ -304,6 +305,19 @@ def main():
                          "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
                     if with_cpu:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration
                         e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _ = cpu_baseline(sc, r, 30.0, full_spp=sp)
+                        # and the REFERENCE'S OWN code beside it (oracle/_ref, one thread, a bounded sample of the same frame); absent
+                        # where oracle/_ref was not built
+                        # (in a child process: libref.so brings its own operator new and the reference's symbols)
+                        import subprocess
+                        code = ("import json, sys; sys.path.insert(0, %r); from oracle.check import reference_rate; "
+                                "from luisarender_amd.scenes import cornell_box; "
+                                "print(json.dumps(reference_rate(cornell_box(resolution=%d, spp=%d, depth=%d), 10.0)))" % (ROOT, r[0], sp, WORKLOADS[w][3]))
+                        try:
+                            ref = json.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                        except Exception:  # noqa: BLE001
+                            ref = None
+                        if ref is not None:
+                            e["cpu_reference"] = ref
                     extra.append(e)
                 out["extra_configs"] = extra
             out["source_hash"] = source_hash()  # the kernel + BVH-builder sources this line was measured on (profiles/*.json carry the same)

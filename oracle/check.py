@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -135,3 +136,48 @@ def algorithmic_bytes(counters: dict) -> float:
     """B = 64*nodes + 48*tris + 188*hits + 208*nee + 32 per sample (film read+write)."""
     return (64.0 * counters["nodes_visited"] + 48.0 * counters["tris_tested"] + 188.0 * counters["surface_hits"]
             + 208.0 * counters["nee_samples"] + 32.0 * counters["paths"])
+
+
+def reference_rate(scene_text: str, budget_s: float = 10.0):
+    """Throughput of the REFERENCE'S OWN MegaPath code on this scene, one host thread: oracle/_ref/libref.so = /root/reference/src
+    compiled in place against the scalar LuisaCompute stand-in (oracle/Makefile.ref), driven sample by sample (its Li() through
+    ref_li, the entry tests/test_oracle_vs_ref.py pins the oracle with).  None where libref.so is absent.  This is the reference's
+    SOURCE on a scalar interpreter of its DSL, not its LLVM / CPU backend: the figure says what a sample costs when every DSL
+    statement is one C++ statement, nothing about LuisaCompute's code generation.  bench.py's cpu_baseline leg only."""
+    import ctypes as C
+    import tempfile
+    ref_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+    path = os.path.join(ref_dir, "libref.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib.ref_scene_load.restype = C.c_void_p
+    lib.ref_scene_load.argtypes = [C.c_char_p, C.c_char_p]
+    lib.ref_scene_destroy.argtypes = [C.c_void_p]
+    lib.ref_resolution.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_li.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+    with tempfile.TemporaryDirectory() as tmp:
+        scene_path = os.path.join(tmp, "scene.luisa")
+        with open(scene_path, "w") as f:
+            f.write(scene_text)
+        handle = lib.ref_scene_load(scene_path.encode(), ref_dir.encode())
+        if not handle:
+            return None
+        res = (C.c_uint32 * 2)()
+        lib.ref_resolution(handle, res)
+        width, height = int(res[0]), int(res[1])
+        out = (C.c_float * 3)()
+        # a regular grid of pixels over the whole frame, sample after sample, until the budget is spent
+        step = max(1, min(width, height) // 32)
+        pixels = [(x, y) for y in range(step // 2, height, step) for x in range(step // 2, width, step)]
+        done, sample, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            for x, y in pixels:
+                lib.ref_li(handle, x, y, sample, 0.0, out)
+            done += len(pixels)
+            sample += 1
+        dt = time.perf_counter() - t0
+        lib.ref_scene_destroy(handle)
+    return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "sample": f"the reference's own MegaPath::Li (oracle/_ref: /root/reference/src compiled in place on a scalar LuisaCompute stand-in, NOT its "
+                      f"LLVM backend), {len(pixels)} pixels on a regular grid of the {width}x{height} frame x {sample} samples = {done} paths in {dt:.1f} s, 1 thread"}
