@@ -52,6 +52,16 @@ def test_committed_headline_line_follows_the_contract():
     assert c1["spp_timed"] == 64 and "512x512 at 64 spp" in c1["cpu_baseline"]["sample"] and c1["value"] > 100 * c1["cpu_baseline"]["value"]
 
 
+def test_committed_line_times_the_reference_code_beside_the_kernel():
+    """BASELINE configs[0] (Cornell 512x512, 64 spp) rides in extra_configs with BOTH CPU legs: the oracle on all cores ("port") and
+    the reference's own MegaPath code through oracle/_ref on one thread ("reference")."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02j_bench_c2_1gpu.json")))
+    c1 = line["extra_configs"][0]
+    assert "Cornell" in c1["workload"] and c1["cpu_baseline"]["kind"] == "port" and c1["cpu_baseline"]["cores"] >= 1
+    ref = c1["cpu_reference"]
+    assert ref["kind"] == "reference" and ref["cores"] == 1 and ref["unit"] == "Msamples/s" and 0.01 < ref["value"] < c1["value"]
+
+
 def test_product_package_never_imports_the_oracle():
     """oracle/ is the checker: nothing under luisarender_amd/ (Python or C++/HIP) may import, include, link or dlopen it."""
     import re
