@@ -194,3 +194,26 @@ def test_catmull_clark_handles_triangles_and_ngons_and_renders(tmp_path):
     assert img[12:20, 12:20].mean() < 0.95 * img[0:4, 0:4].mean() and np.isfinite(img).all()  # the solid shades, the sky is 1
     with pytest.raises(Exception, match="out of range"):
         _cc(tmp_path, tet, 9)
+
+
+def test_catmull_clark_joins_topology_by_position_across_uv_seams(tmp_path):
+    """a cube whose six faces carry their own uvs (24 distinct corners, 8 positions): the subdivider's adjacency goes by position, so
+    the surface stays closed and lands on the same 26 points as the cube without uvs.  Every attribute goes through the same
+    weights over that adjacency, so uvs are blended ACROSS the seams (the restated behaviour of assimp's subdivider, unpinned):
+    corners that share a position come out with one uv and are joined again"""
+    lines = [l for l in CUBE_OBJ.strip().splitlines() if l.startswith("v ")] + ["vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1"]
+    for l in [l for l in CUBE_OBJ.strip().splitlines() if l.startswith("f ")]:
+        idx = l.split()[1:]
+        lines.append("f " + " ".join(f"{v}/{k + 1}" for k, v in enumerate(idx)))
+    verts, tris = _mesh(_cc(tmp_path, "\n".join(lines), 1, flags="drop_normal { true } flip_uv { true }"))
+    plain, _ = _mesh(_cc(tmp_path, CUBE_OBJ, 1))
+    pos = {tuple(np.round(p, 5)) for p in verts[:, :3]}
+    assert pos == {tuple(np.round(p, 5)) for p in plain[:, :3]} and len(pos) == 26
+    assert len(tris) == 48
+    by_pos = {}
+    for a, b in _edges(tris).tolist():  # watertight BY POSITION: every edge has its opposite
+        key = (tuple(np.round(verts[a, :3], 5)), tuple(np.round(verts[b, :3], 5)))
+        by_pos[key] = by_pos.get(key, 0) + 1
+    assert all(by_pos.get((b, a), 0) == n for (a, b), n in by_pos.items())
+    uv = verts[:, 6:]
+    assert uv.min() >= -1e-6 and uv.max() <= 1 + 1e-6 and np.isfinite(verts).all()
