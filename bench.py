@@ -115,6 +115,10 @@ def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
     import subprocess
     if shutil.which("rocprofv3") is None:
         return None
+    # already under a profiler (someone runs `rocprofv3 ... -- python bench.py`): no nested passes; the committed profile of the same
+    # source hash (profiles/pmc_<workload>.json) answers instead
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
     desc, res, _, _ = WORKLOADS[workload]
     samples = res[0] * res[1] * spp
     out = {"spp": spp, "samples_per_launch": samples, "tool": "rocprofv3 --pmc (separate passes) --kernel-trace"}
@@ -271,6 +275,7 @@ def main():
                     try:
                         p = json.load(open(prof))
                         if p.get("source_hash") == source_hash() and p.get("hbm_bytes_per_sample"):  # a profile of another build is not evidence
+                            p.setdefault("valu_wave_instr_per_sample", p.get("valu_wave_instructions_per_sample"))
                             pmc, pmc_source = p, f"profiles/pmc_{args.workload}.json (same source hash)"
                     except Exception:
                         pass
