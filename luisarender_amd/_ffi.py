@@ -217,5 +217,6 @@ def hip_lib() -> C.CDLL:
         lib.lrhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         lib.lrhip_last_variant.restype = C.c_uint32
         lib.lrhip_last_variant.argtypes = [C.c_void_p]
+        lib.lrhip_set_diagnostics.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
         lib._lr_ready = True
     return lib

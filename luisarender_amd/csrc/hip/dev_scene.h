@@ -180,11 +180,6 @@ struct RenderArgs {
     uint32_t *spill;       // traversal stack overflow area [kSpillEntries][total_threads]
     uint32_t total_threads;
     DCounters *counters;
-    // deferred heavy hits (megapath_kernel.h, variants with out-of-line closures): per wave `heavy_capacity` entries of
-    // kHeavyQueueWords words, field-major ([field][slot]) so that a wave's pushes and pops are coalesced; nullptr / 0 = none
-    uint32_t *heavy_queue;
-    uint32_t heavy_capacity;
 };
-constexpr uint32_t kHeavyQueueWords = 30u;// 22 words of path state + up to 8 of sampler state
 
 }// namespace lrd

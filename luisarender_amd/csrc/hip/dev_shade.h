@@ -615,7 +615,7 @@ LR_D void resolve_pending_alpha(const DScene &scene, const TraversalStack &stack
     if ((tr.phase & kPhasePendingAlpha) != 0u) {
         const auto phase = tr.phase & ~kPhasePendingAlpha;
         const auto tri_index = tr.cur & ((1u << 27u) - 1u);
-        const auto tb = reinterpret_cast<const float4 *>(scene.bvh_tris) + static_cast<size_t>(tri_index) * (LR_TRI_STRIDE / 16u);
+        const auto tb = reinterpret_cast<const float4 *>(scene.bvh_tris) + static_cast<size_t>(tri_index) * 3u;
         const auto inst = __float_as_uint(tb[0].w), prim = __float_as_uint(tb[1].w);
         if (!alpha_skip(scene, inst, prim, tr.pend_u, tr.pend_v)) {
             tr.t_max = tr.pend_t;

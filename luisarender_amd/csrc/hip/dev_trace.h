@@ -85,22 +85,23 @@ struct TraversalStack {
     }
 };
 
-#ifndef LR_SLAB_SIGN
-#define LR_SLAB_SIGN 1
+// Round 3 (profiles/r03_valu_peak.json: on gfx950 only v_fma / v_mul / v_add / v_and / v_xor / v_mov issue every 2 cycles per
+// wave64; every min / max / cvt / cndmask / cmp / shift / 64-bit add / DPP / packed op takes 4, LDS-crossing ds_bpermute 25):
+//   LR_FETCH_QUAD  the packet fetch is organised by QUADS: load j of lane l fetches quarter (l & 3) of the packet of lane
+//                  (l & ~3) + j, whose node index comes over a DPP quad_perm broadcast (VALU) instead of a ds_bpermute (LDS);
+//                  addresses are 32-bit offsets from the scalar table base (global_load_lds saddr form), the LDS destinations
+//                  are wave-uniform SGPRs.  The four 1 KiB regions are 1040 bytes apart, which staggers them over the banks:
+//                  every lane's four ds_read_b128 are conflict-free without an XOR swizzle.
+//   LR_CHILD_LDS   the reference of a sorted child is read back from the staged packet (ds_read_b32 at slot * 4) instead of
+//                  a three-v_cndmask select per push; the four child words never enter the VGPRs.
+#ifndef LR_FETCH_QUAD
+#define LR_FETCH_QUAD 1
 #endif
-#ifndef LR_SLAB_PACKED
-#define LR_SLAB_PACKED 0// 1: the 24 plane FMAs as 12 v_pk_fma_f32 (round 1); 0: 24 v_fma_f32 -- +2.2 % once the SLP vectorizer is off (775 -> 792 on C2 at 256 spp): a v_pk_fma_f32 issues in 4.2 cycles against 2 x 2.4 and needs its operands in register pairs
+#ifndef LR_CHILD_LDS
+#define LR_CHILD_LDS 1
 #endif
-#ifndef LR_PUSH_UNSORTED
-#define LR_PUSH_UNSORTED 0
-#endif
-#ifndef LR_TRI_STRIDE
-#define LR_TRI_STRIDE 48u// bytes between baked BVH triangles on the device (64: one cache line each)
-#endif
-#ifndef LR_LDS_DIRECT
-#define LR_LDS_DIRECT 1
-#endif
-typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr uint32_t kStageRegion = LR_FETCH_QUAD ? 65u : 64u;// float4 per load region of the wave's staging area
+constexpr uint32_t kStageWave = 4u * kStageRegion;          // float4 per wave
 
 LR_D void cswap(uint32_t &a, uint32_t &b) {
     auto lo = min(a, b), hi = max(a, b);
@@ -116,6 +117,13 @@ LR_D f3 safe_inverse(f3 d) {
     };
     return mk3(one(d.x), one(d.y), one(d.z));
 }
+
+// fmaxf / fminf make the compiler canonicalise every operand that is not the result of an arithmetic instruction (a v_max_f32 x, x
+// per ray bound per node step); the slab test's operands are never signalling NaNs, so it names its instructions itself
+LR_D float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+LR_D float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+LR_D float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+LR_D float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 LR_D float ubyte_to_float(uint32_t v, int byte) {// v_cvt_f32_ubyteN
     return static_cast<float>((v >> (8 * byte)) & 0xffu);
@@ -162,61 +170,67 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
 template<bool COUNT, bool ALPHA>
 LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next,
                       const Ray &next_closest, int refill, TraceStats &stats, bool idle_at_entry) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(1))) const void global_void;
     const auto lane = threadIdx.x & 63u;
-    const auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
     const auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
-    // staging geometry: lane l loads part (l & 3) of the packets of owners (l >> 2) + 16 k, k = 0..3
+#if LR_FETCH_QUAD
+    // load j: lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j into region j, float4 slot l.  Lane o therefore finds
+    // its own packet in region (o & 3), slots 4 (o >> 2) .. + 3, in order
+    const auto node_bytes = reinterpret_cast<const char *>(scene.nodes);
+    const auto quarter = (lane & 3u) << 4u;
+    const auto mine = stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u;
+#else
+    // load k: lane l fetches quarter (l & 3) ^ swizzle of the packet of lane (l >> 2) + 16 k
+    const auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
     const auto part = lane & 3u;
     const auto owner0 = lane >> 2u;
     const auto my_swz = (lane >> 2u) & 3u;
+    const auto mine = stack.stage + lane * 4u;
+#endif
     auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
         auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
         auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
         if (__any(is_inner)) {
-            // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS -> 4 ds_read_b128 per lane
+            // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
+            // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
             auto want = is_inner ? tr.cur : 0u;
+#if LR_FETCH_QUAD
+#define LR_FETCH(j) { \
+                const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, false)); /* quad_perm:[j,j,j,j] */ \
+                __builtin_amdgcn_global_load_lds((global_void *)(node_bytes + ((w << 6u) | quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
+            LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
+#undef LR_FETCH
+#else
             auto n0 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0)));
             auto n1 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 16u)));
             auto n2 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 32u)));
             auto n3 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 48u)));
-#if LR_LDS_DIRECT
-            // global_load_lds_dwordx4: the 16 bytes of lane l land at stage[l] without a trip through the VGPRs; the XOR
-            // swizzle moves from the LDS address to WHICH part of the packet a lane asks for
-            {
-                typedef __attribute__((address_space(3))) void lds_void;
-                typedef __attribute__((address_space(1))) const void global_void;
-                const auto psw = part ^ ((owner0 >> 2u) & 3u);
-                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n0) * 4u + psw), (lds_void *)(stack.stage), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n1) * 4u + psw), (lds_void *)(stack.stage + 64), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n2) * 4u + psw), (lds_void *)(stack.stage + 128), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n3) * 4u + psw), (lds_void *)(stack.stage + 192), 16, 0, 0);
-                __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-#else
-            auto v0 = nodes[static_cast<size_t>(n0) * 4u + part];
-            auto v1 = nodes[static_cast<size_t>(n1) * 4u + part];
-            auto v2 = nodes[static_cast<size_t>(n2) * 4u + part];
-            auto v3 = nodes[static_cast<size_t>(n3) * 4u + part];
-            auto slot = owner0 * 4u + (part ^ ((owner0 >> 2u) & 3u));// ((owner0 + 16 k) >> 2) & 3 == (owner0 >> 2) & 3
-            stack.stage[slot] = v0;
-            stack.stage[slot + 64u] = v1;
-            stack.stage[slot + 128u] = v2;
-            stack.stage[slot + 192u] = v3;
-            // the packets were written by other lanes of this wave: order LDS writes before the reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const auto psw = part ^ ((owner0 >> 2u) & 3u);// the XOR swizzle that keeps the 16-lane ds_read_b128 groups conflict-free
+            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n0) * 4u + psw), (lds_void *)(stack.stage), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n1) * 4u + psw), (lds_void *)(stack.stage + 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n2) * 4u + psw), (lds_void *)(stack.stage + 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n3) * 4u + psw), (lds_void *)(stack.stage + 192), 16, 0, 0);
+#endif
+            __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if LR_FETCH_QUAD
+            const auto p0 = 0u, p1 = 1u, p2 = 2u, p3 = 3u;
+#else
+            const auto p0 = 0u ^ my_swz, p1 = 1u ^ my_swz, p2 = 2u ^ my_swz, p3 = 3u ^ my_swz;
 #endif
-            auto q0 = stack.stage[lane * 4u + (0u ^ my_swz)];
-            auto q1 = stack.stage[lane * 4u + (1u ^ my_swz)];
-            auto q2 = stack.stage[lane * 4u + (2u ^ my_swz)];
-            auto q3 = stack.stage[lane * 4u + (3u ^ my_swz)];
+            auto q0 = mine[p0], q1 = mine[p1], q2 = mine[p2];
+#if LR_CHILD_LDS
+            const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + p3));
+#else
+            auto q3 = mine[p3];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#endif
             if (is_inner) {
                 if (COUNT) { stats.nodes++; }
 #ifdef LR_PROBE_NODE
@@ -229,75 +243,38 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
 #endif
                 // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
                 //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
+                // An EMPTY slot has inverted planes (lo 255, hi 0) and names the scene's sentinel leaf (a triangle nothing hits,
+                // lrhip.hip: quantise_node), so it needs no test of its own: it fails the slab test wherever the node has an extent
+                // and costs one wasted triangle test where it has none.
                 auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
                 auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
                 auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
                 auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-                uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
                 uint32_t key[4];
-#if LR_SLAB_SIGN
-                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis,
-                // and the 24 plane FMAs go out as 12 v_pk_fma_f32 over child pairs
+                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis
                 auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
                 auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
                 auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
-#if !LR_SLAB_PACKED
 #pragma unroll
-                for (auto i = 0; i < 4; i++) {// the same with 24 scalar v_fma_f32
-                    auto tn = fmaxf(fmaxf(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by)),
-                                    fmaxf(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
-                    auto tf = fminf(fminf(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by)),
-                                    fminf(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
-                    auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
+                for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
+                    auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),
+                                    vmax2(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
+                    auto tf = vmin3(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by),
+                                    vmin2(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
+                    auto h = tn <= tf * 1.0000004f;
                     key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
                 }
+#if LR_CHILD_LDS
+                auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
 #else
-                v2f a_x = {ax, ax}, a_y = {ay, ay}, a_z = {az, az}, b_x = {bx, bx}, b_y = {by, by}, b_z = {bz, bz};
-#pragma unroll
-                for (auto p = 0; p < 4; p += 2) {
-                    v2f qnx = {ubyte_to_float(nx, p), ubyte_to_float(nx, p + 1)}, qfx = {ubyte_to_float(fx, p), ubyte_to_float(fx, p + 1)};
-                    v2f qny = {ubyte_to_float(ny, p), ubyte_to_float(ny, p + 1)}, qfy = {ubyte_to_float(fy, p), ubyte_to_float(fy, p + 1)};
-                    v2f qnz = {ubyte_to_float(nz, p), ubyte_to_float(nz, p + 1)}, qfz = {ubyte_to_float(fz, p), ubyte_to_float(fz, p + 1)};
-                    auto tnx = __builtin_elementwise_fma(qnx, a_x, b_x), tfx = __builtin_elementwise_fma(qfx, a_x, b_x);
-                    auto tny = __builtin_elementwise_fma(qny, a_y, b_y), tfy = __builtin_elementwise_fma(qfy, a_y, b_y);
-                    auto tnz = __builtin_elementwise_fma(qnz, a_z, b_z), tfz = __builtin_elementwise_fma(qfz, a_z, b_z);
-#pragma unroll
-                    for (auto j = 0; j < 2; j++) {
-                        auto i = p + j;
-                        auto tn = fmaxf(fmaxf(tnx[j], tny[j]), fmaxf(tnz[j], tr.t_min));
-                        auto tf = fminf(fminf(tfx[j], tfy[j]), fminf(tfz[j], tr.t_max));
-                        auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
-                        key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
-                    }
-                }
-#endif
-#else
-#pragma unroll
-                for (auto i = 0; i < 4; i++) {
-                    auto t0x = fmaf(ubyte_to_float(lox, i), ax, bx), t1x = fmaf(ubyte_to_float(hix, i), ax, bx);
-                    auto t0y = fmaf(ubyte_to_float(loy, i), ay, by), t1y = fmaf(ubyte_to_float(hiy, i), ay, by);
-                    auto t0z = fmaf(ubyte_to_float(loz, i), az, bz), t1z = fmaf(ubyte_to_float(hiz, i), az, bz);
-                    auto tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tr.t_min));
-                    auto tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tr.t_max));
-                    auto h = (tn <= tf * 1.0000004f) && (ch[i] != kInvalid);
-                    key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
-                }
-#endif
+                uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
                 auto ref_of = [&](uint32_t k) {// two-level v_cndmask select on the slot bits (no branches)
                     auto lo = (k & 1u) ? ch[1] : ch[0];
                     auto hi = (k & 1u) ? ch[3] : ch[2];
                     return (k & 2u) ? hi : lo;
                 };
-#if LR_PUSH_UNSORTED
-                // the nearest child continues in `cur`; the other hit children are pushed in slot order (their refs are
-                // plain registers then, no select) — only the order among the far children is not by distance
-                auto kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-#pragma unroll
-                for (auto i = 0; i < 4; i++) {
-                    if (key[i] != kInvalid && key[i] != kmin) { stack.push(tr.sp++, ch[i]); }
-                }
-                key[0] = kmin;
-#else
+#endif
+                // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
                 cswap(key[0], key[1]);
                 cswap(key[2], key[3]);
                 cswap(key[0], key[2]);
@@ -307,12 +284,17 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
                 if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
                 if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
-#endif
                 if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
                 if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
                 else if (tr.sp > 0u) { tr.cur = stack.pop(--tr.sp); }
                 else { tr.cur = kInvalid; }
             }
+#if LR_CHILD_LDS
+            // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
+            __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#endif
         }
         // ---- leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds one-triangle
         // leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
@@ -321,7 +303,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
             auto found = false;
             {
-                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * (LR_TRI_STRIDE / 16u);
+                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
                 auto a = tb[0], b = tb[1], c = tb[2];
                 if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF

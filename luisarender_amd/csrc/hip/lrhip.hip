@@ -95,7 +95,7 @@ struct lrhip_ctx {
     bool scene_ready{false};
     uint32_t width{0}, height{0};
     float film_scale[3]{1.f, 1.f, 1.f};
-    DeviceBuffer film_own, converted, partial, spill, counters, work_counter, heavy_queue;
+    DeviceBuffer film_own, converted, partial, spill, counters, work_counter;
     DeviceBuffer scene_record;// lrd::DScene in device memory: the kernels read it through scalar loads (dev_scene.h: DScenePtr)
     float4 *film{nullptr};// bound film (own or external)
     float4 *film_external{nullptr};// lrhip_bind_film's buffer; kept across uploads of the same resolution
@@ -107,6 +107,8 @@ struct lrhip_ctx {
     uint32_t last_variant{0u};// feature mask of the kernel the last lrhip_render launched
     uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
+    uint32_t diag_force_features{0u};// lrhip_set_diagnostics (tests / tools)
+    double diag_item_scale{0.};
 };
 
 namespace {
@@ -162,7 +164,10 @@ void normal_matrix(const float *m, float out[9]) {
 
 // fp32 child boxes -> 64-byte quantised packet; conservative: decoded lo <= lo, decoded hi >= hi in the
 // same fp32 fma the kernel uses (dev_trace.h)
-lrd::DNodeQ quantise_node(const lr_bvh4_node &n) {
+// An empty slot gets inverted planes (lo 255, hi 0) AND the reference of the sentinel leaf (`empty_ref`: a triangle nothing hits, behind
+// the last baked triangle): the kernel tests no child word, an empty slot misses wherever the node has an extent and costs one
+// wasted triangle test where it has none.
+lrd::DNodeQ quantise_node(const lr_bvh4_node &n, uint32_t empty_ref) {
     lrd::DNodeQ q{};
     const float *lo[3] = {n.lo_x, n.lo_y, n.lo_z};
     const float *hi[3] = {n.hi_x, n.hi_y, n.hi_z};
@@ -199,7 +204,7 @@ lrd::DNodeQ quantise_node(const lr_bvh4_node &n) {
     q.scale_x = scale[0], q.scale_y = scale[1], q.scale_z = scale[2];
     q.lo_x = plo[0], q.lo_y = plo[1], q.lo_z = plo[2];
     q.hi_x = phi[0], q.hi_y = phi[1], q.hi_z = phi[2];
-    for (auto c = 0; c < 4; c++) { q.child[c] = n.child[c]; }
+    for (auto c = 0; c < 4; c++) { q.child[c] = n.child[c] == LR_INVALID_ID ? empty_ref : n.child[c]; }
     return q;
 }
 
@@ -224,13 +229,14 @@ uint32_t bvh_depth(const lr_accel &accel) {
 // lrhip_update_scene, which copies them over the existing device buffers
 std::vector<lrd::DNodeQ> build_packed_nodes(const lr_scene *s) {
     std::vector<lrd::DNodeQ> packed(s->accel.node_count);
-    for (uint32_t i = 0; i < s->accel.node_count; i++) { packed[i] = quantise_node(s->accel.nodes[i]); }
+    const auto empty_ref = lrd::kLeafFlag | s->accel.triangle_count;// the sentinel of build_padded_triangles
+    for (uint32_t i = 0; i < s->accel.node_count; i++) { packed[i] = quantise_node(s->accel.nodes[i], empty_ref); }
     return packed;
 }
 
-std::vector<uint8_t> build_padded_triangles(const lr_scene *s) {// the baked triangles at the device stride (dev_trace.h: LR_TRI_STRIDE)
-    std::vector<uint8_t> out(static_cast<size_t>(s->accel.triangle_count) * LR_TRI_STRIDE, 0u);
-    for (uint32_t i = 0; i < s->accel.triangle_count; i++) { std::memcpy(out.data() + static_cast<size_t>(i) * LR_TRI_STRIDE, s->accel.triangles + i, sizeof(lr_bvh_triangle)); }
+std::vector<uint8_t> build_padded_triangles(const lr_scene *s) {// the baked triangles + the all-zero sentinel the empty node slots name (flags 0: never hit)
+    std::vector<uint8_t> out((static_cast<size_t>(s->accel.triangle_count) + 1u) * sizeof(lr_bvh_triangle), 0u);
+    std::memcpy(out.data(), s->accel.triangles, static_cast<size_t>(s->accel.triangle_count) * sizeof(lr_bvh_triangle));
     return out;
 }
 
@@ -327,7 +333,7 @@ void lrhip_destroy(lrhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     release_scene(ctx);
     ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
-    ctx->spill.release(), ctx->heavy_queue.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
+    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -451,6 +457,10 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     ctx->bvh_depth = bvh_depth(s->accel);
     if (ctx->bvh_depth == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the BVH must have one-triangle leaves (lrhost_scene_build_accel builds them)"); }
     ctx->features = s->any_non_opaque != 0u ? lrd::kFeatAlpha : 0u;
+    // a leaf names its triangle in 27 bits (the sentinel of the empty slots is one more) and the fetch addresses packets by 32-bit byte offsets
+    if (s->accel.triangle_count >= (1u << 27u) - 1u || s->accel.node_count >= (1u << 26u)) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 2^27 - 2 BVH triangles or 2^26 - 1 BVH packets");
+    }
     if (ctx->bvh_depth * 3u > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");
@@ -715,7 +725,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // hint — uses the same chunking.
     auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
     auto item_scale = 1.25;
-    if (auto e = std::getenv("LRHIP_ITEM_SCALE")) { item_scale *= std::max(0.01, std::atof(e)); }// tools/ only: sweep of the loss model's constant
+    if (ctx->diag_item_scale > 0.) { item_scale *= std::max(0.01, ctx->diag_item_scale); }// lrhip_set_diagnostics: sweep of the loss model's constant
     auto s_item = std::sqrt(item_scale * spp * shard_tiles / kNominalWaves);
     auto chunk_count = static_cast<uint32_t>(std::lround(spp / std::max(s_item, 1.0)));
     chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
@@ -740,7 +750,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
     auto features = ctx->features;
-    if (auto force = std::getenv("LRHIP_FORCE_FEATURES")) { features |= static_cast<uint32_t>(std::atoi(force)) & lrd::kFeatSceneMask; }// tools/ only: A/B of a variant on a scene that does not need it
+    features |= ctx->diag_force_features & lrd::kFeatSceneMask;// lrhip_set_diagnostics: A/B of a variant on a scene that does not need it
     auto vi = pick_variant(features, count, generic);
     if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +
@@ -753,18 +763,6 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
-    // deferred heavy hits (megapath_kernel.h, -DLR_HEAVY_QUEUE=1 builds only -- measured and off in the shipped library): a queue
-    // per resident wave in the variants with out-of-line closures, LRHIP_HEAVY_QUEUE=<entries per wave> (2048 entries x 120 B x
-    // 4096 waves = 1 GB of the 288).  Unset: nothing is allocated and such a build parks in the lane like the shipped one.
-    if ((kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u && (kVariants[vi].mask & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        auto capacity = 0u;
-        if (auto e = std::getenv("LRHIP_HEAVY_QUEUE")) { capacity = static_cast<uint32_t>(std::max(0, std::atoi(e))); }
-        if (capacity != 0u) {
-            auto waves = static_cast<size_t>(args.total_threads / 64u);
-            if (auto r = ensure(ctx->heavy_queue, waves * capacity * lrd::kHeavyQueueWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
-            args.heavy_queue = static_cast<uint32_t *>(ctx->heavy_queue.ptr), args.heavy_capacity = capacity;
-        }
-    }
     auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns
@@ -781,6 +779,12 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
                            args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
         LR_HIP_CHECK(hipGetLastError());
     }
+    return LRHIP_OK;
+}
+
+int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale) {
+    if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_diagnostics: ctx is NULL"); }
+    ctx->diag_force_features = force_features, ctx->diag_item_scale = item_scale;
     return LRHIP_OK;
 }
 

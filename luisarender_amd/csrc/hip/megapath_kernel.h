@@ -114,65 +114,19 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #ifndef LR_HEAVY_BATCH_LAYERED
 #define LR_HEAVY_BATCH_LAYERED 16
 #endif
-// Deferred heavy hits (round 2, second step).  Parking keeps the lane: it waits idle through the traversal rounds of the others
-// (traversal lane occupancy 58 % -> 46 % on the kitchen stand-in) and the heavy code still runs for 12-16 lanes of 64.  With a queue
-// in HBM (RenderArgs::heavy_queue, ~100 bytes per entry, 288 GB are there) the lane writes the 22 + sampler words of its path out,
-// takes the next sample of the item, and the path comes back when the item's sample queue has run dry and LR_HEAVY_POP lanes are
-// free (or nothing else is left): the out-of-line closures then run for full waves, and the continuation rays of those paths are
-// traced together.  The queue is per wave and per item; a full queue falls back to parking.  LR_HEAVY_DIRECT ready heavy lanes
-// are shaded on the spot.
-// MEASURED, OFF BY DEFAULT: kitchen stand-in 274 -> 300 Msamples/s with the default SGPR spilling -- and 256 -> 246 with the
-// spill-to-memory flag the call-making variants are built with (Makefile: CALL_SAFE_FLAGS), under which its extra wave-uniform
-// state costs more than the full batches give back.  -DLR_HEAVY_QUEUE=1 with LRHIP_HEAVY_QUEUE=<entries per wave> at run time
-// brings it back (tools/ only; the shipped library allocates nothing for it).
-#ifndef LR_HEAVY_QUEUE
-#define LR_HEAVY_QUEUE 0
-#endif
-#ifndef LR_HEAVY_FENCE
-#define LR_HEAVY_FENCE 0
-#endif
-#ifndef LR_HEAVY_POP
-#define LR_HEAVY_POP 48
-#endif
-#ifndef LR_HEAVY_DIRECT
-#define LR_HEAVY_DIRECT 40
-#endif
 #ifndef LR_WAVES_MIX
 #define LR_WAVES_MIX LR_MIN_WAVES
 #endif
 constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : (f & kFeatMix) ? LR_WAVES_MIX : LR_MIN_WAVES; }
 
-// Work distribution, XCD-aware: MI355X is 8 XCDs with an L2 each, and workgroups are dealt to the XCDs round-robin
-// (blockIdx.x & 7).  The item space (tiles x sample-chunks, tile-major) is cut into 8 contiguous ranges with a counter each
-// (128 bytes apart); a wave draws from the range of its own XCD, so the waves that share an L2 work on neighbouring tiles
-// and re-use each other's BVH lines, and steals from the other ranges, in order, once its own is dry.  Which wave renders
-// an item never shows in the film (megapath_kernel.h header), so this changes speed only.  LR_XCD_QUEUES=0: one counter.
-// MEASURED AND NOT KEPT (round 2, C2 at 256 spp, two A/B pairs): 677 / 678 Msamples/s with the per-XCD ranges against 684 / 685 with
-// one counter.  With one counter the 4096 resident waves work on a moving front of ~300 neighbouring tiles, so every L2 already
-// holds the front's BVH lines; eight separate fronts only add eight tails.  The code stays for the next scene that disagrees.
-#ifndef LR_XCD_QUEUES
-#define LR_XCD_QUEUES 0
-#endif
-constexpr uint32_t kXcdCount = 8u, kWorkCounterStride = 32u;// counters 128 B apart
-LR_D uint32_t next_item(const RenderArgs &args, uint32_t lane, uint32_t &probe) {
-#if LR_XCD_QUEUES
-    const auto per = (args.item_count + kXcdCount - 1u) / kXcdCount;
-    const auto home = blockIdx.x & (kXcdCount - 1u);
-    for (; probe < kXcdCount; probe++) {// wave-uniform
-        const auto q = (home + probe) & (kXcdCount - 1u);
-        const auto lo = q * per, hi = min(lo + per, args.item_count);
-        uint32_t i = 0u;
-        if (lane == 0u) { i = atomicAdd(args.work_counter + q * kWorkCounterStride, 1u); }
-        i = __shfl(i, 0);
-        if (lo + i < hi) { return lo + i; }
-    }
-    return kInvalid;
-#else
+// Work distribution: ONE atomic counter over the item space (tiles x sample-chunks, tile-major).  The 4096 resident waves then work
+// on a moving front of ~300 neighbouring tiles, so every XCD's L2 already holds the front's BVH lines; per-XCD item ranges were
+// measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/r02b_ab_xcd_waves.txt).
+LR_D uint32_t next_item(const RenderArgs &args, uint32_t lane) {
     uint32_t item = 0u;
     if (lane == 0u) { item = atomicAdd(args.work_counter, 1u); }
     item = __shfl(item, 0);
     return item < args.item_count ? item : kInvalid;
-#endif
 }
 
 template<uint32_t F>
@@ -184,22 +138,20 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
     constexpr int HEAVY_BATCH = LAYERED ? LR_HEAVY_BATCH_LAYERED : LR_HEAVY_BATCH;
     constexpr bool PARK_HEAVY = (MIX || LAYERED) && !AUX && HEAVY_BATCH > 1;
-    constexpr bool DEFER_HEAVY = PARK_HEAVY && LR_HEAVY_QUEUE != 0;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
-    __shared__ float4 s_stage[kWavesPerBlock * 256u];// 4 KiB of node packets per wave
+    __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
     __shared__ float4 s_film[kWavesPerBlock * 64u];// per-wave tile accumulators (sum r, g, b, n)
-    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + (tid >> 6u) * 256u};
+    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + __builtin_amdgcn_readfirstlane(tid >> 6u) * kStageWave};
     const auto film_tile = s_film + (tid >> 6u) * 64u;
     DCounters local{};
     const auto t_wave = COUNT ? __builtin_readcyclecounter() : 0ull;
-    auto xcd_probe = 0u;// how many item ranges this wave has found empty (next_item)
 
     for (;;) {
         // ---- next work item of this wavefront
-        uint32_t item = next_item(args, lane, xcd_probe);
+        uint32_t item = next_item(args, lane);
         if (item == kInvalid) { break; }
         const auto tile_index = item / args.chunk_count;
         const auto chunk = item - tile_index * args.chunk_count;
@@ -224,18 +176,6 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         auto pdf_bsdf = 1e16f;
         auto depth = 0u;
         auto path_open = false, traced_shadow = false, traced_closest = false;
-        // deferred heavy hits of this item (wave-uniform count; `forced`: a path that just came back and is shaded now)
-        auto heavy_count = 0u;
-        auto forced = false;
-        const auto heavy_cap = DEFER_HEAVY ? args.heavy_capacity : 0u;
-        const auto heavy_base = DEFER_HEAVY && heavy_cap != 0u ? args.heavy_queue + static_cast<size_t>(gtid >> 6u) * heavy_cap * kHeavyQueueWords : nullptr;
-        auto heavy_put = [&](uint32_t slot, uint32_t field, uint32_t v) {
-            __hip_atomic_store(heavy_base + static_cast<size_t>(field) * heavy_cap + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto heavy_get = [&](uint32_t slot, uint32_t field) {
-            return __hip_atomic_load(heavy_base + static_cast<size_t>(field) * heavy_cap + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-
         for (;;) {
             // ==== (A) lanes without a ray in flight: consume results and shade
             auto want_shadow = false, want_closest = false;
@@ -260,35 +200,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
 #endif
                     heavy_hit = (flags & LR_SHAPE_HAS_SURFACE) != 0u && scene.closures[(tags >> 12u) & 4095u].kind >= LR_SURFACE_DISNEY;
                 }
-                if (forced) { heavy_hit = false; }// (back from the queue: shaded in this round whatever the company)
-                const auto heavy_mask = __ballot(heavy_hit);
-                const auto heavy_lanes = __popcll(heavy_mask);
-                if (DEFER_HEAVY && heavy_lanes > 0 && heavy_lanes < LR_HEAVY_DIRECT && heavy_count + 64u <= heavy_cap) {
-                    if (heavy_hit) {// the path leaves the lane: everything the shading of this vertex and the rest of the path need
-                        const auto slot = heavy_count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(heavy_mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(heavy_mask), 0u));
-                        auto fb = [](float x) { return __float_as_uint(x); };
-                        const uint32_t fields[21] = {fb(tr.o.x), fb(tr.o.y), fb(tr.o.z), fb(tr.d.x), fb(tr.d.y), fb(tr.d.z), fb(tr.hit.u), fb(tr.hit.v),
-                                                     fb(beta.x), fb(beta.y), fb(beta.z), fb(Li.x), fb(Li.y), fb(Li.z), fb(nee.x), fb(nee.y), fb(nee.z),
-                                                     fb(pdf_bsdf), tr.hit.inst, tr.hit.prim, tr.hit.tri};
-#pragma unroll
-                        for (auto f = 0u; f < 21u; f++) { heavy_put(slot, f, fields[f]); }
-#if LR_HEAVY_FENCE
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-                        heavy_put(slot, 21u, depth | (static_cast<uint32_t>(pixel - film_tile) << 16u) | (traced_shadow ? 1u << 24u : 0u) | (tr.occluded ? 1u << 25u : 0u));
-                        uint32_t words[8];
-                        const auto n_words = sampler.save(words);
-                        for (auto f = 0u; f < n_words; f++) { heavy_put(slot, 22u + f, words[f]); }
-                        path_open = false, traced_closest = false, traced_shadow = false;// the lane is free for the next sample
-                    }
-                    heavy_count += static_cast<uint32_t>(heavy_lanes);
-                } else if (heavy_lanes > 0 && heavy_lanes < HEAVY_BATCH) {
+                const auto heavy_lanes = __popcll(__ballot(heavy_hit));
+                if (heavy_lanes > 0 && heavy_lanes < HEAVY_BATCH) {
                     const auto others = __any(tr.phase != kPhaseIdle || (ready && !heavy_hit) || (tr.phase == kPhaseIdle && !path_open && q_next < q_total));
                     parked = heavy_hit && others;
                 }
             }
             if (tr.phase == kPhaseIdle && !parked) {
-                forced = false;
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
                     if (!tr.occluded) { Li += nee; }
                     traced_shadow = false;
@@ -468,41 +386,6 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     }
                 }
             }
-            // ==== (A'') deferred heavy hits come back: once the item's samples are handed out (or the queue is nearly full), as soon
-            // as LR_HEAVY_POP lanes are free or nothing else is going on; they are shaded in the next round, together
-            if (DEFER_HEAVY && heavy_count > 0u) {
-                const auto free_lane = tr.phase == kPhaseIdle && !path_open && !want_shadow && !want_closest;
-                const auto free_mask = __ballot(free_lane);
-                const auto free_count = static_cast<uint32_t>(__popcll(free_mask));
-                const auto busy = __any(tr.phase != kPhaseIdle || want_shadow || want_closest || parked);
-                if ((q_next >= q_total || heavy_count + 128u > heavy_cap) && free_count > 0u && (free_count >= min(heavy_count, static_cast<uint32_t>(LR_HEAVY_POP)) || !busy)) {
-                    const auto n = min(free_count, heavy_count);
-                    const auto rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(free_mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(free_mask), 0u));
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");// the pushes of this wave have landed; nothing stale is read
-                    if (free_lane && rank < n) {
-                        const auto slot = heavy_count - 1u - rank;
-                        uint32_t fields[21];
-#pragma unroll
-                        for (auto f = 0u; f < 21u; f++) { fields[f] = heavy_get(slot, f); }
-                        auto bf = [](uint32_t x) { return __uint_as_float(x); };
-                        tr.o = mk3(bf(fields[0]), bf(fields[1]), bf(fields[2])), tr.d = mk3(bf(fields[3]), bf(fields[4]), bf(fields[5]));
-                        tr.hit.u = bf(fields[6]), tr.hit.v = bf(fields[7]);
-                        beta = mk3(bf(fields[8]), bf(fields[9]), bf(fields[10])), Li = mk3(bf(fields[11]), bf(fields[12]), bf(fields[13]));
-                        nee = mk3(bf(fields[14]), bf(fields[15]), bf(fields[16]));
-                        pdf_bsdf = bf(fields[17]);
-                        tr.hit.inst = fields[18], tr.hit.prim = fields[19], tr.hit.tri = fields[20];
-                        const auto packed = heavy_get(slot, 21u);
-                        depth = packed & 0xffffu;
-                        pixel = film_tile + ((packed >> 16u) & 63u);
-                        traced_shadow = (packed & (1u << 24u)) != 0u, tr.occluded = (packed & (1u << 25u)) != 0u;
-                        uint32_t words[8];
-                        for (auto f = 0u; f < PathSampler<PCG>::kSavedWords; f++) { words[f] = heavy_get(slot, 22u + f); }
-                        sampler.restore(scene, words);
-                        path_open = true, traced_closest = true, forced = true;
-                    }
-                    heavy_count -= n;
-                }
-            }
             if (tr.phase == kPhaseIdle) {
                 // ---- launch: shadow ray first, the continuation ray follows inside the traversal loop
                 if (want_shadow || want_closest) {
@@ -515,7 +398,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                 }
             }
             if (!__any(tr.phase != kPhaseIdle)) {
-                if (PARK_HEAVY && (heavy_count > 0u || __any(parked || forced))) { continue; }// parked / deferred paths are left: shade them now
+                if (PARK_HEAVY && __any(parked)) { continue; }// parked paths are left: shade them now
                 break;// every lane of the tile is out of samples
             }
             // ==== (B) traverse until `refill` lanes have results to shade

@@ -177,12 +177,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
     const DScene &scene = *(const DScene *)scene_ptr;
     constexpr bool COUNT = (F & 1u) != 0u, PCG = (F & 2u) != 0u;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
-    __shared__ float4 s_stage[kWavesPerBlock * 256u];
+    __shared__ float4 s_stage[kWavesPerBlock * kStageWave];
     __shared__ float4 s_film[kWavesPerBlock * 64u];
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
-    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + (tid >> 6u) * 256u};
+    TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + __builtin_amdgcn_readfirstlane(tid >> 6u) * kStageWave};
     const auto film_tile = s_film + (tid >> 6u) * 64u;
     DCounters local{};
 

@@ -413,7 +413,7 @@ public:
             if (path.empty()) { throw Error{"No valid values given for property 'file'. [" + d->location() + "]"}; }
             auto ext = fs::path{path}.extension().string();
             for (auto &c : ext) { c = static_cast<char>(std::tolower(c)); }
-            auto encoding = d->string_or("encoding", (ext == ".exr" || ext == ".hdr" || ext == ".pfm") ? "linear" : "sRGB");
+            auto encoding = d->string_or("encoding", (ext == ".exr" || ext == ".hdr") ? "linear" : "sRGB");
             for (auto &c : encoding) { c = static_cast<char>(std::tolower(c)); }
             t.gamma[0] = t.gamma[1] = t.gamma[2] = 1.f;
             if (encoding == "srgb") { t.encoding = LR_TEX_ENC_SRGB; }

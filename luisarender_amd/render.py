@@ -120,6 +120,11 @@ class MegaPathRenderer:
         """feature mask of the precompiled megakernel variant the last render() launched (lrhip.h LRHIP_FEAT_*)"""
         return int(self._lib.lrhip_last_variant(self._ctx))
 
+    def set_diagnostics(self, force_features: int = 0, item_scale: float = 0.0) -> None:
+        """tests / tools only (lrhip_set_diagnostics): render with a larger precompiled variant than the scene needs, or sweep
+        the work-item size; the library itself reads no environment variable"""
+        self._check(self._lib.lrhip_set_diagnostics(self._ctx, force_features, item_scale))
+
     def close(self) -> None:
         if self._ctx:
             self._lib.lrhip_destroy(self._ctx)

@@ -94,6 +94,18 @@ def tess_box(n):
     return np.concatenate(vs), np.concatenate(fs), None
 
 
+def inline_mesh(name, v, f, n=None, uv=None):
+    """the same mesh as an InlineMesh node (src/shapes/inline_mesh.cpp: positions / indices / normals / uvs) instead of a
+    Wavefront file behind `Mesh`: the reference's own plugins can load it without assimp (tests/test_oracle_vs_ref.py)"""
+    num = lambda a: ", ".join(f"{x:.7g}" for x in np.asarray(a, np.float64).reshape(-1))
+    s = f"Shape {name} : InlineMesh {{\n  positions {{ {num(v)} }}\n  indices {{ {', '.join(str(int(i)) for i in np.asarray(f).reshape(-1))} }}\n"
+    if n is not None:
+        s += f"  normals {{ {num(n)} }}\n"
+    if uv is not None:
+        s += f"  uvs {{ {num(uv)} }}\n"
+    return s + "}\n"
+
+
 _QUAD = "0, 1, 2, 0, 2, 3"
 
 
@@ -109,16 +121,20 @@ def _quad_shape(name, pts, surface=None, light=None):
 
 def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 1024), spp=1024, depth=16, seed=19980810,
                         glass_fraction=0.07, environment=None, open_windows=False, file="render.exr",
-                        sampler="Independent", name="bathroom"):
-    """Writes <out_dir>/<name>.luisa (+ OBJ meshes) and returns its path."""
+                        sampler="Independent", name="bathroom", inline_meshes=False,
+                        mesh_levels=(3, 4), torus_res=(48, 24), box_n=8):
+    """Writes <out_dir>/<name>.luisa (+ OBJ meshes) and returns its path.  inline_meshes: the fixtures' meshes as InlineMesh nodes
+    instead of OBJ files (same instances, transforms and materials; the form the reference's own code can load here)."""
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
     meshes = {
-        "ico3": icosphere(3), "ico4": icosphere(4), "torus": torus(48, 24), "box8": tess_box(8),
+        f"ico{mesh_levels[0]}": icosphere(mesh_levels[0]), f"ico{mesh_levels[1]}": icosphere(mesh_levels[1]),
+        "torus": torus(*torus_res), f"box{box_n}": tess_box(box_n),
     }
     tri_counts = {k: len(m[1]) for k, m in meshes.items()}
-    for k, (v, f, n) in meshes.items():
-        _write_obj(os.path.join(out_dir, f"{k}.obj"), v, f, n)
+    if not inline_meshes:
+        for k, (v, f, n) in meshes.items():
+            _write_obj(os.path.join(out_dir, f"{k}.obj"), v, f, n)
     out = []
     # surfaces: a palette per class
     other = 1.0 - glass_fraction
@@ -147,8 +163,8 @@ def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 102
     surf_names["mirror"].append("mirror0")
     out.append("Surface wall : Matte { Kd : Constant { v { 0.75, 0.73, 0.7 } } }\n")
     out.append("Surface floor_s : Matte { Kd : Constant { v { 0.4, 0.35, 0.3 } } }\n")
-    for k in meshes:
-        out.append(f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
+    for k, (v, f, n) in meshes.items():
+        out.append(inline_mesh(f"mesh_{k}", v, f, n) if inline_meshes else f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
     # room 4 x 3 x 4
     X, Y, Z = 4.0, 3.0, 4.0
     shapes = []

@@ -19,7 +19,7 @@ import zlib
 
 import numpy as np
 
-from .bathroom import _quad_shape, icosphere, tess_box, torus
+from .bathroom import _quad_shape, icosphere, inline_mesh, tess_box, torus
 
 
 def write_png(path, img8):
@@ -38,6 +38,37 @@ def write_png(path, img8):
     with open(path, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, color_type, 0, 0, 0))
                 + chunk(b"IDAT", zlib.compress(raw, 3)) + chunk(b"IEND", b""))
+
+
+def write_pfm(path, img):
+    """float RGB PFM (bottom row first)"""
+    img = np.asarray(img, np.float32)
+    h, w = img.shape[:2]
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(np.ascontiguousarray(img[::-1, :, :3]).tobytes())
+
+
+def _image(out_dir, stem, img8, inline, srgb):
+    """an 8-bit procedural image as PNG -- or, `inline`, as a float PFM holding byte / 255 with the encoding spelled out (the
+    reference's code compiled on the scalar stand-in reads PFM only, oracle/ref_shim); returns (file name, encoding property)"""
+    if not inline:
+        write_png(os.path.join(out_dir, stem + ".png"), img8)
+        return stem + ".png", "" if srgb else 'encoding { "linear" }'
+    img = np.asarray(img8, np.float32) / 255.0
+    if img.ndim == 2:
+        img = np.repeat(img[..., None], 3, axis=-1)
+    write_pfm(os.path.join(out_dir, stem + ".pfm"), img)
+    return stem + ".pfm", 'encoding { "sRGB" }' if srgb else 'encoding { "linear" }'
+
+
+def _sky(out_dir, img, inline):
+    from ..scene import save_image
+    if inline:
+        write_pfm(os.path.join(out_dir, "sky.pfm"), img)
+        return 'sky.pfm" } encoding { "linear'  # (only .exr / .hdr default to linear, src/textures/image.cpp:85-90)
+    save_image(os.path.join(out_dir, "sky.exr"), img)
+    return "sky.exr"
 
 
 def sun_sky_image(w=2048, h=1024, sun_dir=(0.55, 0.62, 0.3), sun_power=900.0, sun_sharpness=600.0):
@@ -202,10 +233,13 @@ render {{
 """)
 
 
-def _write_meshes(out_dir, out, meshes):
+def _write_meshes(out_dir, out, meshes, inline=False):
     for k, (v, f, n, uv) in meshes.items():
-        _write_obj_uv(os.path.join(out_dir, f"{k}.obj"), v, f, n, uv)
-        out.append(f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
+        if inline:
+            out.append(inline_mesh(f"mesh_{k}", v, f, n, uv))
+        else:
+            _write_obj_uv(os.path.join(out_dir, f"{k}.obj"), v, f, n, uv)
+            out.append(f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
     return {k: len(m[1]) for k, m in meshes.items()}
 
 
@@ -215,13 +249,13 @@ def _const(v):
 
 
 def generate_bedroom_scene(out_dir, target_triangles=600_000, resolution=(1280, 720), spp=4096, depth=16, seed=19980810,
-                           env_resolution=(2048, 1024), sampler="Independent", file="render.exr", name="bedroom"):
+                           env_resolution=(2048, 1024), sampler="Independent", file="render.exr", name="bedroom", inline=False,
+                           mesh_levels=(3, 4), torus_res=(48, 24), box_n=8):
     """C3: window openings + image environment (sun/sky) + 10 % Glass; no interior lamps (the room is lit through the
     windows and by the sun lobe, as the reference's Bedroom is)."""
-    from ..scene import save_image
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
-    save_image(os.path.join(out_dir, "sky.exr"), sun_sky_image(*env_resolution, sun_dir=(1.0, 0.55, 0.1)))
+    sky = _sky(out_dir, sun_sky_image(*env_resolution, sun_dir=(1.0, 0.55, 0.1)), inline)
     out, shapes = [], []
     palette = {"matte": [], "plastic": [], "metal": [], "glass": [], "mirror": []}
     for i in range(12):
@@ -241,7 +275,7 @@ def generate_bedroom_scene(out_dir, target_triangles=600_000, resolution=(1280, 
     palette["mirror"].append("mirror0")
     out.append("Surface wall : Matte { Kd : Constant { v { 0.75, 0.73, 0.7 } } }\n")
     out.append("Surface floor_s : Matte { Kd : Constant { v { 0.4, 0.35, 0.3 } } }\n")
-    tri_counts = _write_meshes(out_dir, out, _uv_meshes())
+    tri_counts = _write_meshes(out_dir, out, _uv_meshes(levels=mesh_levels, torus_res=torus_res, box_n=box_n), inline)
     _room(out, shapes, open_windows=True, lamps=False)
     classes = ["matte", "plastic", "metal", "glass", "mirror"]
     probs = np.array([0.58, 0.19, 0.08, 0.10, 0.05])
@@ -251,7 +285,7 @@ def generate_bedroom_scene(out_dir, target_triangles=600_000, resolution=(1280, 
         return palette[c][r.integers(len(palette[c]))]
 
     _scatter(out, shapes, rng, tri_counts, target_triangles, pick)
-    env = '  environment : Spherical { emission : Image { file { "sky.exr" } } transform : SRT { rotate { 0, 1, 0, 15 } } }\n'
+    env = f'  environment : Spherical {{ emission : Image {{ file {{ "{sky}" }} }} transform : SRT {{ rotate {{ 0, 1, 0, 15 }} }} }}\n'
     _tail(out, shapes, env, resolution, spp, depth, seed, sampler, file)
     path = os.path.join(out_dir, f"{name}.luisa")
     with open(path, "w") as f:
@@ -260,18 +294,18 @@ def generate_bedroom_scene(out_dir, target_triangles=600_000, resolution=(1280, 
 
 
 def generate_camera_scene(out_dir, target_triangles=1_000_000, resolution=(3840, 2160), spp=1024, depth=16, seed=19980810,
-                          texture_size=2048, env_resolution=(2048, 1024), sampler="Independent", file="render.exr", name="camera"):
+                          texture_size=2048, env_resolution=(2048, 1024), sampler="Independent", file="render.exr", name="camera",
+                          inline=False, mesh_levels=(3, 4), torus_res=(48, 24), box_n=8):
     """C4: Disney / Plastic / Matte mix on 8 procedural images (4 albedo sRGB PNG + 4 roughness grey PNG), env + lamps."""
-    from ..scene import save_image
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
-    save_image(os.path.join(out_dir, "sky.exr"), sun_sky_image(*env_resolution, sun_power=300.0))
+    sky = _sky(out_dir, sun_sky_image(*env_resolution, sun_power=300.0), inline)
     out, shapes = [], []
     for i in range(4):
-        write_png(os.path.join(out_dir, f"albedo{i}.png"), albedo_image(rng, texture_size))
-        write_png(os.path.join(out_dir, f"rough{i}.png"), roughness_image(rng, texture_size))
-        out.append(f'Texture albedo{i} : Image {{ file {{ "albedo{i}.png" }} uv_scale {{ {1 + i % 2}, {1 + i // 2} }} }}\n')
-        out.append(f'Texture rough{i} : Image {{ file {{ "rough{i}.png" }} encoding {{ "linear" }} }}\n')
+        fa, ea = _image(out_dir, f"albedo{i}", albedo_image(rng, texture_size), inline, srgb=True)
+        fr, er = _image(out_dir, f"rough{i}", roughness_image(rng, texture_size), inline, srgb=False)
+        out.append(f'Texture albedo{i} : Image {{ file {{ "{fa}" }} {ea} uv_scale {{ {1 + i % 2}, {1 + i // 2} }} }}\n')
+        out.append(f'Texture rough{i} : Image {{ file {{ "{fr}" }} {er} }}\n')
     palette = {"disney": [], "plastic": [], "matte": []}
     for i in range(8):
         met, cc = rng.uniform(0, 0.8), rng.uniform(0, 1)
@@ -287,7 +321,7 @@ def generate_camera_scene(out_dir, target_triangles=1_000_000, resolution=(3840,
         palette["matte"].append(f"matte{i}")
     out.append("Surface wall : Matte { Kd { @albedo0 } }\n")
     out.append("Surface floor_s : Plastic { Kd { @albedo1 } roughness { @rough2 } eta : Constant { v { 1.5 } } }\n")
-    tri_counts = _write_meshes(out_dir, out, _uv_meshes())
+    tri_counts = _write_meshes(out_dir, out, _uv_meshes(levels=mesh_levels, torus_res=torus_res, box_n=box_n), inline)
     _room(out, shapes, open_windows=True, lamps=True)
     classes = ["disney", "plastic", "matte"]
     probs = np.array([0.45, 0.25, 0.30])
@@ -297,7 +331,7 @@ def generate_camera_scene(out_dir, target_triangles=1_000_000, resolution=(3840,
         return palette[c][r.integers(len(palette[c]))]
 
     _scatter(out, shapes, rng, tri_counts, target_triangles, pick)
-    env = '  environment : Spherical { emission : Image { file { "sky.exr" } } scale { 0.5 } }\n'
+    env = f'  environment : Spherical {{ emission : Image {{ file {{ "{sky}" }} }} scale {{ 0.5 }} }}\n'
     _tail(out, shapes, env, resolution, spp, depth, seed, sampler, file, camera="ThinLens",
           camera_extra="aperture { 4 } focal_length { 35 } focus_distance { 2.5 }")
     path = os.path.join(out_dir, f"{name}.luisa")
@@ -307,17 +341,18 @@ def generate_camera_scene(out_dir, target_triangles=1_000_000, resolution=(3840,
 
 
 def generate_kitchen_scene(out_dir, target_triangles=600_000, resolution=(1280, 720), spp=65536, depth=16, seed=19980810,
-                           sampler="Independent", file="render.exr", name="kitchen"):
+                           sampler="Independent", file="render.exr", name="kitchen", inline=False, mesh_levels=(3, 4), torus_res=(48, 24), box_n=8,
+                           environment="Spherical { emission : Constant { v { 0.05, 0.06, 0.08 } } }"):
     """C5: the full surface closure set of SURVEY row a14 + the NormalMap / Opacity wrappers + image textures."""
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
     out, shapes = [], []
-    write_png(os.path.join(out_dir, "albedo.png"), albedo_image(rng, 1024))
-    write_png(os.path.join(out_dir, "rough.png"), roughness_image(rng, 1024))
-    write_png(os.path.join(out_dir, "normal.png"), normal_image(rng, 512))
-    out.append('Texture albedo : Image { file { "albedo.png" } }\n')
-    out.append('Texture rough : Image { file { "rough.png" } encoding { "linear" } }\n')
-    out.append('Texture nmap : Image { file { "normal.png" } encoding { "linear" } }\n')
+    fa, ea = _image(out_dir, "albedo", albedo_image(rng, 1024), inline, srgb=True)
+    fr, er = _image(out_dir, "rough", roughness_image(rng, 1024), inline, srgb=False)
+    fn, en = _image(out_dir, "normal", normal_image(rng, 512), inline, srgb=False)
+    out.append(f'Texture albedo : Image {{ file {{ "{fa}" }} {ea} }}\n')
+    out.append(f'Texture rough : Image {{ file {{ "{fr}" }} {er} }}\n')
+    out.append(f'Texture nmap : Image {{ file {{ "{fn}" }} {en} }}\n')
     out.append("Texture chk : Checkerboard { on : Constant { v { 1 } } off : Constant { v { 0.15 } } scale { 6 } }\n")
     palette = []
     for i in range(4):
@@ -356,13 +391,15 @@ def generate_kitchen_scene(out_dir, target_triangles=600_000, resolution=(1280, 
     palette += [("bumpy", 0.04), ("lace", 0.02)]
     out.append("Surface wall : Matte { Kd : Constant { v { 0.75, 0.73, 0.7 } } }\n")
     out.append("Surface floor_s : Plastic { Kd { @albedo } roughness : Constant { v { 0.25 } } eta : Constant { v { 1.5 } } }\n")
-    tri_counts = _write_meshes(out_dir, out, _uv_meshes())
+    tri_counts = _write_meshes(out_dir, out, _uv_meshes(levels=mesh_levels, torus_res=torus_res, box_n=box_n), inline)
     _room(out, shapes, open_windows=False, lamps=True)
     names = [n for n, _ in palette]
     probs = np.array([p for _, p in palette])
     probs /= probs.sum()
     _scatter(out, shapes, rng, tri_counts, target_triangles, lambda r: names[r.choice(len(names), p=probs)])
-    env = "  environment : Spherical { emission : Constant { v { 0.05, 0.06, 0.08 } } }\n"
+    # (environment=None: a constant Spherical is the one node the reference's own code cannot be asked about -- it dereferences an
+    # empty optional there, src/environments/spherical.cpp:97-105 -- so the reference-pinned reduced scene goes without)
+    env = f"  environment : {environment}\n" if environment else ""
     _tail(out, shapes, env, resolution, spp, depth, seed, sampler, file)
     path = os.path.join(out_dir, f"{name}.luisa")
     with open(path, "w") as f:

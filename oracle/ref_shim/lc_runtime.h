@@ -730,6 +730,32 @@ public:
     [[nodiscard]] StructVar<CommittedHit> trace() const noexcept;
 };
 
+// World -> object matrix of an acceleration-structure instance.  The ray-tracing unit is LuisaCompute's (absent from the
+// snapshot); this stand-in inverts the affine instance transform in double precision and rounds once, exactly as the oracle's
+// ray-tracing unit does (oracle/oracle_bvh.h), so that the two intersect instanced geometry identically and the per-sample
+// comparison of instanced scenes is bit for bit (round 3; a glm-style fp32 inverse here left them 1 ulp apart).
+[[nodiscard]] inline float4x4 accel_world_to_object(const float4x4 &m) noexcept {
+    double a[3][3], inv[3][3];
+    for (auto r = 0; r < 3; r++) {
+        for (auto c = 0; c < 3; c++) { a[r][c] = m[c][r]; }
+    }
+    auto det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+               a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    auto id = 1.0 / det;
+    inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) * id, inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) * id;
+    inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) * id, inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) * id;
+    inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) * id, inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) * id;
+    inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) * id, inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) * id;
+    inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) * id;
+    float4x4 out{};
+    for (auto r = 0; r < 3; r++) {
+        for (auto c = 0; c < 3; c++) { out[c][r] = static_cast<float>(inv[r][c]); }
+        out[3][r] = static_cast<float>(-(inv[r][0] * m[3].x + inv[r][1] * m[3].y + inv[r][2] * m[3].z));
+    }
+    out[0].w = 0.f, out[1].w = 0.f, out[2].w = 0.f, out[3].w = 1.f;
+    return out;
+}
+
 class AccelVar {
 public:
     struct Instance {
@@ -819,9 +845,9 @@ public:
     Accel &operator=(Accel &&) noexcept = default;
     [[nodiscard]] size_t size() const noexcept { return _instances.size(); }
     void emplace_back(const Mesh &mesh, float4x4 transform = float4x4{}, bool visible = true, bool opaque = true) noexcept {
-        _instances.push_back({&mesh, transform, luisa::inverse(transform), visible, opaque});
+        _instances.push_back({&mesh, transform, accel_world_to_object(transform), visible, opaque});
     }
-    void set_transform_on_update(size_t i, float4x4 m) noexcept { _instances[i].to_world = m, _instances[i].to_object = luisa::inverse(m); }
+    void set_transform_on_update(size_t i, float4x4 m) noexcept { _instances[i].to_world = m, _instances[i].to_object = accel_world_to_object(m); }
     void set_visibility_on_update(size_t i, bool v) noexcept { _instances[i].visible = v; }
     ShimCommand build() noexcept { return {}; }
     ShimCommand update() noexcept { return {}; }

@@ -724,12 +724,11 @@ def test_nested_mix_layered_only_in_megapath(renderer):
 
 @pytest.mark.parametrize("sampler", ["Independent", "Sobol"])
 def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
-    """The SAME scene through every precompiled scene-feature variant (LRHIP_FORCE_FEATURES, a tools-only override of the variant
-    choice): a binary that holds more features than the scene needs must still render the scene -- same sample counts, the same
+    """The SAME scene through every precompiled scene-feature variant (lrhip_set_diagnostics: a per-context override of the variant
+    choice for tests and tools): a binary that holds more features than the scene needs must still render the scene -- same sample counts, the same
     image up to the rounding of a different instruction schedule, identical when run twice.  This reaches the shipped binaries
     that no BASELINE stand-in launches with this sampler (<12>, <62>, <126>, ...)."""
     from helpers import MATERIALS
-    import os
     extra = "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in ("glass", "metal"))
     sc = Scene.from_string(cornell_box(resolution=48, spp=8, short_box_surface="glass", tall_box_surface="metal", extra_surfaces=extra, sampler=sampler))
     generic = 0 if sampler == "Independent" else 2
@@ -739,7 +738,7 @@ def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
     base = renderer.download(converted=False)
     try:
         for force in (4, 8, 12, 16, 20, 60, 124):
-            os.environ["LRHIP_FORCE_FEATURES"] = str(force)
+            renderer.set_diagnostics(force_features=force)
             films = []
             for _ in range(2):
                 renderer.upload(sc)
@@ -752,4 +751,4 @@ def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
             print(f"variant {force | generic}: rel-L1 vs <{generic}> {err:.2e}")
             assert err < 3e-3, (force, err)
     finally:
-        os.environ.pop("LRHIP_FORCE_FEATURES", None)
+        renderer.set_diagnostics()

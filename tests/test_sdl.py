@@ -108,3 +108,21 @@ def test_cornell_box_layout():
     assert v.instance_count == 16 and v.triangle_count == 32 and v.light_instance_count == 1
     assert v.surface_count == 3 and v.accel.triangle_count == 32
     assert v.integrator.light_count == 1 and v.integrator.env_prob == 0.0
+
+
+def test_image_texture_default_encoding_follows_the_extension_rule_of_the_reference(tmp_path):
+    """src/textures/image.cpp:85-90: only `.exr` and `.hdr` default to linear, every other extension -- `.pfm` included --
+    to sRGB.  (Round 3: the host had `.pfm` on the linear side; found by running the reduced C3 generator through the reference's
+    own code, tests/test_oracle_vs_ref.py::test_li_baseline_stand_ins.)"""
+    import numpy as np
+    from luisarender_amd.scenes.configs import write_pfm
+    from luisarender_amd.scene import save_image
+    img = np.full((4, 4, 4), 0.5, np.float32)
+    write_pfm(str(tmp_path / "a.pfm"), img)
+    save_image(str(tmp_path / "a.exr"), img)
+    save_image(str(tmp_path / "a.hdr"), img)
+    for ext, srgb in ((".pfm", True), (".exr", False), (".hdr", False)):
+        text = MINI.replace("#SPP", "1").replace("Kd : Constant { v { 0.5, 0.5, 0.5 } }", f'Kd : Image {{ file {{ "a{ext}" }} }}')
+        view = Scene.from_string(text, virtual_path=str(tmp_path / "scene.luisa")).view(0)
+        encodings = [view.textures[i].encoding for i in range(view.texture_count) if view.textures[i].kind == 1]
+        assert encodings == [1 if srgb else 0], (ext, encodings)

@@ -6,7 +6,7 @@ from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
 from luisarender_amd.scenes.configs import generate_kitchen_scene
 
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # LRHIP_FORCE_FEATURES=60 forces a larger kernel variant, LRHIP_LIB an experimental build
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64  # FORCE_FEATURES=60 forces a larger kernel variant (lrhip_set_diagnostics), LRHIP_LIB an experimental build
 MATTE = "Matte { Kd : Constant { v { 0.5, 0.5, 0.5 } } }"
 
 
@@ -33,6 +33,7 @@ with tempfile.TemporaryDirectory() as tmp:
     if len(sys.argv) > 2:
         cases = {k: v for k, v in cases.items() if k in sys.argv[2:]}
     r = MegaPathRenderer(0)
+    r.set_diagnostics(force_features=int(os.environ.get("FORCE_FEATURES", "0")))
     for name, text in cases.items():
         p = os.path.join(tmp, name + ".luisa")
         open(p, "w").write(text)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep of the work-item size (LRHIP_ITEM_SCALE x the loss model's constant, lrhip_render) on C2: full frame and the 1/8 shard."""
+"""Sweep of the work-item size (lrhip_set_diagnostics: item_scale x the loss model's constant, lrhip_render) on C2: full frame and the 1/8 shard."""
 import os, sys, tempfile
 sys.path.insert(0, ".")
 from luisarender_amd import Scene
@@ -12,7 +12,7 @@ with tempfile.TemporaryDirectory() as tmp:
     r.upload(sc)
     for world in (1, 8):
         for scale in ("0.25", "0.5", "1", "2", "4", "8"):
-            os.environ["LRHIP_ITEM_SCALE"] = scale
+            r.set_diagnostics(item_scale=float(scale))
             ms = []
             for _ in range(2):
                 r.clear(); r.render(0, spp, rank=0, world=world, sync=True, balance_shards=world)
