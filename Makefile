@@ -30,7 +30,7 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean hip-variant variant-lib ref
+.PHONY: all host hip oracle cli clean hip-variant variant-lib ref ieee
 all: host oracle hip cli
 
 # oracle/_ref: the reference's OWN sources compiled in place against the scalar LuisaCompute stand-in of oracle/ref_shim
@@ -91,6 +91,14 @@ hip-variant:
 	    LIBDIR_OUT=$(LIBDIR)/variants/liblrhip_$(NAME).so variant-lib
 variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $(LIBDIR_OUT) $^
+
+# The lean kernel <0> / <1> once more with IEEE arithmetic (no fp contraction, correctly rounded division / sqrt, exact functions),
+# for experiments (MegaPathRenderer(lib_path=...)): round 3 used it to test the claim that fast math is what separates the device
+# from the oracle on the C2 stand-in -- it is not (8.57e-3 vs 8.85e-3; it is the instance transform's rounding, see
+# tests/test_gpu_parity.py::test_what_separates_c2_from_the_oracle_is_the_instance_transform).  Not part of `all`.
+ieee: $(LIBDIR)/variants/liblrhip_ieee.so
+$(LIBDIR)/variants/liblrhip_ieee.so: $(HIP_SRC) $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
+	$(MAKE) --no-print-directory hip-variant NAME=ieee HIPFLAGS='$(VPT_HIPFLAGS)' DEFS= VARIANT_MASKS='0 1'
 
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)

@@ -21,8 +21,13 @@ Rank 0 prints ONE JSON line with the driver's contract plus
                   (wave-level VALU instructions) against the issue rates calibrated on the box by tools/valu_peak.hip.
   "cpu_baseline": the CPU oracle ("port": reference-faithful restatement, not the reference binary; it is pinned to the
                   reference's own code, tests/test_oracle_vs_ref.py) timed on the host cores on a bounded sample of the workload.
-  "extra_configs": short runs of the other BASELINE configs (C1 with its full CPU leg = configs[0], C3, C5) in the same line; C1 also
-  carries "cpu_reference": the reference's OWN MegaPath code (oracle/_ref) timed on one host thread over a bounded sample.
+  "parity":       the frame the CPU leg just rendered (the oracle, pinned to the reference's own code) against the SAME samples
+                  rendered by the shipped kernel, outside the timed region: rel-L1, per-pixel RMSE, mean bias, a FLIP-class error.
+  "rays_per_s", "mean_path_length": from the device counters of a short counting render of the same frame.
+  "extra_configs": short runs of the other BASELINE configs in the same line -- C1 (with its full CPU leg = configs[0], its parity and
+                  "cpu_reference": the reference's OWN MegaPath code, oracle/_ref, on one host thread), C3, C4, C5 -- and C2 with the
+                  sampler + filter the reference's converter writes for the README scenes (a low-discrepancy sampler + Gaussian r = 1).
+  N > 1 adds "multi_gpu": the collective's own time, per-rank kernel times, and a check of the reduced film against a 1-GPU render.
 """
 from __future__ import annotations
 
@@ -61,19 +66,19 @@ SHADER_CLOCK_HZ = 2.4e9
 METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
-def build_scene(workload: str, tmpdir: str, spp_override: int | None):
+def build_scene(workload: str, tmpdir: str, spp_override: int | None, sampler: str = "Independent"):
     from luisarender_amd import Scene
     from luisarender_amd.scenes import cornell_box, generate_room_scene
     desc, res, spp, depth = WORKLOADS[workload]
     spp = spp_override or min(spp, BENCH_SPP_CAP.get(workload, spp))
     if workload == "c1":
-        scene = Scene.from_string(cornell_box(resolution=res[0], spp=spp, depth=depth))
+        scene = Scene.from_string(cornell_box(resolution=res[0], spp=spp, depth=depth, sampler=sampler))
     elif workload == "c2":
-        scene = Scene.load(generate_room_scene(tmpdir, resolution=res, spp=spp, depth=depth))
+        scene = Scene.load(generate_room_scene(tmpdir, resolution=res, spp=spp, depth=depth, sampler=sampler))
     else:
         from luisarender_amd.scenes import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
         gen = {"c3": generate_bedroom_scene, "c4": generate_camera_scene, "c5": generate_kitchen_scene}[workload]
-        scene = Scene.load(gen(tmpdir, resolution=res, spp=spp, depth=depth))
+        scene = Scene.load(gen(tmpdir, resolution=res, spp=spp, depth=depth, sampler=sampler))
     return scene, desc, res, spp
 
 
@@ -88,13 +93,50 @@ def cpu_baseline(scene, res, budget_s: float, full_spp: int | None = None):
     rate = c0["paths"] / max(time.perf_counter() - t0, 1e-6)
     spp = int(max(1, min(full_spp or 16, budget_s * rate / (res[0] * res[1]))))
     t0 = time.perf_counter()
-    _, counters = oracle.render(0, spp, threads=cores)
+    film, counters = oracle.render(0, spp, threads=cores)
     dt = time.perf_counter() - t0
     return {
         "value": counters["paths"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (reference-faithful restatement, not the reference binary), full frame {res[0]}x{res[1]} at {spp} spp "
                   f"= {counters['paths']} paths in {dt:.1f} s",
-    }, algorithmic_bytes(counters) / counters["paths"], counters
+    }, algorithmic_bytes(counters) / counters["paths"], counters, (oracle.convert(film), spp)
+
+
+def device_parity(scene, local_rank, cpu_frame, spp):
+    """The frame the CPU leg just rendered against the SAME samples [0, spp) on the device, shipped kernel, outside any timed region
+    (VERDICT r02 1c).  FLIP on the central 512 x 512 of larger frames (the numpy restatement takes seconds per megapixel)."""
+    import numpy as np
+    from luisarender_amd.render import MegaPathRenderer
+    from oracle import image_metrics as M
+    r = MegaPathRenderer(local_rank)
+    r.upload(scene)
+    r.render(0, spp, counters=False, sync=True)
+    gpu = r.download(converted=True)
+    variant = r.last_variant()
+    r.close()
+    out = M.summary(gpu[..., :3], cpu_frame[..., :3], with_flip=False)
+    h, w = gpu.shape[:2]
+    y0, x0 = max(0, (h - 512) // 2), max(0, (w - 512) // 2)
+    out["flip"] = M.flip(gpu[y0:y0 + 512, x0:x0 + 512, :3], cpu_frame[y0:y0 + 512, x0:x0 + 512, :3])
+    out.update({"samples": int(h * w * spp), "spp": spp, "kernel": f"lrd::megapath_kernel<{variant}u>", "finite": bool(np.isfinite(gpu).all()),
+                "against": "the CPU oracle's frame of the same samples (the oracle is bit-equal to the reference's own code: tests/test_oracle_vs_ref.py, "
+                           "tests/test_ref_golden.py); rmse = per-pixel L2 of the converted linear RGB, flip = LDR-FLIP restated in oracle/image_metrics.py "
+                           "(clip + sRGB), on the central 512 x 512"})
+    return out
+
+
+def path_statistics(scene, local_rank, spp=4):
+    """rays per sample and mean path length from the device counters of a short counting render (the COUNT twin of the kernel)"""
+    from luisarender_amd.render import MegaPathRenderer
+    r = MegaPathRenderer(local_rank)
+    r.upload(scene)
+    r.render(0, spp, counters=True, sync=True)
+    c = r.counters()
+    r.close()
+    paths = max(c["paths"], 1)
+    return {"rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
+            "shadow_rays_per_sample": c["shadow_rays"] / paths, "mean_path_length": c["path_length_sum"] / paths,
+            "nodes_per_ray": c["nodes_visited"] / max(c["closest_rays"] + c["shadow_rays"], 1), "spp": spp}
 
 
 def source_hash() -> str:
@@ -127,7 +169,7 @@ def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
         env = dict(os.environ, TMPDIR="/tmp")
         for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"])):
             cmd = ["rocprofv3", "--pmc", *pmc, "--kernel-trace", "-d", os.path.join(d, name), "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-extra"]
+                   "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-stats"]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
                 dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(d, name)) for f in fs if f.endswith(".db")]
@@ -147,13 +189,14 @@ def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
     return out
 
 
-def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None):
+def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None, sampler="Independent"):
     """times `steps` frames of one workload -> (value Msamples/s, ms_per_step, kernel_ms, variant, scene, res, spp, desc)"""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from luisarender_amd.parallel import FilmReducer
     from luisarender_amd.render import MegaPathRenderer
-    scene, desc, res, spp = build_scene(workload, tmp, spp_override)
+    scene, desc, res, spp = build_scene(workload, tmp, spp_override, sampler)
     renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     renderer.upload(scene)
     film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -161,29 +204,44 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
     # communicator through the C ABI: the timed collective is the product's lrhip_film_reduce.  LR_BENCH_FORCE_COLLECTIVE=1 runs
     # the same code with one rank (1-GPU boxes).  Should the C-ABI communicator fail on a node this was never run on, the same
     # RCCL reduce goes through torch.distributed instead and the line says so (config.collective) -- a bench that dies has no line.
+    # ALL ranks take the same path: the outcome of the attempt is all-reduced (MIN) over the process group the launcher made, so a
+    # rank whose ncclCommInitRank failed cannot sit in dist.reduce while the others sit in ncclReduce.
     force = os.environ.get("LR_BENCH_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
     collective = "none (single GPU)"
     reducer = None
     if world > 1 or force:
+        error = ""
         try:
             reducer = FilmReducer(renderer, rank, world, force=force)
-            collective = "lrhip_film_reduce (ncclReduce through the C ABI, on the render stream)"
         except Exception as e:  # noqa: BLE001
-            collective = f"torch.distributed.reduce (C-ABI communicator failed: {e})"
+            error = str(e)
+        ok = torch.tensor([0 if reducer is None or reducer.comm is None else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            collective = "lrhip_film_reduce (ncclReduce through the C ABI, on the render stream)"
+        else:
+            if reducer is not None:
+                reducer.close()
+            reducer = None
+            collective = f"torch.distributed.reduce (the C-ABI communicator failed on at least one rank{': ' + error if error else ''})"
     run_workload.collective = collective
     torch.cuda.synchronize()
+    reduce_ms = []
 
     def step():
         film.zero_()
         torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
         renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
-        if reducer is not None:
-            reducer.reduce(0)  # ncclReduce on the renderer's stream, behind the megakernel
-            renderer.synchronize()
-        elif world > 1:
-            renderer.synchronize()
-            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
+        if reducer is not None or world > 1:
+            renderer.synchronize()  # (one host round trip per step: it separates the collective's time from the kernel's)
+            t = time.perf_counter()
+            if reducer is not None:
+                reducer.reduce(0)  # ncclReduce on the renderer's stream, behind the megakernel
+                renderer.synchronize()
+            else:
+                dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+            reduce_ms.append((time.perf_counter() - t) * 1e3)
         else:
             renderer.synchronize()
         return renderer.last_render_ms()
@@ -195,16 +253,39 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
 
     for _ in range(warmup):
         step()
+    reduce_ms.clear()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = [step() for _ in range(steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     mean_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-    if world > 1:
-        t = torch.tensor([elapsed, mean_kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+    run_workload.multi_gpu = None
+    if world > 1 or force:
+        mean_reduce_ms = sum(reduce_ms) / max(len(reduce_ms), 1)
+        t = torch.tensor([elapsed, mean_kernel_ms, -mean_kernel_ms, mean_reduce_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, mean_kernel_ms = float(t[0]), float(t[1])
+        info = {"kernel_ms_max_over_ranks": float(t[1]), "kernel_ms_min_over_ranks": -float(t[2]), "reduce_ms": float(t[3]),
+                "reduce_bytes": res[0] * res[1] * 16, "note": "reduce_ms = host time from the end of the slowest rank's megakernel to the end of the collective (waiting for stragglers included)"}
+        # The reduced film must BE the frame: rank 0 renders the first 8 tile rows (64 pixel rows, every rank owns tiles there) on its
+        # own with the same balance_shards and compares them bit for bit with what the collective delivered.  A wrong collective
+        # fails the line instead of only slowing it.
+        if rank == 0:
+            reduced = film.cpu().numpy().copy()
+            check = torch.zeros_like(film)
+            renderer.bind_film(check.data_ptr())
+            tiles_x = (res[0] + 7) // 8
+            rows = min(8, (res[1] + 7) // 8)
+            p_world, p_rank = 1, 0
+            renderer.render(0, spp, rank=p_rank, world=p_world, balance_shards=world, sync=True, tile_end=rows * tiles_x)
+            mine = check.cpu().numpy()
+            band = slice(0, min(rows * 8, res[1]))
+            info["reduced_film_equals_1gpu_render"] = bool(np.array_equal(reduced[band], mine[band]))
+            info["checked_pixel_rows"] = int(band.stop)
+            info["checked_sample_counts_ok"] = bool((reduced[..., 3] == float(spp)).all())
+            renderer.bind_film(film.data_ptr())
+        run_workload.multi_gpu = info
     variant = renderer.last_variant()
     if reducer is not None:
         reducer.close()
@@ -224,6 +305,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic from profiles/ or null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configs")
+    ap.add_argument("--no-stats", action="store_true", help="skip the short counting render behind rays_per_s / mean_path_length (the PMC passes: ONE megakernel dispatch per process)")
     args = ap.parse_args()
 
     import torch
@@ -261,8 +343,19 @@ def main():
                 out["config"]["note"] = f"timed at {spp} spp of the same frame (Independent sampler: throughput is spp-invariant)"
             bytes_per_sample = ALGORITHMIC_BYTES_PER_SAMPLE[args.workload]
             if world == 1 and not args.no_cpu_baseline:  # the CPU leg runs on rank 0 at N = 1 only
-                cpu, bytes_per_sample, _ = cpu_baseline(scene, res, args.cpu_seconds)
+                cpu, bytes_per_sample, _, (cpu_frame, cpu_spp) = cpu_baseline(scene, res, args.cpu_seconds)
                 out["cpu_baseline"] = cpu
+                out["parity"] = device_parity(scene, local_rank, cpu_frame, cpu_spp)
+            if world == 1 and not args.no_stats:
+                stats = path_statistics(scene, local_rank)
+                out["rays_per_s"] = value * 1e6 * stats["rays_per_sample"]
+                out["mean_path_length"] = stats["mean_path_length"]
+                out["path_statistics"] = stats
+            if getattr(run_workload, "multi_gpu", None):
+                out["multi_gpu"] = run_workload.multi_gpu
+                if run_workload.multi_gpu.get("reduced_film_equals_1gpu_render") is False:
+                    out["value"] = None  # a frame that is not the frame has no throughput
+                    out["error"] = "the film the collective delivered differs from a 1-GPU render of the same tiles"
             # one launch renders this rank's shard: samples_per_step / world samples
             launch_samples = samples_per_step / world
             algorithmic_gbps = bytes_per_sample * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
@@ -300,16 +393,23 @@ def main():
                     "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"],
                     "issue_frac_if_all_full_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[0] / simd_cycles,
                     "issue_frac_if_all_quarter_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[1] / simd_cycles,
-                    "calibration": "profiles/r02_valu_peak.json (tools/valu_peak.hip): 2.4 cycles per wave64 v_fma / v_add, 4.2 per v_max / v_cvt_ubyte / v_pk_fma; the kernel's mix lies between",
+                    "calibration": "profiles/r03_valu_peak.json (tools/valu_peak2.hip, 64 opcodes): 2.4 cycles per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every "
+                                   "min / max / cvt / cmp / cndmask / shift / packed op, 8.2 per transcendental; the kernel's mix lies between (tools/isa_census.py prices its loops)",
                 }
             if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None:
                 extra = []
-                for w, steps, spp_o, with_cpu in (("c1", 3, None, True), ("c3", 2, 1024, False), ("c5", 1, 512, False)):
-                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o)
-                    e = {"workload": d, "spp_timed": sp, "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms, "kernel": f"lrd::megapath_kernel<{var}u>",
-                         "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
+                # (workload, steps, spp, CPU leg, sampler): C1 = BASELINE configs[0] whole; C4 = the 8-GPU configuration's 1-GPU number;
+                # C2 once more with the sampler class + filter the reference's converter writes for the README scenes
+                # (tools/tungsten2luisa.py:373-412 there: a low-discrepancy sampler, Gaussian r = 1 -- the stand-in's filter already)
+                for w, steps, spp_o, with_cpu, sampler in (("c1", 3, None, True, "Independent"), ("c3", 2, 1024, False, "Independent"),
+                                                           ("c4", 2, 64, False, "Independent"), ("c5", 1, 512, False, "Independent"),
+                                                           ("c2", 3, 256, False, "PaddedSobol")):
+                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler)
+                    e = {"workload": d, "sampler": sampler, "spp_timed": sp, "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
+                         "kernel": f"lrd::megapath_kernel<{var}u>", "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
                     if with_cpu:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration
-                        e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _ = cpu_baseline(sc, r, 30.0, full_spp=sp)
+                        e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _, (cpu_frame, cpu_spp) = cpu_baseline(sc, r, 30.0, full_spp=sp)
+                        e["parity"] = device_parity(sc, local_rank, cpu_frame, cpu_spp)
                         # and the REFERENCE'S OWN code beside it (oracle/_ref, one thread, a bounded sample of the same frame); absent
                         # where oracle/_ref was not built
                         # (in a child process: libref.so brings its own operator new and the reference's symbols)

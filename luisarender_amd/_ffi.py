@@ -181,8 +181,9 @@ def host_lib() -> C.CDLL:
     return lib
 
 
-def hip_lib() -> C.CDLL:
-    """The product's device library.  Fails loudly when the HIP extension is missing."""
+def hip_lib(path: str | None = None) -> C.CDLL:
+    """The product's device library.  Fails loudly when the HIP extension is missing.  `path`: another build of the same library
+    (tests: the IEEE-arithmetic build of the lean kernel; tools: A/B variants) beside the shipped one in the same process."""
     # One HIP runtime and one RCCL per process: PyTorch-ROCm bundles its own libamdhip64 / librccl (same sonames as /opt/rocm's,
     # older versions), and whichever is loaded first serves both.  A Python host shares device pointers and streams with torch
     # (bench.py's film tensor, torch.distributed's process group), so torch's copies must be the ones: import it BEFORE the
@@ -193,7 +194,7 @@ def hip_lib() -> C.CDLL:
     except ImportError:
         pass
     # LRHIP_LIB selects an experimental build variant (tools/ only); the default is the shipped library
-    lib = _load(os.environ.get("LRHIP_LIB") or os.path.join(LIB_DIR, "liblrhip.so"))
+    lib = _load(path or os.environ.get("LRHIP_LIB") or os.path.join(LIB_DIR, "liblrhip.so"))
     if not getattr(lib, "_lr_ready", False):
         lib.lrhip_last_error.restype = C.c_char_p
         lib.lrhip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

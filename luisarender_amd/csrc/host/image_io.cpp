@@ -488,12 +488,15 @@ LoadedImage read_exr(const fs::path &path) {
         throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP / PIZ are): '" + path.string() + "'."};
     }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
-    // nothing is allocated on the word of the header alone: at most 2^28 pixels (the JPEG reader's cap), and the file must be
-    // long enough for the chunk-offset table and the 8-byte header of every chunk the data window promises
+    // nothing is allocated on the word of the header alone: at most 2^28 pixels (the JPEG reader's cap), the file must be long
+    // enough for the chunk-offset table and the 8-byte header of every chunk the data window promises, and the 16 bytes per decoded
+    // pixel must be within what the file's bytes can expand to (8192 : 1 -- beyond deflate's 1032 : 1 and RLE's 64 : 1; a PIZ chunk
+    // of one constant colour is the densest case): an 8 KB file claiming 16384 x 16384 no longer gets 4 GiB
     {
         const auto per_chunk = compression == 3u ? 16u : (compression == 4u ? 32u : 1u);
         auto chunks = (static_cast<uint64_t>(h) + per_chunk - 1u) / per_chunk;
-        if (static_cast<uint64_t>(w) * h > (1ull << 28u) || p > data.size() || (data.size() - p) / 16u < chunks) {
+        if (static_cast<uint64_t>(w) * h > (1ull << 28u) || p > data.size() || (data.size() - p) / 16u < chunks ||
+            static_cast<uint64_t>(w) * h * 16u > static_cast<uint64_t>(data.size()) * 8192u) {
             throw Error{"EXR data window " + std::to_string(w) + "x" + std::to_string(h) + " is too large for the file (or beyond 2^28 pixels): '" + path.string() + "'."};
         }
     }

@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string_view>
+#include <algorithm>
 
 #include <thread>
 
@@ -106,7 +108,12 @@ public:
         // this process flattens the scene and builds the BVH ONCE, one host thread per GPU uploads the same host tables and renders
         // the tiles {r, r + W, ...} (lrhip.h: diagonals of the frame) with balance_shards = W, and ONE collective -- lrhip_film_reduce
         // = ncclReduce over xGMI, communicators from ncclCommInitAll -- sums the films on the first device, which converts and saves.
-        // Every pixel is owned by one GPU and the others hold exact zeros there, so the image is the 1-GPU image bit for bit.
+        // Every pixel is owned by one GPU and the others hold exact zeros there, and the work items are ALWAYS sized for a frame cut into
+        // kNominalShards shards (lrhip_render_params.balance_shards: the chunking, and with it the order of a pixel's float adds, is a
+        // function of that number, not of the device count), so `-d 0`, `-d 0,1` ... `-d 0,..,7` write the same image bit for bit.
+        // (A full frame is insensitive to the finer items: C2 at 7 / 14 / 28 chunks 1992 / 1987 / 1987 ms)
+        // LR_FORCE_COLLECTIVE=1 runs the communicator + reduce with ONE device as well (tests: the standalone binary must find RCCL).
+        constexpr uint32_t kNominalShards = 8u;
         std::vector<int> devices;
         if (stream.device != nullptr && stream.device->indices.size() > 1u) { devices = stream.device->indices; }
         else { devices = {stream.device != nullptr ? std::max(stream.device->index, 0) : 0}; }
@@ -119,7 +126,10 @@ public:
                 std::abort();
             }
         }
-        if (world > 1u) {
+        const auto force_collective = std::getenv("LR_FORCE_COLLECTIVE") != nullptr && std::string_view{std::getenv("LR_FORCE_COLLECTIVE")} == "1";
+        const auto collective = world > 1u || force_collective;
+        const auto balance_shards = std::max(world, kNominalShards);
+        if (collective) {
             if (api.comm_init_all == nullptr || api.film_reduce_group == nullptr || api.comm_init_all(static_cast<int>(world), devices.data(), comms.data()) != LRHIP_OK) {
                 std::fprintf(stderr, "[error] lrhip_comm_init_all: %s\n", api.last_error());
                 std::abort();
@@ -166,14 +176,14 @@ public:
                     on_every_gpu([&](uint32_t r) -> std::string {
                         if (upload && (was_first ? api.upload_scene(ctxs[r], &view) : api.update_scene(ctxs[r], &view)) != LRHIP_OK) { return std::string{"lrhip_upload_scene: "} + api.last_error(); }
                         if (was_first && api.film_clear(ctxs[r]) != LRHIP_OK) { return std::string{"lrhip_film_clear: "} + api.last_error(); }
-                        lrhip_render_params params{begin, begin + s.spp, r, tiles, world, shutter.size() > 1u ? LRHIP_RENDER_SHUTTER_WEIGHT : 0u, world, s.weight};
+                        lrhip_render_params params{begin, begin + s.spp, r, tiles, world, shutter.size() > 1u ? LRHIP_RENDER_SHUTTER_WEIGHT : 0u, balance_shards, s.weight};
                         if (api.render(ctxs[r], &params) != LRHIP_OK || api.synchronize(ctxs[r]) != LRHIP_OK) { return std::string{"lrhip_render: "} + api.last_error(); }
                         return {};
                     });
                     first = false;
                     sample_id += s.spp;
                 }
-                if (world > 1u) {// the path's one collective: per-GPU films -> devices[0]
+                if (collective) {// the path's one collective: per-GPU films -> devices[0]
                     if (api.film_reduce_group(static_cast<int>(world), ctxs.data(), comms.data(), 0) != LRHIP_OK) {
                         std::fprintf(stderr, "[error] lrhip_film_reduce: %s\n", api.last_error());
                         std::abort();
@@ -183,7 +193,8 @@ public:
                 auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 std::fprintf(stderr, "[info] Rendering finished in %g ms.\n", ms);
                 auto samples = static_cast<double>(width) * height * camera.camera.spp;
-                std::fprintf(stderr, "[info] %.2f Msamples/s on %u HIP device(s), first %d.\n", samples / ms * 1e-3, world, device_index);
+                std::fprintf(stderr, "[info] %.2f Msamples/s on %u HIP device(s), first %d%s.\n", samples / ms * 1e-3, world, device_index,
+                             collective ? ", films reduced over RCCL" : "");
                 if (api.film_download(ctx, pixels.data(), 1) != LRHIP_OK) {
                     std::fprintf(stderr, "[error] lrhip_film_download: %s\n", api.last_error());
                     std::abort();

@@ -22,8 +22,8 @@ class MegaPathRenderer:
     """One lrhip_ctx on one GPU.  Mirrors the reference's ProgressiveIntegrator::Instance::render
     (src/base/integrator.cpp:34-49): prepare film -> render spp -> download (convert) -> save."""
 
-    def __init__(self, device: int = 0):
-        self._lib = _ffi.hip_lib()  # raises if liblrhip.so is missing: there is no CPU fallback
+    def __init__(self, device: int = 0, lib_path: str | None = None):
+        self._lib = _ffi.hip_lib(lib_path)  # raises if liblrhip.so is missing: there is no CPU fallback
         self._ctx = C.c_void_p()
         self._check(self._lib.lrhip_create(device, C.byref(self._ctx)))
         self._scene = None
@@ -50,7 +50,7 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_film_clear(self._ctx))
 
     def render(self, spp_begin: int, spp_end: int, rank: int = 0, world: int = 1, counters: bool = False,
-               sync: bool = False, balance_shards: int = 1, shutter_weight: float | None = None) -> None:
+               sync: bool = False, balance_shards: int = 1, shutter_weight: float | None = None, tile_end: int | None = None) -> None:
         """Render samples [spp_begin, spp_end) of the round-robin tile shard `rank` of `world`.
         `balance_shards` sizes the work items for a frame split into that many shards (lrhip.h): films rendered with
         the same value are bit-identical under any sharding; the multi-GPU bench passes its world size."""
@@ -58,6 +58,7 @@ class MegaPathRenderer:
         p.balance_shards = balance_shards
         p.spp_begin, p.spp_end = spp_begin, spp_end
         tiles = tile_count(self.width, self.height)
+        tiles = min(tiles, tile_end) if tile_end is not None else tiles  # (tile_end: only the first tiles of the frame, for checks)
         p.tile_begin, p.tile_end, p.tile_stride = min(rank, tiles), tiles, world  # rank >= tiles: an empty shard
         p.flags = 1 if counters else 0
         if shutter_weight is not None:  # Camera::ShutterSample weight of these samples (integrator.cpp:74)

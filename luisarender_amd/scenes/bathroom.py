@@ -122,9 +122,12 @@ def _quad_shape(name, pts, surface=None, light=None):
 def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 1024), spp=1024, depth=16, seed=19980810,
                         glass_fraction=0.07, environment=None, open_windows=False, file="render.exr",
                         sampler="Independent", name="bathroom", inline_meshes=False,
-                        mesh_levels=(3, 4), torus_res=(48, 24), box_n=8):
+                        mesh_levels=(3, 4), torus_res=(48, 24), box_n=8, bake_transforms=False):
     """Writes <out_dir>/<name>.luisa (+ OBJ meshes) and returns its path.  inline_meshes: the fixtures' meshes as InlineMesh nodes
-    instead of OBJ files (same instances, transforms and materials; the form the reference's own code can load here)."""
+    instead of OBJ files (same instances, transforms and materials; the form the reference's own code can load here).
+    bake_transforms: every fixture is its own InlineMesh whose vertices and normals already are in world space (scale, rotation and
+    translation applied here, in double precision) and carries no transform node: the same room with object space = world space
+    (tests/test_gpu_parity.py: what separates the device from the oracle on this scene is the instance transform's rounding)."""
     os.makedirs(out_dir, exist_ok=True)
     rng = np.random.default_rng(seed)
     meshes = {
@@ -132,7 +135,7 @@ def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 102
         "torus": torus(*torus_res), f"box{box_n}": tess_box(box_n),
     }
     tri_counts = {k: len(m[1]) for k, m in meshes.items()}
-    if not inline_meshes:
+    if not inline_meshes and not bake_transforms:
         for k, (v, f, n) in meshes.items():
             _write_obj(os.path.join(out_dir, f"{k}.obj"), v, f, n)
     out = []
@@ -164,7 +167,8 @@ def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 102
     out.append("Surface wall : Matte { Kd : Constant { v { 0.75, 0.73, 0.7 } } }\n")
     out.append("Surface floor_s : Matte { Kd : Constant { v { 0.4, 0.35, 0.3 } } }\n")
     for k, (v, f, n) in meshes.items():
-        out.append(inline_mesh(f"mesh_{k}", v, f, n) if inline_meshes else f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
+        if not bake_transforms:
+            out.append(inline_mesh(f"mesh_{k}", v, f, n) if inline_meshes else f'Shape mesh_{k} : Mesh {{ file {{ "{k}.obj" }} }}\n')
     # room 4 x 3 x 4
     X, Y, Z = 4.0, 3.0, 4.0
     shapes = []
@@ -207,9 +211,17 @@ def generate_room_scene(out_dir, target_triangles=600_000, resolution=(1024, 102
         axis = rng.normal(size=3)
         axis /= np.linalg.norm(axis)
         ang = rng.uniform(0, 360)
-        out.append(f"Shape obj{i} : Instance {{ shape {{ @mesh_{k} }} surface {{ @{surf} }} transform : SRT {{ "
-                   f"scale {{ {s:.4f}, {s:.4f}, {s:.4f} }} rotate {{ {axis[0]:.4f}, {axis[1]:.4f}, {axis[2]:.4f}, {ang:.2f} }} "
-                   f"translate {{ {x:.4f}, {y:.4f}, {z:.4f} }} }} }}\n")
+        if bake_transforms:
+            a = axis / np.linalg.norm(axis)
+            th = np.radians(ang)
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)  # Rodrigues
+            v, f, n = meshes[k]
+            out.append(inline_mesh(f"obj{i}", (s * v) @ R.T + np.array([x, y, z]), f, None if n is None else n @ R.T)[:-2] + f"  surface {{ @{surf} }}\n}}\n")
+        else:
+            out.append(f"Shape obj{i} : Instance {{ shape {{ @mesh_{k} }} surface {{ @{surf} }} transform : SRT {{ "
+                       f"scale {{ {s:.4f}, {s:.4f}, {s:.4f} }} rotate {{ {axis[0]:.4f}, {axis[1]:.4f}, {axis[2]:.4f}, {ang:.2f} }} "
+                       f"translate {{ {x:.4f}, {y:.4f}, {z:.4f} }} }} }}\n")
         shapes.append(f"@obj{i}")
         total += tri_counts[k]
         i += 1

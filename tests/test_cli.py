@@ -82,8 +82,10 @@ def test_cli_renders_motion_blur_like_the_c_abi(tmp_path):
 def test_cli_shards_a_frame_over_several_gpus(tmp_path):
     """The C++ host's multi-GPU path (plugin_megapath.cpp: one host thread + one lrhip_ctx per GPU, ncclCommInitAll, the tiles
     {r, r + W, ...}, lrhip_film_reduce to the first device) against the same frame rendered on one GPU with the same work-item
-    sizing: bit for bit.  With a single visible GPU the list `-d 0` / LR_DEVICES=0 still goes through the threaded path
-    (world 1); world 2 runs when the box has two GPUs (the driver's multi-GPU node; a 1-GPU box skips that half)."""
+    sizing (the CLI sizes its work items for 8 shards whatever the device count, so `-d 0` and `-d 0,1` write the same bits): bit
+    for bit.  With a single visible GPU the list `-d 0` / LR_DEVICES=0 still goes through the threaded path (world 1) and
+    LR_FORCE_COLLECTIVE=1 makes it create its RCCL communicator and run the reduce with one rank -- the standalone binary has no
+    torch beside it and must find librccl on its own; world 2 runs when the box has two GPUs (a 1-GPU box skips that half)."""
     import ctypes as C
     from luisarender_amd import _ffi
     from luisarender_amd.render import MegaPathRenderer
@@ -97,13 +99,13 @@ def test_cli_shards_a_frame_over_several_gpus(tmp_path):
     for world in (1, 2):
         if world > n.value:
             pytest.skip(f"{n.value} GPU(s) visible: the world-{world} half needs {world}")
-        env = dict(os.environ, LR_DEVICES=",".join(str(d) for d in range(world)))
+        env = dict(os.environ, LR_DEVICES=",".join(str(d) for d in range(world)), LR_FORCE_COLLECTIVE="1")
         r = subprocess.run([CLI, "-b", "hip", str(scene_file)], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0 and f"on {world} HIP device(s)" in r.stderr, r.stderr
+        assert r.returncode == 0 and f"on {world} HIP device(s)" in r.stderr and "films reduced over RCCL" in r.stderr, r.stderr
         img, _ = load_image(str(tmp_path / "out.exr"))
         one = MegaPathRenderer(0)
         one.upload(sc)
-        one.render(0, 8, balance_shards=world, sync=True)
+        one.render(0, 8, balance_shards=8, sync=True)
         ref = one.download(converted=True)
         one.close()
         assert np.array_equal(img.reshape(ref.shape), ref), world

@@ -389,7 +389,34 @@ def test_full_size_c2_properties(renderer, tmp_path):
     a, b = film[384:640, 384:640, :3], sub[384:640, 384:640, :3]
     # Same seeded paths; specular chains through alpha = 1e-4 GGX lobes amplify fp32 rounding differences (fma
     # contraction, hardware division) into per-pixel differences without bias.  Measured: mean 1e-4, rel-L1 8e-3.
-    assert abs(a.mean() - b.mean()) / b.mean() < 2e-3 and _rel_l1(a, b) < 2e-2
+    fast = _rel_l1(a, b)
+    assert abs(a.mean() - b.mean()) / b.mean() < 2e-3 and fast < 2e-2
+
+
+def test_what_separates_c2_from_the_oracle_is_the_instance_transform(renderer, tmp_path):
+    """Where do the 5e-3 .. 9e-3 relative L1 between the device and the oracle on the C2 stand-in come from?  NOT from fast math: round 3
+    built the lean kernel with IEEE arithmetic (make ieee: no contraction, correctly rounded division / sqrt, exact functions) and
+    measured 8.57e-3 against the shipped build's 8.85e-3 on the full-size window (VERDICT r02 1d asked; the hypothesis of rounds 1-2
+    was wrong).  It is the intersector: the device intersects BAKED world-space triangles (one-level BVH, dev_trace.h), the oracle --
+    like the reference's ray-tracing unit -- transforms the ray into object space per instance; hit points differ in their last
+    bits, and the room's near-specular chains (GGX alpha 1e-4 mirrors, smooth glass) amplify that into different paths, without bias.
+    Shown here with the SAME room twice: fixtures as scaled + rotated instances (the bench scene's form), and with the transforms
+    applied to the vertices beforehand (object space = world space, nothing to transform).  Same shipped kernel <0>, same oracle:
+    the second scene must agree two orders of magnitude better than the first -- as the instance-free Cornell scenes do (1e-6)."""
+    kw = dict(target_triangles=100_000, resolution=(256, 256), spp=8)
+    errs = {}
+    for name, opt in (("instanced", dict(inline_meshes=True)), ("baked", dict(bake_transforms=True))):
+        sc = Scene.load(generate_room_scene(str(tmp_path), name=name, **opt, **kw))
+        renderer.upload(sc)
+        renderer.render(0, 8, counters=False, sync=True)
+        assert renderer.last_variant() == 0
+        g = renderer.download(False)
+        c, _ = Oracle(sc).render(0, 8)
+        assert np.array_equal(g[..., 3], c[..., 3])
+        errs[name] = (_rel_l1(g, c), abs(g[..., :3].mean() - c[..., :3].mean()) / c[..., :3].mean())
+        print(f"C2-class room, {name}: device vs oracle rel-L1 {errs[name][0]:.2e}, mean {errs[name][1]:.2e}")
+    assert errs["instanced"][1] < 2e-3 and errs["baked"][1] < 2e-4
+    assert errs["baked"][0] < 5e-4 and errs["baked"][0] < 0.05 * errs["instanced"][0], errs
 
 
 @pytest.mark.parametrize("config", ["c3", "c4", "c5"])
@@ -720,6 +747,36 @@ def test_nested_mix_layered_only_in_megapath(renderer):
     for integrator in ('Direct { importance_sampling { "both" }', "MegaVPTNaive {"):
         with pytest.raises(DeviceError, match="MegaPath integrator only"):
             renderer.upload(Scene.from_string(text.replace("integrator : MegaPath {", "integrator : " + integrator)))
+
+
+def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):
+    """lrhip_upload_scene walks every Mix / Layered tree itself: what the C++ loader refuses -- a Layered surface
+    anywhere under an interface of a Layered surface, a Mix tree whose recorded depth (u[2]) is not its depth, a cycle -- is an
+    error for a C-ABI caller too, not silently wrong shading.  The host tables of a valid scene are tampered with in place."""
+    from helpers import MATERIALS
+    from luisarender_amd.render import DeviceError
+    extra = "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in ("mix_layered", "mix_nested"))
+    sc = Scene.from_string(cornell_box(resolution=16, spp=1, short_box_surface="mix_layered", tall_box_surface="mix_nested", extra_surfaces=extra))
+    view = sc.view(0)
+    renderer.upload(sc)  # valid as loaded
+    surfaces = [view.surfaces[i] for i in range(view.surface_count)]
+    mixes = [i for i, x in enumerate(surfaces) if x.kind == 7]  # LR_SURFACE_MIX
+    layered = [i for i, x in enumerate(surfaces) if x.kind == 8]  # LR_SURFACE_LAYERED
+    assert mixes and layered, [x.kind for x in surfaces]
+    deep = max(mixes, key=lambda i: surfaces[i].u[2])
+    saved = surfaces[deep].u[2]
+    view.surfaces[deep].u[2] = saved + 1  # a wrong depth
+    with pytest.raises(DeviceError, match="u\\[2\\] is not the depth"):
+        renderer.upload(sc)
+    view.surfaces[deep].u[2] = saved
+    lay = layered[0]
+    top = view.surfaces[lay].u[0]
+    holder = next(i for i in mixes if lay in (surfaces[i].u[0], surfaces[i].u[1]))  # Mix -> Layered ...
+    view.surfaces[lay].u[0] = holder                                                 # ... -> Mix -> Layered: a cycle through a Layered interface
+    with pytest.raises(DeviceError, match="inside a Layered surface|cyclic"):
+        renderer.upload(sc)
+    view.surfaces[lay].u[0] = top
+    renderer.upload(sc)  # and valid again
 
 
 @pytest.mark.parametrize("sampler", ["Independent", "Sobol"])

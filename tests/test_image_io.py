@@ -297,6 +297,14 @@ def test_exr_header_cannot_make_the_reader_allocate_gigabytes(tmp_path):
     bad.write_bytes(bytes(raw))
     with pytest.raises(HostError, match="too large"):
         load_image(str(bad))
+    # under the 2^28-pixel cap and with a long-enough offset table, but 16 bytes per pixel are more than the file could ever expand to
+    # (an 8 KB file with a 16384 x 16384 window used to get its 4 GiB): 8 KB of padding behind the chunks, 16384 x 512
+    padded = bytes(raw) + b"\0" * 8192
+    raw2 = bytearray(padded)
+    struct.pack_into("<4i", raw2, at, 0, 0, 16383, 511)
+    bad.write_bytes(bytes(raw2))
+    with pytest.raises(HostError, match="too large"):
+        load_image(str(bad))
     got, _ = load_image(str(good))
     assert got.shape == (4, 6, 4) and np.allclose(got[..., :3], 0.5)
 

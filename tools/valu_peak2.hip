@@ -77,10 +77,17 @@ constexpr int kChains = 8, kUnroll = 32;
     X(60, "v_mbcnt_lo_u32_b32", "v_mbcnt_lo_u32_b32 %0, %2, %0") \
     X(61, "v_cmp_eq_u32 sgpr (e64)", "v_cmp_eq_u32_e64 s[40:41], %0, %2") \
     X(62, "v_cmp_class_f32", "v_cmp_class_f32 vcc, %0, %2") \
-    X(63, "v_dot2c_f32_f16", "v_dot2c_f32_f16 %0, %2, %3")
-constexpr int kOps = 64;
+    X(63, "v_dot2c_f32_f16", "v_dot2c_f32_f16 %0, %2, %3") \
+    X(64, "v_cmp + 2 x v_cndmask (per instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %0, %3, %0, vcc") \
+    X(65, "s_mov vcc + v_cndmask vcc (per pair)", "s_mov_b64 vcc, %4\n\tv_cndmask_b32 %0, %0, %2, vcc") \
+    X(66, "v_cmp (e64 -> sgpr) + v_cndmask e64 (per instruction)", "v_cmp_lt_f32_e64 s[40:41], %0, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]") \
+    X(67, "v_mul_f32 sdwa src0 BYTE_1 (is SDWA full rate?)", "v_mul_f32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD") \
+    X(68, "v_or_b32", "v_or_b32 %0, %0, %2") \
+    X(69, "v_cvt_f32_ubyte0 sdwa-free: v_and + v_or (per pair)", "v_and_b32 %0, %0, %2\n\tv_or_b32 %0, %0, %3")
+constexpr int kOps = 70;
+constexpr int instr_per_asm(int idx) { return idx == 19 || idx == 65 || idx == 66 || idx == 69 ? 2 : (idx == 64 ? 3 : 1); }
 // (an asm statement that clobbers SGPRs makes the compiler put an s_nop behind it: only the opcodes that write one declare it)
-constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62; }
+constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62 || idx == 64 || idx == 65 || idx == 66; }
 
 template<int KIND>
 __global__ __launch_bounds__(64) void valu_kernel(float *out, int trips, float seed) {
@@ -181,7 +188,7 @@ int main() {
             CHECK(hipEventSynchronize(e1));
             float ms = 0.f;
             CHECK(hipEventElapsedTime(&ms, e0, e1));
-            const double instr_per_wave = double(trips) * kChains * kUnroll * (kind == 19 ? 2 : 1);
+            const double instr_per_wave = double(trips) * kChains * kUnroll * instr_per_asm(kind);
             const double cycles = ms * 1e-3 * clock_hz / (instr_per_wave * waves);
             std::printf(", \"w%d\": %.2f", waves, cycles);
         }
