@@ -50,9 +50,12 @@ oracle/liboracle.so: oracle/oracle.cpp $(wildcard oracle/*.h) include/lr_scene.h
 # The megakernel is precompiled for a curated set of feature masks (csrc/hip/variants.h), one object per mask so
 # that they build in parallel (make -j).  VARIANT_MASKS may be narrowed for experiments (a missing variant is a
 # run-time error of lrhip_render, never a fallback).
-VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 636 637 638 639 252 253 254 255 256 257 258 259
+VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 60 61 62 63 124 125 126 127 636 637 638 639 252 253 254 255 256 257 258 259 \
+                 1032 1033 1034 1035 1036 1037 1038 1039 3080 3081 3082 3083 3084 3085 3086 3087
+# the heavy-closure kernels of wavefront mode (csrc/hip/heavy_kernel.h; mask: 1 counters, 2 generic sampler, 512 nested Mix / Layered)
+HEAVY_MASKS ?= 0 1 2 3 512 513 514 515
 OBJDIR := $(LIBDIR)/obj
-VARIANT_OBJ := $(foreach m,$(VARIANT_MASKS),$(OBJDIR)/variant_$(m).o)
+VARIANT_OBJ := $(foreach m,$(VARIANT_MASKS),$(OBJDIR)/variant_$(m).o) $(foreach m,$(HEAVY_MASKS),$(OBJDIR)/heavy_$(m).o)
 
 hip: $(LIBDIR)/liblrhip.so
 # The volumetric megakernel (variants 256+) is built with IEEE arithmetic: no fp contraction, correctly rounded division / sqrt, no
@@ -76,6 +79,11 @@ variant_flags = $(if $(filter 256 257 258 259,$(1)),$(VPT_HIPFLAGS),$(HIPFLAGS))
 $(OBJDIR)/variant_%.o: $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(call variant_flags,$*) -DLR_VARIANT=$* -c -o $@ $(HIPDIR)/megapath_variant.hip
+# (they make real calls -- the closure interpreters stay out of line -- so they take the same safe flag)
+HEAVY_DEFS ?=
+$(OBJDIR)/heavy_%.o: $(HIPDIR)/heavy_variant.hip $(HIP_HDR) Makefile
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(CALL_SAFE_FLAGS) $(HEAVY_DEFS) -DLR_HVARIANT=$* -c -o $@ $(HIPDIR)/heavy_variant.hip
 $(OBJDIR)/lrhip.o: $(HIP_SRC) $(HIP_HDR) Makefile
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(HIP_SRC)
@@ -87,7 +95,7 @@ $(LIBDIR)/liblrhip.so: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 VOBJDIR := $(LIBDIR)/variants/obj_$(NAME)
 hip-variant:
 	@mkdir -p $(VOBJDIR)
-	$(MAKE) --no-print-directory OBJDIR=$(VOBJDIR) HIPFLAGS='$(HIPFLAGS) $(DEFS)' VARIANT_MASKS='$(VARIANT_MASKS)' \
+	$(MAKE) --no-print-directory OBJDIR=$(VOBJDIR) HIPFLAGS='$(HIPFLAGS) $(DEFS)' VARIANT_MASKS='$(VARIANT_MASKS)' HEAVY_MASKS='$(HEAVY_MASKS)' \
 	    LIBDIR_OUT=$(LIBDIR)/variants/liblrhip_$(NAME).so variant-lib
 variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $(LIBDIR_OUT) $^

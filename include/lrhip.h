@@ -156,6 +156,16 @@ uint32_t lrhip_last_variant(lrhip_ctx *ctx);
  *                   A value other than the default changes the order of a pixel's float adds, i.e. the film's last bits.        */
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale);
 
+/* Wavefront mode (round 3): a scene with Mix or Layered surfaces under the MegaPath integrator is rendered by a lean megakernel that
+ * parks the paths reaching a Disney / Mix / Layered surface in HBM queues, a heavy-closure kernel that shades those vertices in full
+ * waves of one closure kind, and a continuation pass of the megakernel -- alternating until the queues are empty.  The frame is cut
+ * into slices of the sample range whose paths fit the queues.
+ *   mode         0 = automatic (default), 1 = never: the all-in-one megakernel variants (A/B, tests)
+ *   slice_paths  paths per slice = slots per queue (0 = default 2^25: ~10 GB of queues)
+ * lrhip_last_variant reports LRHIP_FEAT_WAVEFRONT | the lean kernel's bits | the closure bits the heavy kernel served.          */
+#define LRHIP_FEAT_WAVEFRONT 1024u
+int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
+
 const char *lrhip_last_error(void);
 
 #ifdef __cplusplus

@@ -114,6 +114,30 @@ struct DShadeTri {// 8 x float4
 };
 static_assert(sizeof(DShadeTri) == 128, "one line per triangle");
 
+// ---- wavefront mode (round 3): scenes with Mix / Layered surfaces.  The out-of-line closures do not live in the megakernel any
+// more: a LEAN megakernel (kFeatWf variants) PARKS a path that hits a Disney / Mix / Layered surface -- its state goes into a queue
+// in HBM, one queue per closure kind, and the lane takes the next sample -- a separate kernel (heavy_kernel.h) shades the parked
+// vertices in full waves of ONE closure kind with a register allocation of its own and writes CONTINUATION records (shadow ray,
+// next ray, throughput), which the lean megakernel's continuation pass (kFeatCont) traces and carries on like any other path.
+// Rounds alternate until the queues are empty (at most max_depth of them).  All queues are field-major [field][slot] so that a
+// wave's pushes and pops are coalesced.  The reference's own design for the same idea: src/integrators/wave_path_v2.cpp:419-440.
+constexpr uint32_t kWfKinds = 3u;            // Disney, Mix, Layered (LR_SURFACE_DISNEY .. LR_SURFACE_LAYERED)
+constexpr uint32_t kWfHeavyWords = 14u;      // + sampler words: d(3) tri u v beta(3) Li(3) pixel depth
+constexpr uint32_t kWfContWords = 25u;       // + sampler words: ray o d (6) shadow o d tmax (7) nee(3) beta(3) Li(3) pdf pixel depth|flags
+constexpr uint32_t kWfSamplerWordsMax = 8u;
+constexpr uint32_t kWfItemRecords = 512u;    // continuation records per work item of the continuation pass
+// device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the heavy
+// kernel, [5] work counter of the continuation pass
+enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkHeavy = 4u, kWfWorkCont = 5u, kWfCounterWords = 8u };
+struct WfArgs {
+    uint32_t *heavy;             // [kWfKinds][kWfHeavyWords + sampler words][capacity]
+    uint32_t *cont;              // [kWfContWords + sampler words][capacity]
+    uint32_t *counts;            // kWfCounterWords counters of THIS round
+    uint32_t capacity;           // records per queue (>= paths of one slice: a path is parked at most once per round)
+    unsigned long long *accum;   // fixed-point radiance sums [pixel][3] of the paths that finish outside their tile's wave
+    float accum_scale;           // 2^k: radiance -> fixed point (the film gets accum / 2^k once per lrhip_render)
+};
+
 struct DScene {
     // acceleration structure
     const DNodeQ *nodes;
@@ -155,6 +179,7 @@ struct DScene {
     const uint32_t *sobol_matrices;// [1024][52]
     const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
     const DEnvironment *env;
+    WfArgs wf;// wavefront mode only (behind the scene pointer like everything else: scalar loads where a field is used)
 };
 
 // The scene record reaches the kernels through a pointer into constant memory, not by value: as a 400-byte kernel argument
@@ -166,30 +191,6 @@ typedef const DScene __attribute__((address_space(4))) *DScenePtr;
 struct DCounters {
     unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
         path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles, nodes_empty;
-};
-
-// ---- wavefront mode (round 3): scenes with Mix / Layered surfaces.  The out-of-line closures do not live in the megakernel any
-// more: a LEAN megakernel (kFeatWf variants) PARKS a path that hits a Disney / Mix / Layered surface -- its state goes into a queue
-// in HBM, one queue per closure kind, and the lane takes the next sample -- a separate kernel (heavy_kernel.h) shades the parked
-// vertices in full waves of ONE closure kind with a register allocation of its own and writes CONTINUATION records (shadow ray,
-// next ray, throughput), which the lean megakernel's continuation pass (kFeatCont) traces and carries on like any other path.
-// Rounds alternate until the queues are empty (at most max_depth of them).  All queues are field-major [field][slot] so that a
-// wave's pushes and pops are coalesced.  The reference's own design for the same idea: src/integrators/wave_path_v2.cpp:419-440.
-constexpr uint32_t kWfKinds = 3u;            // Disney, Mix, Layered (LR_SURFACE_DISNEY .. LR_SURFACE_LAYERED)
-constexpr uint32_t kWfHeavyWords = 14u;      // + sampler words: d(3) tri u v beta(3) Li(3) pixel depth
-constexpr uint32_t kWfContWords = 24u;       // + sampler words: ray o d (6) shadow o d tmax (7) nee(3) beta(3) Li(3) pdf pixel depth|flags
-constexpr uint32_t kWfSamplerWordsMax = 8u;
-constexpr uint32_t kWfItemRecords = 512u;    // continuation records per work item of the continuation pass
-// device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the heavy
-// kernel, [5] work counter of the continuation pass
-enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkHeavy = 4u, kWfWorkCont = 5u, kWfCounterWords = 8u };
-struct WfArgs {
-    uint32_t *heavy;             // [kWfKinds][kWfHeavyWords + sampler words][capacity]
-    uint32_t *cont;              // [kWfContWords + sampler words][capacity]
-    uint32_t *counts;            // kWfCounterWords counters of THIS round
-    uint32_t capacity;           // records per queue (>= paths of one slice: a path is parked at most once per round)
-    unsigned long long *accum;   // fixed-point radiance sums [pixel][3] of the paths that finish outside their tile's wave
-    float accum_scale;           // 2^k: radiance -> fixed point (the film gets accum / 2^k once per lrhip_render)
 };
 
 struct RenderArgs {
@@ -204,7 +205,6 @@ struct RenderArgs {
     uint32_t *spill;       // traversal stack overflow area [kSpillEntries][total_threads]
     uint32_t total_threads;
     DCounters *counters;
-    WfArgs wf;             // kFeatWf variants and the heavy kernel only
 };
 
 }// namespace lrd

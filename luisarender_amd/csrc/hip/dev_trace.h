@@ -251,7 +251,9 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
                 auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
                 uint32_t key[4];
-                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis
+                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis.  (Bit selects on
+                // a per-ray sign mask, six v_bfi_b32 instead of three v_cmp + six v_cndmask, were measured in round 3 -- the issue-cost
+                // table has the second v_cndmask behind one v_cmp at ~14 cycles -- and changed nothing: 836.3 / 836.7 vs 834.8 / 836.3.)
                 auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
                 auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
                 auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;

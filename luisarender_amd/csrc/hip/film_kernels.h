@@ -23,6 +23,21 @@ __global__ void resolve_partial_kernel(float4 *film, const float4 *partial, uint
     film[i] = v;
 }
 
+// wavefront mode: the fixed-point radiance sums of the paths that finished outside their tile's wave (dev_wavefront.h:
+// wf_film_accumulate) join the film once per lrhip_render, and the sums are cleared for the next call
+__global__ void wf_resolve_kernel(float4 *film, unsigned long long *accum, uint32_t pixel_count, double inv_scale) {
+    auto i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixel_count) { return; }
+    auto a = accum + static_cast<size_t>(i) * 3u;
+    if ((a[0] | a[1] | a[2]) == 0ull) { return; }
+    auto v = film[i];
+    v.x += static_cast<float>(static_cast<double>(a[0]) * inv_scale);
+    v.y += static_cast<float>(static_cast<double>(a[1]) * inv_scale);
+    v.z += static_cast<float>(static_cast<double>(a[2]) * inv_scale);
+    film[i] = v;
+    a[0] = 0ull, a[1] = 0ull, a[2] = 0ull;
+}
+
 // convert kernel of the Color film, color.cpp:87-93
 __global__ void film_convert_kernel(const float4 *film, float4 *out, uint32_t pixel_count, float sx, float sy, float sz) {
     auto i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,6 +27,13 @@
     extern "C" __attribute__((weak)) hipError_t lrhip_variant_occupancy_##mask(int *);
 LR_VARIANT_LIST(LR_DECLARE_VARIANT)
 #undef LR_DECLARE_VARIANT
+// the heavy-closure kernels of wavefront mode, one translation unit each (heavy_variant.hip, -DLR_HVARIANT=<mask>)
+#define LR_HEAVY_LIST(X) X(0) X(1) X(2) X(3) X(512) X(513) X(514) X(515)
+#define LR_HEAVY_DECL(mask)                                                                                                   \
+    extern "C" __attribute__((weak)) hipError_t lrhip_heavy_launch_##mask(unsigned, hipStream_t, const lrd::DScene *, const lrd::RenderArgs *); \
+    extern "C" __attribute__((weak)) hipError_t lrhip_heavy_occupancy_##mask(int *);
+LR_HEAVY_LIST(LR_HEAVY_DECL)
+#undef LR_HEAVY_DECL
 
 namespace {
 
@@ -39,6 +46,17 @@ struct VariantEntry {
 const VariantEntry kVariants[] = {LR_VARIANT_LIST(LR_VARIANT_ENTRY)};
 #undef LR_VARIANT_ENTRY
 static_assert(sizeof(kVariants) / sizeof(kVariants[0]) == lrd::kSceneVariantCount * 4u, "variants.h and kSceneVariants disagree");
+
+// (mask: bit 0 counters, bit 1 generic sampler, 512 nested Mix / Layered)
+#define LR_HEAVY_ENTRY(mask) VariantEntry{mask##u, lrhip_heavy_launch_##mask, lrhip_heavy_occupancy_##mask},
+const VariantEntry kHeavyVariants[] = {LR_HEAVY_LIST(LR_HEAVY_ENTRY)};
+#undef LR_HEAVY_ENTRY
+int find_variant(const VariantEntry *table, size_t n, uint32_t mask) {
+    for (size_t k = 0; k < n; k++) {
+        if (table[k].mask == mask) { return static_cast<int>(k); }
+    }
+    return -1;
+}
 
 // smallest precompiled superset of the scene's feature bits (+ the count / generic-sampler bits, which are exact)
 int pick_variant(uint32_t scene_features, bool count, bool generic) {
@@ -110,6 +128,11 @@ struct lrhip_ctx {
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
     uint32_t diag_force_features{0u};// lrhip_set_diagnostics (tests / tools)
     double diag_item_scale{0.};
+    // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
+    DeviceBuffer wf_heavy, wf_cont, wf_counts, wf_accum;
+    int heavy_blocks[8]{-1, -1, -1, -1, -1, -1, -1, -1};// resident blocks per CU of each heavy-kernel variant
+    uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never
+    uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
 };
 
 namespace {
@@ -334,7 +357,7 @@ void lrhip_destroy(lrhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     release_scene(ctx);
     ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
-    ctx->spill.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
+    ctx->spill.release(), ctx->wf_heavy.release(), ctx->wf_cont.release(), ctx->wf_counts.release(), ctx->wf_accum.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -720,6 +743,124 @@ int lrhip_film_clear(lrhip_ctx *ctx) {
     return LRHIP_OK;
 }
 
+// ---- wavefront mode (dev_scene.h: WfArgs): a scene with Mix or Layered surfaces under the MegaPath integrator.  The frame is cut
+// into SLICES of the sample range whose paths fit the queues (a path is parked at most once per round, so a queue never needs more
+// slots than the slice has paths); per slice: the camera pass of the lean megakernel <.. | Wf> (its own work items, chunked by the
+// same loss model as the plain megakernel), then up to max_depth ROUNDS of { heavy kernel -> continuation pass <.. | Wf | Cont> }.
+// Nothing comes back to the host in between: the kernels read their record counts from device memory and the grids are the
+// persistent ones (an empty round costs a few microseconds), so a slice is one uninterrupted stretch of the stream.
+static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32_t tiles_x, uint32_t tiles_y, uint32_t tiles_in_range,
+                            uint32_t tile_count, bool count, bool generic) {
+    const auto spp = p->spp_end - p->spp_begin;
+    const auto pixel_count = ctx->width * ctx->height;
+    const auto sampler_words = generic ? lrd::kWfSamplerWordsMax : 1u;
+    const auto paths_per_spp = static_cast<uint64_t>(tiles_in_range) * 64u;
+    // 2^25 paths per slice by default: 33.5 M x (3 queues x 15..22 words + 26..33 words) x 4 B = 9.5 .. 13 GB of the 288
+    const auto want_paths = static_cast<uint64_t>(ctx->wf_slice_paths != 0u ? ctx->wf_slice_paths : (1u << 25u));
+    const auto slice_spp = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(spp, want_paths / std::max<uint64_t>(paths_per_spp, 1u))));
+    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(paths_per_spp * slice_spp, (1ull << 31u) - 1u));
+    const auto heavy_words = static_cast<size_t>(lrd::kWfKinds) * (lrd::kWfHeavyWords + sampler_words) * capacity;
+    const auto cont_words = static_cast<size_t>(lrd::kWfContWords + sampler_words) * capacity;
+    if (auto r = ensure(ctx->wf_heavy, heavy_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->wf_cont, cont_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    if (ctx->wf_counts.ptr == nullptr) {
+        if (auto r = ensure(ctx->wf_counts, lrd::kWfCounterWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    }
+    if (ctx->wf_accum.bytes < static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long)) {
+        if (auto r = ensure(ctx->wf_accum, static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long)); r != LRHIP_OK) { return r; }
+        LR_HIP_CHECK(hipMemsetAsync(ctx->wf_accum.ptr, 0, static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long), ctx->stream));
+    }
+    // fixed point: one sample adds at most clamp x |shutter weight| per channel and a pixel takes at most `spp` of them in this call;
+    // the scale is the largest power of two that keeps that sum below 2^62 (and at most 2^40: 1e-12 of absolute resolution)
+    auto &scene = ctx->scene;
+    scene.shutter_weight = (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f;
+    const auto bound = std::max(1.0, static_cast<double>(scene.film_clamp) * std::max(1.0, std::fabs(static_cast<double>(scene.shutter_weight)))) * std::max(1u, spp);
+    const auto scale_log2 = std::min(40, std::max(0, 61 - static_cast<int>(std::ceil(std::log2(bound)))));
+    const auto accum_scale = std::ldexp(1.0, scale_log2);
+    scene.wf.heavy = static_cast<uint32_t *>(ctx->wf_heavy.ptr), scene.wf.cont = static_cast<uint32_t *>(ctx->wf_cont.ptr);
+    scene.wf.counts = static_cast<uint32_t *>(ctx->wf_counts.ptr), scene.wf.capacity = capacity;
+    scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr), scene.wf.accum_scale = static_cast<float>(accum_scale);
+    // kernels: the lean camera pass + continuation pass with the scene's environment / alpha needs, the heavy kernel with its nesting
+    const auto lean = ((ctx->features & lrd::kFeatEnv) != 0u ? lrd::kFeatEnv : 0u) | lrd::kFeatAlpha | lrd::kFeatWf | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
+    const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
+    const auto vi_camera = find_variant(kVariants, n_variants, lean), vi_cont = find_variant(kVariants, n_variants, lean | lrd::kFeatCont);
+    const auto hi = find_variant(kHeavyVariants, 8u, ((ctx->features & lrd::kFeatNest) != 0u ? 512u : 0u) | (count ? 1u : 0u) | (generic ? 2u : 0u));
+    if (vi_camera < 0 || vi_cont < 0 || hi < 0 || kVariants[vi_camera].launch == nullptr || kVariants[vi_cont].launch == nullptr || kHeavyVariants[hi].launch == nullptr) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: the wavefront kernels for feature mask " + std::to_string(ctx->features) + " were not compiled into this library");
+    }
+    auto blocks_of = [&](int &cache, const VariantEntry &v, int &out) -> int {
+        if (cache < 0) {
+            int per_cu = 0;
+            LR_HIP_CHECK(v.occupancy(&per_cu));
+            cache = std::max(1, std::min(per_cu, static_cast<int>(kMaxBlocksPerCu)));
+        }
+        out = cache;
+        return LRHIP_OK;
+    };
+    int b_camera = 0, b_cont = 0, b_heavy = 0;
+    if (auto r = blocks_of(ctx->variant_blocks[vi_camera], kVariants[vi_camera], b_camera); r != LRHIP_OK) { return r; }
+    if (auto r = blocks_of(ctx->variant_blocks[vi_cont], kVariants[vi_cont], b_cont); r != LRHIP_OK) { return r; }
+    if (auto r = blocks_of(ctx->heavy_blocks[hi], kHeavyVariants[hi], b_heavy); r != LRHIP_OK) { return r; }
+    const auto resident = ctx->cu_count * static_cast<uint32_t>(std::max(b_camera, b_cont));
+    if (auto r = ensure(ctx->spill, static_cast<size_t>(resident) * lrd::kBlockThreads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
+    LR_HIP_CHECK(hipMemcpyAsync(ctx->scene_record.ptr, &scene, sizeof(lrd::DScene), hipMemcpyHostToDevice, ctx->stream));
+    const auto device_scene = static_cast<const lrd::DScene *>(ctx->scene_record.ptr);
+    lrd::RenderArgs args{};
+    args.film = ctx->film;
+    args.tile_begin = p->tile_begin, args.tile_end = p->tile_end, args.tile_stride = p->tile_stride;
+    args.tiles_x = tiles_x, args.tiles_y = tiles_y;
+    args.work_counter = static_cast<uint32_t *>(ctx->work_counter.ptr);
+    args.spill = static_cast<uint32_t *>(ctx->spill.ptr);
+    args.counters = static_cast<lrd::DCounters *>(ctx->counters.ptr);
+    const auto counts = static_cast<uint32_t *>(ctx->wf_counts.ptr);
+    const auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
+    auto item_scale = 1.25;
+    if (ctx->diag_item_scale > 0.) { item_scale *= std::max(0.01, ctx->diag_item_scale); }
+    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    for (auto s0 = p->spp_begin; s0 < p->spp_end; s0 += slice_spp) {
+        const auto s1 = std::min(p->spp_end, s0 + slice_spp);
+        const auto n = s1 - s0;
+        // ---- camera pass: samples [s0, s1) of every tile of the shard; heavy hits are parked
+        auto s_item = std::sqrt(item_scale * n * shard_tiles / kNominalWaves);
+        auto chunk_count = static_cast<uint32_t>(std::lround(n / std::max(s_item, 1.0)));
+        chunk_count = std::max(1u, std::min({chunk_count, n, kMaxChunks}));
+        args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = tiles_in_range * chunk_count;
+        args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_camera) * lrd::kBlockThreads;
+        if (chunk_count > 1u) {
+            if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
+            args.partial = static_cast<float4 *>(ctx->partial.ptr);
+        }
+        LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
+        LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
+        LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
+        if (chunk_count > 1u) {
+            hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
+                               args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
+        }
+        // ---- rounds: a path leaves a round either finished or parked again (one level deeper), so max_depth rounds empty the queues
+        args.chunk_count = 1u, args.item_count = 0u;// (the continuation pass reads its item count from the device)
+        for (auto round = 0u; round < std::max(scene.max_depth, 1u); round++) {
+            LR_HIP_CHECK(kHeavyVariants[hi].launch(ctx->cu_count * static_cast<uint32_t>(b_heavy), ctx->stream, device_scene, &args));
+            // the heavy kernel has consumed the parked paths: their counters (and its work counter) restart for the continuation pass
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountHeavy, 0, 3u * sizeof(uint32_t), ctx->stream));
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkHeavy, 0, sizeof(uint32_t), ctx->stream));
+            args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_cont) * lrd::kBlockThreads;
+            LR_HIP_CHECK(kVariants[vi_cont].launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, sizeof(uint32_t), ctx->stream));
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkCont, 0, sizeof(uint32_t), ctx->stream));
+        }
+    }
+    hipLaunchKernelGGL(lrd::wf_resolve_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
+                       static_cast<unsigned long long *>(ctx->wf_accum.ptr), pixel_count, 1.0 / accum_scale);
+    LR_HIP_CHECK(hipGetLastError());
+    LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
+    ctx->timed = true;
+    // what rendered: the lean camera-pass kernel's mask + the closure bits the heavy kernel served
+    ctx->last_variant = kVariants[vi_camera].mask | (ctx->features & (lrd::kFeatDisney | lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatNest));
+    return LRHIP_OK;
+}
+
 int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (ctx == nullptr || p == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_render: no scene uploaded"); }
     auto tiles_x = (ctx->width + 7u) / 8u, tiles_y = (ctx->height + 7u) / 8u;
@@ -735,6 +876,10 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone && ctx->scene.integrator_kind != LR_INTEGRATOR_NORMAL) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
+    if (ctx->wf_mode == 0u && (ctx->features & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u,
+                                ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT);
+    }
     // Chunking is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile range
     // of this call.  Two losses are balanced: the drain at the end of every item (the last paths of its queue finish
     // with most lanes idle, a share of ~a / S for S samples per pixel and item) and the tail of the launch (waves that
@@ -805,6 +950,12 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale) {
     if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_diagnostics: ctx is NULL"); }
     ctx->diag_force_features = force_features, ctx->diag_item_scale = item_scale;
+    return LRHIP_OK;
+}
+
+int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths) {
+    if (ctx == nullptr || mode > 1u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_wavefront: invalid argument"); }
+    ctx->wf_mode = mode, ctx->wf_slice_paths = slice_paths;
     return LRHIP_OK;
 }
 

@@ -19,27 +19,9 @@
 // (src/integrators/mega_path.cpp:49-156) and film accumulation ColorFilmInstance::_accumulate
 // (src/films/color.cpp:107-130).
 #pragma once
-#include "dev_heavy.h"
+#include "dev_wavefront.h"
 
 namespace lrd {
-
-// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) into the wave's LDS copy of its tile.
-LR_D void film_accumulate(float4 *pixel, f3 rgb, float clamp) {
-    if (!(any_nan(rgb) || any_inf(rgb))) {
-        auto threshold = clamp * fmaxf(1.f, 1.f);
-        auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
-        auto c = rgb * (threshold / fmaxf(strength, threshold));
-        if (c.x != 0.f || c.y != 0.f || c.z != 0.f) {
-            atomicAdd(&pixel->x, c.x), atomicAdd(&pixel->y, c.y), atomicAdd(&pixel->z, c.z);
-        }
-        atomicAdd(&pixel->w, 1.f);
-    }
-}
-
-LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp:133-140
-    auto sum = f_pdf + g_pdf;
-    return sum == 0.0f ? 0.0f : f_pdf / sum;
-}
 
 #ifndef LR_MIN_WAVES
 #define LR_MIN_WAVES 4
@@ -60,16 +42,10 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 //   kFeatLayered  Layered closure (random walk over two nested closures; implies the Disney interpreter)
 //   kFeatNest     free composition of Mix and Layered (round 2): Mix trees with Layered leaves, Layered surfaces whose interfaces are
 //                 Mix trees.  Its own variant: the larger call graph cost the everything-variant 9 % on a scene that does not nest
+//   kFeatWf/Cont  wavefront mode (round 3): every scene with Mix or Layered surfaces.  See the enum below and dev_scene.h
 //   kFeatAux      the sibling integrators that reuse this kernel's pieces: DirectLighting
 //                 (src/integrators/direct.cpp:66-200) and NormalVisualizer (normal.cpp:36-70), selected at run time by
 //                 scene.integrator_kind; debug / AOV views, so they only exist on top of the all-features variant
-enum : uint32_t {
-    kFeatCount = 1u, kFeatGeneric = 2u, kFeatEnv = 4u, kFeatAlpha = 8u, kFeatDisney = 16u, kFeatMix = 32u, kFeatLayered = 64u,
-    kFeatAux = 128u,
-    kFeatVpt = 256u,// the volumetric megakernel (megavpt_kernel.h): a different kernel, same launch interface
-    kFeatNest = 512u,
-    kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
-};
 // the precompiled scene-feature sets, smallest first (each also exists x {Count} x {Generic}); csrc/hip/variants/*.hip
 constexpr uint32_t kSceneVariants[] = {
     0u,
@@ -83,6 +59,12 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatSceneMask | kFeatNest,
     kFeatSceneMask | kFeatAux,
     kFeatVpt,
+    // wavefront mode: the lean kernel that parks heavy hits (camera pass) and its continuation pass; picked by lrhip_render for scenes
+    // with Mix / Layered surfaces, never by the superset search (they hold none of the closure bits)
+    kFeatAlpha | kFeatWf,
+    kFeatEnv | kFeatAlpha | kFeatWf,
+    kFeatAlpha | kFeatWf | kFeatCont,
+    kFeatEnv | kFeatAlpha | kFeatWf | kFeatCont,
 };
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
@@ -122,11 +104,11 @@ constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAV
 // Work distribution: ONE atomic counter over the item space (tiles x sample-chunks, tile-major).  The 4096 resident waves then work
 // on a moving front of ~300 neighbouring tiles, so every XCD's L2 already holds the front's BVH lines; per-XCD item ranges were
 // measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/r02b_ab_xcd_waves.txt).
-LR_D uint32_t next_item(const RenderArgs &args, uint32_t lane) {
+LR_D uint32_t next_item(uint32_t *counter, uint32_t item_count, uint32_t lane) {
     uint32_t item = 0u;
-    if (lane == 0u) { item = atomicAdd(args.work_counter, 1u); }
+    if (lane == 0u) { item = atomicAdd(counter, 1u); }
     item = __shfl(item, 0);
-    return item < args.item_count ? item : kInvalid;
+    return item < item_count ? item : kInvalid;
 }
 
 template<uint32_t F>
@@ -134,8 +116,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
     const DScene &scene = *(const DScene *)scene_ptr;
     constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u, ENV = (F & kFeatEnv) != 0u,
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, MIX = (F & kFeatMix) != 0u,
-                   LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u;
+                   LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u, WF = (F & kFeatWf) != 0u, CONT = (F & kFeatCont) != 0u;
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
+    static_assert(!WF || !(DISNEY || MIX || LAYERED || AUX), "a wavefront variant is a lean kernel: the heavy closures live in heavy_kernel.h");
+    static_assert(!CONT || WF, "the continuation pass exists in wavefront mode only");
+    constexpr uint32_t SAMPLER_WORDS = PathSampler<PCG>::kSavedWords;
     constexpr int HEAVY_BATCH = LAYERED ? LR_HEAVY_BATCH_LAYERED : LR_HEAVY_BATCH;
     constexpr bool PARK_HEAVY = (MIX || LAYERED) && !AUX && HEAVY_BATCH > 1;
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
@@ -149,9 +134,14 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
     DCounters local{};
     const auto t_wave = COUNT ? __builtin_readcyclecounter() : 0ull;
 
+    // the continuation pass (CONT) works through the records the heavy kernel wrote this round, kWfItemRecords of them per item;
+    // their number is only known on the device
+    const auto cont_total = CONT ? scene.wf.counts[kWfCountCont] : 0u;
+    const auto item_count = CONT ? (cont_total + kWfItemRecords - 1u) / kWfItemRecords : args.item_count;
+    const auto cont_queue = wf_cont_queue(scene);
     for (;;) {
         // ---- next work item of this wavefront
-        uint32_t item = next_item(args, lane);
+        uint32_t item = next_item(CONT ? scene.wf.counts + kWfWorkCont : args.work_counter, item_count, lane);
         if (item == kInvalid) { break; }
         const auto tile_index = item / args.chunk_count;
         const auto chunk = item - tile_index * args.chunk_count;
@@ -161,12 +151,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
         const auto s_begin = args.spp_begin + chunk * per_chunk;
         const auto s_end = min(s_begin + per_chunk, args.spp_end);
-        // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile
-        const auto q_total = s_end > s_begin ? (s_end - s_begin) * 64u : 0u;
+        // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * kWfItemRecords + k)
+        const auto q_total = CONT ? min(kWfItemRecords, cont_total - item * kWfItemRecords) : (s_end > s_begin ? (s_end - s_begin) * 64u : 0u);
         auto q_next = 0u;// wave-uniform
         film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         auto px = 0u, py = 0u;
         auto pixel = film_tile;// LDS accumulator of the pixel this lane's current sample belongs to
+        auto pixel_index = 0u; // WF: the same pixel in the film (a parked path takes it along)
         // ---- per-lane path state
         PathSampler<PCG> sampler{};
         TravState tr{};
@@ -206,6 +197,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     parked = heavy_hit && others;
                 }
             }
+            auto park_kind = kInvalid;// WF: closure kind (0 Disney, 1 Mix, 2 Layered) of the heavy surface this lane's path just reached
             if (tr.phase == kPhaseIdle && !parked) {
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
                     if (!tr.occluded) { Li += nee; }
@@ -276,6 +268,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                             Li = beta * ns;
                             has_surface = false;
                         }
+                    }
+                    // wavefront mode: a Disney / Mix / Layered surface is not shaded here.  The path -- direction, hit, throughput,
+                    // radiance so far (the emission of this vertex included), sampler position -- goes into the queue of its
+                    // closure kind; heavy_kernel.h shades the vertex and hands the path back as a continuation record.
+                    if (WF && has_surface) {
+                        const auto kind = scene.closures[(it.tags >> 12u) & 4095u].kind;
+                        if (kind >= LR_SURFACE_DISNEY) { park_kind = kind - LR_SURFACE_DISNEY, has_surface = false; }
                     }
                     if (has_surface) {
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
@@ -356,9 +355,32 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                         want_closest = alive && depth < scene.max_depth;
                     }
                 }
+                if (WF && park_kind != kInvalid) { path_open = false; }// (it goes on elsewhere: nothing to accumulate here)
                 if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
-                    film_accumulate(pixel, Li * scene.shutter_weight, scene.film_clamp);
+                    if (CONT) { wf_film_accumulate(scene, args.film, pixel_index, Li * scene.shutter_weight, scene.film_clamp); }
+                    else { film_accumulate(pixel, Li * scene.shutter_weight, scene.film_clamp); }
                     path_open = false;
+                }
+            }
+            if (WF) {// ---- park: one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
+                if (__any(park_kind != kInvalid)) {
+#pragma unroll
+                    for (auto k = 0u; k < kWfKinds; k++) {
+                        const auto mask = __ballot(park_kind == k);
+                        if (mask == 0ull) { continue; }
+                        const auto slot = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
+                        if (park_kind == k && slot < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
+                            const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
+                            q.put3(slot, 0u, tr.d);// (the hit and the ray are still in the traversal state: the launch below resets them)
+                            q.put(slot, 3u, tr.hit.tri), q.put(slot, 4u, tr.hit.u), q.put(slot, 5u, tr.hit.v);
+                            q.put3(slot, 6u, beta), q.put3(slot, 9u, Li);
+                            q.put(slot, 12u, pixel_index), q.put(slot, 13u, depth);
+                            uint32_t words[kWfSamplerWordsMax];
+                            sampler.save(words);
+#pragma unroll
+                            for (auto w = 0u; w < SAMPLER_WORDS; w++) { q.put(slot, kWfHeavyWords + w, words[w]); }
+                        }
+                    }
                 }
             }
             // ==== (A') path regeneration: lanes with no path take the next samples of the item's queue, in lane order
@@ -367,10 +389,31 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                 const auto mask = __ballot(need);
                 const auto k = q_next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
                 q_next = min(q_next + static_cast<uint32_t>(__popcll(mask)), q_total);
-                if (need && k < q_total) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
+                if (CONT) {
+                    if (need && k < q_total) {// a path comes back from the heavy kernel: as if this lane had just shaded its vertex
+                        const auto slot = item * kWfItemRecords + k;
+                        const auto &q = cont_queue;
+                        ray.o = q.get3(slot, 0u), ray.d = q.get3(slot, 3u);
+                        ray.t_min = 0.f, ray.t_max = kFloatMax;
+                        shadow.o = q.get3(slot, 6u), shadow.d = q.get3(slot, 9u);
+                        shadow.t_min = 0.f, shadow.t_max = q.getf(slot, 12u);
+                        nee = q.get3(slot, 13u), beta = q.get3(slot, 16u), Li = q.get3(slot, 19u);
+                        pdf_bsdf = q.getf(slot, 22u);
+                        pixel_index = q.get(slot, 23u);
+                        const auto packed = q.get(slot, 24u);
+                        depth = packed & 0xffffu;
+                        want_shadow = (packed & (1u << 16u)) != 0u, want_closest = (packed & (1u << 17u)) != 0u;
+                        uint32_t words[kWfSamplerWordsMax];
+#pragma unroll
+                        for (auto w = 0u; w < SAMPLER_WORDS; w++) { words[w] = q.get(slot, kWfContWords + w); }
+                        sampler.restore(scene, words);
+                        path_open = true;
+                    }
+                } else if (need && k < q_total) {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
                     const auto pix = k & 63u;
                     px = tx * 8u + (pix & 7u), py = ty * 8u + (pix >> 3u);
                     pixel = film_tile + pix;
+                    if (WF) { pixel_index = py * scene.camera.width + px; }
                     if (px < scene.camera.width && py < scene.camera.height) {
                         sampler.start(scene, px, py, s_begin + (k >> 6u));
                         auto u_filter = sampler.next_pixel_2d();
@@ -414,7 +457,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         }
         // ---- item complete: lane l adds pixel l of the tile to the film (or stores this chunk's partial plane)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
+        if (!CONT) {
             const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
             if (wx < scene.camera.width && wy < scene.camera.height) {
                 const auto acc = film_tile[lane];

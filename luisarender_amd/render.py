@@ -126,6 +126,11 @@ class MegaPathRenderer:
         the work-item size; the library itself reads no environment variable"""
         self._check(self._lib.lrhip_set_diagnostics(self._ctx, force_features, item_scale))
 
+    def set_wavefront(self, enabled: bool = True, slice_paths: int = 0) -> None:
+        """lrhip_set_wavefront: scenes with Mix / Layered surfaces render in wavefront mode by default (lean megakernel + heavy-closure
+        kernel + continuation pass); enabled=False keeps them on the all-in-one megakernel variants (A/B, tests)"""
+        self._check(self._lib.lrhip_set_wavefront(self._ctx, 0 if enabled else 1, slice_paths))
+
     def close(self) -> None:
         if self._ctx:
             self._lib.lrhip_destroy(self._ctx)

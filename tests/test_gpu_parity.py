@@ -10,6 +10,8 @@ import pytest
 
 from luisarender_amd import Scene
 from oracle.check import Oracle
+
+WF = 1024  # LRHIP_FEAT_WAVEFRONT: scenes with Mix / Layered surfaces render in wavefront mode (lean megakernel | closure bits the heavy kernel serves)
 from luisarender_amd.scenes import (cornell_box, generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene,
                                     generate_room_scene)
 
@@ -288,7 +290,7 @@ def test_kitchen_class_scene(renderer, tmp_path):
     block rel-L1 2.1e-2, mean 2e-5, closest rays 1 810 464 vs 1 810 586."""
     sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
-    assert renderer.last_variant() == 124 | 1  # every scene feature + COUNT (Independent sampler: no generic bit)
+    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64 | 1  # wavefront mode: lean alpha kernel + Disney / Mix / Layered in the heavy kernel + COUNT
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-3 * cc["closest_rays"]
     g, c = _blocks(gpu), _blocks(cpu)
@@ -316,8 +318,14 @@ def test_kernel_variant_selection(renderer):
     renderer.upload(sc)
     renderer.render(0, 1, sync=True)
     assert renderer.last_variant() == 8  # alpha-tested traversal on the lean kernel
-    assert variant("mix") == 60          # no <Mix only> variant is precompiled: next superset
-    assert variant("layered") == 124
+    # Mix / Layered surfaces: wavefront mode -- the lean alpha kernel parks them for the heavy-closure kernel (lrhip.h: lrhip_set_wavefront)
+    assert variant("mix") == WF | 8 | 32
+    assert variant("layered") == WF | 8 | 16 | 64
+    try:  # ... unless it is switched off: the all-in-one megakernel variants, next precompiled superset
+        renderer.set_wavefront(False)
+        assert variant("mix") == 60 and variant("layered") == 124
+    finally:
+        renderer.set_wavefront(True)
 
 
 def test_progressive_calls_and_determinism(renderer):
@@ -427,7 +435,7 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
     C5 holds Layered and alpha-tested surfaces, statistical by construction: 8x8 block means there)."""
     gen, res, spp, variant, rect = {"c3": (generate_bedroom_scene, (1280, 720), 4, 4, (512, 232, 768, 488)),
                                     "c4": (generate_camera_scene, (3840, 2160), 2, 20, (1792, 952, 2048, 1208)),
-                                    "c5": (generate_kitchen_scene, (1280, 720), 8, 124, (512, 232, 768, 488))}[config]
+                                    "c5": (generate_kitchen_scene, (1280, 720), 8, WF | 8 | 16 | 32 | 64, (512, 232, 768, 488))}[config]
     kw = {"texture_size": 1024} if config == "c4" else {}
     sc = Scene.load(gen(str(tmp_path), resolution=res, spp=spp, target_triangles=150_000, **kw))
     renderer.upload(sc)
@@ -477,18 +485,18 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         "env_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="cutout", extra_surfaces=alpha).replace("render {", env), 12),
         "disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", tall_box_surface="disney_thin", extra_surfaces=mat("disney", "disney_thin")), 16),
         "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), 20),
-        "mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha), 60),
-        "layered": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium")), 124),
-        "nested": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix")), 636),
+        "mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha), WF | 8 | 32),
+        "layered": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium")), WF | 8 | 16 | 64),
+        "nested": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix")), WF | 8 | 16 | 32 | 64 | 512),
         "direct": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass")).replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 252),
         "vpt": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                 .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 256),
         "sobol": (cornell_box(resolution=(96, 64), spp=8, sampler="Sobol"), 2),
         # the generic-sampler twins (| 2) of the variants that make real calls: every shipped binary of that kind is held to its
         # counting twin (they are the ones a compiler mishap has hit, Makefile: CALL_SAFE_FLAGS)
-        "mix_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha, sampler="Sobol"), 62),
-        "layered_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium"), sampler="PCG32"), 126),
-        "nested_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix"), sampler="PaddedSobol"), 638),
+        "mix_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha, sampler="Sobol"), WF | 8 | 32 | 2),
+        "layered_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium"), sampler="PCG32"), WF | 8 | 16 | 64 | 2),
+        "nested_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix"), sampler="PaddedSobol"), WF | 8 | 16 | 32 | 64 | 512 | 2),
         "direct_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PCG32").replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 254),
         "vpt_pcg": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin", sampler="PCG32").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                     .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 258),
@@ -743,10 +751,49 @@ def test_nested_mix_layered_only_in_megapath(renderer):
     text = cornell_box(resolution=32, spp=4, short_box_surface="mix_layered", extra_surfaces=extra)
     renderer.upload(Scene.from_string(text))
     renderer.render(0, 4, sync=True)
-    assert renderer.last_variant() == 636
+    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64 | 512
     for integrator in ('Direct { importance_sampling { "both" }', "MegaVPTNaive {"):
         with pytest.raises(DeviceError, match="MegaPath integrator only"):
             renderer.upload(Scene.from_string(text.replace("integrator : MegaPath {", "integrator : " + integrator)))
+
+
+def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_one_kernel(renderer, tmp_path):
+    """Scenes with Mix / Layered surfaces render in wavefront mode (lean megakernel that parks heavy hits -> heavy-closure kernel ->
+    continuation pass, dev_scene.h: WfArgs).  Paths that were parked finish in whatever wave picked their record up, so their film
+    adds are 64-bit fixed-point atomics: the film must still be bit-identical run to run and under tile sharding.  Slicing the frame
+    differently (smaller queues) regroups float sums: equal to rounding.  And the all-in-one megakernel <124> (lrhip_set_wavefront
+    off) renders the same estimator: every path draws the same random numbers, so the two films agree far below the noise."""
+    sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16, target_triangles=60_000))
+    renderer.upload(sc)
+    films = []
+    for _ in range(2):
+        renderer.clear()
+        renderer.render(0, 16, sync=True)
+        films.append(renderer.download(False))
+    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64
+    assert np.array_equal(films[0], films[1]) and np.isfinite(films[0]).all() and (films[0][..., 3] == 16).all()
+    total = np.zeros_like(films[0])
+    for rank in range(3):
+        renderer.clear()
+        renderer.render(0, 16, rank=rank, world=3, sync=True)
+        total += renderer.download(False)
+    assert np.array_equal(total, films[0])
+    try:
+        renderer.set_wavefront(True, slice_paths=256 * 144 * 3)  # 3 spp per slice: six slices, the last one short
+        renderer.clear()
+        renderer.render(0, 16, sync=True)
+        sliced = renderer.download(False)
+        assert np.array_equal(sliced[..., 3], films[0][..., 3]) and np.allclose(sliced, films[0], rtol=2e-5, atol=1e-5)
+        renderer.set_wavefront(False)
+        renderer.clear()
+        renderer.render(0, 16, sync=True)
+        assert renderer.last_variant() == 124
+        mono = renderer.download(False)
+    finally:
+        renderer.set_wavefront(True)
+    err = _rel_l1(films[0], mono)
+    print(f"wavefront vs all-in-one <124>: rel-L1 {err:.2e}")
+    assert np.array_equal(mono[..., 3], films[0][..., 3]) and err < 2e-2 and abs(films[0][..., :3].mean() - mono[..., :3].mean()) / mono[..., :3].mean() < 2e-3
 
 
 def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):

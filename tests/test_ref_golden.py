@@ -30,9 +30,9 @@ DEVICE_TOL = {"cornell": 1e-5, "materials": 5e-4, "disney_mix_sobol": 5e-4, "thi
               "env_combined": 1e-4, "direct_both": 1e-4, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 1e-4,
               "disney": 5e-4, "env_disney": 5e-4, "cornell_sobol": 1e-5, "layered": "blocks", "nested": "blocks"}
 # the smallest precompiled kernel variant each scene needs (lrhip.h LRHIP_FEAT_*; bit 0 = counters must be OFF here)
-VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {60}, "thin_lens_plastic": {0}, "env_image": {4},
+VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {1024 | 8 | 16 | 32}, "thin_lens_plastic": {0}, "env_image": {4},
            "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256},
-           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {124}, "nested": {636}}
+           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {1024 | 8 | 16 | 64}, "nested": {1024 | 8 | 16 | 32 | 64 | 512}}
 
 
 def _fixture(name):

@@ -110,3 +110,33 @@ def test_sobol_render_converges_to_the_independent_estimate():
         imgs[sampler] = o.convert(film)[..., :3]
     ref = imgs["Independent"].mean()
     assert abs(imgs["Sobol"].mean() - ref) / ref < 0.03 and abs(imgs["PaddedSobol"].mean() - ref) / ref < 0.03
+
+
+def test_dimensions_0_and_1_have_the_closed_forms_the_device_uses():
+    """csrc/hip/dev_shade.h: PaddedSobol on the device does not walk the matrix table for its two dimensions: dimension 0 is the bit
+    reversal, dimension 1 the product with Pascal's triangle mod 2 as a five-step butterfly.  Both must equal the table walk of
+    sobol.cpp:52-60 on the committed (= the reference's) matrices: every column (unit vectors), and random 32-bit indices."""
+    m, _, _ = _load_committed()
+
+    def brev(x):
+        return int("{:032b}".format(x)[::-1], 2)
+
+    def walk(idx, dim):
+        v, k = 0, 0
+        while idx:
+            if idx & 1:
+                v ^= int(m[dim][k])
+            idx >>= 1
+            k += 1
+        return v
+
+    def dim1(x):
+        for shift, mask in ((1, 0x55555555), (2, 0x33333333), (4, 0x0F0F0F0F), (8, 0x00FF00FF), (16, 0x0000FFFF)):
+            x ^= (x >> shift) & mask
+        return brev(x)
+
+    rng = np.random.default_rng(7)
+    indices = [1 << k for k in range(32)] + [int(v) for v in rng.integers(0, 2 ** 32, 4000, dtype=np.uint64)] + list(range(300))
+    for idx in indices:
+        assert walk(idx, 0) == brev(idx), idx
+        assert walk(idx, 1) == dim1(idx), idx

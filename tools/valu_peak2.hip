@@ -83,11 +83,19 @@ constexpr int kChains = 8, kUnroll = 32;
     X(66, "v_cmp (e64 -> sgpr) + v_cndmask e64 (per instruction)", "v_cmp_lt_f32_e64 s[40:41], %0, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]") \
     X(67, "v_mul_f32 sdwa src0 BYTE_1 (is SDWA full rate?)", "v_mul_f32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD") \
     X(68, "v_or_b32", "v_or_b32 %0, %0, %2") \
-    X(69, "v_cvt_f32_ubyte0 sdwa-free: v_and + v_or (per pair)", "v_and_b32 %0, %0, %2\n\tv_or_b32 %0, %0, %3")
-constexpr int kOps = 70;
-constexpr int instr_per_asm(int idx) { return idx == 19 || idx == 65 || idx == 66 || idx == 69 ? 2 : (idx == 64 ? 3 : 1); }
+    X(69, "v_cvt_f32_ubyte0 sdwa-free: v_and + v_or (per pair)", "v_and_b32 %0, %0, %2\n\tv_or_b32 %0, %0, %3") \
+    X(70, "v_cmp e64 -> sgpr + 2 x v_cndmask e64 (per instruction)", "v_cmp_lt_f32_e64 s[40:41], %0, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]\n\tv_cndmask_b32_e64 %0, %3, %0, s[40:41]") \
+    X(71, "v_cmp vcc + v_cndmask + v_fma + v_cndmask (per instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_fma_f32 %0, %0, %2, %3\n\tv_cndmask_b32 %0, %3, %0, vcc") \
+    X(72, "v_cmp vcc + 3 x v_cndmask (per instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc") \
+    X(73, "v_cmp e64 -> sgpr + 3 x v_cndmask e64 (per instruction)", "v_cmp_lt_f32_e64 s[40:41], %0, %2\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]\n\tv_cndmask_b32_e64 %0, %3, %0, s[40:41]\n\tv_cndmask_b32_e64 %0, %0, %2, s[40:41]") \
+    X(74, "v_cmp vcc + 4 x v_fma + 2 x v_cndmask (per instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %0, %3, %0, vcc") \
+    X(75, "v_cmp vcc + s_mov sgpr, vcc + 2 x v_cndmask e64 on the copy (per VALU instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\ts_mov_b64 s[40:41], vcc\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]\n\tv_cndmask_b32_e64 %0, %3, %0, s[40:41]")
+constexpr int kOps = 76;
+constexpr int instr_per_asm(int idx) {
+    return idx == 19 || idx == 65 || idx == 66 || idx == 69 ? 2 : (idx == 64 || idx == 70 || idx == 75 ? 3 : (idx == 71 || idx == 72 || idx == 73 ? 4 : (idx == 74 ? 7 : 1)));
+}
 // (an asm statement that clobbers SGPRs makes the compiler put an s_nop behind it: only the opcodes that write one declare it)
-constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62 || idx == 64 || idx == 65 || idx == 66; }
+constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62 || idx == 64 || idx == 65 || idx == 66 || (idx >= 70 && idx <= 75); }
 
 template<int KIND>
 __global__ __launch_bounds__(64) void valu_kernel(float *out, int trips, float seed) {

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Timeline of a wavefront-mode render from a rocprofv3 --kernel-trace database: per kernel launches / total / mean duration, and the
+idle gaps between consecutive kernels of the stream (what a round of { heavy kernel -> continuation pass } costs beyond its work).
+    rocprofv3 --kernel-trace -d gpurun_out/x -o trace -- python tools/c5_ablation.py 64 full ; python tools/wf_trace.py gpurun_out/x"""
+import os
+import sqlite3
+import sys
+
+dbs = [os.path.join(r, f) for r, _, fs in os.walk(sys.argv[1]) for f in fs if f.endswith(".db")]
+db = sqlite3.connect(dbs[0])
+rows = list(db.execute("select name, start, end, scratch_size from kernels order by start"))
+agg = {}
+for name, s, e, scratch in rows:
+    short = name.split("(")[0][-60:]
+    a = agg.setdefault(short, [0, 0.0, scratch])
+    a[0] += 1
+    a[1] += (e - s) / 1e6
+print(f"{len(rows)} kernel launches, span {(rows[-1][2] - rows[0][1]) / 1e6:.1f} ms, busy {sum(a[1] for a in agg.values()):.1f} ms")
+for k, (n, ms, scratch) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:62s} x{n:5d}  total {ms:9.2f} ms  mean {ms / n * 1e3:9.1f} us  scratch/lane {scratch}")
+gaps = [(rows[i + 1][1] - rows[i][2]) / 1e3 for i in range(len(rows) - 1)]
+gaps_small = [g for g in gaps if g < 5000]
+print(f"gaps between consecutive kernels: mean {sum(gaps_small) / max(len(gaps_small), 1):.1f} us, total {sum(gaps_small) / 1e3:.1f} ms (gaps above 5 ms -- host work -- left out: {len(gaps) - len(gaps_small)})")
+by_prev = {}
+for i, g in enumerate(gaps):
+    if g < 5000:
+        k = rows[i][0].split("(")[0][-40:] + " -> " + rows[i + 1][0].split("(")[0][-40:]
+        a = by_prev.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += g
+for k, (n, us) in sorted(by_prev.items(), key=lambda kv: -kv[1][1])[:8]:
+    print(f"  {k:90s} x{n:5d} mean {us / n:8.1f} us")
