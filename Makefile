@@ -31,7 +31,7 @@ HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
 .PHONY: all host hip oracle cli clean hip-variant variant-lib ref ieee
-all: host oracle hip cli
+all: host oracle hip cli ieee
 
 # oracle/_ref: the reference's OWN sources compiled in place against the scalar LuisaCompute stand-in of oracle/ref_shim
 # (test infrastructure: pins oracle/ to the reference; needs /root/reference, so only where the reference tree exists)
@@ -100,13 +100,13 @@ hip-variant:
 variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $(LIBDIR_OUT) $^
 
-# The lean kernel <0> / <1> once more with IEEE arithmetic (no fp contraction, correctly rounded division / sqrt, exact functions),
-# for experiments (MegaPathRenderer(lib_path=...)): round 3 used it to test the claim that fast math is what separates the device
-# from the oracle on the C2 stand-in -- it is not (8.57e-3 vs 8.85e-3; it is the instance transform's rounding, see
-# tests/test_gpu_parity.py::test_what_separates_c2_from_the_oracle_is_the_instance_transform).  Not part of `all`.
+# The lean kernel <0> / <1> once more with the oracle's arithmetic (no fp contraction, correctly rounded division / sqrt, exact
+# functions, 1 / det in the triangle test): TEST INFRASTRUCTURE (MegaPathRenderer(lib_path=...)).  Round 3 used it to test the claim
+# that fast math is what separates the device from the oracle on the C2 stand-in: only where both sides intersect identical vertices
+# (tests/test_gpu_parity.py::test_what_separates_c2_from_the_oracle).
 ieee: $(LIBDIR)/variants/liblrhip_ieee.so
 $(LIBDIR)/variants/liblrhip_ieee.so: $(HIP_SRC) $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
-	$(MAKE) --no-print-directory hip-variant NAME=ieee HIPFLAGS='$(VPT_HIPFLAGS)' DEFS= VARIANT_MASKS='0 1'
+	$(MAKE) --no-print-directory hip-variant NAME=ieee HIPFLAGS='$(VPT_HIPFLAGS) -DLR_EXACT_LEAF=1' DEFS= VARIANT_MASKS='0 1' HEAVY_MASKS=
 
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)

@@ -320,7 +320,11 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
                 auto pvec = cross(tr.d, e2);
                 auto det = dot(e1, pvec);
+#ifdef LR_EXACT_LEAF
+                auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
+#else
                 auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
+#endif
                 auto tvec = tr.o - p0;
                 auto u = dot(tvec, pvec) * inv_det;
                 auto qvec = cross(tvec, e1);

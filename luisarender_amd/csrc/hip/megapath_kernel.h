@@ -136,8 +136,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
 
     // the continuation pass (CONT) works through the records the heavy kernel wrote this round, kWfItemRecords of them per item;
     // their number is only known on the device
-    const auto cont_total = CONT ? scene.wf.counts[kWfCountCont] : 0u;
-    const auto item_count = CONT ? (cont_total + kWfItemRecords - 1u) / kWfItemRecords : args.item_count;
+    // -- and their number shrinks from round to round.  A wave works through an item 64 records at a time, each batch as long as
+    // its longest path, so with few records left the items get smaller (down to one batch): a late round then takes one batch's
+    // latency instead of eight (round 3: rounds with a few thousand records took 2.5 ms each with fixed 512-record items).
+    const auto cont_total = CONT ? min(scene.wf.counts[kWfCountCont], scene.wf.capacity) : 0u;
+    const auto cont_waves = gridDim.x * kWavesPerBlock;
+    const auto item_records = CONT ? min(kWfItemRecords, max(64u, ((cont_total + cont_waves - 1u) / cont_waves + 63u) & ~63u)) : 1u;
+    const auto item_count = CONT ? (cont_total + item_records - 1u) / item_records : args.item_count;
     const auto cont_queue = wf_cont_queue(scene);
     for (;;) {
         // ---- next work item of this wavefront
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
         const auto s_begin = args.spp_begin + chunk * per_chunk;
         const auto s_end = min(s_begin + per_chunk, args.spp_end);
-        // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * kWfItemRecords + k)
-        const auto q_total = CONT ? min(kWfItemRecords, cont_total - item * kWfItemRecords) : (s_end > s_begin ? (s_end - s_begin) * 64u : 0u);
+        // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * item_records + k)
+        const auto q_total = CONT ? min(item_records, cont_total - item * item_records) : (s_end > s_begin ? (s_end - s_begin) * 64u : 0u);
         auto q_next = 0u;// wave-uniform
         film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         auto px = 0u, py = 0u;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                 q_next = min(q_next + static_cast<uint32_t>(__popcll(mask)), q_total);
                 if (CONT) {
                     if (need && k < q_total) {// a path comes back from the heavy kernel: as if this lane had just shaded its vertex
-                        const auto slot = item * kWfItemRecords + k;
+                        const auto slot = item * item_records + k;
                         const auto &q = cont_queue;
                         ray.o = q.get3(slot, 0u), ray.d = q.get3(slot, 3u);
                         ray.t_min = 0.f, ray.t_max = kFloatMax;
