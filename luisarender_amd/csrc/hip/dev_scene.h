@@ -125,7 +125,10 @@ constexpr uint32_t kWfKinds = 3u;            // Disney, Mix, Layered (LR_SURFACE
 constexpr uint32_t kWfHeavyWords = 14u;      // + sampler words: d(3) tri u v beta(3) Li(3) pixel depth
 constexpr uint32_t kWfContWords = 25u;       // + sampler words: ray o d (6) shadow o d tmax (7) nee(3) beta(3) Li(3) pdf pixel depth|flags
 constexpr uint32_t kWfSamplerWordsMax = 8u;
-constexpr uint32_t kWfItemRecords = 512u;    // continuation records per work item of the continuation pass, at most (megapath_kernel.h)
+#ifndef LR_WF_ITEM
+#define LR_WF_ITEM 1024// (256 / 512 / 1024: 433 / 442 / 444 Msamples/s on C5 at 512 spp)
+#endif
+constexpr uint32_t kWfItemRecords = LR_WF_ITEM;    // continuation records per work item of the continuation pass, at most (megapath_kernel.h)
 // device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the heavy
 // kernel, [5] work counter of the continuation pass
 enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkHeavy = 4u, kWfWorkCont = 5u, kWfCounterWords = 8u };

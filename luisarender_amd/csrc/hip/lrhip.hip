@@ -885,9 +885,15 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (!ctx->scene.has_lights && ctx->scene.env_kind == lrd::kEnvNone && ctx->scene.integrator_kind != LR_INTEGRATOR_NORMAL) { return LRHIP_OK; }
     auto tiles_in_range = (p->tile_end - p->tile_begin + p->tile_stride - 1u) / p->tile_stride;
     auto spp = p->spp_end - p->spp_begin;
-    if (ctx->wf_mode == 0u && (ctx->features & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u,
-                                ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT);
+    // Wavefront mode (render_wavefront above) for every MegaPath scene that would otherwise land in an all-in-one variant with
+    // out-of-line closures: Mix / Layered surfaces, and Disney together with an alpha test (no lean <Alpha | Disney> variant is
+    // precompiled; such a scene ran at 433 Msamples/s on <60> where its Mix-holding sibling ran at 480 in wavefront mode).
+    if (ctx->wf_mode == 0u && ctx->diag_force_features == 0u && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
+        const auto plain = pick_variant(ctx->features, false, generic_sampler);
+        if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) {
+            return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u, generic_sampler);
+        }
     }
     // Chunking is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile range
     // of this call.  Two losses are balanced: the drain at the end of every item (the last paths of its queue finish

@@ -11,7 +11,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra"
+CMD="python $REPO/bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
