@@ -199,6 +199,13 @@ typedef struct lr_sampler {
     const uint32_t *sobol_matrices;
     const uint64_t *vdc_sobol;
     const uint64_t *vdc_sobol_inv;
+    /* TileShared wrapper (src/samplers/tile_shared.cpp:44-62): tile_size[0] != 0 -> the base sampler above is started with the TILE
+     * of the pixel, (pixel [+ jitter]) / tile_size, so all pixels of a tile share one sample sequence; `scale` is then that of the
+     * tile grid (the wrapper resets its base with the tile count as the resolution).  tile_jitter: the pixel is first moved by
+     * uint2(float2(h >> 16, h & 0xffff) * 2^-16 * resolution) % resolution, h = xxhash32(sample index) (:52-56). */
+    uint32_t tile_size[2];
+    uint32_t tile_jitter;
+    uint32_t tile_pad;
 } lr_sampler;
 
 typedef enum lr_integrator_kind {

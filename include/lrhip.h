@@ -78,6 +78,9 @@ typedef struct lrhip_counters {
      * loop (B), and from a wave's first to its last instruction */
     uint64_t shade_cycles, trace_cycles, wave_cycles;
     uint64_t nodes_empty;    /* node visits in which no child was hit (popped after the ray had already shortened, or plain misses) */
+    /* wave cycles of three sections of the shading block: hit reconstruction + emission + light sample, closure evaluate + sample +
+     * Russian roulette, path regeneration (camera rays); the remainder of shade_cycles is queue bookkeeping and ray launch */
+    uint64_t shade_light_cycles, shade_closure_cycles, shade_regen_cycles;
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);

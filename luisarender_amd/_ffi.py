@@ -83,7 +83,7 @@ class Film(C.Structure):
 
 class Sampler(C.Structure):
     _fields_ = [("kind", u32), ("seed", u32), ("spp", u32), ("scale", u32), ("sobol_matrices", C.c_void_p),
-                ("vdc_sobol", C.c_void_p), ("vdc_sobol_inv", C.c_void_p)]
+                ("vdc_sobol", C.c_void_p), ("vdc_sobol_inv", C.c_void_p), ("tile_size", u32 * 2), ("tile_jitter", u32), ("tile_pad", u32)]
 
 
 class Integrator(C.Structure):
@@ -137,7 +137,8 @@ STRUCTS = {"lr_scene": Scene, "lr_vertex": Vertex, "lr_triangle": Triangle, "lr_
 class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
-                                   "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles", "nodes_empty")]
+                                   "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles", "nodes_empty",
+                                   "shade_light_cycles", "shade_closure_cycles", "shade_regen_cycles")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

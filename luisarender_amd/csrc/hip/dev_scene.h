@@ -129,9 +129,9 @@ constexpr uint32_t kWfSamplerWordsMax = 8u;
 #define LR_WF_ITEM 1024// (256 / 512 / 1024: 433 / 442 / 444 Msamples/s on C5 at 512 spp)
 #endif
 constexpr uint32_t kWfItemRecords = LR_WF_ITEM;    // continuation records per work item of the continuation pass, at most (megapath_kernel.h)
-// device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the heavy
-// kernel, [5] work counter of the continuation pass
-enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkHeavy = 4u, kWfWorkCont = 5u, kWfCounterWords = 8u };
+// device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the continuation
+// pass, [5..7] work counters of the heavy kernels (one per kind)
+enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkCont = 4u, kWfWorkHeavy = 5u, kWfCounterWords = 8u };
 struct WfArgs {
     uint32_t *heavy;             // [kWfKinds][kWfHeavyWords + sampler words][capacity]
     uint32_t *cont;              // [kWfContWords + sampler words][capacity]
@@ -178,7 +178,8 @@ struct DScene {
     uint32_t sampler_spp;          // PaddedSobol permutation length
     uint32_t sobol_scale;          // global Sobol pixel grid
     float shutter_weight;          // radiance scale of the current lrhip_render call (integrator.cpp:74: film()->accumulate(pixel, shutter_weight * L))
-    uint32_t pad[2];
+    uint32_t sampler_tile;         // TileShared wrapper (tile_shared.cpp): tile width | height << 16, 0 = none
+    uint32_t sampler_tile_jitter;
     const uint32_t *sobol_matrices;// [1024][52]
     const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
     const DEnvironment *env;
@@ -193,7 +194,8 @@ typedef const DScene __attribute__((address_space(4))) *DScenePtr;
 
 struct DCounters {
     unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
-        path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles, nodes_empty;
+        path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles, nodes_empty,
+        shade_light_cycles, shade_closure_cycles, shade_regen_cycles;// sections of the shading block (round 3)
 };
 
 struct RenderArgs {

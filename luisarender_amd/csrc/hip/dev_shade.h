@@ -33,7 +33,30 @@ LR_HD uint32_t xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
     return h ^ (h >> 16u);
 }
 
+LR_HD uint32_t xxhash32_1(uint32_t p) {// rng.cpp:12-23
+    constexpr uint32_t P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    auto h = p + P5;
+    h = P4 * ((h << 17u) | (h >> 15u));
+    h = P2 * (h ^ (h >> 15u));
+    h = P3 * (h ^ (h >> 13u));
+    return h ^ (h >> 16u);
+}
+
 LR_HD float uint_to_unit_float(uint32_t u) { return fminf(kOneMinusEpsilon, static_cast<float>(u) * 0x1p-32f); }
+
+// TileSharedSamplerInstance::start (src/samplers/tile_shared.cpp:51-62): a wrapped sampler is started with the TILE of the pixel
+// (after an optional per-sample jitter of the pixel), so that all pixels of a tile share one sequence
+LR_D void tile_shared_pixel(const DScene &scene, uint32_t &x, uint32_t &y, uint32_t index) {
+    if (scene.sampler_tile != 0u) {
+        if (scene.sampler_tile_jitter != 0u) {
+            const auto offset = xxhash32_1(index);
+            const auto ox = static_cast<float>(offset >> 16u) * 0x1p-16f, oy = static_cast<float>(offset & 0xffffu) * 0x1p-16f;
+            x += static_cast<uint32_t>(ox * static_cast<float>(scene.camera.width)) % scene.camera.width;
+            y += static_cast<uint32_t>(oy * static_cast<float>(scene.camera.height)) % scene.camera.height;
+        }
+        x /= scene.sampler_tile & 0xffffu, y /= scene.sampler_tile >> 16u;
+    }
+}
 
 // One sampler object per path.  GENERIC = false reproduces the reference's default stream bit for bit
 // (IndependentSampler: xxhash32 seed + LCG); GENERIC = true: PCG32 / Sobol / PaddedSobol chosen at run time.
@@ -43,7 +66,10 @@ struct PathSampler;
 template<>
 struct PathSampler<false> {
     uint32_t state;
-    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) { state = xxhash32_4(px, py, scene.seed, index); }
+    LR_D void start(const DScene &scene, uint32_t px, uint32_t py, uint32_t index) {
+        tile_shared_pixel(scene, px, py, index);
+        state = xxhash32_4(px, py, scene.seed, index);
+    }
     LR_D float next_1d() {
         state = 1664525u * state + 1013904223u;// lcg, rng.cpp:132-140
         return uint_to_unit_float(state);
@@ -155,6 +181,7 @@ struct PathSampler<true> {
     }
     LR_D void start(const DScene &s, uint32_t x, uint32_t y, uint32_t index) {
         scene = &s;
+        tile_shared_pixel(s, x, y, index);
         px = x, py = y, sample_index = index;
         if (s.sampler_kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
             dimension = 2u;

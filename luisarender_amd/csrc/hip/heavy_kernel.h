@@ -12,8 +12,7 @@
 // next ray) that the megakernel's continuation pass traces (kFeatCont); a path that needs no ray ends here (film add).
 // The reference's wavefront integrator queues paths per surface tag for the same reason: src/integrators/wave_path_v2.cpp:419-440.
 //
-// Work distribution: chunks of 64 records, kind-major (all Disney chunks, then Mix, then Layered); waves draw chunks from an atomic
-// counter, so a Layered chunk (dozens of closure evaluations per path) does not hold up the waves working through Disney chunks.
+// Work distribution: chunks of 64 records of the kernel's closure kind; waves draw chunks from an atomic counter.
 #pragma once
 #include "dev_wavefront.h"
 
@@ -23,35 +22,30 @@ namespace lrd {
 #define LR_HEAVY_WAVES 2// waves per SIMD the register allocator may assume (2: 256 VGPRs)
 #endif
 
+// One instantiation per closure KIND (0 Disney, 1 Mix, 2 Layered): the Disney kernel holds the Disney closure inline and nothing
+// else (no calls, a fraction of the registers and of the 1.8 KB of scratch the interpreters' records take), the Mix kernel the Mix
+// interpreter, the Layered kernel the random walk; a round launches the three back to back (an empty queue costs microseconds).
 // F: kFeatCount (diagnostics counters), kFeatGeneric (PCG32 / Sobol / PaddedSobol sampler), kFeatNest (Mix / Layered nested in each
 // other; the translation unit defines LR_NEST to match, dev_layered.h)
-template<uint32_t F>
+template<uint32_t F, uint32_t KIND>
 __global__ __launch_bounds__(kBlockThreads, LR_HEAVY_WAVES) void heavy_kernel(DScenePtr scene_ptr, RenderArgs args) {
     const DScene &scene = *(const DScene *)scene_ptr;
     constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u;
     constexpr uint32_t SAMPLER_WORDS = PathSampler<PCG>::kSavedWords;
+    static_assert(KIND < kWfKinds, "closure kind: 0 Disney, 1 Mix, 2 Layered");
     const auto lane = threadIdx.x & 63u;
-    uint32_t count[kWfKinds], chunks[kWfKinds];
-    auto total_chunks = 0u;
-#pragma unroll
-    for (auto k = 0u; k < kWfKinds; k++) {
-        count[k] = min(scene.wf.counts[kWfCountHeavy + k], scene.wf.capacity);
-        chunks[k] = (count[k] + 63u) / 64u;
-        total_chunks += chunks[k];
-    }
+    const auto count = min(scene.wf.counts[kWfCountHeavy + KIND], scene.wf.capacity);
+    const auto total_chunks = (count + 63u) / 64u;
     const auto cont = wf_cont_queue(scene);
+    const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, KIND);
     unsigned long long n_vertices = 0ull;
     for (;;) {
         uint32_t chunk = 0u;
-        if (lane == 0u) { chunk = atomicAdd(scene.wf.counts + kWfWorkHeavy, 1u); }
+        if (lane == 0u) { chunk = atomicAdd(scene.wf.counts + kWfWorkHeavy + KIND, 1u); }
         chunk = static_cast<uint32_t>(__shfl(static_cast<int>(chunk), 0));
         if (chunk >= total_chunks) { break; }
-        auto kind = 0u;
-        if (chunk >= chunks[0]) { chunk -= chunks[0], kind = 1u; }
-        if (kind == 1u && chunk >= chunks[1]) { chunk -= chunks[1], kind = 2u; }
         const auto slot = chunk * 64u + lane;
-        const auto active = slot < count[kind];
-        const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, kind);
+        const auto active = slot < count;
         auto want_shadow = false, want_closest = false;
         Ray ray{}, shadow{};
         f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
@@ -83,8 +77,13 @@ __global__ __launch_bounds__(kBlockThreads, LR_HEAVY_WAVES) void heavy_kernel(DS
             HeavyCtx heavy;
             load_lobe(tables, it.uv, it.ng, wo, (it.tags >> 12u) & 4095u, it.shading, heavy.closure, heavy.shading);
             heavy.tb = tables, heavy.uv = it.uv, heavy.ng = it.ng, heavy.p = it.p, heavy.wo = wo;
+            // the interpreters this kind needs: Disney none (inline closure); a Mix tree may hold Layered leaves and a Layered surface
+            // Mix interfaces only in the nested variants
+            constexpr bool MIX = KIND == 1u || (KIND == 2u && LR_NEST != 0), LAYERED = KIND == 2u || (KIND == 1u && LR_NEST != 0);
             if (pick.pdf > 0.0f) {// mega_path.cpp:111-130
-                const auto eval = heavy_evaluate<true, true>(&heavy, shadow.d);
+                BsdfEval eval;
+                if constexpr (KIND == 0u) { eval = closure_evaluate<true>(heavy.closure, heavy.shading, it.ng, wo, shadow.d); }
+                else { eval = heavy_evaluate<MIX, LAYERED>(&heavy, shadow.d); }
                 const auto w = balance(pick.pdf, eval.pdf) / pick.pdf;
                 nee = w * beta * eval.f * pick.L;
                 // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
@@ -92,7 +91,14 @@ __global__ __launch_bounds__(kBlockThreads, LR_HEAVY_WAVES) void heavy_kernel(DS
             }
             const auto u_lobe = sampler.next_1d();
             const auto u_bsdf = sampler.next_2d();
-            const auto hs = heavy_sample<true, true>(&heavy, u_lobe, u_bsdf);// mega_path.cpp:132-143
+            HeavySample hs;// mega_path.cpp:132-143
+            if constexpr (KIND == 0u) {
+                hs.bs = closure_sample<true>(heavy.closure, heavy.shading, it.ng, wo, u_lobe, u_bsdf);
+                hs.eta = 1.f;
+                hs.has_eta = closure_eta(heavy.closure, hs.eta) ? 1u : 0u;
+            } else {
+                hs = heavy_sample<MIX, LAYERED>(&heavy, u_lobe, u_bsdf);
+            }
             const auto bs = hs.bs;
             ray.o = robust_origin(it, bs.wi);// spawn_ray, interaction.cpp:21-23
             ray.d = bs.wi;

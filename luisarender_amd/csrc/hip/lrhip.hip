@@ -28,7 +28,7 @@
 LR_VARIANT_LIST(LR_DECLARE_VARIANT)
 #undef LR_DECLARE_VARIANT
 // the heavy-closure kernels of wavefront mode, one translation unit each (heavy_variant.hip, -DLR_HVARIANT=<mask>)
-#define LR_HEAVY_LIST(X) X(0) X(1) X(2) X(3) X(512) X(513) X(514) X(515)
+#define LR_HEAVY_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(516) X(517) X(518) X(519) X(520) X(521) X(522) X(523)
 #define LR_HEAVY_DECL(mask)                                                                                                   \
     extern "C" __attribute__((weak)) hipError_t lrhip_heavy_launch_##mask(unsigned, hipStream_t, const lrd::DScene *, const lrd::RenderArgs *); \
     extern "C" __attribute__((weak)) hipError_t lrhip_heavy_occupancy_##mask(int *);
@@ -47,7 +47,7 @@ const VariantEntry kVariants[] = {LR_VARIANT_LIST(LR_VARIANT_ENTRY)};
 #undef LR_VARIANT_ENTRY
 static_assert(sizeof(kVariants) / sizeof(kVariants[0]) == lrd::kSceneVariantCount * 4u, "variants.h and kSceneVariants disagree");
 
-// (mask: bit 0 counters, bit 1 generic sampler, 512 nested Mix / Layered)
+// (mask: bit 0 counters, bit 1 generic sampler, bits 2-3 closure kind (0 Disney, 4 Mix, 8 Layered), 512 nested Mix / Layered)
 #define LR_HEAVY_ENTRY(mask) VariantEntry{mask##u, lrhip_heavy_launch_##mask, lrhip_heavy_occupancy_##mask},
 const VariantEntry kHeavyVariants[] = {LR_HEAVY_LIST(LR_HEAVY_ENTRY)};
 #undef LR_HEAVY_ENTRY
@@ -130,7 +130,7 @@ struct lrhip_ctx {
     double diag_item_scale{0.};
     // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
     DeviceBuffer wf_heavy, wf_cont, wf_counts, wf_accum;
-    int heavy_blocks[8]{-1, -1, -1, -1, -1, -1, -1, -1};// resident blocks per CU of each heavy-kernel variant
+    int heavy_blocks[20];// resident blocks per CU of each heavy-kernel variant (-1: not asked yet)
     uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
 };
@@ -683,6 +683,11 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     d.has_lights = s->light_count != 0u ? 1u : 0u;
     d.sampler_kind = s->sampler.kind, d.seed = s->sampler.seed;
     d.sampler_spp = s->sampler.spp, d.sobol_scale = s->sampler.scale;
+    if (s->sampler.tile_size[0] > 0xffffu || s->sampler.tile_size[1] > 0xffffu || (s->sampler.tile_size[0] != 0u) != (s->sampler.tile_size[1] != 0u)) {
+        release_scene(ctx);
+        return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: invalid sampler tile size");
+    }
+    d.sampler_tile = s->sampler.tile_size[0] | (s->sampler.tile_size[1] << 16u), d.sampler_tile_jitter = s->sampler.tile_jitter;
     if (d.sampler_kind == LR_SAMPLER_SOBOL || d.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
         if (s->sampler.sobol_matrices == nullptr || (d.sampler_kind == LR_SAMPLER_SOBOL && d.sobol_scale > 1u && (s->sampler.vdc_sobol == nullptr || s->sampler.vdc_sobol_inv == nullptr))) {
             release_scene(ctx);
@@ -718,6 +723,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
     // traversal-stack overflow area is sized for the densest variant
     for (auto &b : ctx->variant_blocks) { b = -1; }
+    for (auto &b : ctx->heavy_blocks) { b = -1; }
     ctx->grid_blocks = ctx->cu_count * kMaxBlocksPerCu;
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
     if (auto r = ensure(ctx->spill, total_threads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
@@ -793,8 +799,14 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto lean = ((ctx->features & lrd::kFeatEnv) != 0u ? lrd::kFeatEnv : 0u) | lrd::kFeatAlpha | lrd::kFeatWf | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
     const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
     const auto vi_camera = find_variant(kVariants, n_variants, lean), vi_cont = find_variant(kVariants, n_variants, lean | lrd::kFeatCont);
-    const auto hi = find_variant(kHeavyVariants, 8u, ((ctx->features & lrd::kFeatNest) != 0u ? 512u : 0u) | (count ? 1u : 0u) | (generic ? 2u : 0u));
-    if (vi_camera < 0 || vi_cont < 0 || hi < 0 || kVariants[vi_camera].launch == nullptr || kVariants[vi_cont].launch == nullptr || kHeavyVariants[hi].launch == nullptr) {
+    const auto n_heavy = sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0]);
+    int hi[lrd::kWfKinds];// the heavy kernel of each closure kind (Disney has no nested form)
+    auto heavy_ok = true;
+    for (auto k = 0u; k < lrd::kWfKinds; k++) {
+        hi[k] = find_variant(kHeavyVariants, n_heavy, (k << 2u) | (k != 0u && (ctx->features & lrd::kFeatNest) != 0u ? 512u : 0u) | (count ? 1u : 0u) | (generic ? 2u : 0u));
+        heavy_ok = heavy_ok && hi[k] >= 0 && kHeavyVariants[hi[k]].launch != nullptr;
+    }
+    if (vi_camera < 0 || vi_cont < 0 || !heavy_ok || kVariants[vi_camera].launch == nullptr || kVariants[vi_cont].launch == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: the wavefront kernels for feature mask " + std::to_string(ctx->features) + " were not compiled into this library");
     }
     auto blocks_of = [&](int &cache, const VariantEntry &v, int &out) -> int {
@@ -806,10 +818,14 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         out = cache;
         return LRHIP_OK;
     };
-    int b_camera = 0, b_cont = 0, b_heavy = 0;
+    int b_camera = 0, b_cont = 0, b_heavy[lrd::kWfKinds] = {0, 0, 0};
     if (auto r = blocks_of(ctx->variant_blocks[vi_camera], kVariants[vi_camera], b_camera); r != LRHIP_OK) { return r; }
     if (auto r = blocks_of(ctx->variant_blocks[vi_cont], kVariants[vi_cont], b_cont); r != LRHIP_OK) { return r; }
-    if (auto r = blocks_of(ctx->heavy_blocks[hi], kHeavyVariants[hi], b_heavy); r != LRHIP_OK) { return r; }
+    for (auto k = 0u; k < lrd::kWfKinds; k++) {
+        if (auto r = blocks_of(ctx->heavy_blocks[hi[k]], kHeavyVariants[hi[k]], b_heavy[k]); r != LRHIP_OK) { return r; }
+    }
+    // which closure kinds the scene holds at all (a Mix / Layered surface may reach a Disney child, which is shaded inside that kind's kernel)
+    const bool has_kind[lrd::kWfKinds] = {(ctx->features & lrd::kFeatDisney) != 0u, (ctx->features & lrd::kFeatMix) != 0u, (ctx->features & lrd::kFeatLayered) != 0u};
     const auto resident = ctx->cu_count * static_cast<uint32_t>(std::max(b_camera, b_cont));
     if (auto r = ensure(ctx->spill, static_cast<size_t>(resident) * lrd::kBlockThreads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
@@ -850,14 +866,15 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         // ---- rounds: a path leaves a round either finished or parked again (one level deeper), so max_depth rounds empty the queues
         args.chunk_count = 1u, args.item_count = 0u;// (the continuation pass reads its item count from the device)
         for (auto round = 0u; round < std::max(scene.max_depth, 1u); round++) {
-            LR_HIP_CHECK(kHeavyVariants[hi].launch(ctx->cu_count * static_cast<uint32_t>(b_heavy), ctx->stream, device_scene, &args));
-            // the heavy kernel has consumed the parked paths: their counters (and its work counter) restart for the continuation pass
+            for (auto k = 0u; k < lrd::kWfKinds; k++) {
+                if (has_kind[k]) { LR_HIP_CHECK(kHeavyVariants[hi[k]].launch(ctx->cu_count * static_cast<uint32_t>(b_heavy[k]), ctx->stream, device_scene, &args)); }
+            }
+            // the heavy kernels have consumed the parked paths: their counters (and work counters) restart for the continuation pass
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountHeavy, 0, 3u * sizeof(uint32_t), ctx->stream));
-            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkHeavy, 0, sizeof(uint32_t), ctx->stream));
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkHeavy, 0, 3u * sizeof(uint32_t), ctx->stream));
             args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_cont) * lrd::kBlockThreads;
             LR_HIP_CHECK(kVariants[vi_cont].launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
-            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, sizeof(uint32_t), ctx->stream));
-            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkCont, 0, sizeof(uint32_t), ctx->stream));
+            LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, 2u * sizeof(uint32_t), ctx->stream));// (+ its work counter, next to it)
         }
     }
     hipLaunchKernelGGL(lrd::wf_resolve_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,

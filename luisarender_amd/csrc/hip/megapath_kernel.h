@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     parked = heavy_hit && others;
                 }
             }
+            unsigned long long t_closure_sum = 0ull;// (COUNT: wave cycles inside the closure section of this round; lanes agree)
             auto park_kind = kInvalid;// WF: closure kind (0 Disney, 1 Mix, 2 Layered) of the heavy surface this lane's path just reached
             if (tr.phase == kPhaseIdle && !parked) {
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                             auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
                             shadow = pick.shadow, light_L = pick.L, light_pdf = pick.pdf;
                         }
+                        const auto t_closure = COUNT ? __builtin_readcyclecounter() : 0ull;
                         // ---- material, mega_path.cpp:111-143.  The five basic closures are evaluated inline; Disney / Mix /
                         // Layered surfaces go through the out-of-line heavy path (dev_heavy.h) when this variant holds Mix or
                         // Layered (HEAVY_CALL), so that their registers are not the main loop's.  A <Disney only> variant keeps
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                         }
                         depth++;
                         want_closest = alive && depth < scene.max_depth;
+                        if (COUNT) { t_closure_sum += __builtin_readcyclecounter() - t_closure; }
                     }
                 }
                 if (WF && park_kind != kInvalid) { path_open = false; }// (it goes on elsewhere: nothing to accumulate here)
@@ -391,6 +394,10 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                 }
             }
             // ==== (A') path regeneration: lanes with no path take the next samples of the item's queue, in lane order
+            const auto t_regen = COUNT ? __builtin_readcyclecounter() : 0ull;
+            if (COUNT) {// (the closure section is timed by the lanes that ran it: lane 0 reports the wave's figure)
+                for (auto off = 32; off > 0; off >>= 1) { t_closure_sum = max(t_closure_sum, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(t_closure_sum), off))); }
+            }
             {
                 const auto need = tr.phase == kPhaseIdle && !path_open;
                 const auto mask = __ballot(need);
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     }
                 }
             }
+            const auto t_launch = COUNT ? __builtin_readcyclecounter() : 0ull;
             if (tr.phase == kPhaseIdle) {
                 // ---- launch: shadow ray first, the continuation ray follows inside the traversal loop
                 if (want_shadow || want_closest) {
@@ -456,7 +464,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
             const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
             trace_until_refill<COUNT, ALPHA>(scene, stack, tr, traced_closest, ray, LR_REFILL, ts);
             if (COUNT) {
-                if (lane == 0u) { local.shade_cycles += t_trace - t_shade, local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
+                if (lane == 0u) {
+                    local.shade_cycles += t_trace - t_shade, local.trace_cycles += __builtin_readcyclecounter() - t_trace;
+                    local.shade_closure_cycles += t_closure_sum, local.shade_regen_cycles += t_launch - t_regen;
+                    local.shade_light_cycles += (t_regen - t_shade) - t_closure_sum;// everything of (A) that is not the closure section
+                }
                 local.nodes_visited += ts.nodes, local.tris_tested += ts.tris, local.nodes_empty += ts.nodes_empty;
                 local.trace_steps += ts.steps, local.trace_steps_busy += ts.steps_busy, local.trace_steps_starved += ts.steps_starved;
                 local.shade_calls++;
@@ -503,6 +515,9 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         reduce(local.trace_cycles, &args.counters->trace_cycles);
         reduce(local.wave_cycles, &args.counters->wave_cycles);
         reduce(local.nodes_empty, &args.counters->nodes_empty);
+        reduce(local.shade_light_cycles, &args.counters->shade_light_cycles);
+        reduce(local.shade_closure_cycles, &args.counters->shade_closure_cycles);
+        reduce(local.shade_regen_cycles, &args.counters->shade_regen_cycles);
     }
 }
 

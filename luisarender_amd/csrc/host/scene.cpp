@@ -109,6 +109,11 @@ lr_scene SceneData::view(size_t camera_index) const {
     s.sampler = sampler;
     s.sampler.spp = s.camera.spp;// sampler()->reset(.., resolution, pixel_count, spp), integrator.cpp:59
     s.sampler.scale = next_pow2(std::max(s.camera.width, s.camera.height));
+    if (sampler.tile_size[0] != 0u) {// TileSharedSamplerInstance::reset (tile_shared.cpp:44-50): the base sees the tile grid as its resolution
+        const auto tw = std::min(s.camera.width, sampler.tile_size[0]), th = std::min(s.camera.height, sampler.tile_size[1]);
+        s.sampler.tile_size[0] = tw, s.sampler.tile_size[1] = th;
+        s.sampler.scale = next_pow2(std::max((s.camera.width + tw - 1u) / tw, (s.camera.height + th - 1u) / th));
+    }
     if (sampler.kind == LR_SAMPLER_SOBOL || sampler.kind == LR_SAMPLER_PADDED_SOBOL) {
         s.sampler.sobol_matrices = sobol_matrices.data();
         if (sampler.kind == LR_SAMPLER_SOBOL) {
@@ -1326,6 +1331,16 @@ public:
         auto sampler = integrator->node_or_null("sampler");
         if (sampler == nullptr) { sampler = NodeDesc::shared_default(Tag::SAMPLER, "independent"); }
         _check_tag(sampler, Tag::SAMPLER);
+        if (sampler->impl_type() == "tileshared") {// src/samplers/tile_shared.cpp:21-29: a wrapper around `base`
+            std::vector<uint32_t> size{16u};// property_uint2_or_default("tile_size", uint or_default 16)
+            if (!sampler->float_list_or_empty("tile_size").empty()) { size = sampler->uint_list("tile_size"); }
+            if (size.empty() || size.size() > 2u || size[0] == 0u || size.back() == 0u) { throw Error{"Invalid tile_size of the TileShared sampler. [" + sampler->location() + "]"}; }
+            _out.sampler.tile_size[0] = size[0], _out.sampler.tile_size[1] = size.back();
+            _out.sampler.tile_jitter = sampler->bool_or("jitter", false) ? 1u : 0u;
+            sampler = sampler->node("base");
+            _check_tag(sampler, Tag::SAMPLER);
+            if (sampler->impl_type() == "tileshared") { throw Error{"A TileShared sampler inside a TileShared sampler is not supported. [" + sampler->location() + "]"}; }
+        }
         _out.sampler.seed = sampler->uint_or("seed", 19980810u);
         if (sampler->impl_type() == "independent") { _out.sampler.kind = LR_SAMPLER_INDEPENDENT; }
         else if (sampler->impl_type() == "sobol") { _out.sampler.kind = LR_SAMPLER_SOBOL; }

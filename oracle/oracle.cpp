@@ -104,9 +104,18 @@ struct Sampler {
         return (i + p) % l;
     }
 
-    void start(const lr_sampler &s, uint32_t x, uint32_t y, uint32_t index) {
+    void start(const lr_sampler &s, uint32_t x, uint32_t y, uint32_t index, uint32_t width = 0u, uint32_t height = 0u) {
         cfg = &s;
         kind = s.kind;
+        if (s.tile_size[0] != 0u) {// TileSharedSamplerInstance::start, tile_shared.cpp:51-62: the base is started with the pixel's tile
+            if (s.tile_jitter != 0u) {
+                auto offset = xxhash32(index);
+                auto ox = static_cast<float>(offset >> 16u) * 0x1p-16f, oy = static_cast<float>(offset & 0xffffu) * 0x1p-16f;
+                x += static_cast<uint32_t>(ox * static_cast<float>(width)) % width;
+                y += static_cast<uint32_t>(oy * static_cast<float>(height)) % height;
+            }
+            x /= s.tile_size[0], y /= s.tile_size[1];
+        }
         px = x, py = y, sample_index = index;
         if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
             dimension = 2u;
@@ -500,7 +509,7 @@ struct oracle_ctx {
     float3 Li_normal(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
         auto &s = *scene;
         Sampler sampler;
-        sampler.start(s.sampler, px, py, sample_index);
+        sampler.start(s.sampler, px, py, sample_index, s.camera.width, s.camera.height);
         auto u_filter = sampler.generate_pixel_2d();
         auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
         auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
@@ -526,7 +535,7 @@ struct oracle_ctx {
     float3 Li_direct(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
         auto &s = *scene;
         Sampler sampler;
-        sampler.start(s.sampler, px, py, sample_index);
+        sampler.start(s.sampler, px, py, sample_index, s.camera.width, s.camera.height);
         auto u_filter = sampler.generate_pixel_2d();
         auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
         auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);// (fixed sRGB spectrum: no wavelength draw, :72)
@@ -777,7 +786,7 @@ struct oracle_ctx {
     float3 Li_vpt(uint32_t px, uint32_t py, uint32_t sample_index, PathStats &stats) const {
         auto &s = *scene;
         Sampler sampler;
-        sampler.start(s.sampler, px, py, sample_index);
+        sampler.start(s.sampler, px, py, sample_index, s.camera.width, s.camera.height);
         auto u_filter = sampler.generate_pixel_2d();
         auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
         auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
@@ -909,7 +918,7 @@ struct oracle_ctx {
         if (s.integrator.kind == LR_INTEGRATOR_DIRECT) { return Li_direct(px, py, sample_index, stats); }
         if (s.integrator.kind == LR_INTEGRATOR_VPT_NAIVE) { return Li_vpt(px, py, sample_index, stats); }
         Sampler sampler;
-        sampler.start(s.sampler, px, py, sample_index);
+        sampler.start(s.sampler, px, py, sample_index, s.camera.width, s.camera.height);
         auto u_filter = sampler.generate_pixel_2d();
         auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
         auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
@@ -1062,7 +1071,7 @@ void oracle_trace_closest(oracle_ctx *ctx, const float o[3], const float d[3], f
 void oracle_camera_ray(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sample_index, float out[7]) {
     auto &s = *ctx->scene;
     Sampler sampler;
-    sampler.start(s.sampler, px, py, sample_index);
+    sampler.start(s.sampler, px, py, sample_index, s.camera.width, s.camera.height);
     auto u_filter = sampler.generate_pixel_2d();
     auto u_lens = s.camera.kind == LR_CAMERA_THIN_LENS ? sampler.generate_2d() : float2{.5f, .5f};
     auto cs = generate_camera_ray(s, px, py, u_filter, u_lens);
@@ -1073,7 +1082,7 @@ void oracle_camera_ray(oracle_ctx *ctx, uint32_t px, uint32_t py, uint32_t sampl
 
 void oracle_sampler_stream(const lr_scene *scene, uint32_t px, uint32_t py, uint32_t sample_index, uint32_t n, float *out) {
     Sampler sampler;
-    sampler.start(scene->sampler, px, py, sample_index);
+    sampler.start(scene->sampler, px, py, sample_index, scene->camera.width, scene->camera.height);
     auto p = sampler.generate_pixel_2d();
     out[0] = p.x, out[1] = p.y;
     for (uint32_t i = 0; i < n; i++) { out[2u + i] = sampler.generate_1d(); }

@@ -238,6 +238,22 @@ def test_sobol_samplers(renderer, sampler):
     assert np.array_equal(gpu[..., 3], cpu[..., 3]) and _rel_l1(gpu, cpu) < 1e-4
 
 
+@pytest.mark.parametrize("base", ["Independent", "Sobol"])
+def test_tile_shared_sampler_wrapper(renderer, base):
+    """src/samplers/tile_shared.cpp (round 3): all pixels of a tile share their base sampler's sequence; with jitter the tile grid moves
+    per sample.  Integer pipeline in front of the base sampler: the same paths as the oracle (which is bit-equal to the reference's
+    wrapper, tests/test_oracle_vs_ref.py::test_li_tile_shared_sampler_bit_exact)."""
+    wrapped = f"TileShared {{ base : {base} {{ seed {{ 77 }} }} tile_size {{ 8, 4 }} jitter {{ true }} }}"
+    sc = Scene.from_string(cornell_box(resolution=(96, 64), spp=16).replace("sampler : Independent { seed { 19980810 } }", "sampler : " + wrapped))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    for k in ("closest_rays", "surface_hits"):
+        assert abs(gc[k] - cc[k]) <= max(1, 1e-5 * cc[k]), (k, gc[k], cc[k])
+    assert np.array_equal(gpu[..., 3], cpu[..., 3]) and _rel_l1(gpu, cpu) < 1e-4
+    plain = Scene.from_string(cornell_box(resolution=(96, 64), spp=16))
+    other, _, _, _ = _render_both(renderer, plain, 16)
+    assert not np.array_equal(other, gpu)  # the wrapper does something
+
+
 def test_bathroom_class_instanced_scene(renderer, tmp_path):
     """~600 k instanced triangles, all five closures (BASELINE C2 geometry at reduced resolution/spp)."""
     path = generate_room_scene(str(tmp_path), resolution=(192, 192), spp=4)

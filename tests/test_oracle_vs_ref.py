@@ -293,6 +293,16 @@ def test_li_cameras_samplers_filters_bit_exact(variant):
     _compare_li(src)
 
 
+@pytest.mark.parametrize("base,jitter", [("Independent", False), ("Independent", True), ("PaddedSobol", True), ("Sobol", False), ("Sobol", True)])
+def test_li_tile_shared_sampler_bit_exact(base, jitter):
+    """src/samplers/tile_shared.cpp: the wrapper starts its base sampler with the pixel's TILE (after an optional per-sample jitter of
+    the pixel) and resets it with the tile grid as the resolution (the global Sobol sampler's pixel grid shrinks with it)."""
+    wrapped = f"TileShared {{ base : {base} {{ seed {{ 77 }} }} tile_size {{ 5, 3 }} jitter {{ {'true' if jitter else 'false'} }} }}"
+    src = cornell_box(resolution=(24, 16), spp=3).replace("sampler : Independent { seed { 19980810 } }", "sampler : " + wrapped)
+    assert "TileShared" in src
+    _compare_li(src)
+
+
 ENV_SCENE = """
 Surface ground : Matte {{ Kd : Constant {{ v {{ 0.5, 0.5, 0.5 }} }} }}
 Surface shiny : Plastic {{ Kd : Constant {{ v {{ 0.7, 0.2, 0.1 }} }} roughness : Constant {{ v {{ 0.15 }} }} }}

@@ -27,3 +27,6 @@ with tempfile.TemporaryDirectory() as tmp:
     print('shade lane utilisation', c['shade_busy'] / max(c['shade_calls'], 1))
     print('wave cycles: shade %.3f  trace %.3f  of wave lifetime; cycles per wave-level trace step %.0f, per wave-level shade call %.0f' % (
         c['shade_cycles'] / c['wave_cycles'], c['trace_cycles'] / c['wave_cycles'], c['trace_cycles'] / (c['trace_steps'] / 64), c['shade_cycles'] / (c['shade_calls'] / 64)))
+    print('shading block split (of wave lifetime): hit + emission + light sample + parking %.3f  closure evaluate / sample / RR %.3f  path regeneration %.3f  launch + rest %.3f' % (
+        c['shade_light_cycles'] / c['wave_cycles'], c['shade_closure_cycles'] / c['wave_cycles'], c['shade_regen_cycles'] / c['wave_cycles'],
+        (c['shade_cycles'] - c['shade_light_cycles'] - c['shade_closure_cycles'] - c['shade_regen_cycles']) / c['wave_cycles']))
