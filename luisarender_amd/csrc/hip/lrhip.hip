@@ -762,15 +762,16 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto sampler_words = generic ? lrd::kWfSamplerWordsMax : 1u;
     const auto paths_per_spp = static_cast<uint64_t>(tiles_in_range) * 64u;
     // Slice size: every slice pays the latency of its last rounds (a handful of paths, one batch each), so slices are as large as
-    // the memory allows -- C5 at 512 spp: 356 / 404 / 442 Msamples/s with 2^25 / 2^26 / 2^27 paths per slice.  Default 2^27:
-    // 134 M x (3 queues x 15..22 words + 26..33 words) x 4 B = 38 .. 53 GB of the 288, and never more than a quarter of what is free.
+    // the memory allows -- C5 at 512 spp: 356 / 404 / 442 Msamples/s with 2^25 / 2^26 / 2^27 paths per slice.  Default: a quarter of
+    // the free HBM, at most 2^28 paths; a path takes (3 queues x 15..22 words + 26..33 words) x 4 B = 284 .. 396 B, so on an idle
+    // MI355X that is ~250 M paths = 71 GB of the 288.
     auto want_paths = static_cast<uint64_t>(ctx->wf_slice_paths);
     if (want_paths == 0u) {
         size_t free_bytes = 0u, total_bytes = 0u;
         LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
         const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
         const auto per_path = static_cast<uint64_t>(lrd::kWfKinds * (lrd::kWfHeavyWords + sampler_words) + lrd::kWfContWords + sampler_words) * sizeof(uint32_t);
-        want_paths = std::min<uint64_t>(1ull << 27u, std::max<uint64_t>(1ull << 20u, have / 4u / per_path));
+        want_paths = std::min<uint64_t>(1ull << 28u, std::max<uint64_t>(1ull << 20u, have / 4u / per_path));
     }
     const auto slice_spp = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(spp, want_paths / std::max<uint64_t>(paths_per_spp, 1u))));
     const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(paths_per_spp * slice_spp, (1ull << 31u) - 1u));
