@@ -155,7 +155,8 @@ uint32_t lrhip_last_variant(lrhip_ctx *ctx);
 /* Diagnostics of ONE context, for tests and tools (the product path never calls it; the library reads no environment variable):
  *   force_features  scene-feature bits (LRHIP_FEAT_ENVIRONMENT .. LRHIP_FEAT_LAYERED) OR-ed into what the uploaded scene needs, so
  *                   that a larger precompiled variant renders a scene that does not need it (A/B of variants, twin tests); 0 = none
- *   item_scale      factor on the loss model's constant behind the work-item size of lrhip_render (sweeps); <= 0 or 1 = default.
+ *   item_scale      factor on the loss model's constant behind the work-item size of lrhip_render (sweeps); 0 or 1 = default; a
+ *                   negative value = its magnitude with UNIFORM work items (rounds 1-2) instead of the tapered ones of round 3.
  *                   A value other than the default changes the order of a pixel's float adds, i.e. the film's last bits.        */
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale);
 

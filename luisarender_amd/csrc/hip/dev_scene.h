@@ -210,6 +210,38 @@ struct RenderArgs {
     uint32_t *spill;       // traversal stack overflow area [kSpillEntries][total_threads]
     uint32_t total_threads;
     DCounters *counters;
+    // Work items shrink towards the end of the launch (round 3): the first chunk_big_count chunks of a tile's sample range hold
+    // chunk_big samples per pixel each, the rest chunk_small; all big items are handed out before the first small one.  Big items
+    // keep the drain at the end of an item (its last paths finish with most lanes idle) rare, small ones at the end keep the tail
+    // of the launch (waves out of items while the last ones finish) short.  Uniform chunks: chunk_big_count = chunk_count.
+    uint32_t chunk_big_count, chunk_big, chunk_small;
 };
+
+// item number -> (tile of the range, chunk, sample range) under the chunking above
+struct ItemRange {
+    uint32_t tile_index, chunk, s_begin, s_end;
+};
+__device__ __forceinline__ ItemRange item_range(const RenderArgs &args, uint32_t item) {
+    const auto tiles = args.item_count / args.chunk_count;
+    const auto big_items = tiles * args.chunk_big_count;
+    ItemRange r;
+    if (item < big_items) {
+        r.tile_index = item / args.chunk_big_count;
+        r.chunk = item - r.tile_index * args.chunk_big_count;
+        r.s_begin = args.spp_begin + r.chunk * args.chunk_big;
+        r.s_end = r.s_begin + args.chunk_big;
+    } else {
+        const auto small_count = args.chunk_count - args.chunk_big_count;
+        const auto j = item - big_items;
+        r.tile_index = j / small_count;
+        const auto c = j - r.tile_index * small_count;
+        r.chunk = args.chunk_big_count + c;
+        r.s_begin = args.spp_begin + args.chunk_big_count * args.chunk_big + c * args.chunk_small;
+        r.s_end = r.s_begin + args.chunk_small;
+    }
+    r.s_begin = r.s_begin < args.spp_end ? r.s_begin : args.spp_end;
+    r.s_end = r.s_end < args.spp_end ? r.s_end : args.spp_end;
+    return r;
+}
 
 }// namespace lrd

@@ -749,6 +749,48 @@ int lrhip_film_clear(lrhip_ctx *ctx) {
     return LRHIP_OK;
 }
 
+// Work items of a launch over `spp` samples per pixel of a shard with `shard_tiles` tiles (dev_scene.h: RenderArgs / item_range).
+// Two losses are balanced.  The drain at the end of every item -- its last paths finish with most lanes idle -- is a share of
+// ~a / S of an item of S samples per pixel; the tail of the launch -- waves out of items while the last ones finish -- is
+// ~S_last * waves / (2 * spp * tiles).  With uniform items both depend on the same S and the optimum is S = sqrt(2a * spp * tiles /
+// waves) (a = 0.625 from sweeps, rounds 1-2).  Round 3: the items TAPER -- the first ~85 % of the samples go out in items 2.5x that
+// size, the rest in items a third of it, and all big items are handed out before the first small one: the bulk drains rarely, the
+// end of the launch is made of short items.  The partition is a function of (spp, shard_tiles, scale) only -- never of the device
+// or of the tile range of the call -- so films stay bit-identical under any sharding with the same balance_shards.
+#ifndef LR_TAPER_BIG
+#define LR_TAPER_BIG 2.5
+#endif
+#ifndef LR_TAPER_SMALL
+#define LR_TAPER_SMALL 3.0
+#endif
+#ifndef LR_TAPER_FRACTION
+#define LR_TAPER_FRACTION 0.85
+#endif
+struct Chunking {
+    uint32_t count, big_count, big, small;
+};
+static Chunking chunking_of(uint32_t spp, double shard_tiles, double item_scale, bool taper) {
+    const auto s_opt = std::max(1.0, std::sqrt(item_scale * spp * shard_tiles / kNominalWaves));
+    Chunking c{};
+    if (taper && spp >= 16u) {
+        c.big = static_cast<uint32_t>(std::clamp(std::lround(LR_TAPER_BIG * s_opt), 1l, static_cast<long>(spp)));
+        c.small = static_cast<uint32_t>(std::clamp(std::lround(s_opt / LR_TAPER_SMALL), 1l, static_cast<long>(c.big)));
+        c.big_count = static_cast<uint32_t>(std::floor(LR_TAPER_FRACTION * spp / c.big));
+        const auto rest = spp - c.big_count * c.big;
+        auto small_count = (rest + c.small - 1u) / c.small;
+        if (c.big_count + small_count > kMaxChunks) {// (few tiles and many samples: fall back to what fits the partial planes)
+            c.small = (rest + (kMaxChunks - c.big_count) - 1u) / (kMaxChunks - c.big_count);
+            small_count = (rest + c.small - 1u) / c.small;
+        }
+        c.count = c.big_count + small_count;
+        if (c.big_count >= 1u && small_count >= 1u && c.count <= kMaxChunks) { return c; }
+    }
+    auto count = static_cast<uint32_t>(std::lround(spp / s_opt));
+    count = std::max(1u, std::min({count, spp, kMaxChunks}));
+    c.count = c.big_count = count, c.big = (spp + count - 1u) / count, c.small = c.big;
+    return c;
+}
+
 // ---- wavefront mode (dev_scene.h: WfArgs): a scene with Mix or Layered surfaces under the MegaPath integrator.  The frame is cut
 // into SLICES of the sample range whose paths fit the queues (a path is parked at most once per round, so a queue never needs more
 // slots than the slice has paths); per slice: the camera pass of the lean megakernel <.. | Wf> (its own work items, chunked by the
@@ -842,16 +884,16 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto counts = static_cast<uint32_t *>(ctx->wf_counts.ptr);
     const auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
     auto item_scale = 1.25;
-    if (ctx->diag_item_scale > 0.) { item_scale *= std::max(0.01, ctx->diag_item_scale); }
+    if (ctx->diag_item_scale != 0.) { item_scale *= std::max(0.01, std::fabs(ctx->diag_item_scale)); }
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
     for (auto s0 = p->spp_begin; s0 < p->spp_end; s0 += slice_spp) {
         const auto s1 = std::min(p->spp_end, s0 + slice_spp);
         const auto n = s1 - s0;
         // ---- camera pass: samples [s0, s1) of every tile of the shard; heavy hits are parked
-        auto s_item = std::sqrt(item_scale * n * shard_tiles / kNominalWaves);
-        auto chunk_count = static_cast<uint32_t>(std::lround(n / std::max(s_item, 1.0)));
-        chunk_count = std::max(1u, std::min({chunk_count, n, kMaxChunks}));
+        const auto ck = chunking_of(n, shard_tiles, item_scale, ctx->diag_item_scale >= 0.);
+        const auto chunk_count = ck.count;
         args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = tiles_in_range * chunk_count;
+        args.chunk_big_count = ck.big_count, args.chunk_big = ck.big, args.chunk_small = ck.small;
         args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_camera) * lrd::kBlockThreads;
         if (chunk_count > 1u) {
             if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
@@ -866,6 +908,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         }
         // ---- rounds: a path leaves a round either finished or parked again (one level deeper), so max_depth rounds empty the queues
         args.chunk_count = 1u, args.item_count = 0u;// (the continuation pass reads its item count from the device)
+        args.chunk_big_count = 1u, args.chunk_big = 0u, args.chunk_small = 0u;
         for (auto round = 0u; round < std::max(scene.max_depth, 1u); round++) {
             for (auto k = 0u; k < lrd::kWfKinds; k++) {
                 if (has_kind[k]) { LR_HIP_CHECK(kHeavyVariants[hi[k]].launch(ctx->cu_count * static_cast<uint32_t>(b_heavy[k]), ctx->stream, device_scene, &args)); }
@@ -913,20 +956,15 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
             return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u, generic_sampler);
         }
     }
-    // Chunking is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile range
-    // of this call.  Two losses are balanced: the drain at the end of every item (the last paths of its queue finish
-    // with most lanes idle, a share of ~a / S for S samples per pixel and item) and the tail of the launch (waves that
-    // run out of items while the last ones finish, ~S * waves / (2 * spp * tiles))  ->  S = sqrt(2 a * spp * tiles / waves).
-    // a = 0.625 from sweeps on C2 (1024 spp, full frame: 7 / 14 / 28 chunks -> 1992 / 1987 / 1987 ms; the 1/8 shard:
-    // 14 / 28 / 56 / 64 chunks -> 305 / 271 / 266 / 265 ms).  tile_count is that of ONE shard of the frame as the caller
-    // declares it (balance_shards), so that every shard of a frame — and the unsharded frame rendered with the same
-    // hint — uses the same chunking.
+    // Chunking (chunking_of above) is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile
+    // range of this call: tile_count is that of ONE shard of the frame as the caller declares it (balance_shards), so that every shard
+    // of a frame -- and the unsharded frame rendered with the same hint -- uses the same chunking.  (Uniform items, rounds 1-2, C2 at
+    // 1024 spp: full frame 7 / 14 / 28 chunks -> 1992 / 1987 / 1987 ms; the 1/8 shard 14 / 28 / 56 / 64 chunks -> 305 / 271 / 266 / 265 ms.)
     auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
     auto item_scale = 1.25;
-    if (ctx->diag_item_scale > 0.) { item_scale *= std::max(0.01, ctx->diag_item_scale); }// lrhip_set_diagnostics: sweep of the loss model's constant
-    auto s_item = std::sqrt(item_scale * spp * shard_tiles / kNominalWaves);
-    auto chunk_count = static_cast<uint32_t>(std::lround(spp / std::max(s_item, 1.0)));
-    chunk_count = std::max(1u, std::min({chunk_count, spp, kMaxChunks}));
+    if (ctx->diag_item_scale != 0.) { item_scale *= std::max(0.01, std::fabs(ctx->diag_item_scale)); }// lrhip_set_diagnostics: sweep of the loss model's constant (< 0: uniform items)
+    const auto ck = chunking_of(spp, shard_tiles, item_scale, ctx->diag_item_scale >= 0.);
+    const auto chunk_count = ck.count;
     lrd::RenderArgs args{};
     args.film = ctx->film;
     ctx->scene.shutter_weight = (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f;
@@ -934,6 +972,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     args.tile_begin = p->tile_begin, args.tile_end = p->tile_end, args.tile_stride = p->tile_stride;
     args.tiles_x = tiles_x, args.tiles_y = tiles_y;
     args.chunk_count = chunk_count;
+    args.chunk_big_count = ck.big_count, args.chunk_big = ck.big, args.chunk_small = ck.small;
     args.item_count = tiles_in_range * chunk_count;
     args.work_counter = static_cast<uint32_t *>(ctx->work_counter.ptr);
     args.spill = static_cast<uint32_t *>(ctx->spill.ptr);

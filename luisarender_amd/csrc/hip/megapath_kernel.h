@@ -150,14 +150,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
         // ---- next work item of this wavefront
         uint32_t item = next_item(CONT ? scene.wf.counts + kWfWorkCont : args.work_counter, item_count, lane);
         if (item == kInvalid) { break; }
-        const auto tile_index = item / args.chunk_count;
-        const auto chunk = item - tile_index * args.chunk_count;
+        const auto range = CONT ? ItemRange{0u, 0u, 0u, 0u} : item_range(args, item);
+        const auto tile_index = range.tile_index, chunk = range.chunk;
         const auto tile = args.tile_begin + tile_index * args.tile_stride;
         const auto ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
-        const auto spp_total = args.spp_end - args.spp_begin;
-        const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
-        const auto s_begin = args.spp_begin + chunk * per_chunk;
-        const auto s_end = min(s_begin + per_chunk, args.spp_end);
+        const auto s_begin = range.s_begin, s_end = range.s_end;
         // the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * item_records + k)
         const auto q_total = CONT ? min(item_records, cont_total - item * item_records) : (s_end > s_begin ? (s_end - s_begin) * 64u : 0u);
         auto q_next = 0u;// wave-uniform

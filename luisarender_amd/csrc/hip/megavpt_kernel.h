@@ -191,14 +191,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
         if (lane == 0u) { item = atomicAdd(args.work_counter, 1u); }
         item = __shfl(item, 0);
         if (item >= args.item_count) { break; }
-        const auto tile_index = item / args.chunk_count;
-        const auto chunk = item - tile_index * args.chunk_count;
+        const auto range = item_range(args, item);
+        const auto tile_index = range.tile_index, chunk = range.chunk;
         const auto tile = args.tile_begin + tile_index * args.tile_stride;
         const auto ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
-        const auto spp_total = args.spp_end - args.spp_begin;
-        const auto per_chunk = (spp_total + args.chunk_count - 1u) / args.chunk_count;
-        const auto s_begin = args.spp_begin + chunk * per_chunk;
-        const auto s_end = min(s_begin + per_chunk, args.spp_end);
+        const auto s_begin = range.s_begin, s_end = range.s_end;
         film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
         const auto px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3u);
         const auto inside = px < scene.camera.width && py < scene.camera.height;

@@ -277,29 +277,69 @@ void huffman_decode(const uint8_t *src, size_t size, uint16_t *out, size_t count
         auto fill = offset;
         for (auto i = im; i <= iM; i++) { if (length[i] != 0u) { symbols[fill[length[i]]++] = i; } }
     }
-    BitReader bits{data, src + size};
+    // Short codes through a lookup table (round 3, ADVICE r02: the bit-serial walk below took up to 58 iterations per symbol and made
+    // large PIZ environment maps slow to load): kLutBits bits of lookahead index a table of (symbol, length) for every code of at most
+    // kLutBits bits -- in a PIZ stream nearly all symbols -- and only longer codes fall back to the walk, which starts at kLutBits + 1.
+    constexpr int kLutBits = 12;
+    struct Short {
+        uint32_t symbol;
+        uint8_t length;// 0: no code of <= kLutBits bits has this prefix
+    };
+    std::vector<Short> lut(size_t{1} << kLutBits, Short{0u, 0u});
+    for (auto l = 1; l <= kLutBits; l++) {
+        for (uint64_t k = 0; k < count_of[l]; k++) {
+            const auto code = first[l] + k;
+            if (code >> l) { throw Error{}; }// (an over-subscribed code table)
+            const auto lo = code << (kLutBits - l);
+            for (uint64_t fill = 0; fill < (uint64_t{1} << (kLutBits - l)); fill++) { lut[lo + fill] = Short{symbols[offset[l] + static_cast<uint32_t>(k)], static_cast<uint8_t>(l)}; }
+        }
+    }
+    struct PeekReader {// the BitReader with a non-consuming look at the next bits (zero-padded behind the end of the stream)
+        const uint8_t *p, *end;
+        uint64_t c{0u};
+        int lc{0};
+        uint32_t peek(int n) {
+            while (lc < n) {
+                c = (c << 8u) | (p < end ? *p : 0u);
+                p++;
+                lc += 8;
+            }
+            return static_cast<uint32_t>((c >> (lc - n)) & ((1ull << n) - 1ull));
+        }
+        void skip(int n) { lc -= n; }
+        uint32_t get(int n) { auto v = peek(n); skip(n); return v; }
+    } bits{data, src + size};
     uint64_t used = 0u;
     size_t produced = 0u;
     const auto rlc = iM;
+    auto emit = [&](uint32_t symbol) {
+        if (symbol == rlc) {
+            if (used + 8u > n_bits || produced == 0u) { throw Error{}; }
+            auto run = bits.get(8);
+            used += 8u;
+            if (produced + run > count) { throw Error{}; }
+            for (auto k = 0u; k < run; k++) { out[produced + k] = out[produced - 1u]; }
+            produced += run;
+        } else {
+            if (produced >= count) { throw Error{}; }
+            out[produced++] = static_cast<uint16_t>(symbol);
+        }
+    };
     while (used < n_bits) {
+        const auto s = lut[bits.peek(kLutBits)];
+        if (s.length != 0u && used + s.length <= n_bits) {
+            bits.skip(s.length);
+            used += s.length;
+            emit(s.symbol);
+            continue;
+        }
         uint64_t code = 0u;
         auto found = false;
         for (auto l = 1; l <= 58 && used < n_bits; l++) {
             code = (code << 1u) | bits.get(1);
             used++;
-            if (count_of[l] != 0u && code >= first[l] && code - first[l] < count_of[l]) {
-                auto symbol = symbols[offset[l] + static_cast<uint32_t>(code - first[l])];
-                if (symbol == rlc) {
-                    if (used + 8u > n_bits || produced == 0u) { throw Error{}; }
-                    auto run = bits.get(8);
-                    used += 8u;
-                    if (produced + run > count) { throw Error{}; }
-                    for (auto k = 0u; k < run; k++) { out[produced + k] = out[produced - 1u]; }
-                    produced += run;
-                } else {
-                    if (produced >= count) { throw Error{}; }
-                    out[produced++] = static_cast<uint16_t>(symbol);
-                }
+            if (l > kLutBits && count_of[l] != 0u && code >= first[l] && code - first[l] < count_of[l]) {
+                emit(symbols[offset[l] + static_cast<uint32_t>(code - first[l])]);
                 found = true;
                 break;
             }

@@ -11,13 +11,17 @@ with tempfile.TemporaryDirectory() as tmp:
     sc = Scene.load(generate_room_scene(tmp, resolution=(1024, 1024), spp=spp))
     r = MegaPathRenderer(0)
     r.upload(sc)
-    base = None
-    for world in (1, 2, 4, 8):
-        for balance in sorted({1, world}):
+    modes = (("tapered work items (round 3)", 0.0), ("uniform work items (rounds 1-2)", -1.0))
+    if len(sys.argv) > 2:
+        modes = modes[:1]
+    for label, scale in modes:
+        r.set_diagnostics(item_scale=scale)
+        base = None
+        for world in ((1, 8) if len(sys.argv) > 2 else (1, 2, 4, 8)):
             ms = []
             for _ in range(2):
-                r.clear(); r.render(0, spp, rank=0, world=world, sync=True, balance_shards=balance)
+                r.clear(); r.render(0, spp, rank=0, world=world, sync=True, balance_shards=world)
                 ms.append(r.last_render_ms())
             t = min(ms)
             base = base or t
-            print(f"world {world} balance_shards {balance}: shard {t:.1f} ms, efficiency {base / (world * t):.3f}", flush=True)
+            print(f"{label}: world {world}: shard {t:.1f} ms, kernel-level strong-scaling efficiency {base / (world * t):.3f}", flush=True)
