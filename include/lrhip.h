@@ -160,6 +160,12 @@ uint32_t lrhip_last_variant(lrhip_ctx *ctx);
  *                   A value other than the default changes the order of a pixel's float adds, i.e. the film's last bits.        */
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale);
 
+/* The work-item partition lrhip_render uses for `spp` samples per pixel of a frame cut into `balance_shards` shards (no device
+ * needed): out = { chunks per tile, how many of them are big, samples per pixel of a big chunk, of a small chunk }.  Chunk k of a
+ * tile covers samples [k * big, ..) for k < big count and [big count * big + (k - big count) * small, ..) after that, clipped to spp;
+ * all big items of a launch are handed out before the first small one (items taper towards the end of the launch).              */
+int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t balance_shards, uint32_t out[4]);
+
 /* Wavefront mode (round 3): a scene with Mix or Layered surfaces under the MegaPath integrator is rendered by a lean megakernel that
  * parks the paths reaching a Disney / Mix / Layered surface in HBM queues, a heavy-closure kernel that shades those vertices in full
  * waves of one closure kind, and a continuation pass of the megakernel -- alternating until the queues are empty.  The frame is cut

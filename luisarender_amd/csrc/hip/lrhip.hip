@@ -753,9 +753,11 @@ int lrhip_film_clear(lrhip_ctx *ctx) {
 // Two losses are balanced.  The drain at the end of every item -- its last paths finish with most lanes idle -- is a share of
 // ~a / S of an item of S samples per pixel; the tail of the launch -- waves out of items while the last ones finish -- is
 // ~S_last * waves / (2 * spp * tiles).  With uniform items both depend on the same S and the optimum is S = sqrt(2a * spp * tiles /
-// waves) (a = 0.625 from sweeps, rounds 1-2).  Round 3: the items TAPER -- the first ~85 % of the samples go out in items 2.5x that
+// waves) (a = 0.625 from sweeps, rounds 1-2).  Round 3: the items TAPER -- the first ~90 % of the samples go out in items 2.5x that
 // size, the rest in items a third of it, and all big items are handed out before the first small one: the bulk drains rarely, the
-// end of the launch is made of short items.  The partition is a function of (spp, shard_tiles, scale) only -- never of the device
+// end of the launch is made of short items.  C2 at 1024 spp, full frame / 1-of-8 shard: uniform 1213.5 / 164.5 ms, tapered 1197.5 /
+// 158.0 ms (kernel-level strong-scaling efficiency at 8 shards 0.922 -> 0.947); big factor 2 / 2.5 / 3.5 / 4, small divisor 2 / 3 /
+// 4 / 5 and fractions 0.75 / 0.85 / 0.9 were swept (profiles/r03p_taper_sweep.txt).  The partition is a function of (spp, shard_tiles, scale) only -- never of the device
 // or of the tile range of the call -- so films stay bit-identical under any sharding with the same balance_shards.
 #ifndef LR_TAPER_BIG
 #define LR_TAPER_BIG 2.5
@@ -764,7 +766,7 @@ int lrhip_film_clear(lrhip_ctx *ctx) {
 #define LR_TAPER_SMALL 3.0
 #endif
 #ifndef LR_TAPER_FRACTION
-#define LR_TAPER_FRACTION 0.85
+#define LR_TAPER_FRACTION 0.9
 #endif
 struct Chunking {
     uint32_t count, big_count, big, small;
@@ -773,12 +775,14 @@ static Chunking chunking_of(uint32_t spp, double shard_tiles, double item_scale,
     const auto s_opt = std::max(1.0, std::sqrt(item_scale * spp * shard_tiles / kNominalWaves));
     Chunking c{};
     if (taper && spp >= 16u) {
-        c.big = static_cast<uint32_t>(std::clamp(std::lround(LR_TAPER_BIG * s_opt), 1l, static_cast<long>(spp)));
+        // (the partial planes bound the chunk count: at most half of them for the big items, the rest for the small ones)
+        const auto big_min = static_cast<long>((static_cast<uint64_t>(spp) * 2u + kMaxChunks - 1u) / kMaxChunks);
+        c.big = static_cast<uint32_t>(std::clamp(std::max(std::lround(LR_TAPER_BIG * s_opt), big_min), 1l, static_cast<long>(spp)));
         c.small = static_cast<uint32_t>(std::clamp(std::lround(s_opt / LR_TAPER_SMALL), 1l, static_cast<long>(c.big)));
         c.big_count = static_cast<uint32_t>(std::floor(LR_TAPER_FRACTION * spp / c.big));
         const auto rest = spp - c.big_count * c.big;
         auto small_count = (rest + c.small - 1u) / c.small;
-        if (c.big_count + small_count > kMaxChunks) {// (few tiles and many samples: fall back to what fits the partial planes)
+        if (c.big_count + small_count > kMaxChunks && c.big_count < kMaxChunks) {// (few tiles and many samples: what fits the partial planes)
             c.small = (rest + (kMaxChunks - c.big_count) - 1u) / (kMaxChunks - c.big_count);
             small_count = (rest + c.small - 1u) / c.small;
         }
@@ -956,7 +960,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
             return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u, generic_sampler);
         }
     }
-    // Chunking (chunking_of above) is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile
+    // Chunking (chunking_of above: tapered items) is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile
     // range of this call: tile_count is that of ONE shard of the frame as the caller declares it (balance_shards), so that every shard
     // of a frame -- and the unsharded frame rendered with the same hint -- uses the same chunking.  (Uniform items, rounds 1-2, C2 at
     // 1024 spp: full frame 7 / 14 / 28 chunks -> 1992 / 1987 / 1987 ms; the 1/8 shard 14 / 28 / 56 / 64 chunks -> 305 / 271 / 266 / 265 ms.)
@@ -1022,6 +1026,14 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale) {
     if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_diagnostics: ctx is NULL"); }
     ctx->diag_force_features = force_features, ctx->diag_item_scale = item_scale;
+    return LRHIP_OK;
+}
+
+int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t balance_shards, uint32_t out[4]) {
+    if (out == nullptr || width == 0u || height == 0u || spp == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_work_items: invalid argument"); }
+    const auto tile_count = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+    const auto c = chunking_of(spp, static_cast<double>(tile_count) / std::max(balance_shards, 1u), 1.25, true);
+    out[0] = c.count, out[1] = c.big_count, out[2] = c.big, out[3] = c.small;
     return LRHIP_OK;
 }
 

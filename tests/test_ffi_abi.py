@@ -52,3 +52,29 @@ def test_plugin_exports_reference_plugin_abi():
     _ffi.host_lib()
     lib = C.CDLL(path)
     assert hasattr(lib, "create") and hasattr(lib, "destroy")  # scene_node.h:58-67
+
+
+def test_work_items_partition_the_sample_range():
+    """lrhip_work_items (no device needed): the tapered work items of lrhip_render -- big chunks first, small ones at the end of the
+    launch -- must partition [0, spp) exactly, within the 64 partial planes, for every frame size / spp / shard count."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(_ffi.REPO_ROOT, "luisarender_amd", "lib", "liblrhip.so"))
+    lib.lrhip_work_items.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32 * 4)]
+    out = (C.c_uint32 * 4)()
+    tapered = 0
+    for width, height in ((16, 16), (96, 64), (512, 512), (1024, 1024), (1280, 720), (3840, 2160)):
+        for shards in (1, 2, 8, 64):
+            for spp in list(range(1, 40)) + [63, 64, 65, 256, 1000, 1024, 4096, 65536]:
+                assert lib.lrhip_work_items(width, height, spp, shards, C.byref(out)) == 0
+                count, big_count, big, small = out
+                assert 1 <= count <= 64 and big_count <= count and big >= 1 and small >= 1, (width, height, spp, shards, list(out))
+                covered = 0
+                for k in range(count):
+                    b = k * big if k < big_count else big_count * big + (k - big_count) * small
+                    e = min(b + (big if k < big_count else small), spp)
+                    assert min(b, spp) == covered or b >= spp, (width, height, spp, shards, list(out), k)
+                    covered = max(covered, e)
+                assert covered == spp, (width, height, spp, shards, list(out))
+                tapered += big_count < count
+    assert tapered > 100  # the taper is what is normally used
+    assert lib.lrhip_work_items(0, 16, 1, 1, C.byref(out)) != 0
