@@ -14,11 +14,10 @@
 //     construction (lo rounded down, hi rounded up);
 //   * each wave fetches the 64 packets its lanes need with FOUR fully coalesced 16-byte-per-lane loads
 //     (4 consecutive lanes read one packet = 16 lines per instruction instead of 64) straight into a
-//     4 KiB per-wave LDS staging area (gfx950: global_load_lds_dwordx4), XOR-swizzled by which quarter
-//     of the packet a lane asks for, and every lane reads its own packet back with four conflict-free
-//     ds_read_b128;
+//     4 KiB per-wave LDS staging area (gfx950: global_load_lds_dwordx4), organised by quads (below), and
+//     every lane reads its own packet back with conflict-free ds_read_b128;
 //   * slab tests run directly on the quantised planes: t = fma(q, scale * inv_d, (origin - o) * inv_d),
-//     near / far plane words picked by the sign of the ray direction, 24 v_cvt_f32_ubyteN + 12 v_pk_fma_f32
+//     near / far plane words picked by the sign of the ray direction, 24 v_cvt_f32_ubyteN + 24 v_fma_f32
 //     per packet;
 //   * hits are ordered near->far with a 5-comparator network on packed (t | slot) integer keys;
 //   * the traversal stack lives in LDS, [entry][lane] interleaved (conflict-free push/pop); entries
@@ -90,23 +89,17 @@ struct TraversalStack {
 
 // Round 3 (profiles/r03_valu_peak.json: on gfx950 only v_fma / v_mul / v_add / v_and / v_xor / v_mov issue every 2 cycles per
 // wave64; every min / max / cvt / cndmask / cmp / shift / 64-bit add / DPP / packed op takes 4, LDS-crossing ds_bpermute 25):
-//   LR_FETCH_QUAD  the packet fetch is organised by QUADS: load j of lane l fetches quarter (l & 3) of the packet of lane
-//                  (l & ~3) + j, whose node index comes over a DPP quad_perm broadcast (VALU) instead of a ds_bpermute (LDS);
-//                  addresses are 32-bit offsets from the scalar table base (global_load_lds saddr form), the LDS destinations
-//                  are wave-uniform SGPRs.  The four 1 KiB regions are 1040 bytes apart, which staggers them over the banks:
-//                  every lane's four ds_read_b128 are conflict-free without an XOR swizzle.
-//   LR_CHILD_LDS   the reference of a sorted child is read back from the staged packet (ds_read_b32 at slot * 4) instead of
-//                  a three-v_cndmask select per push; the four child words never enter the VGPRs.
-#ifndef LR_FETCH_QUAD
-#define LR_FETCH_QUAD 1
-#endif
-#ifndef LR_CHILD_LDS
-#define LR_CHILD_LDS 1
-#endif
-#ifndef LR_STACK_FAST
-#define LR_STACK_FAST 1
-#endif
-constexpr uint32_t kStageRegion = LR_FETCH_QUAD ? 65u : 64u;// float4 per load region of the wave's staging area
+//   * the packet fetch is organised by QUADS: load j of lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j, whose node
+//     index comes over a DPP quad_perm broadcast (VALU) instead of a ds_bpermute (LDS); addresses are 32-bit offsets from the scalar
+//     table base (global_load_lds saddr form), the LDS destinations are wave-uniform SGPRs.  The four 1 KiB regions are 1040 bytes
+//     apart, which staggers them over the banks: every lane's ds_read_b128 are conflict-free without an XOR swizzle;
+//   * the reference of a sorted child is read back from the staged packet (ds_read_b32 at slot * 4) instead of a three-v_cndmask
+//     select per push; the four child words never enter the VGPRs;
+//   * one wave-level test per iteration decides whether any lane could reach the HBM overflow area of the stack; if not, every push
+//     and pop of the iteration is a bare LDS access.
+// A/B of the three against the round-2 forms (ds_bpermute + XOR swizzle, v_cndmask selects, per-entry range checks), C2 at 256 spp:
+// 813 -> 828 (quad fetch) / 820 (child reads) / 835 (both) -> 844 (stack test) Msamples/s; profiles/r03b_ab_quad_fetch.txt.
+constexpr uint32_t kStageRegion = 65u;     // float4 per load region of the wave's staging area (64 + one float4 of bank stagger)
 constexpr uint32_t kStageWave = 4u * kStageRegion;          // float4 per wave
 
 LR_D void cswap(uint32_t &a, uint32_t &b) {
@@ -181,66 +174,34 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
     typedef __attribute__((address_space(1))) const void global_void;
     const auto lane = threadIdx.x & 63u;
     const auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
-#if LR_FETCH_QUAD
     // load j: lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j into region j, float4 slot l.  Lane o therefore finds
     // its own packet in region (o & 3), slots 4 (o >> 2) .. + 3, in order
     const auto node_bytes = reinterpret_cast<const char *>(scene.nodes);
     const auto quarter = (lane & 3u) << 4u;
     const auto mine = stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u;
-#else
-    // load k: lane l fetches quarter (l & 3) ^ swizzle of the packet of lane (l >> 2) + 16 k
-    const auto nodes = reinterpret_cast<const float4 *>(scene.nodes);
-    const auto part = lane & 3u;
-    const auto owner0 = lane >> 2u;
-    const auto my_swz = (lane >> 2u) & 3u;
-    const auto mine = stack.stage + lane * 4u;
-#endif
     auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
         auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
         auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
-        // LR_STACK_FAST (round 3: +1 %, 835 -> 844 Msamples/s on C2 at 256 spp): one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in
-        // this iteration (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of
-        // the iteration is a bare LDS access instead of a compare + branch + access per entry
-        const auto deep = !LR_STACK_FAST || __any(live && tr.sp + 3u > kStackLds);
+        // one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in this iteration
+        // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
+        // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
+        const auto deep = __any(live && tr.sp + 3u > kStackLds);
         if (__any(is_inner)) {
             // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
             // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
             auto want = is_inner ? tr.cur : 0u;
-#if LR_FETCH_QUAD
 #define LR_FETCH(j) { \
                 const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, false)); /* quad_perm:[j,j,j,j] */ \
                 __builtin_amdgcn_global_load_lds((global_void *)(node_bytes + ((w << 6u) | quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
             LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
 #undef LR_FETCH
-#else
-            auto n0 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0)));
-            auto n1 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 16u)));
-            auto n2 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 32u)));
-            auto n3 = static_cast<uint32_t>(__shfl(static_cast<int>(want), static_cast<int>(owner0 + 48u)));
-            const auto psw = part ^ ((owner0 >> 2u) & 3u);// the XOR swizzle that keeps the 16-lane ds_read_b128 groups conflict-free
-            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n0) * 4u + psw), (lds_void *)(stack.stage), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n1) * 4u + psw), (lds_void *)(stack.stage + 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n2) * 4u + psw), (lds_void *)(stack.stage + 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((global_void *)(nodes + static_cast<size_t>(n3) * 4u + psw), (lds_void *)(stack.stage + 192), 16, 0, 0);
-#endif
             __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if LR_FETCH_QUAD
-            const auto p0 = 0u, p1 = 1u, p2 = 2u, p3 = 3u;
-#else
-            const auto p0 = 0u ^ my_swz, p1 = 1u ^ my_swz, p2 = 2u ^ my_swz, p3 = 3u ^ my_swz;
-#endif
-            auto q0 = mine[p0], q1 = mine[p1], q2 = mine[p2];
-#if LR_CHILD_LDS
-            const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + p3));
-#else
-            auto q3 = mine[p3];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#endif
+            auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
+            const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + 3));// q3 = child[4] stays in LDS
             if (is_inner) {
                 if (COUNT) { stats.nodes++; }
 #ifdef LR_PROBE_NODE
@@ -276,17 +237,8 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                     auto h = tn <= tf * 1.0000004f;
                     key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
                 }
-#if LR_CHILD_LDS
                 // (the slot kept in the key as a byte offset, slot * 4 in four key bits, saves the shift: measured, no change)
                 auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
-#else
-                uint32_t ch[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
-                auto ref_of = [&](uint32_t k) {// two-level v_cndmask select on the slot bits (no branches)
-                    auto lo = (k & 1u) ? ch[1] : ch[0];
-                    auto hi = (k & 1u) ? ch[3] : ch[2];
-                    return (k & 2u) ? hi : lo;
-                };
-#endif
                 // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
                 cswap(key[0], key[1]);
                 cswap(key[2], key[3]);
@@ -308,12 +260,10 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                 else if (tr.sp > 0u) { tr.cur = deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp); }
                 else { tr.cur = kInvalid; }
             }
-#if LR_CHILD_LDS
             // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
             __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#endif
         }
         // ---- leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds one-triangle
         // leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
