@@ -80,8 +80,9 @@ LR_D float hg_phase(float cos_t, float g) {// HGPhaseFunction::HenyeyGreenstein,
 LR_D f3 hg_sample(f3 wo, float g, f2 u, float &pdf) {// :25-38
     auto cos_t = fabsf(g) < 1e-3f ? 1.f - 2.f * u.x : -1.f / (2.f * g) * (1.f + sqr(g) - sqr((1.f - sqr(g)) / (1.f + g - 2.f * g * u.x)));
     auto sin_t = sqrtf(1.f - sqr(cos_t));
-    auto phi = 2.f * kPi * u.y;
-    auto wi = to_world(frame_from_normal(wo), mk3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t));
+    float sn, cs;
+    sincos_2pi(u.y, sn, cs);// phi = 2 pi u.y
+    auto wi = to_world(frame_from_normal(wo), mk3(sin_t * cs, sin_t * sn, cos_t));
     pdf = hg_phase(cos_t, g);
     return wi;
 }
