@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=None, help="override the workload's spp (invalidates the headline number)")
+    ap.add_argument("--sampler", default="Independent", choices=["Independent", "PaddedSobol", "Sobol"],
+                    help="sampler of the timed frame (anything but Independent invalidates the headline number)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic from profiles/ or null)")
@@ -324,7 +326,7 @@ def main():
 
     with tempfile.TemporaryDirectory(prefix="lr_bench_") as tmp:
         value, ms_per_step, mean_kernel_ms, variant, scene, res, spp, desc = run_workload(
-            args.workload, args, rank, world, local_rank, tmp, args.steps, args.warmup, args.spp)
+            args.workload, args, rank, world, local_rank, tmp, args.steps, args.warmup, args.spp, args.sampler)
         elapsed = ms_per_step * args.steps * 1e-3
 
         if rank == 0:
@@ -333,12 +335,12 @@ def main():
                 "metric": METRIC, "value": value, "unit": "Msamples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)",
+                "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)" if args.sampler == "Independent" else args.sampler,
                            "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
                            "collective": getattr(run_workload, "collective", None)},
             }
-            if args.spp is not None:
-                out["config"]["note"] = "spp overridden: not the headline configuration"
+            if args.spp is not None or args.sampler != "Independent":
+                out["config"]["note"] = "spp / sampler overridden: not the headline configuration"
             elif args.workload in BENCH_SPP_CAP:
                 out["config"]["note"] = f"timed at {spp} spp of the same frame (Independent sampler: throughput is spp-invariant)"
             bytes_per_sample = ALGORITHMIC_BYTES_PER_SAMPLE[args.workload]

@@ -133,7 +133,7 @@ typedef struct lr_light {
 
 /* ---- environment (src/environments/{spherical,directional}.cpp) */
 enum { LR_ENV_NONE = 0, LR_ENV_SPHERICAL = 1, LR_ENV_DIRECTIONAL = 2,
-       LR_ENV_COMBINED = 3 /* src/environments/combined.cpp: two children in lr_scene.environment_children */ };
+       LR_ENV_COMBINED = 3 /* src/environments/combined.cpp: children in lr_scene.environment_children */ };
 typedef struct lr_environment {
     uint32_t kind;
     int32_t emission_tex;
@@ -150,10 +150,15 @@ typedef struct lr_environment {
     float direction[3];
     float cos_half_angle;
     uint32_t visible;
-    /* combined: scales of children a and b (both > 0; a Combined with one live child is flattened by the host) */
+    /* combined: scales of children a and b (both > 0; a Combined with one live child is flattened by the host) and their
+     * records, indices into lr_scene.environment_children.  A child may be a Combined node itself (combined.cpp:23-111 composes
+     * freely): children precede their parents in the array (child[k] < own index for a node IN the array), at most
+     * LR_ENV_MAX_COMBINED_DEPTH Combined nodes on a root-to-leaf path. */
     float child_scale[2];
+    uint32_t child[2];
     uint32_t pad;
 } lr_environment;
+enum { LR_ENV_MAX_COMBINED_DEPTH = 4 };
 
 /* ---- camera / filter / film / sampler / integrator */
 enum { LR_CAMERA_PINHOLE = 0, LR_CAMERA_THIN_LENS = 1, LR_CAMERA_ORTHO = 2 };
@@ -298,7 +303,7 @@ typedef struct lr_scene {
     lr_accel accel;                    /* nodes == NULL when not built */
     uint32_t any_non_opaque;           /* Geometry::_any_non_opaque, geometry.cpp:124 */
     uint32_t environment_child_count;  /* 2 when environment.kind == LR_ENV_COMBINED, else 0 */
-    const lr_environment *environment_children; /* Spherical / Directional records with their own tables */
+    const lr_environment *environment_children; /* records below a Combined root (leaves with their own tables, nested Combined nodes) */
     const lr_medium *media;            /* Pipeline::_media in registration order (tag = index) */
     uint32_t medium_count;
     uint32_t pad_media;

@@ -40,7 +40,7 @@ class Mesh(C.Structure):
 
 
 class Instance(C.Structure):
-    _fields_ = [("handle", UInt4), ("object_to_world", f32 * 16), ("visible", u32), ("child_scale", f32 * 2), ("pad", u32)]
+    _fields_ = [("handle", UInt4), ("object_to_world", f32 * 16), ("visible", u32), ("pad", u32 * 3)]
 
 
 class Texture(C.Structure):
@@ -63,7 +63,7 @@ class Environment(C.Structure):
     _fields_ = [("kind", u32), ("emission_tex", i32), ("scale", f32), ("compensate_mis", u32),
                 ("world_to_env", f32 * 9), ("env_to_world", f32 * 9), ("map_width", u32), ("map_height", u32),
                 ("alias", C.c_void_p), ("pdf", C.c_void_p), ("direction", f32 * 3), ("cos_half_angle", f32),
-                ("visible", u32), ("child_scale", f32 * 2), ("pad", u32)]
+                ("visible", u32), ("child_scale", f32 * 2), ("child", u32 * 2), ("pad", u32)]
 
 
 class Camera(C.Structure):

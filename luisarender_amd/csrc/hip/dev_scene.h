@@ -92,7 +92,7 @@ struct DEnvironment {
     uint32_t visible, constant_emission;
     uint32_t kind;                         // kEnv* of this record
     float child_scale[2];                  // kEnvCombined (combined.cpp): scales and records of children a, b
-    uint32_t pad;
+    uint32_t tree;                         // kEnvCombined: a child is a Combined node itself (dev_shade.h: env_evaluate_tree)
     const DEnvironment *child[2];
 };
 

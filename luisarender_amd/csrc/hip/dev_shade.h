@@ -166,7 +166,9 @@ struct PathSampler<true> {
             i &= w;
             i ^= i >> 5u;
         } while (i >= l);
-        return (i + p) % l;
+        // (l a power of two -- every spp anyone renders at: w == l - 1, the loop ran once, and the modulo is a mask instead of the ~35
+        // instructions of a 32-bit division, once per draw; wave-uniform)
+        return (l & w) == 0u ? (i + p) & w : (i + p) % l;
     }
     static constexpr uint32_t kSavedWords = 8u;// (megapath_kernel.h: deferred heavy hits)
     LR_D uint32_t save(uint32_t *w) const {
@@ -343,7 +345,7 @@ LR_D int texel_wrap(uint32_t address, int v, int n, bool &zero) {
     }
     const auto period = address == LR_TEX_ADDR_MIRROR ? 2 * n : n;
     int m;
-    if (v > -(1 << 23) && v < (1 << 23)) {
+    if (v > -(1 << 20) && v < (1 << 20)) {// (quotient error < 0.2 for any period >= 1)
         const auto q = static_cast<int>(floorf(static_cast<float>(v) * (1.f / static_cast<float>(period))));
         m = v - q * period;// off by at most one period when v / period is within rounding of an integer
         m += m < 0 ? period : 0;
@@ -846,10 +848,85 @@ LR_CALL EnvSample env_sample_one(EnvTables tb, const DEnvironment *envp, f2 u) {
     return r;
 }
 
+// Combined nodes nested in each other (combined.cpp composes freely; device code has no recursion): the tree is walked with an
+// explicit stack, in the reference's operation order (post-order: a.L * scale_a + b.L * scale_b, the pdfs interpolated), by out-of-line
+// functions that only the variants which make real calls anyway hold (lrhip.hip picks one for such a scene) -- the lean kernels' register
+// allocation never sees them.  At most LR_ENV_MAX_COMBINED_DEPTH Combined nodes on a path (lr_scene.h; checked at upload).
+#if defined(LR_VARIANT) && ((LR_VARIANT) & (96 | 256))
+#define LR_ENV_TREE 1
+__device__ __noinline__ EnvEval env_evaluate_tree(EnvTables tb, const DEnvironment *root, f3 wi) {// CombinedInstance::evaluate, combined.cpp:57-78
+    const DEnvironment *node[LR_ENV_MAX_COMBINED_DEPTH];
+    f3 local[LR_ENV_MAX_COMBINED_DEPTH];
+    EnvEval first[LR_ENV_MAX_COMBINED_DEPTH];
+    bool second[LR_ENV_MAX_COMBINED_DEPTH];
+    auto sp = 0;
+    auto cur = root;
+    for (;;) {
+        while (cur->kind == kEnvCombined && sp < LR_ENV_MAX_COMBINED_DEPTH) {// down the first children
+            node[sp] = cur, second[sp] = false;
+            wi = normalize(mul3(cur->world_to_env, wi));
+            local[sp] = wi;
+            cur = cur->child[0], sp++;
+        }
+        auto r = env_evaluate_one(tb, cur, wi);
+        for (;;) {// up: a finished first child starts the second one, a finished second child finishes the node
+            if (sp == 0) { return r; }
+            const auto top = sp - 1;
+            if (!second[top]) {
+                first[top] = r, second[top] = true;
+                cur = node[top]->child[1], wi = local[top];
+                break;
+            }
+            const auto sa = node[top]->child_scale[0], sb = node[top]->child_scale[1];
+            r = EnvEval{first[top].L * sa + r.L * sb, lerp(first[top].pdf, r.pdf, sb / (sa + sb))};
+            sp = top;
+        }
+    }
+}
+__device__ __noinline__ EnvSample env_sample_tree(EnvTables tb, const DEnvironment *root, f2 u) {// CombinedInstance::sample, combined.cpp:80-111
+    const DEnvironment *node[LR_ENV_MAX_COMBINED_DEPTH];
+    bool took_a[LR_ENV_MAX_COMBINED_DEPTH];
+    auto sp = 0;
+    auto cur = root;
+    while (cur->kind == kEnvCombined && sp < LR_ENV_MAX_COMBINED_DEPTH) {// choose a child by u.x, all the way down
+        const auto sa = cur->child_scale[0], sb = cur->child_scale[1];
+        const auto weight_a = sa / (sa + sb);
+        const auto a = u.x < weight_a;
+        u.x = a ? u.x / weight_a : (u.x - weight_a) / (1.f - weight_a);
+        node[sp] = cur, took_a[sp] = a;
+        cur = cur->child[a ? 0 : 1], sp++;
+    }
+    auto s = env_sample_one(tb, cur, u);
+    while (sp > 0) {// up: the other child evaluated in the sampled direction, the node's transform applied
+        sp--;
+        const auto n = node[sp];
+        const auto sa = n->child_scale[0], sb = n->child_scale[1];
+        const auto weight_a = sa / (sa + sb);
+        const auto o = env_evaluate_tree(tb, n->child[took_a[sp] ? 1 : 0], s.wi);
+        if (took_a[sp]) {
+            s.L = s.L * sa + o.L * sb;
+            s.pdf = lerp(s.pdf, o.pdf, 1.f - weight_a);
+        } else {
+            s.L = o.L * sa + s.L * sb;
+            s.pdf = lerp(o.pdf, s.pdf, 1.f - weight_a);
+        }
+        s.wi = normalize(mul3(n->env_to_world, s.wi));
+    }
+    return s;
+}
+#endif
+
 // root environment: one record, or CombinedInstance over two (combined.cpp:57-111)
 LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
     auto &env = *scene.env;
     EnvTables tb{scene.textures, scene.texels};
+#ifdef LR_ENV_TREE
+    if (env.kind == kEnvCombined && env.tree != 0u) {
+        auto e = env_evaluate_tree(tb, scene.env, wi);
+        L = e.L, pdf = e.pdf;
+        return;
+    }
+#endif
     if (env.kind != kEnvCombined) {
         auto e = env_evaluate_one(tb, scene.env, wi);
         L = e.L, pdf = e.pdf;
@@ -865,6 +942,13 @@ LR_D void env_evaluate(const DScene &scene, f3 wi, f3 &L, float &pdf) {
 LR_D void env_sample(const DScene &scene, f2 u, f3 &wi, f3 &L, float &pdf) {
     auto &env = *scene.env;
     EnvTables tb{scene.textures, scene.texels};
+#ifdef LR_ENV_TREE
+    if (env.kind == kEnvCombined && env.tree != 0u) {
+        auto s = env_sample_tree(tb, scene.env, u);
+        wi = s.wi, L = s.L, pdf = s.pdf;
+        return;
+    }
+#endif
     if (env.kind != kEnvCombined) {
         auto s = env_sample_one(tb, scene.env, u);
         wi = s.wi, L = s.L, pdf = s.pdf;

@@ -125,6 +125,7 @@ struct lrhip_ctx {
     uint32_t update_counts[7]{};// table sizes of the uploaded scene: what lrhip_update_scene checks its argument against
     uint32_t last_variant{0u};// feature mask of the kernel the last lrhip_render launched
     uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
+    bool env_tree{false};// Combined environments nested in each other: only the call-making variants walk them (dev_shade.h)
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
     uint32_t diag_force_features{0u};// lrhip_set_diagnostics (tests / tools)
     double diag_item_scale{0.};
@@ -455,13 +456,30 @@ static std::string validate_indices(const lr_scene *s) {
     for (uint32_t i = 0; i < s->light_instance_count; i++) {
         if (s->light_instances[i].instance_id >= s->instance_count) { return "light instance " + std::to_string(i) + ": instance id out of range"; }
     }
-    if (s->environment.kind == LR_ENV_COMBINED) {
+    if (s->environment.kind == LR_ENV_COMBINED) {// a tree of Combined nodes over Spherical / Directional leaves (lr_scene.h: children before parents)
+        std::vector<uint32_t> depth(s->environment_child_count, 0u);// Combined nodes from the record down, itself included
+        auto check_node = [&](const lr_environment &c, uint32_t limit, uint32_t &d) -> std::string {
+            d = 0u;
+            if (c.kind != LR_ENV_COMBINED) { return {}; }
+            for (auto k = 0; k < 2; k++) {
+                if (c.child[k] >= limit) { return "child index out of range (children precede their parents in environment_children)"; }
+                if (!(c.child_scale[k] > 0.f)) { return "child scales must be positive (a Combined node with one live child is flattened by the host)"; }
+                d = std::max(d, depth[c.child[k]]);
+            }
+            d += 1u;
+            return {};
+        };
         for (uint32_t i = 0; i < s->environment_child_count; i++) {
             auto &c = s->environment_children[i];
-            if (c.kind != LR_ENV_NONE && c.kind != LR_ENV_COMBINED && (c.emission_tex < 0 || static_cast<uint32_t>(c.emission_tex) >= s->texture_count)) {
+            if (c.kind != LR_ENV_SPHERICAL && c.kind != LR_ENV_DIRECTIONAL && c.kind != LR_ENV_COMBINED) { return "environment child " + std::to_string(i) + ": invalid kind"; }
+            if (c.kind != LR_ENV_COMBINED && (c.emission_tex < 0 || static_cast<uint32_t>(c.emission_tex) >= s->texture_count)) {
                 return "environment child " + std::to_string(i) + ": emission texture out of range";
             }
+            if (auto bad = check_node(c, i, depth[i]); !bad.empty()) { return "environment child " + std::to_string(i) + ": " + bad; }
         }
+        uint32_t root_depth = 0u;
+        if (auto bad = check_node(s->environment, s->environment_child_count, root_depth); !bad.empty()) { return "environment: " + bad; }
+        if (root_depth > static_cast<uint32_t>(LR_ENV_MAX_COMBINED_DEPTH)) { return "environment: Combined nodes nested deeper than LR_ENV_MAX_COMBINED_DEPTH"; }
     }
     return {};
 }
@@ -471,7 +489,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->accel.nodes == nullptr || s->accel.node_count == 0u) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: scene->accel is not built (lrhost_scene_build_accel)");
     }
-    if (s->environment.kind > LR_ENV_COMBINED || (s->environment.kind == LR_ENV_COMBINED && (s->environment_child_count != 2u || s->environment_children == nullptr))) {
+    if (s->environment.kind > LR_ENV_COMBINED || (s->environment.kind == LR_ENV_COMBINED && (s->environment_child_count < 2u || s->environment_children == nullptr))) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: environment kind not supported");
     }
     if (auto bad = validate_indices(s); !bad.empty()) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: " + bad); }
@@ -481,6 +499,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     ctx->bvh_depth = bvh_depth(s->accel);
     if (ctx->bvh_depth == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the BVH must have one-triangle leaves (lrhost_scene_build_accel builds them)"); }
     ctx->features = s->any_non_opaque != 0u ? lrd::kFeatAlpha : 0u;
+    ctx->env_tree = false;
     // a leaf names its triangle in 27 bits (the sentinel of the empty slots is one more) and the fetch addresses packets by 32-bit byte offsets
     if (s->accel.triangle_count >= (1u << 27u) - 1u || s->accel.node_count >= (1u << 26u)) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 2^27 - 2 BVH triangles or 2^26 - 1 BVH packets");
@@ -635,20 +654,30 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
                 return upload(ctx, r.pdf, texels, &de.pdf);
             };
             ctx->features |= lrd::kFeatEnv;
+            // a Combined node points at its two children (uploaded before it: lr_scene.h orders children before parents)
+            std::vector<const lrd::DEnvironment *> uploaded(e.kind == LR_ENV_COMBINED ? s->environment_child_count : 0u, nullptr);
+            auto make_node = [&](const lr_environment &r, lrd::DEnvironment &de) -> int {
+                if (r.kind != LR_ENV_COMBINED) { return make_record(r, de); }
+                de = lrd::DEnvironment{};
+                std::memcpy(de.world_to_env, r.world_to_env, sizeof(de.world_to_env));
+                std::memcpy(de.env_to_world, r.env_to_world, sizeof(de.env_to_world));
+                de.kind = lrd::kEnvCombined;
+                for (auto k = 0; k < 2; k++) {
+                    de.child_scale[k] = r.child_scale[k], de.child[k] = uploaded[r.child[k]];
+                    if (s->environment_children[r.child[k]].kind == LR_ENV_COMBINED) { de.tree = 1u; }
+                }
+                return LRHIP_OK;
+            };
             lrd::DEnvironment root{};
             int rc2 = LRHIP_OK;
-            if (e.kind == LR_ENV_COMBINED) {
-                std::memcpy(root.world_to_env, e.world_to_env, sizeof(root.world_to_env));
-                std::memcpy(root.env_to_world, e.env_to_world, sizeof(root.env_to_world));
-                root.kind = lrd::kEnvCombined;
-                root.child_scale[0] = e.child_scale[0], root.child_scale[1] = e.child_scale[1];
-                for (auto i = 0; i < 2 && rc2 == LRHIP_OK; i++) {
-                    lrd::DEnvironment child{};
-                    if ((rc2 = make_record(s->environment_children[i], child)) == LRHIP_OK) { rc2 = upload(ctx, &child, 1u, &root.child[i]); }
-                }
-            } else {
-                rc2 = make_record(e, root);
+            for (uint32_t i = 0; i < uploaded.size() && rc2 == LRHIP_OK; i++) {
+                lrd::DEnvironment child{};
+                if ((rc2 = make_node(s->environment_children[i], child)) == LRHIP_OK) { rc2 = upload(ctx, &child, 1u, &uploaded[i]); }
             }
+            if (rc2 == LRHIP_OK) { rc2 = make_node(e, root); }
+            // a root over nested Combined nodes is walked by out-of-line code that only the call-making variants hold (dev_shade.h:
+            // env_evaluate_tree); lrhip_render picks one of those
+            ctx->env_tree = root.tree != 0u;
             if (rc2 == LRHIP_OK) { rc2 = upload(ctx, &root, 1u, &d.env); }
             if (rc2 != LRHIP_OK) {
                 release_scene(ctx);
@@ -953,7 +982,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // Wavefront mode (render_wavefront above) for every MegaPath scene that would otherwise land in an all-in-one variant with
     // out-of-line closures: Mix / Layered surfaces, and Disney together with an alpha test (no lean <Alpha | Disney> variant is
     // precompiled; such a scene ran at 433 Msamples/s on <60> where its Mix-holding sibling ran at 480 in wavefront mode).
-    if (ctx->wf_mode == 0u && ctx->diag_force_features == 0u && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+    if (ctx->wf_mode == 0u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
         const auto plain = pick_variant(ctx->features, false, generic_sampler);
         if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) {
@@ -992,6 +1021,9 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
     auto features = ctx->features;
     features |= ctx->diag_force_features & lrd::kFeatSceneMask;// lrhip_set_diagnostics: A/B of a variant on a scene that does not need it
+    // nested Combined environments are walked by out-of-line code (dev_shade.h: LR_ENV_TREE), which the variants that make real calls
+    // anyway hold -- the ones with the Mix interpreter (the auxiliary and volumetric kernels are such variants already)
+    if (ctx->env_tree && (features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) { features |= lrd::kFeatMix; }
     auto vi = pick_variant(features, count, generic);
     if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +

@@ -1245,7 +1245,8 @@ public:
     }
 
     void build_environment(const NodeDesc *d);
-    lr_environment build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf);
+    lr_environment build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf, bool is_root, uint32_t depth);
+    lr_environment build_combined(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf, uint32_t depth);
 
     // tables of src/util/sobolmatrices.cpp, re-derived by tools/gen_sobol_tables.py into data/sobol_tables.bin
     void load_sobol_tables() {
@@ -1395,15 +1396,17 @@ public:
 };
 
 // one Spherical / Directional record (kind LR_ENV_NONE when null or black)
-lr_environment Builder::build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf) {
+// (the record of a Combined node is what CombinedInstance computes over its children: build_combined below)
+lr_environment Builder::build_environment_node(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf, bool is_root, uint32_t depth) {
     lr_environment env{};
     env.emission_tex = -1;
     alias.clear(), pdf.clear();
     if (d == nullptr || d->impl_type() == "null") { return env; }
     _check_tag(d, Tag::ENVIRONMENT);
+    if (d->impl_type() == "combined") { return build_combined(d, alias, pdf, depth); }
     auto m = transform_matrix(d->node_or_null("transform"));
     if (transform_is_animated(d->node_or_null("transform"))) {
-        if (&alias != &_out.env_alias) { throw Error{"Animated transforms on the children of a Combined environment are not supported. [" + d->location() + "]"}; }
+        if (!is_root) { throw Error{"Animated transforms on the children of a Combined environment are not supported. [" + d->location() + "]"}; }
         _out.environment_xform = static_cast<int32_t>(compile_transform(d->node_or_null("transform")));
     }
     // Environment::Instance::transform_to_world: 3x3 of the env transform (environment.cpp:17-19)
@@ -1437,25 +1440,24 @@ lr_environment Builder::build_environment_node(const NodeDesc *d, std::vector<lr
         auto dir = dv ? normalize(float3{static_cast<float>((*dv)[0]), static_cast<float>((*dv)[1]), static_cast<float>((*dv)[2])}) : float3{0.f, 1.f, 0.f};
         env.direction[0] = dir.x, env.direction[1] = dir.y, env.direction[2] = dir.z;
         if (env.scale == 0.f || texture_is_black(env.emission_tex)) { env.kind = LR_ENV_NONE; }
-    } else if (d->impl_type() == "combined") {
-        throw Error{"A Combined environment nested inside a Combined environment is not supported. [" + d->location() + "]"};
     } else {
         throw Error{"Unknown environment implementation '" + d->impl_type() + "'. [" + d->location() + "]"};
     }
     return env;
 }
 
-void Builder::build_environment(const NodeDesc *d) {
-    _out.env_children.clear();
-    if (d == nullptr || d->impl_type() != "combined") {
-        _out.environment = build_environment_node(d, _out.env_alias, _out.env_pdf);
-        return;
+// Combined (combined.cpp:17-124): the record of the node, its children appended to _out.env_children (children before parents, so
+// that the indices of a record's children are smaller than its own).  `depth`: Combined nodes above this one.
+lr_environment Builder::build_combined(const NodeDesc *d, std::vector<lr_alias_entry> &alias, std::vector<float> &pdf, uint32_t depth) {
+    if (depth >= static_cast<uint32_t>(LR_ENV_MAX_COMBINED_DEPTH)) {
+        throw Error{"Combined environments nested more than " + std::to_string(LR_ENV_MAX_COMBINED_DEPTH) + " deep are not supported. [" + d->location() + "]"};
     }
     // combined.cpp:23-36: a null or black child gets scale 0
-    _check_tag(d, Tag::ENVIRONMENT);
     lr_environment child[2];
-    child[0] = build_environment_node(d->node_or_null("a"), _out.env_child_alias[0], _out.env_child_pdf[0]);
-    child[1] = build_environment_node(d->node_or_null("b"), _out.env_child_alias[1], _out.env_child_pdf[1]);
+    std::vector<lr_alias_entry> child_alias[2];
+    std::vector<float> child_pdf[2];
+    child[0] = build_environment_node(d->node_or_null("a"), child_alias[0], child_pdf[0], false, depth + 1u);
+    child[1] = build_environment_node(d->node_or_null("b"), child_alias[1], child_pdf[1], false, depth + 1u);
     float scales[2] = {std::max(d->float_or("scale_a", 1.f), 0.f), std::max(d->float_or("scale_b", 1.f), 0.f)};
     for (auto i = 0; i < 2; i++) {
         if (child[i].kind == LR_ENV_NONE) { scales[i] = 0.f; }
@@ -1466,16 +1468,18 @@ void Builder::build_environment(const NodeDesc *d) {
     for (auto c = 0; c < 3; c++) {
         for (auto r = 0; r < 3; r++) { c2w[c * 3 + r] = m[c][r], w2c[c * 3 + r] = m[r][c]; }
     }
-    auto &env = _out.environment;
-    env = lr_environment{};
+    lr_environment env{};
     env.emission_tex = -1;
-    if (scales[0] == 0.f && scales[1] == 0.f) { return; }// is_black, :36
+    alias.clear(), pdf.clear();
+    if (scales[0] == 0.f && scales[1] == 0.f) { return env; }// is_black, :36
     if (scales[0] == 0.f || scales[1] == 0.f) {
         // only one live child (combined.cpp:72-77,103-109): that child seen through the Combined node's transform with
-        // its radiance scaled — the same function as the child record with composed matrices and scale
+        // its radiance scaled -- the same function as the child record with composed matrices and scale (a live child that
+        // is a Combined node: its children's radiances scale linearly, so its scales take the factor)
         auto live = scales[0] == 0.f ? 1 : 0;
         env = child[live];
-        env.scale *= scales[live];
+        if (env.kind == LR_ENV_COMBINED) { env.child_scale[0] *= scales[live], env.child_scale[1] *= scales[live]; }
+        else { env.scale *= scales[live]; }
         auto mul = [](const float *a, const float *b, float *out) {// out = a * b, column-major 3x3
             for (auto c = 0; c < 3; c++) {
                 for (auto r = 0; r < 3; r++) { out[c * 3 + r] = a[0 * 3 + r] * b[c * 3 + 0] + a[1 * 3 + r] * b[c * 3 + 1] + a[2 * 3 + r] * b[c * 3 + 2]; }
@@ -1485,15 +1489,23 @@ void Builder::build_environment(const NodeDesc *d) {
         mul(child[live].world_to_env, w2c, w);// wi_local = W_child (W_comb wi)
         mul(c2w, child[live].env_to_world, e);// wi_world = E_comb (E_child w)
         std::copy_n(w, 9, env.world_to_env), std::copy_n(e, 9, env.env_to_world);
-        _out.env_alias = std::move(_out.env_child_alias[live]), _out.env_pdf = std::move(_out.env_child_pdf[live]);
-        _out.env_child_alias[0].clear(), _out.env_child_alias[1].clear(), _out.env_child_pdf[0].clear(), _out.env_child_pdf[1].clear();
-        return;
+        alias = std::move(child_alias[live]), pdf = std::move(child_pdf[live]);
+        return env;
     }
     env.kind = LR_ENV_COMBINED;
     std::copy_n(c2w, 9, env.env_to_world), std::copy_n(w2c, 9, env.world_to_env);
-    env.child_scale[0] = scales[0], env.child_scale[1] = scales[1];
-    _out.env_children = {child[0], child[1]};
-    _out.env_alias.clear(), _out.env_pdf.clear();
+    for (auto i = 0; i < 2; i++) {
+        env.child_scale[i] = scales[i];
+        env.child[i] = static_cast<uint32_t>(_out.env_children.size());
+        _out.env_children.push_back(child[i]);
+        _out.env_child_alias.push_back(std::move(child_alias[i])), _out.env_child_pdf.push_back(std::move(child_pdf[i]));
+    }
+    return env;
+}
+
+void Builder::build_environment(const NodeDesc *d) {
+    _out.env_children.clear(), _out.env_child_alias.clear(), _out.env_child_pdf.clear();
+    _out.environment = build_environment_node(d, _out.env_alias, _out.env_pdf, true, 0u);
 }
 
 }// namespace

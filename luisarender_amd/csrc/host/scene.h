@@ -65,10 +65,11 @@ struct SceneData {
     lr_environment environment{};
     std::vector<lr_alias_entry> env_alias;
     std::vector<float> env_pdf;
-    // children of a Combined environment (combined.cpp) with their own importance tables
+    // the records below a Combined environment (combined.cpp: leaves with their own importance tables, nested Combined nodes;
+    // children before parents)
     std::vector<lr_environment> env_children;
-    std::vector<lr_alias_entry> env_child_alias[2];
-    std::vector<float> env_child_pdf[2];
+    std::vector<std::vector<lr_alias_entry>> env_child_alias;// [env_children.size()]
+    std::vector<std::vector<float>> env_child_pdf;
     mutable std::vector<lr_environment> env_children_view;// children with table pointers patched, for view()
     std::vector<CameraRecord> cameras;
     lr_sampler sampler{};

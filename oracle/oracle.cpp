@@ -383,7 +383,7 @@ struct oracle_ctx {
     LightEval env_evaluate(const lr_environment &env, float3 wi) const {
         if (env.kind == LR_ENV_COMBINED) {// CombinedInstance::evaluate, combined.cpp:57-78 (both children live)
             auto wi_local = normalize(mul3(env.world_to_env, wi));
-            auto a = env_evaluate(scene->environment_children[0], wi_local), b = env_evaluate(scene->environment_children[1], wi_local);
+            auto a = env_evaluate(scene->environment_children[env.child[0]], wi_local), b = env_evaluate(scene->environment_children[env.child[1]], wi_local);
             auto sa = env.child_scale[0], sb = env.child_scale[1];
             auto t = sb / (sa + sb);
             return {a.L * sa + b.L * sb, lerp(a.pdf, b.pdf, t)};
@@ -409,7 +409,7 @@ struct oracle_ctx {
     EnvSample env_sample(float2 u) const { return env_sample(scene->environment, u); }
     EnvSample env_sample(const lr_environment &env, float2 u) const {
         if (env.kind == LR_ENV_COMBINED) {// CombinedInstance::sample, combined.cpp:80-111
-            auto &ca = scene->environment_children[0], &cb = scene->environment_children[1];
+            auto &ca = scene->environment_children[env.child[0]], &cb = scene->environment_children[env.child[1]];// (either may be a Combined node)
             auto sa = env.child_scale[0], sb = env.child_scale[1];
             auto weight_a = sa / (sa + sb);
             EnvSample s;

@@ -179,3 +179,44 @@ def test_combined_environment(sky):
     film, _ = o.render(0, 512)
     got = o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0)
     assert np.allclose(got, 0.25 * _plane_radiance(img), rtol=0.03)
+
+
+def test_nested_combined_environments(sky):
+    """combined.cpp composes freely: a Combined node may be the child of a Combined node.  The host lays the tree out children before
+    parents (lr_scene.h), flattens nodes with one live child at any level, and refuses more than LR_ENV_MAX_COMBINED_DEPTH levels."""
+    path, img = sky
+    sun = "Directional { emission : Constant { v { 1, 2, 3 } } scale { 0.5 } angle { 10 } direction { 0, 1, 0 } }"
+    dome = f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} }}'
+    black = "Spherical { emission : Constant { v { 0 } } }"
+    inner = f"Combined {{ a : {sun} b : {sun} scale_a {{ 0.5 }} scale_b {{ 1.5 }} }}"
+    both = f"Combined {{ a : {dome} b : {inner} scale_a {{ 0.5 }} scale_b {{ 1 }} transform : SRT {{ rotate {{ 0, 1, 0, 40 }} }} }}"
+    sc = Scene.from_string(PLANE.format(env=both))
+    view = sc.view()
+    root, kids = view.environment, view.environment_children
+    assert root.kind == 3 and view.environment_child_count == 4
+    kids = C.cast(kids, C.POINTER(type(root)))
+    assert [kids[i].kind for i in range(4)] == [2, 2, 1, 3]            # the inner node's suns, then the root's dome and the inner node
+    assert list(root.child) == [2, 3] and list(kids[3].child) == [0, 1]  # children precede their parents
+    assert list(kids[3].child_scale) == [0.5, 1.5] and kids[2].map_width == W and kids[2].alias and not kids[0].alias
+    o = Oracle(sc)
+    film, _ = o.render(0, 1024)
+    got = o.convert(film)[..., :3].reshape(-1, 3).mean(axis=0)
+    half = np.radians(5.0)
+    sun_part = np.array([0.6, 0.4, 0.2]) / np.pi * (np.array([1.0, 2.0, 3.0]) * 2 * 0.5 / (1 - np.cos(half))) * np.pi * np.sin(half) ** 2
+    assert np.allclose(got, 0.5 * _plane_radiance(img) + 2.0 * sun_part, rtol=0.03)  # the inner node is worth (0.5 + 1.5) suns
+    # an inner node with one live child is that child (scaled); a root whose only live child is a Combined node is that node (scaled)
+    lone_inner = f"Combined {{ a : {black} b : {sun} scale_b {{ 3 }} }}"
+    view = Scene.from_string(PLANE.format(env=f"Combined {{ a : {dome} b : {lone_inner} scale_b {{ 2 }} }}")).view()
+    kids = C.cast(view.environment_children, C.POINTER(type(root)))
+    assert view.environment_child_count == 2 and kids[1].kind == 2 and np.isclose(kids[1].scale, 3 * (2 * 0.5 / (1 - np.cos(half))))
+    view = Scene.from_string(PLANE.format(env=f"Combined {{ a : {black} b : {inner} scale_b {{ 2 }} }}")).view()
+    assert view.environment.kind == 3 and view.environment_child_count == 2 and list(view.environment.child_scale) == [1.0, 3.0]
+    deep = sun
+    for _ in range(5):
+        deep = f"Combined {{ a : {sun} b : {deep} }}"
+    with pytest.raises(Exception, match="nested more than 4 deep"):
+        Scene.from_string(PLANE.format(env=deep))
+    four = sun
+    for _ in range(4):
+        four = f"Combined {{ a : {sun} b : {four} }}"
+    assert Scene.from_string(PLANE.format(env=four)).view().environment_child_count == 8

@@ -181,7 +181,8 @@ render {{ cameras {{ @cam }} shapes {{ @quad, @cube }}
 """
 
 
-@pytest.mark.parametrize("kind", ["image", "image_rotated", "directional", "directional_hidden", "combined", "combined_constant"])
+@pytest.mark.parametrize("kind", ["image", "image_rotated", "directional", "directional_hidden", "combined", "combined_constant", "combined_nested",
+                                  "combined_nested_constant"])
 def test_image_and_directional_environments(renderer, tmp_path, kind):
     """Rows a11 / f1: importance-sampled lat-long environment (alias + pdf tables built by lrhost, shared by both sides) and
     the Directional cone, on the FULL kernel variant.  acos/atan2/sin differ by ulps between libm and the device, which can
@@ -198,9 +199,21 @@ def test_image_and_directional_environments(renderer, tmp_path, kind):
                        'b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } } scale_a { 0.7 } scale_b { 1.5 } '
                        'transform : SRT { rotate { 0, 1, 0, 60 } } }',
            "combined_constant": 'Combined { a : Spherical { emission : Constant { v { 0.4, 0.5, 0.7 } } } '
-                                'b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 12 } direction { -0.3, 1, 0.2 } } }'}[kind]
+                                'b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 12 } direction { -0.3, 1, 0.2 } } }'}
+    if kind.startswith("combined_nested"):
+        # Combined nodes three deep (dev_shade.h: env_evaluate_tree / env_sample_tree, on a call-making variant); the oracle's walk of
+        # the same tree is bit-exact with the reference's own code (test_oracle_vs_ref.py::test_li_environments_bit_exact[combined_nested])
+        from test_oracle_vs_ref import nested_combined_environment
+        text = nested_combined_environment(f'Image {{ file {{ "{path}" }} }}')
+        if kind == "combined_nested_constant":  # a constant sky as the innermost leaf
+            text = text.replace(f'Spherical {{ emission : Image {{ file {{ "{path}" }} }} scale {{ 0.4 }}', "Spherical { emission : Constant { v { 0.2, 0.3, 0.5 } } scale { 0.4 }")
+            assert "Constant { v { 0.2, 0.3, 0.5 } }" in text
+        env[kind] = text
+    env = env[kind]
     sc = Scene.from_string(ENV_SCENE.format(env=env, spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
+    if kind.startswith("combined_nested"):
+        assert renderer.last_variant() & 96 and not renderer.last_variant() & 1024, renderer.last_variant()  # out-of-line environment code, no wavefront mode
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
     assert cpu[..., :3].mean() > 0.01
@@ -712,6 +725,29 @@ render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : Me
     assert _rel_l1(gpu, cpu) < 2e-3 and gpu[..., :3].mean() > 0.01
 
 
+@pytest.mark.parametrize("scale", ["2.5, -3", "170001.25, -290000.5"])
+@pytest.mark.parametrize("filter_mode", ["point", "bilinear"])
+@pytest.mark.parametrize("address", ["repeat", "mirror", "edge", "zero"])
+def test_texture_address_modes(renderer, tmp_path, address, filter_mode, scale):
+    """dev_shade.h: texel_wrap (floor-mod through a float reciprocal, integer path for huge coordinates) against the oracle's
+    integer wrap, uvs outside [0, 1) on both sides; the second scale puts the texel coordinates beyond 2^20 (integer path).  The
+    oracle's wrap is bit-exact with the reference's sampler (test_oracle_vs_ref.py::test_li_texture_address_modes_bit_exact)."""
+    from test_oracle_vs_ref import ADDRESS_SCENE, address_mode_texture
+    address_mode_texture(tmp_path / "tex.pfm")
+    text = ADDRESS_SCENE.format(address=address, filter=filter_mode, spp=8, res="96, 64").replace("uv_scale { 2.5, -3 }", "uv_scale { %s }" % scale)
+    (tmp_path / "scene.luisa").write_text(text)
+    sc = Scene.load(str(tmp_path / "scene.luisa"))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 8)
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    print(f"address {address} {filter_mode} scale {scale}: rel-L1 {_rel_l1(gpu, cpu):.3e}, rays {gc['closest_rays']} / {cc['closest_rays']}")
+    if scale == "2.5, -3":
+        assert gc["closest_rays"] == cc["closest_rays"]
+        assert _rel_l1(gpu, cpu) < 1e-5 and gpu[..., :3].mean() > 0.01
+    else:  # uv rounds to ~1e-2 of a texel up there and the device contracts u * scale + offset: a texel flips now and then
+        assert _rel_l1(gpu, cpu) < 6e-2
+        assert abs(float(gpu[..., :3].mean()) - float(cpu[..., :3].mean())) < 2e-3 * float(cpu[..., :3].mean()) + 1e-6
+
+
 def test_film_reduce_through_the_c_abi_single_rank(renderer):
     """The product's collective end to end through include/lrhip.h: lrhip_comm_unique_id -> lrhip_comm_init_rank (world 1) ->
     lrhip_film_reduce (ncclReduce on the context's stream) -> lrhip_comm_destroy.  With one rank the sum-reduce must leave the
@@ -855,6 +891,33 @@ def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):
     with pytest.raises(DeviceError, match="inside a Layered surface|cyclic"):
         renderer.upload(sc)
     view.surfaces[lay].u[0] = top
+    renderer.upload(sc)  # and valid again
+
+
+def test_c_abi_rejects_malformed_environment_trees(renderer):
+    """lrhip_upload_scene checks the tree of Combined environment records itself (lr_scene.h: children before parents, positive
+    scales, at most LR_ENV_MAX_COMBINED_DEPTH levels): a C-ABI caller's cycle or dangling index is an error, not a device fault."""
+    import ctypes as C
+    from luisarender_amd.render import DeviceError
+    sun = "Directional { emission : Constant { v { 1, 2, 3 } } angle { 10 } direction { 0.2, 1, 0 } }"
+    env = f"Combined {{ a : {sun} b : Combined {{ a : {sun} b : {sun} scale_b {{ 2 }} }} }}"
+    sc = Scene.from_string(ENV_SCENE.format(env=env, spp=1))
+    view = sc.view(0)
+    renderer.upload(sc)  # valid as loaded
+    kids = C.cast(view.environment_children, C.POINTER(type(view.environment)))
+    assert view.environment_child_count == 4 and kids[3].kind == 3
+    kids[3].child[1] = 3  # a node that is its own child
+    with pytest.raises(DeviceError, match="children precede their parents"):
+        renderer.upload(sc)
+    kids[3].child[1] = 1
+    view.environment.child[0] = 4  # past the end of the array
+    with pytest.raises(DeviceError, match="child index out of range"):
+        renderer.upload(sc)
+    view.environment.child[0] = 2
+    kids[3].child_scale[0] = 0.0
+    with pytest.raises(DeviceError, match="scales must be positive"):
+        renderer.upload(sc)
+    kids[3].child_scale[0] = 1.0
     renderer.upload(sc)  # and valid again
 
 

@@ -319,7 +319,7 @@ render {{ cameras {{ @cam }} shapes {{ @quad, @cube }}
 """
 
 
-@pytest.mark.parametrize("kind", ["image_rotated", "directional", "directional_hidden", "combined"])
+@pytest.mark.parametrize("kind", ["image_rotated", "directional", "directional_hidden", "combined", "combined_nested"])
 def test_li_environments_bit_exact(kind, tmp_path):
     """Spherical::build (src/environments/spherical.cpp:144-235: the 2048x1024 scale map, MIS compensation, per-row + marginal
     alias tables, pdf table) is run by the REFERENCE here and by csrc/host/environment.cpp for the oracle: the two only agree
@@ -333,8 +333,22 @@ def test_li_environments_bit_exact(kind, tmp_path):
            "directional_hidden": "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 25 } direction { -0.5, 1, 0.2 } visible { false } normalize { false } scale { 4 } }",
            "combined": f"Combined {{ a : Spherical {{ emission : {img} transform : SRT {{ rotate {{ 1, 0, 0, 20 }} }} }} "
                        "b : Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } } scale_a { 0.7 } scale_b { 1.5 } "
-                       "transform : SRT { rotate { 0, 1, 0, 60 } } }"}[kind]
+                       "transform : SRT { rotate { 0, 1, 0, 60 } } }",
+           "combined_nested": nested_combined_environment(img)}[kind]
     _compare_li(ENV_SCENE.format(env=env), str(tmp_path))
+
+
+def nested_combined_environment(img):
+    """Combined nodes three deep (combined.cpp:23-111 composes freely): (image dome + (sun + (second dome + second sun))), every node
+    with a transform and scales of its own"""
+    sun2 = "Directional { emission : Constant { v { 1, 2, 4 } } angle { 12 } direction { -0.6, 0.5, 0.2 } }"
+    # (no constant Spherical leaf: the reference's evaluate dereferences an empty optional there, DESIGN section 8)
+    sky = f"Spherical {{ emission : {img} scale {{ 0.4 }} compensate_mis {{ false }} transform : SRT {{ rotate {{ 0.3, 1, 0, 200 }} }} }}"
+    inner = f"Combined {{ a : {sky} b : {sun2} scale_a {{ 1.2 }} scale_b {{ 0.8 }} transform : SRT {{ rotate {{ 0, 0, 1, 25 }} }} }}"
+    sun = "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } }"
+    middle = f"Combined {{ a : {sun} b : {inner} scale_a {{ 1.5 }} scale_b {{ 0.6 }} transform : SRT {{ rotate {{ 1, 0, 0, -15 }} }} }}"
+    dome = f"Spherical {{ emission : {img} transform : SRT {{ rotate {{ 1, 0, 0, 20 }} }} }}"
+    return f"Combined {{ a : {dome} b : {middle} scale_a {{ 0.7 }} scale_b {{ 1.1 }} transform : SRT {{ rotate {{ 0, 1, 0, 60 }} }} }}"
 
 
 def test_li_textures_normal_map_shapes_bit_exact(tmp_path):
@@ -359,6 +373,31 @@ Camera cam : Pinhole { fov { 45 } spp { 3 } film : Color { resolution { 24, 16 }
 render { cameras { @cam } shapes { @ball, @blob, @floor, @lamp } integrator : MegaPath { depth { 6 } } }
 """
     _compare_li(src, str(tmp_path))
+
+
+ADDRESS_SCENE = """
+Shape floor : InlineMesh {{ positions {{ -4,0,-4, 4,0,-4, 4,0,4, -4,0,4 }} indices {{ 0,2,1, 0,3,2 }} uvs {{ 0,0, 1,0, 1,1, 0,1 }}
+  surface : Matte {{ Kd : Image {{ file {{ "tex.pfm" }} encoding {{ "linear" }} uv_scale {{ 2.5, -3 }} uv_offset {{ -0.7, 1.9 }}
+                                   address {{ "{address}" }} filter {{ "{filter}" }} }} }} }}
+Shape lamp : InlineMesh {{ positions {{ -1,4,-1, 1,4,-1, 1,4,1, -1,4,1 }} indices {{ 0,1,2, 0,2,3 }} light : Diffuse {{ emission : Constant {{ v {{ 12, 11, 10 }} }} }} }}
+Camera cam : Pinhole {{ fov {{ 50 }} spp {{ {spp} }} film : Color {{ resolution {{ {res} }} }} position {{ 0, 3, 7 }} look_at {{ 0, 0, 0 }} }}
+render {{ cameras {{ @cam }} shapes {{ @floor, @lamp }} integrator : MegaPath {{ depth {{ 3 }} }} }}
+"""
+
+
+def address_mode_texture(path):
+    """a 13 x 7 picture (odd sizes: neither period is a power of two) for the texture address-mode tests"""
+    y, x = np.mgrid[0:7, 0:13]
+    _write_pfm(path, np.stack([0.1 + x / 13.0, 0.9 - y / 8.0, 0.2 + 0.05 * ((x + y) % 3)], axis=-1).astype(np.float32))
+
+
+@pytest.mark.parametrize("filter_mode", ["point", "bilinear"])
+@pytest.mark.parametrize("address", ["repeat", "mirror", "edge", "zero"])
+def test_li_texture_address_modes_bit_exact(tmp_path, address, filter_mode):
+    """TextureSampler address modes (image.cpp:50-63) with uvs well outside [0, 1) on both sides (uv_scale 2.5 / -3, offsets -0.7 / 1.9):
+    the oracle's texel wrap against the reference's Image texture on the shim's sampler"""
+    address_mode_texture(tmp_path / "tex.pfm")
+    _compare_li(ADDRESS_SCENE.format(address=address, filter=filter_mode, spp=2, res="24, 16"), str(tmp_path))
 
 
 def test_li_alpha_test_textured_closures_instancing():

@@ -3,7 +3,7 @@
 SPP=$1; shift
 for v in "$@"; do
   if [ "$v" = base ]; then unset LRHIP_LIB; else export LRHIP_LIB=$PWD/luisarender_amd/lib/variants/liblrhip_$v.so; fi
-  python bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats 2>/dev/null | python -c "
+  python bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats ${SAMPLER:+--sampler $SAMPLER} 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
