@@ -68,49 +68,62 @@ LR_D MixCtx mix_ctx_of(const HeavyCtx &cx) { return MixCtx{cx.tb, cx.uv, cx.ng, 
 // included, and a Layered surface holds two arbitrary interfaces (layered.cpp:195-253).  Device code has no unbounded
 // recursion, so a Mix tree is interpreted by functions templated on the nesting depth still allowed below them
 // (kMixMaxDepth levels under the root: the host loader rejects deeper trees); the leaves go through two out-of-line
-// functions so that each level adds a loop, not another copy of the closure interpreter.  LEAVES: a leaf may be a Layered
-// surface (true for a tree hit by a ray; false for a tree that IS an interface of a Layered surface -- the loader rejects
-// Layered inside Layered, which bounds the call graph: mix<true> -> layered -> mix<false> -> basic / Disney).
+// functions so that each level adds a loop, not another copy of the closure interpreter.  LV: the Layered levels still allowed
+// below (dev_layered.h): a leaf may be a Layered surface while LV > 0, and its interfaces are interpreted with LV - 1 -- the loader
+// bounds the Layered levels on a path (LR_LAYERED_MAX_LEVELS), which bounds the call graph:
+// mix<2> -> layered<1> -> mix<1> / layered<0> -> mix<0> -> basic / Disney.
 #ifndef LR_MIX_DEPTH
 #define LR_MIX_DEPTH 3
 #endif
 constexpr int kMixMaxDepth = LR_MIX_DEPTH;
 
-template<int DEPTH>
-LR_D bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta);
+// (in the free-composition variants the eta walk is out of line: one copy per (DEPTH, LV) instead of one per path through the templates)
+#if LR_NEST
+#define LR_ETA_FN __device__ __noinline__
+#else
+#define LR_ETA_FN LR_D
+#endif
+template<int DEPTH, int LV>
+LR_ETA_FN bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta);
 
 // eta of the closure with record `rec` (tag `tag`): Surface::Closure::eta of a basic closure, MixSurfaceClosure::eta
-// (mix.cpp:148-157), LayeredSurfaceClosure::eta = its bottom's (layered.cpp:252)
-template<int DEPTH>
-LR_D bool node_eta(const MixCtx &cx, uint32_t tag, const Frame &frame, float &eta) {
+// (mix.cpp:148-157), LayeredSurfaceClosure::eta = its bottom's (layered.cpp:252; the Mix levels of a Layered surface's own
+// interfaces count from zero, as in the loader)
+template<int DEPTH, int LV>
+LR_ETA_FN bool node_eta(const MixCtx &cx, uint32_t tag, const Frame &frame, float &eta) {
     auto rec = &cx.tb.closures[tag];// (eta never comes from an image texture: the static record has it)
-    if (rec->kind == LR_SURFACE_LAYERED) { tag = rec->x[1], rec = &cx.tb.closures[tag]; }// (its bottom is never a Layered surface)
+    if (rec->kind == LR_SURFACE_LAYERED) {
+        if constexpr (LV > 0) { return node_eta<kMixMaxDepth, LV - 1>(cx, rec->x[1], frame, eta); }
+        return false;// (the loader bounds the Layered levels: not reached)
+    }
     if constexpr (DEPTH > 0) {
         if (rec->kind == LR_SURFACE_MIX) {
             DClosure child;
             Frame fr;
             load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, tag, frame, child, fr, cx.eta_i);// (its ratio may be textured)
-            return mix_eta<DEPTH - 1>(cx, child, fr, eta);
+            return mix_eta<DEPTH - 1, LV>(cx, child, fr, eta);
         }
     }
     return closure_eta(*rec, eta);
 }
-template<int DEPTH>
-LR_D bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
+template<int DEPTH, int LV>
+LR_ETA_FN bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
     bool has[2];
     float e[2] = {1.f, 1.f};
 #pragma nounroll
-    for (auto k = 0u; k < 2u; k++) { has[k] = node_eta<DEPTH>(cx, node.x[k], frame, e[k]); }
+    for (auto k = 0u; k < 2u; k++) { has[k] = node_eta<DEPTH, LV>(cx, node.x[k], frame, e[k]); }
     eta = !has[0] ? e[1] : (!has[1] ? e[0] : lerp(e[1], e[0], node.s0));
     return has[0] || has[1];
 }
 
 // LayeredSurfaceInstance::populate_closure, layered.cpp:478-500, of the Layered record `c` with frame `own`
+// (LV: the Layered levels allowed inside this stack's interfaces)
+template<int LV>
 LR_D void layer_stack(const MixCtx &cx, const DClosure &c, const Frame &own, LayerStack &layers) {
     load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, c.x[0], own, layers.top, layers.f_top, cx.eta_i);
     float eta_top = 1.f;
 #if LR_NEST
-    if (!node_eta<kMixMaxDepth>(cx, c.x[0], own, eta_top)) { eta_top = 1.f; }
+    if (!node_eta<kMixMaxDepth, LV>(cx, c.x[0], own, eta_top)) { eta_top = 1.f; }
 #else
     closure_eta(layers.top, eta_top);
 #endif
@@ -124,31 +137,31 @@ LR_D void layer_stack(const MixCtx &cx, const DClosure &c, const Frame &own, Lay
 #endif
 }
 
-template<bool LEAVES>
+template<int LV>
 LR_HEAVY BsdfEval mix_leaf_evaluate(const MixCtx *cx, const DClosure *c, const Frame *fr, f3 wo, f3 wi, bool importance) {
-    if constexpr (LEAVES) {
+    if constexpr (LV > 0) {
         if (c->kind == LR_SURFACE_LAYERED) {
             LayerStack layers;
-            layer_stack(*cx, *c, *fr, layers);
-            return layered_evaluate(layers, wo, wi);
+            layer_stack<LV - 1>(*cx, *c, *fr, layers);
+            return layered_evaluate<LV - 1>(layers, wo, wi, importance);
         }
     }
     return closure_evaluate<true>(*c, *fr, cx->ng, wo, wi, importance);
 }
-template<bool LEAVES>
+template<int LV>
 LR_HEAVY BsdfSample mix_leaf_sample(const MixCtx *cx, const DClosure *c, const Frame *fr, f3 wo, float u_lobe, f2 u, bool importance) {
-    if constexpr (LEAVES) {
+    if constexpr (LV > 0) {
         if (c->kind == LR_SURFACE_LAYERED) {
             LayerStack layers;
-            layer_stack(*cx, *c, *fr, layers);
-            return layered_sample(layers, wo, u_lobe, u);
+            layer_stack<LV - 1>(*cx, *c, *fr, layers);
+            return layered_sample<LV - 1>(layers, wo, u_lobe, u, importance);
         }
     }
     return closure_sample<true>(*c, *fr, cx->ng, wo, u_lobe, u, importance);
 }
 
 // MixSurfaceClosure::_evaluate (mix.cpp:169-177) + the public wrapper's side validation (surface.cpp:45-56)
-template<int DEPTH, bool LEAVES>
+template<int DEPTH, int LV>
 LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, f3 wi, bool importance) {
     BsdfEval e[2];
 #pragma nounroll
@@ -158,11 +171,11 @@ LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &node, const Frame &
         load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[k], frame, child, fr, cx.eta_i);
         if constexpr (DEPTH > 0) {
             if (child.kind == LR_SURFACE_MIX) {
-                e[k] = mix_evaluate<DEPTH - 1, LEAVES>(cx, child, fr, wo, wi, importance);
+                e[k] = mix_evaluate<DEPTH - 1, LV>(cx, child, fr, wo, wi, importance);
                 continue;
             }
         }
-        e[k] = mix_leaf_evaluate<LEAVES>(&cx, &child, &fr, wo, wi, importance);
+        e[k] = mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, wi, importance);
     }
     auto eval = mix_blend(e[0], e[1], node.s0);
     if (!valid_sides(cx.ng, frame.n, wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
@@ -171,7 +184,7 @@ LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &node, const Frame &
 
 // MixSurfaceClosure::_sample (mix.cpp:178-196); the "sample b" branch samples A and evaluates B (reference quirk, kept), so
 // sampling always walks down the chain of first children
-template<int DEPTH, bool LEAVES>
+template<int DEPTH, int LV>
 LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, float u_lobe, f2 u_bsdf, bool importance) {
     const auto ratio = node.s0;
     const auto first = u_lobe < ratio;
@@ -183,21 +196,21 @@ LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &
     auto nested = false;
     if constexpr (DEPTH > 0) {
         if (child.kind == LR_SURFACE_MIX) {
-            bs = mix_sample<DEPTH - 1, LEAVES>(cx, child, fr, wo, u_child, u_bsdf, importance);
+            bs = mix_sample<DEPTH - 1, LV>(cx, child, fr, wo, u_child, u_bsdf, importance);
             nested = true;
         }
     }
-    if (!nested) { bs = mix_leaf_sample<LEAVES>(&cx, &child, &fr, wo, u_child, u_bsdf, importance); }
+    if (!nested) { bs = mix_leaf_sample<LV>(&cx, &child, &fr, wo, u_child, u_bsdf, importance); }
     load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[1], frame, child, fr, cx.eta_i);
     BsdfEval eb;
     nested = false;
     if constexpr (DEPTH > 0) {
         if (child.kind == LR_SURFACE_MIX) {
-            eb = mix_evaluate<DEPTH - 1, LEAVES>(cx, child, fr, wo, bs.wi, importance);
+            eb = mix_evaluate<DEPTH - 1, LV>(cx, child, fr, wo, bs.wi, importance);
             nested = true;
         }
     }
-    if (!nested) { eb = mix_leaf_evaluate<LEAVES>(&cx, &child, &fr, wo, bs.wi, importance); }
+    if (!nested) { eb = mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, bs.wi, importance); }
     auto m = first ? mix_blend(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_blend(eb, BsdfEval{bs.f, bs.pdf}, ratio);
     bs.f = m.f, bs.pdf = m.pdf;
     if (!valid_sides(cx.ng, frame.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
@@ -207,13 +220,22 @@ LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &
 #if LR_NEST
 // a Mix tree as an interface of a Layered surface (dev_layered.h: layer_eval / layer_sample); its children are populated with
 // the interface's eta_i (mix.cpp:210-211)
+template<int LV>
 __device__ __noinline__ BsdfEval layer_mix_evaluate(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance) {
     const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
-    return mix_evaluate<kMixMaxDepth, false>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, wi, importance);
+    return mix_evaluate<kMixMaxDepth, LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, wi, importance);
 }
+template<int LV>
 __device__ __noinline__ BsdfSample layer_mix_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance) {
     const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
-    return mix_sample<kMixMaxDepth, false>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, uc, u, importance);
+    return mix_sample<kMixMaxDepth, LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, uc, u, importance);
+}
+// a Layered surface as an interface of a Layered surface: LayeredSurfaceInstance::populate_closure (layered.cpp:478-500) of the
+// interface's record, with the eta_i the interface was populated with.  (Only the outermost level calls this: the inner stack's own
+// interfaces hold no Layered surface any more.)
+__device__ __noinline__ void layer_inner_stack(const LayerStack &L, bool is_top, LayerStack &inner) {
+    const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
+    layer_stack<0>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, inner);
 }
 #endif
 
@@ -223,7 +245,7 @@ LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     auto &cx = *cxp;
     auto &c = cx.closure;
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:169-177
-        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth, LAYERED && LR_NEST>(mix_ctx_of(cx), c, cx.shading, cx.wo, wi, false); }// a tree: the general interpreter
+        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mix_ctx_of(cx), c, cx.shading, cx.wo, wi, false); }// a tree: the general interpreter
         // the common case, two basic / Disney children, keeps the closure interpreter inline (the out-of-line leaves of the
         // general path cost C5 3 %)
         BsdfEval e[2];
@@ -240,8 +262,8 @@ LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     }
     if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
         LayerStack layers;
-        layer_stack(mix_ctx_of(cx), c, cx.shading, layers);
-        return layered_evaluate(layers, cx.wo, wi);
+        layer_stack<kLayerLevels - 1>(mix_ctx_of(cx), c, cx.shading, layers);
+        return layered_evaluate<kLayerLevels - 1>(layers, cx.wo, wi, false);
     }
     return closure_evaluate<true>(c, cx.shading, cx.ng, cx.wo, wi);// Disney
 }
@@ -254,8 +276,8 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
     r.eta = 1.f, r.has_eta = 0u;
     if (MIX && c.kind == LR_SURFACE_MIX && c.x[2] != 0u) {// a Mix tree
         const auto mx = mix_ctx_of(cx);
-        r.bs = mix_sample<kMixMaxDepth, LAYERED && LR_NEST>(mx, c, cx.shading, cx.wo, u_lobe, u_bsdf, false);
-        r.has_eta = mix_eta<kMixMaxDepth>(mx, c, cx.shading, r.eta) ? 1u : 0u;
+        r.bs = mix_sample<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, cx.wo, u_lobe, u_bsdf, false);
+        r.has_eta = mix_eta<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, r.eta) ? 1u : 0u;
         return r;
     }
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
@@ -280,10 +302,10 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
     if (LAYERED && c.kind == LR_SURFACE_LAYERED) {
         const auto mx = mix_ctx_of(cx);
         LayerStack layers;
-        layer_stack(mx, c, cx.shading, layers);
-        r.bs = layered_sample(layers, cx.wo, u_lobe, u_bsdf);
+        layer_stack<kLayerLevels - 1>(mx, c, cx.shading, layers);
+        r.bs = layered_sample<kLayerLevels - 1>(layers, cx.wo, u_lobe, u_bsdf, false);
 #if LR_NEST
-        r.has_eta = node_eta<kMixMaxDepth>(mx, c.x[1], cx.shading, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
+        r.has_eta = node_eta<kMixMaxDepth, kLayerLevels - 1>(mx, c.x[1], cx.shading, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
 #else
         r.has_eta = closure_eta(layers.bottom, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
 #endif

@@ -33,6 +33,15 @@ LR_HD uint32_t xxhash32_3(uint32_t x, uint32_t y, uint32_t z) {// rng.cpp:38-51
 #endif
 #endif
 
+// Layered surfaces on a path through the interfaces (lr_scene.h: LR_LAYERED_MAX_LEVELS; a Layered surface as an interface of a Layered
+// surface needs the free-composition variants).  The functions below are templated on LV, the Layered levels still allowed INSIDE the
+// interfaces of the stack they work on: device code has no recursion, so each level is its own instantiation.
+#ifndef LR_LAYER_LEVELS
+#define LR_LAYER_LEVELS (LR_NEST ? LR_LAYERED_MAX_LEVELS : 1)
+#endif
+constexpr int kLayerLevels = LR_LAYER_LEVELS;
+static_assert(LR_LAYER_LEVELS >= 1 && LR_LAYER_LEVELS <= 2, "dev_heavy.h: layer_inner_stack builds innermost stacks only");
+
 struct LobeTables {// the scene tables closure loading reads (dev_heavy.h: load_lobe)
     const DClosure *closures;
     const lr_surface *surfaces;
@@ -56,10 +65,18 @@ struct LayerStack {
     float eta_i, eta_bottom;// eta_i the top / the bottom (and their children) were populated with, layered.cpp:497-499
 #endif
 };
+template<int LV>
+LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi, bool importance);
+template<int LV>
+LR_HEAVY BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 u, bool importance);
 #if LR_NEST
-// Mix interfaces (dev_heavy.h: the Mix interpreter with basic / Disney leaves; a Layered surface never sits inside a Layered one)
+// Mix interfaces (dev_heavy.h: the Mix interpreter; its leaves may be Layered surfaces again while LV > 0) and Layered interfaces
+// (layer_inner_stack: populate_closure of the interface's own record, layered.cpp:478-500)
+template<int LV>
 __device__ BsdfEval layer_mix_evaluate(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance);
+template<int LV>
 __device__ BsdfSample layer_mix_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance);
+__device__ void layer_inner_stack(const LayerStack &L, bool is_top, LayerStack &inner);
 #endif
 
 struct LayerRng {
@@ -95,16 +112,34 @@ LR_D bool is_black(f3 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
 
 // TopOrBottom (layered.cpp:54-102): `is_top` picks the interface
 // (not inlined: the random walk has ~20 call sites and each inlined copy would carry the whole closure interpreter)
+template<int LV>
 __device__ __noinline__ BsdfEval layer_eval(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance) {
 #if LR_NEST
-    if ((is_top ? L.top.kind : L.bottom.kind) == LR_SURFACE_MIX) { return layer_mix_evaluate(L, is_top, wo, wi, importance); }
+    const auto kind = is_top ? L.top.kind : L.bottom.kind;
+    if (kind == LR_SURFACE_MIX) { return layer_mix_evaluate<LV>(L, is_top, wo, wi, importance); }
+    if constexpr (LV > 0) {
+        if (kind == LR_SURFACE_LAYERED) {// a Layered interface: the walk of the inner stack, in the outer walk's transport mode
+            LayerStack inner;
+            layer_inner_stack(L, is_top, inner);
+            return layered_evaluate<LV - 1>(inner, wo, wi, importance);
+        }
+    }
 #endif
     return is_top ? closure_evaluate<true>(L.top, L.f_top, L.ng, wo, wi, importance) :
                     closure_evaluate<true>(L.bottom, L.f_bottom, L.ng, wo, wi, importance);
 }
+template<int LV>
 __device__ __noinline__ BsdfSample layer_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance) {
 #if LR_NEST
-    if ((is_top ? L.top.kind : L.bottom.kind) == LR_SURFACE_MIX) { return layer_mix_sample(L, is_top, wo, uc, u, importance); }
+    const auto kind = is_top ? L.top.kind : L.bottom.kind;
+    if (kind == LR_SURFACE_MIX) { return layer_mix_sample<LV>(L, is_top, wo, uc, u, importance); }
+    if constexpr (LV > 0) {
+        if (kind == LR_SURFACE_LAYERED) {
+            LayerStack inner;
+            layer_inner_stack(L, is_top, inner);
+            return layered_sample<LV - 1>(inner, wo, uc, u, importance);
+        }
+    }
 #endif
     return is_top ? closure_sample<true>(L.top, L.f_top, L.ng, wo, uc, u, importance) :
                     closure_sample<true>(L.bottom, L.f_bottom, L.ng, wo, uc, u, importance);
@@ -112,9 +147,11 @@ __device__ __noinline__ BsdfSample layer_sample(const LayerStack &L, bool is_top
 LR_D f3 layer_to_local(const LayerStack &L, bool is_top, f3 w) { return to_local(is_top ? L.f_top : L.f_bottom, w); }
 LR_D f3 layer_to_world(const LayerStack &L, bool is_top, f3 w) { return to_world(is_top ? L.f_top : L.f_bottom, w); }
 
-// LayeredSurfaceClosure::_evaluate, :256-398 (+ the public wrapper's side validation, surface.cpp:45-56)
-LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
-    constexpr auto mode = false, reverse_mode = true;// RADIANCE / IMPORTANCE
+// LayeredSurfaceClosure::_evaluate, :256-398 (+ the public wrapper's side validation, surface.cpp:45-56).  importance: the transport
+// mode of this evaluation -- RADIANCE for a surface hit by a path, either for a Layered interface of an outer walk
+template<int LV>
+LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi, bool importance) {
+    const auto mode = importance, reverse_mode = !importance;// :286
     auto samples = static_cast<float>(L.samples);
     auto wi_local = to_local(L.own, wi), wo_local = to_local(L.own, wo);
     auto entered_top = wo_local.z > 0.f;
@@ -123,7 +160,7 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
     auto exit_top = !(sh != entered_top); // TopOrBottom(bottom, top, sh ^ entered_top): flag -> bottom
     auto nonexit_top = sh != entered_top;
     auto exit_z = (sh != entered_top) ? 0.f : L.thickness;
-    auto first = layer_eval(L, enter_top, wo, wi, mode);
+    auto first = layer_eval<LV>(L, enter_top, wo, wi, mode);
     auto f = sh ? samples * first.f : mk3(0.f);
     auto pdf_sum = sh ? samples * first.pdf : 0.f;
     LayerRng rng{xxhash32_4(__float_as_uint(L.p.x), __float_as_uint(L.p.y), __float_as_uint(L.p.z),
@@ -133,10 +170,10 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
         float uc;
         f2 u;
         draw3(uc, u);
-        auto wos = layer_sample(L, enter_top, wo, uc, u, mode);
+        auto wos = layer_sample<LV>(L, enter_top, wo, uc, u, mode);
         if (is_black(wos.f) || wos.pdf <= 0.f) { continue; }
         draw3(uc, u);
-        auto wis = layer_sample(L, exit_top, wi, uc, u, reverse_mode);
+        auto wis = layer_sample<LV>(L, exit_top, wi, uc, u, reverse_mode);
         auto wis_wi_local = layer_to_local(L, exit_top, wis.wi);
         if (is_black(wis.f) || wis.pdf <= 0.f) { continue; }
         auto beta = wos.f * (1.f / wos.pdf);
@@ -157,7 +194,7 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
                 auto zp = w_local.z > 0.f ? z + dz : z - dz;
                 if (z == zp) { continue; }
                 if (zp > 0.f && zp < L.thickness) {
-                    auto wt = power_heuristic(wis.pdf, layer_eval(L, nonexit_top, -w, -wis.wi, mode).pdf);
+                    auto wt = power_heuristic(wis.pdf, layer_eval<LV>(L, nonexit_top, -w, -wis.wi, mode).pdf);
                     f += beta * L.albedo * (hg_phase(dot(-w_local, -wis_wi_local), L.g) * wt * layer_tr(zp - exit_z, wis_wi_local)) * wis.f * (1.f / wis.pdf);
                     f2 up;
                     up.x = rng.next(), up.y = rng.next();
@@ -169,7 +206,7 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
                     w = layer_to_world(L, exit_top, w_local);
                     z = zp;
                     if ((z < exit_z && w_local.z > 0.f) || (z > exit_z && w_local.z < 0.f)) {
-                        auto e = layer_eval(L, exit_top, -w, wi, mode);
+                        auto e = layer_eval<LV>(L, exit_top, -w, wi, mode);
                         if (!is_black(e.f)) { f += beta * e.f * (layer_tr(zp - exit_z, w_local) * power_heuristic(ps_pdf, e.pdf)); }
                     }
                     continue;
@@ -178,22 +215,22 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
             }
             if (z == exit_z) {
                 draw3(uc, u);
-                auto bs = layer_sample(L, exit_top, -w, uc, u, mode);
+                auto bs = layer_sample<LV>(L, exit_top, -w, uc, u, mode);
                 if (is_black(bs.f) || bs.pdf <= 0.f) { break; }
                 beta = beta * bs.f * (1.f / bs.pdf);
                 w = bs.wi;
                 w_local = layer_to_local(L, exit_top, w);
             } else {
-                auto wns = layer_eval(L, nonexit_top, -w, -wis.wi, mode);
+                auto wns = layer_eval<LV>(L, nonexit_top, -w, -wis.wi, mode);
                 auto wt = power_heuristic(wis.pdf, wns.pdf);
                 f += beta * wns.f * (wt * layer_tr(L.thickness, wis_wi_local)) * wis.f * (1.f / wis.pdf);
                 draw3(uc, u);
-                auto bs = layer_sample(L, nonexit_top, -w, uc, u, mode);
+                auto bs = layer_sample<LV>(L, nonexit_top, -w, uc, u, mode);
                 if (is_black(bs.f) || bs.pdf <= 0.f) { break; }
                 beta = beta * bs.f * (1.f / bs.pdf);
                 w = bs.wi;
                 w_local = layer_to_local(L, nonexit_top, w);
-                auto wes = layer_eval(L, exit_top, -w, wi, mode);
+                auto wes = layer_eval<LV>(L, exit_top, -w, wi, mode);
                 if (!is_black(wes.f)) { f += beta * wes.f * (layer_tr(L.thickness, w_local) * power_heuristic(bs.pdf, wes.pdf)); }
             }
         }
@@ -204,27 +241,27 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
         if (sh) {
             auto r_top = !entered_top, t_top = entered_top;
             draw3(uc, u);
-            auto wos = layer_sample(L, t_top, wo, uc, u, mode);
+            auto wos = layer_sample<LV>(L, t_top, wo, uc, u, mode);
             draw3(uc, u);
-            auto wis = layer_sample(L, t_top, wi, uc, u, reverse_mode);
+            auto wis = layer_sample<LV>(L, t_top, wi, uc, u, reverse_mode);
             if (!is_black(wos.f) && wos.pdf > 0.f && !is_black(wis.f) && wis.pdf > 0.f) {
                 draw3(uc, u);
-                auto rs = layer_sample(L, r_top, -wos.wi, uc, u, mode);
+                auto rs = layer_sample<LV>(L, r_top, -wos.wi, uc, u, mode);
                 if (!is_black(rs.f) && rs.pdf > 0.f) {
-                    auto r_pdf = layer_eval(L, r_top, -wos.wi, -wis.wi, mode).pdf;
+                    auto r_pdf = layer_eval<LV>(L, r_top, -wos.wi, -wis.wi, mode).pdf;
                     pdf_sum += power_heuristic(wis.pdf, r_pdf) * r_pdf;
-                    auto t_pdf = layer_eval(L, t_top, -rs.wi, wi, mode).pdf;
+                    auto t_pdf = layer_eval<LV>(L, t_top, -rs.wi, wi, mode).pdf;
                     pdf_sum += power_heuristic(rs.pdf, t_pdf) * t_pdf;
                 }
             }
         } else {
             auto ti_top = !entered_top, to_top = entered_top;
             draw3(uc, u);
-            auto wos = layer_sample(L, to_top, wo, uc, u, mode);
+            auto wos = layer_sample<LV>(L, to_top, wo, uc, u, mode);
             draw3(uc, u);
-            auto wis = layer_sample(L, ti_top, wi, uc, u, reverse_mode);
+            auto wis = layer_sample<LV>(L, ti_top, wi, uc, u, reverse_mode);
             if (is_black(wos.f) || wos.pdf <= 0.f || is_black(wis.f) || wis.pdf <= 0.f) { continue; }
-            pdf_sum += .5f * (layer_eval(L, to_top, wo, -wis.wi, mode).pdf + layer_eval(L, ti_top, -wos.wi, wi, mode).pdf);
+            pdf_sum += .5f * (layer_eval<LV>(L, to_top, wo, -wis.wi, mode).pdf + layer_eval<LV>(L, ti_top, -wos.wi, wi, mode).pdf);
         }
     }
     BsdfEval out{f * (1.f / samples), lerp(1.f / (4.f * kPi), pdf_sum / samples, 0.9f)};
@@ -233,11 +270,12 @@ LR_HEAVY BsdfEval layered_evaluate(const LayerStack &L, f3 wo, f3 wi) {
 }
 
 // LayeredSurfaceClosure::_sample, :399-470
-LR_HEAVY BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 u) {
-    constexpr auto mode = false;
+template<int LV>
+LR_HEAVY BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 u, bool importance) {
+    const auto mode = importance;
     auto wo_local = to_local(L.own, wo);
     auto entered_top = wo_local.z > 0.f;
-    auto bs = layer_sample(L, entered_top, wo, u_lobe, u, mode);
+    auto bs = layer_sample<LV>(L, entered_top, wo, u_lobe, u, mode);
     BsdfSample s{mk3(0.f), 0.f, mk3(0.f, 0.f, 1.f), kEventReflect};
     if (!is_black(bs.f) && bs.pdf != 0.f) {
         auto wi_local = to_local(L.own, bs.wi);
@@ -285,7 +323,7 @@ LR_HEAVY BsdfSample layered_sample(const LayerStack &L, f3 wo, float u_lobe, f2 
                 auto uc = rng.next();
                 f2 ub;
                 ub.x = rng.next(), ub.y = rng.next();
-                auto is = layer_sample(L, interface_top, -w, uc, ub, mode);
+                auto is = layer_sample<LV>(L, interface_top, -w, uc, ub, mode);
                 if (is_black(is.f) || is.pdf <= 0.f) { break; }
                 f = f * is.f;
                 pdf *= is.pdf;

@@ -552,32 +552,37 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         if (surf.kind == LR_SURFACE_MIX) { ctx->features |= lrd::kFeatMix; }
         if (surf.kind == LR_SURFACE_LAYERED) { ctx->features |= lrd::kFeatLayered | lrd::kFeatDisney; }
         if (surf.kind == LR_SURFACE_MIX || surf.kind == LR_SURFACE_LAYERED) {// composition of the two (validate_indices checked the child indices)
-            // The interpreters of dev_heavy.h assume what the C++ loader enforces (scene.cpp: depth_of, surface_contains_layered); a
-            // C-ABI caller gets the same answer here instead of silently wrong shading: no Layered ANYWHERE under an interface of a
-            // Layered surface, Mix trees at most kMixMaxDepth levels deep with u[2] = that depth, no cycles.
+            // The interpreters of dev_heavy.h assume what the C++ loader enforces (scene.cpp: depth_of, surface_layered_levels); a
+            // C-ABI caller gets the same answer here instead of silently wrong shading: at most LR_LAYERED_MAX_LEVELS Layered surfaces on
+            // a path through the interfaces, Mix trees at most kMixMaxDepth levels deep with u[2] = that depth, no cycles.
             std::string bad;
-            std::function<int(uint32_t, uint32_t, bool)> depth_of = [&](uint32_t tag, uint32_t budget, bool under_layered) -> int {
+            std::function<int(uint32_t, uint32_t, uint32_t)> depth_of = [&](uint32_t tag, uint32_t budget, uint32_t layered_above) -> int {
                 auto &c = s->surfaces[tag];
                 if (budget == 0u) { bad = "a Mix / Layered tree that is cyclic or deeper than the interpreter reaches"; return 0; }
                 if (c.kind == LR_SURFACE_LAYERED) {
-                    if (under_layered) { bad = "a Layered surface inside a Layered surface is not supported"; return 0; }
-                    depth_of(c.u[0], budget - 1u, true), depth_of(c.u[1], budget - 1u, true);
+                    if (layered_above >= static_cast<uint32_t>(LR_LAYERED_MAX_LEVELS)) {
+                        bad = "Layered surfaces nested more than " + std::to_string(LR_LAYERED_MAX_LEVELS) + " levels deep are not supported";
+                        return 0;
+                    }
+                    depth_of(c.u[0], budget - 1u, layered_above + 1u), depth_of(c.u[1], budget - 1u, layered_above + 1u);
                     return 1;// a leaf of the tree that holds it (its own interfaces count from zero)
                 }
                 if (c.kind != LR_SURFACE_MIX) { return 0; }
-                auto depth = std::max(depth_of(c.u[0], budget - 1u, under_layered), depth_of(c.u[1], budget - 1u, under_layered));
+                auto depth = std::max(depth_of(c.u[0], budget - 1u, layered_above), depth_of(c.u[1], budget - 1u, layered_above));
                 if (bad.empty() && static_cast<int>(c.u[2]) != depth) { bad = "a Mix surface whose u[2] is not the depth of its tree"; }
                 if (bad.empty() && depth > lrd::kMixMaxDepth) { bad = "Mix surfaces nested more than " + std::to_string(lrd::kMixMaxDepth) + " levels deep are not supported"; }
                 return 1 + depth;
             };
-            depth_of(i, 2u * static_cast<uint32_t>(lrd::kMixMaxDepth) + 6u, false);
+            depth_of(i, (static_cast<uint32_t>(lrd::kMixMaxDepth) + 2u) * (static_cast<uint32_t>(LR_LAYERED_MAX_LEVELS) + 1u) + 2u, 0u);
             if (!bad.empty()) {
                 release_scene(ctx);
                 return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: surface " + std::to_string(i) + ": " + bad);
             }
             for (auto k = 0u; k < 2u; k++) {
                 auto child = s->surfaces[surf.u[k]].kind;
-                if ((surf.kind == LR_SURFACE_MIX && child == LR_SURFACE_LAYERED) || (surf.kind == LR_SURFACE_LAYERED && child == LR_SURFACE_MIX)) { ctx->features |= lrd::kFeatNest; }
+                if ((surf.kind == LR_SURFACE_MIX && child == LR_SURFACE_LAYERED) || (surf.kind == LR_SURFACE_LAYERED && (child == LR_SURFACE_MIX || child == LR_SURFACE_LAYERED))) {
+                    ctx->features |= lrd::kFeatNest;
+                }
             }
         }
         auto dynamic = surf.normal_tex >= 0;

@@ -655,9 +655,9 @@ public:
             auto top = d->node("top"), bottom = d->node("bottom");
             if (surface_is_null(top) || surface_is_null(bottom)) { throw Error{"Creating closure for null LayeredSurface. [" + d->location() + "]"}; }
             children = {register_surface(top), register_surface(bottom)};
-            for (auto c : children) {// interfaces: basic closures, Disney, or Mix trees of those (dev_heavy.h: layer_mix_evaluate)
-                if (surface_contains_layered(c)) {
-                    throw Error{"A Layered surface inside a Layered surface is not supported by the megakernel. [" + d->location() + "]"};
+            for (auto c : children) {// interfaces: basic closures, Disney, Mix trees, and -- one level -- Layered surfaces again (dev_layered.h)
+                if (surface_layered_levels(c) >= static_cast<uint32_t>(LR_LAYERED_MAX_LEVELS)) {
+                    throw Error{"Layered surfaces nested more than " + std::to_string(LR_LAYERED_MAX_LEVELS) + " levels deep are not supported by the megakernel. [" + d->location() + "]"};
                 }
             }
             s.u[0] = children[0], s.u[1] = children[1];
@@ -682,10 +682,10 @@ public:
         return tag;
     }
 
-    bool surface_contains_layered(uint32_t tag) const {
+    uint32_t surface_layered_levels(uint32_t tag) const {// Layered surfaces on the deepest path below (and including) this one
         auto &s = _out.surfaces[tag];
-        if (s.kind == LR_SURFACE_LAYERED) { return true; }
-        return s.kind == LR_SURFACE_MIX && (surface_contains_layered(s.u[0]) || surface_contains_layered(s.u[1]));
+        if (s.kind != LR_SURFACE_LAYERED && s.kind != LR_SURFACE_MIX) { return 0u; }
+        return (s.kind == LR_SURFACE_LAYERED ? 1u : 0u) + std::max(surface_layered_levels(s.u[0]), surface_layered_levels(s.u[1]));
     }
 
     bool surface_maybe_non_opaque(uint32_t tag) const {// OpacitySurfaceWrapper::maybe_non_opaque

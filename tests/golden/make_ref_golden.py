@@ -5,7 +5,7 @@ compiled in place against the scalar LuisaCompute stand-in, oracle/Makefile.ref)
 
 These are the reference-produced golden vectors of SURVEY §8(c): tests/test_ref_golden.py holds the oracle to them on the CPU
 (bit for bit) and the HIP path to them on the GPU box.  Needs /root/reference (make ref); the fixtures travel, libref need not.
-    python tests/golden/make_ref_golden.py
+    python tests/golden/make_ref_golden.py [name ...]      (no names: every fixture)
 """
 import os
 import sys
@@ -25,6 +25,8 @@ from ref_scenes import scenes  # noqa: E402
 def main():
     with tempfile.TemporaryDirectory() as d:
         for name, (text, spp) in scenes(d).items():
+            if len(sys.argv) > 1 and name not in sys.argv[1:]:
+                continue
             rs = R.RefScene(text, d)
             image = rs.render()
             rs.close()

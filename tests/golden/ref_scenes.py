@@ -89,6 +89,17 @@ def scenes(directory):
     # Mix and Layered nested in each other (kernel variant 636): a Mix with a Layered leaf, a Layered surface with Mix interfaces
     nest = "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in ("mix_layered", "layered_mix"))
     out["nested"] = (cornell_box(resolution=32, spp=256, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=nest), 256)
+    # round 3: a Layered surface as the bottom interface of a Layered surface (dev_layered.h: two Layered levels), and Combined
+    # environments three deep (dev_shade.h: env_evaluate_tree)
+    ll = MATERIALS["layered_layered"].replace("Surface m ", "Surface layered_layered ") + "\n"
+    out["layered_layered"] = (cornell_box(resolution=32, spp=256, short_box_surface="layered_layered", tall_box_surface="layered_layered", extra_surfaces=ll), 256)
+    sun2 = "Directional { emission : Constant { v { 1, 2, 4 } } angle { 12 } direction { -0.6, 0.5, 0.2 } }"
+    dome2 = f"Spherical {{ emission : {img} scale {{ 0.4 }} compensate_mis {{ false }} transform : SRT {{ rotate {{ 0.3, 1, 0, 200 }} }} }}"
+    inner = f"Combined {{ a : {dome2} b : {sun2} scale_a {{ 1.2 }} scale_b {{ 0.8 }} transform : SRT {{ rotate {{ 0, 0, 1, 25 }} }} }}"
+    sun = "Directional { emission : Constant { v { 3, 2.5, 2 } } angle { 8 } direction { 0.4, 1, 0.3 } }"
+    middle = f"Combined {{ a : {sun} b : {inner} scale_a {{ 1.5 }} scale_b {{ 0.6 }} transform : SRT {{ rotate {{ 1, 0, 0, -15 }} }} }}"
+    out["env_combined_nested"] = (ENV.format(spp=8, env=f"Combined {{ a : Spherical {{ emission : {img} transform : SRT {{ rotate {{ 1, 0, 0, 20 }} }} }} b : {middle} "
+                                                        "scale_a { 0.7 } scale_b { 1.1 } transform : SRT { rotate { 0, 1, 0, 60 } } }"), 8)
     # the same without an area light to run into: lit through the open front by a Directional + image environment.  No emitter
     # is ever evaluated from a ray origin lying IN its surface (mega_vpt_naive.cpp:331 after homogeneous.cpp:64), which is what
     # makes the lamp-lit case above chaotic in the last bit

@@ -51,15 +51,18 @@ MATERIALS = {
                    "Surface lx_c : Metal { eta { \"Cu\" } roughness : Constant { v { 0.3 } } } "
                    "Surface lx_bot : Mix { a { @lx_m } b { @lx_c } ratio : Constant { v { 0.7 } } } "
                    "Surface m : Layered { top { @lx_top } bottom { @lx_bot } thickness : Constant { v { 0.1 } } }",
-    "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
-}
-
-# rejected by the loader with a clear error (the megakernel bounds its call graph: no Layered inside Layered)
-LAYERED_IN_LAYERED = ("Surface ll_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } } "
+    # a Layered surface as the bottom interface of a Layered surface (a clear coat over a tinted coat over paint), round 3
+    "layered_layered": "Surface ll_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } } "
                        "Surface ll_t2 : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1, 0.8, 0.6 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.3 } } } "
                        "Surface ll_b : Matte { Kd : Constant { v { 0.6, 0.6, 0.6 } } } "
                        "Surface ll_in : Layered { top { @ll_t2 } bottom { @ll_b } thickness : Constant { v { 0.05 } } } "
-                       "Surface m : Layered { top { @ll_t } bottom { @ll_in } thickness : Constant { v { 0.02 } } g : Constant { v { 0.2 } } albedo : Constant { v { 0.5, 0.6, 0.7 } } }")
+                       "Surface m : Layered { top { @ll_t } bottom { @ll_in } thickness : Constant { v { 0.02 } } g : Constant { v { 0.2 } } albedo : Constant { v { 0.5, 0.6, 0.7 } } }",
+    "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
+}
+
+# rejected by the loader with a clear error (the kernels bound their call graph: at most two Layered levels, lr_scene.h LR_LAYERED_MAX_LEVELS)
+LAYERED_THREE_DEEP = (MATERIALS["layered_layered"].replace("Surface m ", "Surface ll_mid ") +
+                      " Surface m : Layered { top { @ll_t } bottom { @ll_mid } thickness : Constant { v { 0.01 } } }")
 
 _PATCH = """
 {surface}

@@ -111,7 +111,7 @@ Surface mx : Mix { a { @ma } b { @mb } ratio { @chk1 } }
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
-@pytest.mark.parametrize("material", ["layered", "layered_medium", "mix_layered", "layered_mix"])
+@pytest.mark.parametrize("material", ["layered", "layered_medium", "mix_layered", "layered_mix", "layered_layered"])
 def test_layered_closure(renderer, material):
     """Row a14, Layered (layered.cpp:195-470): its random walk is seeded from the BITS of the hit position and direction
     (:271,416), which fp contraction changes between the device and the oracle, so parity is statistical (8x8 block means),
@@ -129,7 +129,7 @@ def test_layered_closure(renderer, material):
     assert err < 3e-2 and bias < 8e-3
     assert abs(gc["closest_rays"] - cc["closest_rays"]) < 5e-3 * cc["closest_rays"]
     # and it is not the bare substrate: rendering the bottom closure alone is far outside that tolerance
-    bare = {"layered": "lay_b", "layered_medium": "lm_b", "mix_layered": "ml_p", "layered_mix": "lx_m"}[material]
+    bare = {"layered": "lay_b", "layered_medium": "lm_b", "mix_layered": "ml_p", "layered_mix": "lx_m", "layered_layered": "ll_b"}[material]
     sc2 = Scene.from_string(cornell_box(resolution=64, spp=spp, short_box_surface=bare, tall_box_surface=bare, extra_surfaces=extra))
     renderer.upload(sc2)
     renderer.render(0, spp, sync=True)
@@ -865,8 +865,8 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
 
 
 def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):
-    """lrhip_upload_scene walks every Mix / Layered tree itself: what the C++ loader refuses -- a Layered surface
-    anywhere under an interface of a Layered surface, a Mix tree whose recorded depth (u[2]) is not its depth, a cycle -- is an
+    """lrhip_upload_scene walks every Mix / Layered tree itself: what the C++ loader refuses -- more than two
+    Layered levels on a path through the interfaces, a Mix tree whose recorded depth (u[2]) is not its depth, a cycle -- is an
     error for a C-ABI caller too, not silently wrong shading.  The host tables of a valid scene are tampered with in place."""
     from helpers import MATERIALS
     from luisarender_amd.render import DeviceError
@@ -888,7 +888,7 @@ def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):
     top = view.surfaces[lay].u[0]
     holder = next(i for i in mixes if lay in (surfaces[i].u[0], surfaces[i].u[1]))  # Mix -> Layered ...
     view.surfaces[lay].u[0] = holder                                                 # ... -> Mix -> Layered: a cycle through a Layered interface
-    with pytest.raises(DeviceError, match="inside a Layered surface|cyclic"):
+    with pytest.raises(DeviceError, match="Layered surfaces nested more than 2 levels deep|cyclic"):
         renderer.upload(sc)
     view.surfaces[lay].u[0] = top
     renderer.upload(sc)  # and valid again

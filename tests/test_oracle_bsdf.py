@@ -10,7 +10,7 @@ RNG = np.random.default_rng(11)
 TRANSMISSIVE = ("glass", "disney_trans", "mix_glass")  # sample() may return SURFACE_EVENT_ENTER / EXIT
 
 
-STOCHASTIC = ("layered", "layered_medium", "mix_layered", "layered_mix")  # evaluate() is itself a random-walk estimator (layered.cpp:256-398)
+STOCHASTIC = ("layered", "layered_medium", "mix_layered", "layered_mix", "layered_layered")  # evaluate() is itself a random-walk estimator (layered.cpp:256-398)
 
 
 # (mix_nested: the inner Mix nodes take their "sample b" quirk branch for some lobe numbers; test_nested_mix_is_a_lerp_of_lerps pins it)
@@ -243,10 +243,12 @@ render { cameras { @cam } shapes { @quad, @q2, @q3, @q4 } integrator : MegaPath 
     assert np.allclose([*f, pdf], 0.6 * (0.25 * e_at["a"] + 0.75 * e_at["b"]) + 0.4 * e_at["c"], rtol=1e-4, atol=1e-7)
 
 
-def test_layered_inside_layered_is_rejected_with_a_clear_error():
-    """Mix and Layered compose freely in the reference (mix.cpp:82-212, layered.cpp:195-253); the megakernel interprets Mix trees with
-    Layered leaves and Layered surfaces with Mix-tree interfaces, and bounds its call graph by refusing Layered inside Layered."""
-    from helpers import LAYERED_IN_LAYERED, _PATCH
+def test_layered_three_deep_is_rejected_with_a_clear_error():
+    """Mix and Layered compose freely in the reference (mix.cpp:82-212, layered.cpp:195-253); the kernels interpret Mix trees with
+    Layered leaves, Layered surfaces with Mix-tree interfaces and a Layered surface as an interface of a Layered surface, and bound
+    their call graph at two Layered levels (lr_scene.h: LR_LAYERED_MAX_LEVELS)."""
+    from helpers import LAYERED_THREE_DEEP, _PATCH
     from luisarender_amd import Scene
-    with pytest.raises(Exception, match="Layered surface inside a Layered surface"):
-        Scene.from_string(_PATCH.format(surface=LAYERED_IN_LAYERED))
+    with pytest.raises(Exception, match="Layered surfaces nested more than 2 levels deep"):
+        Scene.from_string(_PATCH.format(surface=LAYERED_THREE_DEEP))
+    assert material_scene("layered_layered").view().surface_count == 5

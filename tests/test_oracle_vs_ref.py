@@ -275,7 +275,7 @@ def test_li_each_closure_bit_exact(material):
     _compare_li(_mat_scene(material))
 
 
-@pytest.mark.parametrize("material", ["layered", "layered_medium", "mix_layered", "layered_mix"])
+@pytest.mark.parametrize("material", ["layered", "layered_medium", "mix_layered", "layered_mix", "layered_layered"])
 def test_li_layered(material):
     _compare_li(_mat_scene(material), tol=2e-6)
 

@@ -21,18 +21,21 @@ from ref_scenes import scenes  # noqa: E402
 from luisarender_amd import Scene  # noqa: E402
 
 NAMES = ["cornell", "materials", "disney_mix_sobol", "thin_lens_plastic", "env_image", "env_combined", "direct_both", "vpt_fog_medium_box",
-         "vpt_fog_env_medium_box", "disney", "env_disney", "cornell_sobol", "layered", "nested"]
+         "vpt_fog_env_medium_box", "disney", "env_disney", "cornell_sobol", "layered", "nested", "layered_layered", "env_combined_nested"]
 # rel-L1 bound of the device image against the reference's; specular chains amplify a rounding flip into a different path
 # (measured on the MI355X, round 2: cornell 1e-7, materials 8e-6, disney_mix_sobol 2e-6, thin_lens_plastic 6e-6, env_image 5e-7,
 #  env_combined 2e-7, direct_both 7e-8, vpt_fog_env_medium_box 4e-8, disney 4e-7, env_disney 1e-7, cornell_sobol 1e-7; the bars
 #  leave room for a flipped lobe choice or two, not for a wrong formula)
 DEVICE_TOL = {"cornell": 1e-5, "materials": 5e-4, "disney_mix_sobol": 5e-4, "thin_lens_plastic": 5e-4, "env_image": 1e-4,
               "env_combined": 1e-4, "direct_both": 1e-4, "vpt_fog_medium_box": None, "vpt_fog_env_medium_box": 1e-4,
-              "disney": 5e-4, "env_disney": 5e-4, "cornell_sobol": 1e-5, "layered": "blocks", "nested": "blocks"}
+              "disney": 5e-4, "env_disney": 5e-4, "cornell_sobol": 1e-5, "layered": "blocks", "nested": "blocks", "layered_layered": "blocks",
+              "env_combined_nested": 1e-4}
 # the smallest precompiled kernel variant each scene needs (lrhip.h LRHIP_FEAT_*; bit 0 = counters must be OFF here)
 VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {1024 | 8 | 16 | 32}, "thin_lens_plastic": {0}, "env_image": {4},
            "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256},
-           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {1024 | 8 | 16 | 64}, "nested": {1024 | 8 | 16 | 32 | 64 | 512}}
+           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {1024 | 8 | 16 | 64}, "nested": {1024 | 8 | 16 | 32 | 64 | 512},
+           "layered_layered": {1024 | 8 | 16 | 64 | 512},  # (the free-composition heavy kernels)
+           "env_combined_nested": {60}}                        # (out-of-line environment code: a call-making variant, no wavefront mode)
 
 
 def _fixture(name):
@@ -53,7 +56,7 @@ def test_oracle_reproduces_the_reference_frame_bit_for_bit(name, tmp_path):
     mine = o.convert(film)
     ref = _fixture(name)
     assert mine.shape == ref.shape and ref[..., :3].mean() > 0.01
-    if name in ("layered", "nested"):  # its walk sums in an order the C++ of the reference leaves to the compiler: ulps (test_oracle_vs_ref.py)
+    if name in ("layered", "nested", "layered_layered"):  # its walk sums in an order the C++ of the reference leaves to the compiler: ulps (test_oracle_vs_ref.py)
         assert np.abs(mine - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(mine - ref).max()
         return
     assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (name, np.abs(mine - ref).max())
