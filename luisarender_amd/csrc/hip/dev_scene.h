@@ -181,7 +181,9 @@ struct DScene {
     uint32_t sampler_tile;         // TileShared wrapper (tile_shared.cpp): tile width | height << 16, 0 = none
     uint32_t sampler_tile_jitter;
     const uint32_t *sobol_matrices;// [1024][52]
+    const uint32_t *sobol_bytes;   // [1024][7][256]: the matrices' products with every value of every index byte (Sobol sampler only)
     const uint64_t *vdc_sobol, *vdc_sobol_inv;// [52] rows for log2(sobol_scale)
+    const uint64_t *vdc_bytes, *vdc_inv_bytes;// [7][256]: their products with every value of every byte (Sobol sampler, scale > 1)
     const DEnvironment *env;
     WfArgs wf;// wavefront mode only (behind the scene pointer like everything else: scalar loads where a field is used)
 };

@@ -121,12 +121,15 @@ struct PathSampler<true> {
         v ^= v * 0x53a22864u;
         return __brev(v);
     }
-    LR_D uint32_t sobol_bits(uint64_t idx, uint32_t dim) const {// sobol.cpp:52-60
-        auto v = 0u;
-        auto m = scene->sobol_matrices + dim * static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE);
-        for (; idx != 0u; idx >>= 1u, m++) {
-            if (idx & 1u) { v ^= *m; }
-        }
+    // sobol.cpp:52-60: the XOR of the matrix columns the index has bits in -- taken a BYTE of the index at a time from the table
+    // lrhip_upload_scene builds out of the same matrices (the product is linear over GF(2)): 4-5 independent loads per draw instead
+    // of a 30-40 trip loop with a dependent load per set bit (C2 stand-in, Sobol sampler: 425 -> see profiles/r03ac)
+    LR_D uint32_t sobol_bits(uint64_t idx, uint32_t dim) const {
+        constexpr uint32_t kBytes = (static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE) + 7u) / 8u;
+        auto t = scene->sobol_bytes + dim * (kBytes * 256u);
+        auto lo = static_cast<uint32_t>(idx), hi = static_cast<uint32_t>(idx >> 32u);
+        auto v = t[lo & 255u] ^ t[256u + ((lo >> 8u) & 255u)] ^ t[512u + ((lo >> 16u) & 255u)] ^ t[768u + (lo >> 24u)];
+        for (t += 1024u; hi != 0u; hi >>= 8u, t += 256u) { v ^= t[hi & 255u]; }// (bits 32+: frames of 4k and more at high spp)
         return v;
     }
     // Dimensions 0 and 1 of the Sobol sequence in closed form, for 32-bit indices (all PaddedSobol ever asks for,
@@ -191,16 +194,13 @@ struct PathSampler<true> {
             if (m == 0u) {
                 a = index;
             } else {
+                // (both products a byte at a time from the tables lrhip_upload_scene builds out of vdc_sobol / vdc_sobol_inv, like sobol_bits)
                 auto frame = index;
                 auto idx = static_cast<uint64_t>(frame) << (m << 1u);
                 uint64_t delta = 0u;
-                for (auto c = 0u; frame != 0u; frame >>= 1u, c++) {
-                    if (frame & 1u) { delta ^= s.vdc_sobol[c]; }
-                }
+                for (auto t = s.vdc_bytes; frame != 0u; frame >>= 8u, t += 256u) { delta ^= t[frame & 255u]; }
                 auto bb = delta ^ ((static_cast<uint64_t>(x) << m) | y);
-                for (auto d = 0u; bb != 0u; bb >>= 1u, d++) {
-                    if (bb & 1u) { idx ^= s.vdc_sobol_inv[d]; }
-                }
+                for (auto t = s.vdc_inv_bytes; bb != 0u; bb >>= 8u, t += 256u) { idx ^= t[bb & 255u]; }
                 a = idx;
             }
         } else if (s.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {

@@ -735,6 +735,47 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
             release_scene(ctx);
             return rc2;
         }
+        if (d.sampler_kind == LR_SAMPLER_SOBOL) {
+            // the global Sobol sampler multiplies a 52-bit index with the generator matrix of the draw's dimension (sobol.cpp:52-60: one
+            // table word per set bit).  The product is linear over GF(2), so it is the XOR of one precomputed word per index BYTE:
+            // [dimension][byte][256] words, 7.3 MB, built here from the same matrices (bit-identical results; dev_shade.h: sobol_bits)
+            constexpr size_t kBytes = (LR_SOBOL_MATRIX_SIZE + 7) / 8;
+            std::vector<uint32_t> table(static_cast<size_t>(LR_SOBOL_DIMENSIONS) * kBytes * 256u, 0u);
+            for (size_t dim = 0; dim < LR_SOBOL_DIMENSIONS; dim++) {
+                auto m = s->sampler.sobol_matrices + dim * LR_SOBOL_MATRIX_SIZE;
+                for (size_t k = 0; k < kBytes; k++) {
+                    auto t = table.data() + (dim * kBytes + k) * 256u;
+                    for (uint32_t b = 1u; b < 256u; b++) {
+                        auto bit = 8u * static_cast<uint32_t>(k) + static_cast<uint32_t>(__builtin_ctz(b));
+                        t[b] = t[b & (b - 1u)] ^ (bit < static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE) ? m[bit] : 0u);
+                    }
+                }
+            }
+            if ((rc2 = upload(ctx, table.data(), table.size(), &d.sobol_bytes)) != LRHIP_OK) {
+                release_scene(ctx);
+                return rc2;
+            }
+            // the same for the two 64-bit products that turn (pixel, sample number) into the sample's index in the global sequence
+            // (_sobol_interval_to_index, sobol.cpp:67-96): [byte][256] each
+            d.vdc_bytes = nullptr, d.vdc_inv_bytes = nullptr;
+            if (s->sampler.vdc_sobol != nullptr) {
+                auto bytewise = [&](const uint64_t *rows) {
+                    std::vector<uint64_t> t(kBytes * 256u, 0ull);
+                    for (size_t k = 0; k < kBytes; k++) {
+                        for (uint32_t b = 1u; b < 256u; b++) {
+                            auto bit = 8u * static_cast<uint32_t>(k) + static_cast<uint32_t>(__builtin_ctz(b));
+                            t[k * 256u + b] = t[k * 256u + (b & (b - 1u))] ^ (bit < static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE) ? rows[bit] : 0ull);
+                        }
+                    }
+                    return t;
+                };
+                auto vdc = bytewise(s->sampler.vdc_sobol), inv = bytewise(s->sampler.vdc_sobol_inv);
+                if ((rc2 = upload(ctx, vdc.data(), vdc.size(), &d.vdc_bytes)) != LRHIP_OK || (rc2 = upload(ctx, inv.data(), inv.size(), &d.vdc_inv_bytes)) != LRHIP_OK) {
+                    release_scene(ctx);
+                    return rc2;
+                }
+            }
+        }
     }
     d.film_clamp = s->film.clamp;
     for (auto i = 0; i < 3; i++) { ctx->film_scale[i] = s->film.scale[i]; }
