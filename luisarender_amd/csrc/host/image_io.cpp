@@ -524,8 +524,11 @@ LoadedImage read_exr(const fs::path &path) {
     // through zlib (the reference reads EXR with tinyexr + miniz, src/util/imageio.cpp:419-538)
     // and RLE (1: one scanline per chunk; signed run bytes, then the same predictor + byte de-interleave as ZIP)
     // and PIZ (4: 32 scanlines per chunk; namespace piz above)
-    if (compression > 4u) {
-        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP / PIZ are): '" + path.string() + "'."};
+    // and PXR24 (5: 16 scanlines per chunk; a deflate stream of byte planes: per row and channel the most significant byte of every
+    // pixel, then the next one ... -- 2 planes for HALF, 4 for UINT, 3 for FLOAT, whose low 8 mantissa bits the format drops -- each
+    // value the difference to its left neighbour; restated from the published format, ImfPxr24Compressor; unpinned like PIZ)
+    if (compression > 5u) {
+        throw Error{"EXR compression " + std::to_string(compression) + " is not supported (NONE / RLE / ZIPS / ZIP / PIZ / PXR24 are): '" + path.string() + "'."};
     }
     auto w = static_cast<uint32_t>(xmax - xmin + 1), h = static_cast<uint32_t>(ymax - ymin + 1);
     // nothing is allocated on the word of the header alone: at most 2^28 pixels (the JPEG reader's cap), the file must be long
@@ -533,7 +536,7 @@ LoadedImage read_exr(const fs::path &path) {
     // pixel must be within what the file's bytes can expand to (8192 : 1 -- beyond deflate's 1032 : 1 and RLE's 64 : 1; a PIZ chunk
     // of one constant colour is the densest case): an 8 KB file claiming 16384 x 16384 no longer gets 4 GiB
     {
-        const auto per_chunk = compression == 3u ? 16u : (compression == 4u ? 32u : 1u);
+        const auto per_chunk = (compression == 3u || compression == 5u) ? 16u : (compression == 4u ? 32u : 1u);
         auto chunks = (static_cast<uint64_t>(h) + per_chunk - 1u) / per_chunk;
         if (static_cast<uint64_t>(w) * h > (1ull << 28u) || p > data.size() || (data.size() - p) / 16u < chunks ||
             static_cast<uint64_t>(w) * h * 16u > static_cast<uint64_t>(data.size()) * 8192u) {
@@ -554,7 +557,7 @@ LoadedImage read_exr(const fs::path &path) {
     if (!has_alpha) {
         for (size_t i = 0; i < static_cast<size_t>(w) * h; i++) { img.pixels[i * 4u + 3u] = 1.f; }
     }
-    auto lines_per_chunk = compression == 3u ? 16u : (compression == 4u ? 32u : 1u);
+    auto lines_per_chunk = (compression == 3u || compression == 5u) ? 16u : (compression == 4u ? 32u : 1u);
     auto chunk_count = (h + lines_per_chunk - 1u) / lines_per_chunk;
     auto table = p;
     std::vector<uint8_t> raw, tmp;
@@ -573,7 +576,38 @@ LoadedImage read_exr(const fs::path &path) {
         auto expect = line_bytes * rows;
         auto src = reinterpret_cast<const uint8_t *>(data.data()) + off + 8u;
         if (packed > data.size() - off - 8u) { throw truncated(); }
-        if (compression == 0u || packed == expect) {// stored
+        if (compression == 5u) {// PXR24: never stored raw (its planes are narrower than the pixels)
+            size_t plane_bytes = 0u;
+            for (auto &c : channels) { plane_bytes += static_cast<size_t>(w) * (c.type == 1u ? 2u : (c.type == 2u ? 3u : 4u)); }
+            tmp.resize(plane_bytes * rows);
+            uLongf out_len = static_cast<uLongf>(tmp.size());
+            if (uncompress(tmp.data(), &out_len, src, packed) != Z_OK || out_len != tmp.size()) {
+                throw Error{"Corrupt PXR24 chunk in EXR image '" + path.string() + "'."};
+            }
+            raw.resize(expect);
+            size_t in = 0u, out = 0u;
+            for (uint32_t r = 0; r < rows; r++) {
+                for (auto &c : channels) {
+                    const auto planes = c.type == 1u ? 2u : (c.type == 2u ? 3u : 4u);
+                    uint32_t pixel = 0u;
+                    for (uint32_t x = 0; x < w; x++) {
+                        uint32_t diff = 0u;
+                        for (auto k = 0u; k < planes; k++) { diff = (diff << 8u) | tmp[in + static_cast<size_t>(k) * w + x]; }
+                        if (c.type == 2u) { diff <<= 8u; }// FLOAT: the three planes are the top 24 bits
+                        pixel += diff;
+                        if (c.type == 1u) {
+                            auto hb = static_cast<uint16_t>(pixel);
+                            std::memcpy(raw.data() + out, &hb, 2);
+                            out += 2u;
+                        } else {
+                            std::memcpy(raw.data() + out, &pixel, 4);
+                            out += 4u;
+                        }
+                    }
+                    in += static_cast<size_t>(planes) * w;
+                }
+            }
+        } else if (compression == 0u || packed == expect) {// stored
             if (packed < expect) { throw truncated(); }
             raw.assign(src, src + expect);
         } else {
@@ -811,7 +845,7 @@ LoadedImage load_image(const std::string &path_in) {
     if (ext == ".jpg" || ext == ".jpeg") { return read_jpeg(path.string()); }
     if (ext == ".bmp") { return read_bmp(path.string()); }
     if (ext == ".tga") { return read_tga(path.string()); }
-    throw Error{"Image format '" + ext + "' is not supported (stb is absent); supported: .pfm .hdr .exr (NONE/ZIPS/ZIP) .png .jpg .bmp .tga .ppm .pgm — '" +
+    throw Error{"Image format '" + ext + "' is not supported (stb is absent); supported: .pfm .hdr .exr (NONE/RLE/ZIPS/ZIP/PIZ/PXR24) .png .jpg .bmp .tga .ppm .pgm — '" +
                 path.string() + "'."};
 }
 

@@ -106,14 +106,29 @@ def _exr(path, img, compression, half):
         attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
         attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + \
         attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
-    lines = 16 if compression == 3 else 1
+    lines = 16 if compression in (3, 5) else 1
     chunks = []
     for y0 in range(0, h, lines):
         raw = b""
         for y in range(y0, min(y0 + lines, h)):
             for c in (2, 1, 0):  # B, G, R
                 raw += img[y, :, c].astype(np.float16 if half else np.float32).tobytes()
-        if compression:
+        if compression == 5:
+            # PXR24 (ImfPxr24Compressor): per row and channel the byte PLANES of the left-neighbour differences, most significant
+            # first -- 2 planes of a half, the top 3 bytes of a float (its low 8 mantissa bits are dropped) -- deflated as one stream
+            planes = bytearray()
+            for y in range(y0, min(y0 + lines, h)):
+                for c in (2, 1, 0):
+                    if half:
+                        v = img[y, :, c].astype(np.float16).view(np.uint16).astype(np.int64)
+                        d = np.diff(v, prepend=0) & 0xFFFF
+                        planes += bytes((d >> 8).astype(np.uint8)) + bytes((d & 255).astype(np.uint8))
+                    else:
+                        v = (img[y, :, c].astype(np.float32).view(np.uint32) >> 8).astype(np.int64)  # (the test image is exact in 24 bits)
+                        d = np.diff(v, prepend=0) & 0xFFFFFF
+                        planes += bytes((d >> 16).astype(np.uint8)) + bytes(((d >> 8) & 255).astype(np.uint8)) + bytes((d & 255).astype(np.uint8))
+            payload = zlib.compress(bytes(planes))
+        elif compression:
             n = len(raw)
             t = bytearray(n)
             t[: (n + 1) // 2] = raw[0::2]
@@ -146,6 +161,27 @@ def test_exr_reader_with_zip_compression(tmp_path, compression, half):
     got, channels = load_image(path)
     assert channels == 3 and got.shape == (h, w, 4)
     assert np.array_equal(got[..., :3], img) and (got[..., 3] == 1).all()
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_exr_reader_with_pxr24_compression(tmp_path, half):
+    """EXR compression 5: a float keeps its top 24 bits, so the picture is made of values that have no more"""
+    w, h = 53, 37
+    img = (RNG.random((h, w, 3)) * 8).astype(np.float32)
+    img[5:9] = 0.25
+    img[20, 10:14] = [[-3.5, 1e-3, 1e4]] * 4  # sign changes and big steps: the differences wrap around
+    img = img.astype(np.float16) if half else (img.view(np.uint32) & np.uint32(0xFFFFFF00)).view(np.float32)
+    img = img.astype(np.float32)
+    path = str(tmp_path / "t.exr")
+    _exr(path, img, 5, half)
+    got, channels = load_image(path)
+    assert channels == 3 and got.shape == (h, w, 4)
+    assert np.array_equal(got[..., :3], img) and (got[..., 3] == 1).all()
+    data = bytearray(open(path, "rb").read())
+    data[-20] ^= 0x55  # a damaged deflate stream is an error, not garbage pixels
+    open(path, "wb").write(bytes(data))
+    with pytest.raises(Exception, match="PXR24|Corrupt|Truncated"):
+        load_image(path)
 
 
 def test_exr_and_hdr_round_trip_of_our_own_writer(tmp_path):
