@@ -73,7 +73,8 @@ VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=o
 # after round 2's changes, broken again without the SLP vectorizer, <124> (not <125>) non-deterministic at 4 waves after one more
 # change -- each time bit-identical to the good builds with this flag.  Some scenes pass on a broken binary (the kitchen parity test
 # did), so tests cannot establish that a fast build is sound; the flag removes the mechanism.  Cost: kitchen stand-in 275 -> 256
-# Msamples/s, <60> 350 -> 298 (profiles/r02f_ab_compiler_flags.txt).  The lean variants make no calls and keep the default.
+# Msamples/s, <60> 350 -> 298 (profiles/r02f_ab_compiler_flags.txt).  The lean variants keep the default: their one call is the texture
+# callback of load_lobe (dev_math.h: LR_TEX_LAMBDA; profiles/r03s_sgpr_spill_repro.txt: every lean binary is bit-identical with and without the flag).
 CALL_MASKS := 60 61 62 63 124 125 126 127 636 637 638 639 252 253 254 255 256 257 258 259
 CALL_SAFE_FLAGS ?= -mllvm -amdgpu-spill-sgpr-to-vgpr=0
 variant_flags = $(if $(filter 256 257 258 259,$(1)),$(VPT_HIPFLAGS),$(HIPFLAGS)) $(if $(filter $(CALL_MASKS),$(1)),$(CALL_SAFE_FLAGS),)

@@ -31,7 +31,7 @@ LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const
         }
         auto dyn = c.dynamic;
         c = resolve_closure(
-            raw, [&](int32_t id) { return texture_eval_tables(tb.textures, tb.texels, id, uv); },
+            raw, [&](int32_t id) LR_TEX_LAMBDA { return texture_eval_tables(tb.textures, tb.texels, id, uv); },
             [&](int32_t id) { return tb.textures[id].channels; }, eta_i);
         c.dynamic = dyn;
     }

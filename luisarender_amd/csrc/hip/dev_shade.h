@@ -123,7 +123,7 @@ struct PathSampler<true> {
     }
     // sobol.cpp:52-60: the XOR of the matrix columns the index has bits in -- taken a BYTE of the index at a time from the table
     // lrhip_upload_scene builds out of the same matrices (the product is linear over GF(2)): 4-5 independent loads per draw instead
-    // of a 30-40 trip loop with a dependent load per set bit (C2 stand-in, Sobol sampler: 425 -> see profiles/r03ac)
+    // of a 30-40 trip loop with a dependent load per set bit (C2 stand-in, Sobol sampler: 425 -> 703 Msamples/s, profiles/r03ac_*)
     LR_D uint32_t sobol_bits(uint64_t idx, uint32_t dim) const {
         constexpr uint32_t kBytes = (static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE) + 7u) / 8u;
         auto t = scene->sobol_bytes + dim * (kBytes * 256u);
@@ -336,7 +336,8 @@ LR_D void camera_ray(const DScene &scene, const lr_filter *filter, uint32_t px, 
 
 // Texel coordinate under the texture's address mode.  The floor-modulo of REPEAT / MIRROR goes through the float reciprocal of the
 // period and one corrective step either way instead of two integer divisions (`((v % n) + n) % n`: ~70 VALU instructions on gfx950,
-// sixteen of them per bilinear lookup before round 3); exact for |v| < 2^23, beyond that the integer form.
+// sixteen of them per bilinear lookup before round 3).  One step is exact while |v / period| < 2^20; beyond that a first step brings
+// the quotient below 2^10 (its own error: |v / period| * 2^-22 periods) and the second one is exact -- no integer division anywhere.
 LR_D int texel_wrap(uint32_t address, int v, int n, bool &zero) {
     if (address == LR_TEX_ADDR_EDGE) { return min(max(v, 0), n - 1); }
     if (address == LR_TEX_ADDR_ZERO) {
@@ -344,16 +345,28 @@ LR_D int texel_wrap(uint32_t address, int v, int n, bool &zero) {
         return v;
     }
     const auto period = address == LR_TEX_ADDR_MIRROR ? 2 * n : n;
-    int m;
-    if (v > -(1 << 20) && v < (1 << 20)) {// (quotient error < 0.2 for any period >= 1)
-        const auto q = static_cast<int>(floorf(static_cast<float>(v) * (1.f / static_cast<float>(period))));
-        m = v - q * period;// off by at most one period when v / period is within rounding of an integer
-        m += m < 0 ? period : 0;
-        m -= m >= period ? period : 0;
-    } else {
-        m = ((v % period) + period) % period;
+    const auto inv_period = 1.f / static_cast<float>(period);
+    auto m = v;
+    if (!(v > -(1 << 20) && v < (1 << 20))) {// (rare: texel coordinates in the millions; the products wrap around consistently)
+        const auto q = static_cast<int>(floorf(static_cast<float>(v) * inv_period));
+        m = static_cast<int>(static_cast<uint32_t>(v) - static_cast<uint32_t>(q) * static_cast<uint32_t>(period));
     }
+    const auto q = static_cast<int>(floorf(static_cast<float>(m) * inv_period));
+    m -= q * period;// off by at most one period when the quotient is within rounding of an integer
+    m += m < 0 ? period : 0;
+    m -= m >= period ? period : 0;
     return address == LR_TEX_ADDR_MIRROR && m >= n ? period - 1 - m : m;
+}
+// pow(c, g) of a texel that is not positive (a negative or zero value under a gamma encoding: practically never), by the cases of
+// IEEE pow instead of libm's general 158 instructions at every decode site
+LR_D float pow_nonpositive(float c, float g) {
+    if (c != c || g != g) { return c + g; }
+    if (c == 0.f) { return g > 0.f ? 0.f : (g == 0.f ? 1.f : __builtin_inff()); }
+    const auto gi = truncf(g);
+    if (gi != g) { return __builtin_nanf(""); }// a negative base with a fractional exponent
+    const auto magnitude = __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(-c));
+    const auto odd = fabsf(gi) < 16777216.f && (static_cast<int>(gi) & 1) != 0;
+    return odd ? -magnitude : magnitude;
 }
 LR_D float4 texel_at(const float *texels, const lr_texture &t, int xx, int yy) {
     return reinterpret_cast<const float4 *>(texels)[t.texel_offset + static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx)];
@@ -411,7 +424,8 @@ LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texe
             const auto x = (c + 0.055f) * (1.0f / 1.055f);
             c = c <= 0.04045f ? c * (1.0f / 12.92f) : x * x * __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf(x));
         } else if (ti.encoding == LR_TEX_ENC_GAMMA) {
-            c = c > 0.f ? __builtin_amdgcn_exp2f(ti.gamma[min(ch, 2)] * __builtin_amdgcn_logf(c)) : (c == 0.f && ti.gamma[min(ch, 2)] > 0.f ? 0.f : powf(c, ti.gamma[min(ch, 2)]));
+            const auto g = ti.gamma[min(ch, 2)];
+            c = c > 0.f ? __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(c)) : pow_nonpositive(c, g);
         }
         return ti.scale[ch] * c;
     };

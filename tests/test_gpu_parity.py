@@ -748,6 +748,27 @@ def test_texture_address_modes(renderer, tmp_path, address, filter_mode, scale):
         assert abs(float(gpu[..., :3].mean()) - float(cpu[..., :3].mean())) < 2e-3 * float(cpu[..., :3].mean()) + 1e-6
 
 
+@pytest.mark.parametrize("gamma", ["2.2", "2", "3"])
+def test_gamma_encoded_texture_with_zero_and_negative_texels(renderer, tmp_path, gamma):
+    """image.cpp:151-152: `scale * pow(rgba, gamma)`.  The device takes x^g as exp2(g log2 x) for positive texels and the cases of IEEE
+    pow otherwise (dev_shade.h: pow_nonpositive: 0^g = 0, (-x)^g = +-x^g for an integer g, NaN for a fractional one) instead of libm's
+    powf: a picture with exact zeros everywhere and negative texels under the integer exponents."""
+    from test_oracle_vs_ref import ADDRESS_SCENE, _write_pfm
+    y, x = np.mgrid[0:16, 0:16]
+    pic = np.stack([0.1 + x / 20.0, 0.9 - y / 20.0, 0.3 + 0.02 * ((x + y) % 5)], axis=-1).astype(np.float32)
+    pic[::3, ::2] = 0.0
+    if gamma != "2.2":
+        pic[1::4, 1::3] *= -1.0
+    _write_pfm(tmp_path / "tex.pfm", pic)
+    text = ADDRESS_SCENE.format(address="repeat", filter="point", spp=8, res="96, 64").replace('encoding { "linear" }', 'encoding { "gamma" } gamma { %s }' % gamma)
+    (tmp_path / "scene.luisa").write_text(text)
+    sc = Scene.load(str(tmp_path / "scene.luisa"))
+    gpu, gc, cpu, cc = _render_both(renderer, sc, 8)
+    assert np.isfinite(gpu).all() and np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
+    assert _rel_l1(gpu, cpu) < 2e-4 and gpu[..., :3].mean() > 0.005
+
+
 def test_film_reduce_through_the_c_abi_single_rank(renderer):
     """The product's collective end to end through include/lrhip.h: lrhip_comm_unique_id -> lrhip_comm_init_rank (world 1) ->
     lrhip_film_reduce (ncclReduce on the context's stream) -> lrhip_comm_destroy.  With one rank the sum-reduce must leave the
