@@ -124,7 +124,7 @@ static_assert(sizeof(DShadeTri) == 128, "one line per triangle");
 constexpr uint32_t kWfKinds = 3u;            // Disney, Mix, Layered (LR_SURFACE_DISNEY .. LR_SURFACE_LAYERED)
 constexpr uint32_t kWfHeavyWords = 14u;      // + sampler words: d(3) tri u v beta(3) Li(3) pixel depth
 constexpr uint32_t kWfContWords = 25u;       // + sampler words: ray o d (6) shadow o d tmax (7) nee(3) beta(3) Li(3) pdf pixel depth|flags
-constexpr uint32_t kWfSamplerWordsMax = 8u;
+constexpr uint32_t kWfSamplerWordsMax = 4u;
 #ifndef LR_WF_ITEM
 #define LR_WF_ITEM 1024// (256 / 512 / 1024: 433 / 442 / 444 Msamples/s on C5 at 512 spp)
 #endif

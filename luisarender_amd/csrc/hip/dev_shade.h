@@ -101,13 +101,18 @@ LR_HD uint32_t xxhash32_2(uint32_t x, uint32_t y) {// rng.cpp:25-36
 // kernel instantiation so the default Independent path keeps a 1-register sampler.
 template<>
 struct PathSampler<true> {
-    uint64_t a, b;            // PCG32: state, inc.  Sobol: a = sequence index.
-    uint32_t px, py, sample_index, dimension;
+    // FOUR words of per-path state (eight until round 3: two 64-bit words and four more, and the kernel spilled 25 VGPRs around them):
+    //   PCG32        lo | hi = state,              w2 | w3 = increment
+    //   Sobol        lo | hi = sequence index,     w2 = dimension,  w3 = pixel (x | y << 16: generate_pixel_2d)
+    //   PaddedSobol  lo = sample index,            w2 = dimension,  w3 = pixel
+    uint32_t lo, hi, w2, w3;
     const DScene *scene;
 
+    LR_D uint64_t wide() const { return lo | (static_cast<uint64_t>(hi) << 32u); }
+    LR_D void set_wide(uint64_t v) { lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32u); }
     LR_D uint32_t pcg_next() {// rng.cpp:142-148
-        auto old = a;
-        a = old * 0x5851f42d4c957f2dull + b;
+        auto old = wide();
+        set_wide(old * 0x5851f42d4c957f2dull + (w2 | (static_cast<uint64_t>(w3) << 32u)));
         auto xorshifted = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u);
         auto rot = static_cast<uint32_t>(old >> 59u);
         return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
@@ -173,26 +178,24 @@ struct PathSampler<true> {
         // instructions of a 32-bit division, once per draw; wave-uniform)
         return (l & w) == 0u ? (i + p) & w : (i + p) % l;
     }
-    static constexpr uint32_t kSavedWords = 8u;// (megapath_kernel.h: deferred heavy hits)
+    static constexpr uint32_t kSavedWords = 4u;// (the stream position of a path that leaves its lane: wavefront mode)
     LR_D uint32_t save(uint32_t *w) const {
-        w[0] = static_cast<uint32_t>(a), w[1] = static_cast<uint32_t>(a >> 32u), w[2] = static_cast<uint32_t>(b), w[3] = static_cast<uint32_t>(b >> 32u);
-        w[4] = px, w[5] = py, w[6] = sample_index, w[7] = dimension;
+        w[0] = lo, w[1] = hi, w[2] = w2, w[3] = w3;
         return kSavedWords;
     }
     LR_D void restore(const DScene &s, const uint32_t *w) {
         scene = &s;
-        a = w[0] | (static_cast<uint64_t>(w[1]) << 32u), b = w[2] | (static_cast<uint64_t>(w[3]) << 32u);
-        px = w[4], py = w[5], sample_index = w[6], dimension = w[7];
+        lo = w[0], hi = w[1], w2 = w[2], w3 = w[3];
     }
     LR_D void start(const DScene &s, uint32_t x, uint32_t y, uint32_t index) {
         scene = &s;
         tile_shared_pixel(s, x, y, index);
-        px = x, py = y, sample_index = index;
+        w3 = x | (y << 16u);// (frames are at most 65535 pixels wide / high: lr_camera, lrhip_upload_scene)
         if (s.sampler_kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
-            dimension = 2u;
+            w2 = 2u;
             auto m = 31u - static_cast<uint32_t>(__clz(static_cast<int>(s.sobol_scale)));
             if (m == 0u) {
-                a = index;
+                lo = index, hi = 0u;
             } else {
                 // (both products a byte at a time from the tables lrhip_upload_scene builds out of vdc_sobol / vdc_sobol_inv, like sobol_bits)
                 auto frame = index;
@@ -201,30 +204,31 @@ struct PathSampler<true> {
                 for (auto t = s.vdc_bytes; frame != 0u; frame >>= 8u, t += 256u) { delta ^= t[frame & 255u]; }
                 auto bb = delta ^ ((static_cast<uint64_t>(x) << m) | y);
                 for (auto t = s.vdc_inv_bytes; bb != 0u; bb >>= 8u, t += 256u) { idx ^= t[bb & 255u]; }
-                a = idx;
+                set_wide(idx);
             }
         } else if (s.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
-            dimension = 0u;
+            lo = index, hi = 0u, w2 = 0u;
         } else {// PCG32::set_sequence(xxhash32 seed), rng.cpp:150-156
-            a = 0u;
-            b = (static_cast<uint64_t>(xxhash32_4(x, y, s.seed, index)) << 1u) | 1u;
+            lo = 0u, hi = 0u;
+            const auto inc = (static_cast<uint64_t>(xxhash32_4(x, y, s.seed, index)) << 1u) | 1u;
+            w2 = static_cast<uint32_t>(inc), w3 = static_cast<uint32_t>(inc >> 32u);
             (void)pcg_next();
-            a += 0x853c49e6748fea9bull;
+            set_wide(wide() + 0x853c49e6748fea9bull);
             (void)pcg_next();
         }
     }
     LR_D float next_1d() {
         auto kind = scene->sampler_kind;
         if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:147-153
-            dimension = dimension >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
-            auto u = static_cast<float>(owen(xxhash32_2(dimension, scene->seed), sobol_bits(a, dimension))) * 0x1p-32f;
-            dimension += 1u;
+            w2 = w2 >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : w2;
+            auto u = static_cast<float>(owen(xxhash32_2(w2, scene->seed), sobol_bits(wide(), w2))) * 0x1p-32f;
+            w2 += 1u;
             return clampf(u, 0.f, kOneMinusEpsilon);
         }
         if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:127-136
-            auto hash = xxhash32_4(px, py, sample_index ^ scene->seed, dimension);
-            auto index = permutation_element(sample_index, scene->sampler_spp, hash);
-            dimension += 1u;
+            auto hash = xxhash32_4(w3 & 0xffffu, w3 >> 16u, lo ^ scene->seed, w2);
+            auto index = permutation_element(lo, scene->sampler_spp, hash);
+            w2 += 1u;
             return fminf(static_cast<float>(owen(hash, sobol_bits_dim0(index))) * 0x1p-32f, kOneMinusEpsilon);
         }
         return uint_to_unit_float(pcg_next());
@@ -233,19 +237,20 @@ struct PathSampler<true> {
         auto kind = scene->sampler_kind;
         f2 u;
         if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:154-162
-            dimension = dimension + 1u >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : dimension;
-            u.x = clampf(static_cast<float>(owen(xxhash32_2(dimension, scene->seed), sobol_bits(a, dimension))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
-            u.y = clampf(static_cast<float>(owen(xxhash32_2(dimension + 1u, scene->seed), sobol_bits(a, dimension + 1u))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
-            dimension += 2u;
+            w2 = w2 + 1u >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : w2;
+            u.x = clampf(static_cast<float>(owen(xxhash32_2(w2, scene->seed), sobol_bits(wide(), w2))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
+            u.y = clampf(static_cast<float>(owen(xxhash32_2(w2 + 1u, scene->seed), sobol_bits(wide(), w2 + 1u))) * 0x1p-32f, 0.f, kOneMinusEpsilon);
+            w2 += 2u;
             return u;
         }
         if (kind == LR_SAMPLER_PADDED_SOBOL) {// padded_sobol.cpp:137-149
-            auto hx = xxhash32_4(px, py, sample_index ^ scene->seed, dimension);
-            auto hy = xxhash32_4(px, py, sample_index ^ scene->seed, dimension + 1u);
-            auto index = permutation_element(sample_index, scene->sampler_spp, hx);
+            const auto x = w3 & 0xffffu, y = w3 >> 16u;
+            auto hx = xxhash32_4(x, y, lo ^ scene->seed, w2);
+            auto hy = xxhash32_4(x, y, lo ^ scene->seed, w2 + 1u);
+            auto index = permutation_element(lo, scene->sampler_spp, hx);
             u.x = fminf(static_cast<float>(owen(hx, sobol_bits_dim0(index))) * 0x1p-32f, kOneMinusEpsilon);
             u.y = fminf(static_cast<float>(owen(hy, sobol_bits_dim1(index))) * 0x1p-32f, kOneMinusEpsilon);
-            dimension += 2u;
+            w2 += 2u;
             return u;
         }
         u.x = next_1d();
@@ -255,8 +260,8 @@ struct PathSampler<true> {
     LR_D f2 next_pixel_2d() {// generate_pixel_2d: sobol.cpp:163-169, default sampler.h:48
         if (scene->sampler_kind == LR_SAMPLER_SOBOL) {
             auto s = static_cast<float>(scene->sobol_scale);
-            return {clampf(static_cast<float>(sobol_bits(a, 0u)) * 0x1p-32f * s - static_cast<float>(px), 0.f, kOneMinusEpsilon),
-                    clampf(static_cast<float>(sobol_bits(a, 1u)) * 0x1p-32f * s - static_cast<float>(py), 0.f, kOneMinusEpsilon)};
+            return {clampf(static_cast<float>(sobol_bits(wide(), 0u)) * 0x1p-32f * s - static_cast<float>(w3 & 0xffffu), 0.f, kOneMinusEpsilon),
+                    clampf(static_cast<float>(sobol_bits(wide(), 1u)) * 0x1p-32f * s - static_cast<float>(w3 >> 16u), 0.f, kOneMinusEpsilon)};
         }
         return next_2d();
     }

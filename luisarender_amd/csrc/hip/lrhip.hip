@@ -722,6 +722,10 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: invalid sampler tile size");
     }
     d.sampler_tile = s->sampler.tile_size[0] | (s->sampler.tile_size[1] << 16u), d.sampler_tile_jitter = s->sampler.tile_jitter;
+    if (s->camera.width == 0u || s->camera.height == 0u || s->camera.width > 0xffffu || s->camera.height > 0xffffu) {// (the generic samplers keep a pixel as x | y << 16)
+        release_scene(ctx);
+        return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the film must be 1 .. 65535 pixels wide and high");
+    }
     if (d.sampler_kind == LR_SAMPLER_SOBOL || d.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
         if (s->sampler.sobol_matrices == nullptr || (d.sampler_kind == LR_SAMPLER_SOBOL && d.sobol_scale > 1u && (s->sampler.vdc_sobol == nullptr || s->sampler.vdc_sobol_inv == nullptr))) {
             release_scene(ctx);
@@ -884,7 +888,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto paths_per_spp = static_cast<uint64_t>(tiles_in_range) * 64u;
     // Slice size: every slice pays the latency of its last rounds (a handful of paths, one batch each), so slices are as large as
     // the memory allows -- C5 at 512 spp: 356 / 404 / 442 Msamples/s with 2^25 / 2^26 / 2^27 paths per slice.  Default: a quarter of
-    // the free HBM, at most 2^28 paths; a path takes (3 queues x 15..22 words + 26..33 words) x 4 B = 284 .. 396 B, so on an idle
+    // the free HBM, at most 2^28 paths; a path takes (3 queues x 15..18 words + 26..29 words) x 4 B = 284 .. 332 B, so on an idle
     // MI355X that is ~250 M paths = 71 GB of the 288.
     auto want_paths = static_cast<uint64_t>(ctx->wf_slice_paths);
     if (want_paths == 0u) {

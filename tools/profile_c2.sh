@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe for the bench workload (run on the GPU box through gpurun):
-#   [WL=c2|c3|c4|c5] tools/profile_c2.sh <tag> <spp>
+#   [WL=c2|c3|c4|c5] [SAMPLER=PaddedSobol|Sobol] tools/profile_c2.sh <tag> <spp>
 #   1. rocprofv3 --kernel-trace --stats    -> per-kernel durations (must agree with bench.py's HIP-event time)
 #   2. separate --pmc passes (FETCH_SIZE / WRITE_SIZE do not fit in one pass; SQ + TCC hit counters in a third)
 # Summaries are written under gpurun_out/prof_<tag>/ and the interesting files copied to profiles/ by hand.
@@ -11,7 +11,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats"
+CMD="python $REPO/bench.py --workload ${WL:-c2} --spp $SPP --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats ${SAMPLER:+--sampler $SAMPLER}"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
