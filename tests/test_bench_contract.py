@@ -80,3 +80,39 @@ def test_product_package_never_imports_the_oracle():
     for line in mk.splitlines():
         if ("liblrhip.so" in line or "liblrhost.so" in line) and "-o" in line:
             assert "oracle" not in line, line
+
+
+def test_round3_line_carries_parity_path_statistics_and_every_baseline_config():
+    """the line of the round-3 state (profiles/r03y_bench_c2_1gpu.json, the driver's default command)"""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03y_bench_c2_1gpu.json")))
+    assert line["n_gpus"] == 1 and line["value"] > 850 and line["roofline"]["traffic_source"].startswith("live") and 0.05 < line["roofline"]["frac"] < 0.5
+    p = line["parity"]
+    assert p["finite"] and p["samples"] == 1024 * 1024 * p["spp"] and p["rel_l1"] < 2e-2 and p["rmse_over_mean"] < 0.5 and abs(p["mean_bias"]) < 1e-3 and p["flip"] < 0.1
+    assert line["rays_per_s"] > 1e9 and 2.0 < line["mean_path_length"] < 6.0 and len(line["source_hash"]) == 16
+    extra = [(e["workload"].split(",")[0].split(" (")[0], e["sampler"]) for e in line["extra_configs"]]
+    assert extra == [("Cornell Box", "Independent"), ("Bedroom-class", "Independent"), ("Camera-class", "Independent"), ("Kitchen-class", "Independent"),
+                     ("Contemporary Bathroom-class", "PaddedSobol")]
+    c1 = line["extra_configs"][0]
+    assert c1["parity"]["rel_l1"] < 1e-4 and c1["cpu_reference"]["kind"] == "reference"  # full C1 against the CPU leg's frame
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_path_runs_as_the_driver_launches_it(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with N = 1 and the collective forced: the code the
+    driver's 2 / 4 / 8-GPU runs take (process group, C-ABI communicator, lrhip_film_reduce inside the timed region, the reduced film
+    checked against a 1-GPU render) on a one-GPU box.  The line must carry the multi_gpu record with a passed film check."""
+    import subprocess
+    import sys
+    env = dict(os.environ, LR_BENCH_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "c1", "--spp", "8",
+           "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-stats"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "lrhip_film_reduce" in line["config"]["collective"], line["config"]
+    m = line["multi_gpu"]
+    assert m["reduced_film_equals_1gpu_render"] is True and m["reduce_ms"] >= 0.0 and m["reduce_bytes"] == 512 * 512 * 16, m
