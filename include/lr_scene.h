@@ -95,10 +95,10 @@ enum {
     LR_SURFACE_LAYERED = 8  /* src/surfaces/layered.cpp: tex[0] thickness, tex[1] g, tex[2] albedo; u[0] top tag, u[1] bottom tag,
                              * u[2] max_depth, u[3] samples */
 };
-/* Composition (mix.cpp:82-212 and layered.cpp:195-500 hold arbitrary child closures): a Mix tree is at most 3 Mix levels deep below
- * its root (u[2] = that depth; a Layered child counts as a leaf), and at most LR_LAYERED_MAX_LEVELS Layered surfaces lie on any path
- * through the interfaces (Layered inside Layered: one level; Mix trees may sit in between). */
-enum { LR_LAYERED_MAX_LEVELS = 2 };
+/* Composition (mix.cpp:82-212 and layered.cpp:195-500 hold arbitrary child closures): a Mix tree is at most LR_MIX_MAX_DEPTH Mix
+ * levels deep below its root (u[2] = that depth; a Layered child counts as a leaf), and at most LR_LAYERED_MAX_LEVELS Layered surfaces
+ * lie on any path through the interfaces (Layered inside Layered: one level; Mix trees may sit in between). */
+enum { LR_MIX_MAX_DEPTH = 7, LR_LAYERED_MAX_LEVELS = 2 };
 enum {
     LR_SURFACE_FLAG_REMAP_ROUGHNESS = 1u << 0,
     LR_SURFACE_FLAG_THIN = 1u << 1,

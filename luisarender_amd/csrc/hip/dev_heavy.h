@@ -65,55 +65,80 @@ struct MixCtx {
 LR_D MixCtx mix_ctx_of(const HeavyCtx &cx) { return MixCtx{cx.tb, cx.uv, cx.ng, cx.p, cx.wo, 1.f}; }
 
 // ---- Mix trees.  The reference's Mix closure holds two arbitrary child closures (mix.cpp:82-212), Mix and Layered surfaces
-// included, and a Layered surface holds two arbitrary interfaces (layered.cpp:195-253).  Device code has no unbounded
-// recursion, so a Mix tree is interpreted by functions templated on the nesting depth still allowed below them
-// (kMixMaxDepth levels under the root: the host loader rejects deeper trees); the leaves go through two out-of-line
-// functions so that each level adds a loop, not another copy of the closure interpreter.  LV: the Layered levels still allowed
-// below (dev_layered.h): a leaf may be a Layered surface while LV > 0, and its interfaces are interpreted with LV - 1 -- the loader
-// bounds the Layered levels on a path (LR_LAYERED_MAX_LEVELS), which bounds the call graph:
-// mix<2> -> layered<1> -> mix<1> / layered<0> -> mix<0> -> basic / Disney.
-#ifndef LR_MIX_DEPTH
-#define LR_MIX_DEPTH 3
-#endif
-constexpr int kMixMaxDepth = LR_MIX_DEPTH;
+// included, and a Layered surface holds two arbitrary interfaces (layered.cpp:195-253).  Device code has no recursion, so a Mix
+// tree is walked with an EXPLICIT stack of its Mix nodes (post-order for evaluate and eta, down the chain of first children and back
+// up for sample), in the reference's operation order; kMixMaxDepth levels under the root (lr_scene.h: LR_MIX_MAX_DEPTH, the loader
+// rejects deeper trees; rounds 1-2 unrolled the recursion in templates and stopped at 3).  The leaves go through two out-of-line
+// functions.  LV: the Layered levels still allowed below (dev_layered.h): a leaf may be a Layered surface while LV > 0, and its
+// interfaces are interpreted with LV - 1 -- the loader bounds the Layered levels on a path (LR_LAYERED_MAX_LEVELS), which bounds the
+// call graph: mix<2> -> layered<1> -> mix<1> / layered<0> -> mix<0> -> basic / Disney.
+constexpr int kMixMaxDepth = LR_MIX_MAX_DEPTH;
 
-// (in the free-composition variants the eta walk is out of line: one copy per (DEPTH, LV) instead of one per path through the templates)
+struct MixLevel {// a Mix node on the path from the root of the tree to the node being worked on
+    Frame frame;      // its own (possibly normal-mapped) frame: its children are loaded on top of it, its sides are validated with it
+    float ratio;
+    uint32_t child[2];
+    uint32_t next;    // the child to visit next (0 / 1)
+};
+
+// (in the free-composition variants the eta walk is out of line: one copy per LV)
 #if LR_NEST
 #define LR_ETA_FN __device__ __noinline__
 #else
 #define LR_ETA_FN LR_D
 #endif
-template<int DEPTH, int LV>
-LR_ETA_FN bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta);
-
-// eta of the closure with record `rec` (tag `tag`): Surface::Closure::eta of a basic closure, MixSurfaceClosure::eta
-// (mix.cpp:148-157), LayeredSurfaceClosure::eta = its bottom's (layered.cpp:252; the Mix levels of a Layered surface's own
-// interfaces count from zero, as in the loader)
-template<int DEPTH, int LV>
+// eta of the closure with tag `tag` under a node with frame `frame`: Surface::Closure::eta of a basic closure, MixSurfaceClosure::eta
+// (mix.cpp:148-157: a's, b's, or their lerp by the ratio), LayeredSurfaceClosure::eta = its bottom's (layered.cpp:252; the Mix levels
+// of a Layered surface's own interfaces count from zero, as in the loader: a fresh stack, one call per Layered level)
+template<int LV>
 LR_ETA_FN bool node_eta(const MixCtx &cx, uint32_t tag, const Frame &frame, float &eta) {
-    auto rec = &cx.tb.closures[tag];// (eta never comes from an image texture: the static record has it)
-    if (rec->kind == LR_SURFACE_LAYERED) {
-        if constexpr (LV > 0) { return node_eta<kMixMaxDepth, LV - 1>(cx, rec->x[1], frame, eta); }
-        return false;// (the loader bounds the Layered levels: not reached)
-    }
-    if constexpr (DEPTH > 0) {
-        if (rec->kind == LR_SURFACE_MIX) {
-            DClosure child;
+    MixLevel level[kMixMaxDepth + 1];
+    float first_eta[kMixMaxDepth + 1];
+    bool first_has[kMixMaxDepth + 1];
+    auto sp = 0;
+    auto cur_frame = frame;
+    for (;;) {
+        auto rec = &cx.tb.closures[tag];// (eta never comes from an image texture: the static record has it)
+        bool has;
+        float e = 1.f;
+        if (rec->kind == LR_SURFACE_MIX && sp <= kMixMaxDepth) {// down
+            DClosure node;
             Frame fr;
-            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, tag, frame, child, fr, cx.eta_i);// (its ratio may be textured)
-            return mix_eta<DEPTH - 1, LV>(cx, child, fr, eta);
+            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, tag, cur_frame, node, fr, cx.eta_i);// (its ratio may be textured)
+            level[sp] = MixLevel{fr, node.s0, {node.x[0], node.x[1]}, 0u};
+            sp++;
+            tag = node.x[0], cur_frame = fr;
+            continue;
+        }
+        if (rec->kind == LR_SURFACE_LAYERED) {
+            if constexpr (LV > 0) { has = node_eta<LV - 1>(cx, rec->x[1], cur_frame, e); }
+            else { has = false; }// (the loader bounds the Layered levels: not reached)
+        } else {
+            has = closure_eta(*rec, e);
+        }
+        for (;;) {// up: a finished first child starts the second, a finished second child finishes the node
+            if (sp == 0) { eta = e; return has; }
+            auto &node = level[sp - 1];
+            if (node.next == 0u) {
+                first_has[sp - 1] = has, first_eta[sp - 1] = e;
+                node.next = 1u, tag = node.child[1], cur_frame = node.frame;
+                break;
+            }
+            const auto ha = first_has[sp - 1];
+            const auto ea = first_eta[sp - 1];
+            e = !ha ? e : (!has ? ea : lerp(e, ea, node.ratio));
+            has = ha || has;
+            sp--;
         }
     }
-    return closure_eta(*rec, eta);
 }
-template<int DEPTH, int LV>
-LR_ETA_FN bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
-    bool has[2];
+// MixSurfaceClosure::eta of a Mix node that is already loaded (the surface a ray hit)
+template<int LV>
+LR_D bool mix_eta(const MixCtx &cx, const DClosure &node, const Frame &frame, float &eta) {
     float e[2] = {1.f, 1.f};
-#pragma nounroll
-    for (auto k = 0u; k < 2u; k++) { has[k] = node_eta<DEPTH, LV>(cx, node.x[k], frame, e[k]); }
-    eta = !has[0] ? e[1] : (!has[1] ? e[0] : lerp(e[1], e[0], node.s0));
-    return has[0] || has[1];
+    const auto ha = node_eta<LV>(cx, node.x[0], frame, e[0]), hb = node_eta<LV>(cx, node.x[1], frame, e[1]);
+    eta = !ha ? e[1] : (!hb ? e[0] : lerp(e[1], e[0], node.s0));
+    return ha || hb;
 }
 
 // LayeredSurfaceInstance::populate_closure, layered.cpp:478-500, of the Layered record `c` with frame `own`
@@ -123,7 +148,7 @@ LR_D void layer_stack(const MixCtx &cx, const DClosure &c, const Frame &own, Lay
     load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, c.x[0], own, layers.top, layers.f_top, cx.eta_i);
     float eta_top = 1.f;
 #if LR_NEST
-    if (!node_eta<kMixMaxDepth, LV>(cx, c.x[0], own, eta_top)) { eta_top = 1.f; }
+    if (!node_eta<LV>(cx, c.x[0], own, eta_top)) { eta_top = 1.f; }
 #else
     closure_eta(layers.top, eta_top);
 #endif
@@ -160,60 +185,74 @@ LR_HEAVY BsdfSample mix_leaf_sample(const MixCtx *cx, const DClosure *c, const F
     return closure_sample<true>(*c, *fr, cx->ng, wo, u_lobe, u, importance);
 }
 
-// MixSurfaceClosure::_evaluate (mix.cpp:169-177) + the public wrapper's side validation (surface.cpp:45-56)
-template<int DEPTH, int LV>
-LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, f3 wi, bool importance) {
-    BsdfEval e[2];
-#pragma nounroll
-    for (auto k = 0u; k < 2u; k++) {
+// MixSurfaceClosure::_evaluate (mix.cpp:169-177) + the public wrapper's side validation (surface.cpp:45-56), of the tree below the
+// loaded Mix node `root`: post-order -- both children, then _mix(a, b, ratio), then the sides against the node's own frame
+template<int LV>
+LR_D BsdfEval mix_evaluate(const MixCtx &cx, const DClosure &root, const Frame &root_frame, f3 wo, f3 wi, bool importance) {
+    MixLevel level[kMixMaxDepth + 1];
+    BsdfEval first[kMixMaxDepth + 1];
+    level[0] = MixLevel{root_frame, root.s0, {root.x[0], root.x[1]}, 0u};
+    auto sp = 1;
+    for (;;) {
         DClosure child;
         Frame fr;
-        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[k], frame, child, fr, cx.eta_i);
-        if constexpr (DEPTH > 0) {
-            if (child.kind == LR_SURFACE_MIX) {
-                e[k] = mix_evaluate<DEPTH - 1, LV>(cx, child, fr, wo, wi, importance);
-                continue;
-            }
+        {
+            const auto &top = level[sp - 1];
+            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, top.child[top.next], top.frame, child, fr, cx.eta_i);
         }
-        e[k] = mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, wi, importance);
+        if (child.kind == LR_SURFACE_MIX && sp <= kMixMaxDepth) {// down
+            level[sp] = MixLevel{fr, child.s0, {child.x[0], child.x[1]}, 0u};
+            sp++;
+            continue;
+        }
+        auto e = mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, wi, importance);
+        for (;;) {// up
+            auto &node = level[sp - 1];
+            if (node.next == 0u) {
+                first[sp - 1] = e, node.next = 1u;
+                break;
+            }
+            e = mix_blend(first[sp - 1], e, node.ratio);
+            if (!valid_sides(cx.ng, node.frame.n, wo, wi)) { e.f = mk3(0.f), e.pdf = 0.f; }
+            if (--sp == 0) { return e; }
+        }
     }
-    auto eval = mix_blend(e[0], e[1], node.s0);
-    if (!valid_sides(cx.ng, frame.n, wo, wi)) { eval.f = mk3(0.f), eval.pdf = 0.f; }
-    return eval;
 }
 
 // MixSurfaceClosure::_sample (mix.cpp:178-196); the "sample b" branch samples A and evaluates B (reference quirk, kept), so
-// sampling always walks down the chain of first children
-template<int DEPTH, int LV>
-LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &frame, f3 wo, float u_lobe, f2 u_bsdf, bool importance) {
-    const auto ratio = node.s0;
-    const auto first = u_lobe < ratio;
-    const auto u_child = first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio);
+// sampling always walks down the chain of first children, and on the way back up every node evaluates its second child's subtree
+// in the sampled direction
+template<int LV>
+LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &root, const Frame &root_frame, f3 wo, float u_lobe, f2 u_bsdf, bool importance) {
+    MixLevel level[kMixMaxDepth + 1];// (.next: 1 if the node's lobe number fell below its ratio)
+    auto sp = 0;
     DClosure child;
     Frame fr;
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[0], frame, child, fr, cx.eta_i);
-    BsdfSample bs;
-    auto nested = false;
-    if constexpr (DEPTH > 0) {
-        if (child.kind == LR_SURFACE_MIX) {
-            bs = mix_sample<DEPTH - 1, LV>(cx, child, fr, wo, u_child, u_bsdf, importance);
-            nested = true;
+    {
+        auto ratio = root.s0;
+        auto first_child = root.x[0], second_child = root.x[1];
+        auto frame = root_frame;
+        for (;;) {
+            const auto first = u_lobe < ratio;
+            u_lobe = first ? u_lobe / ratio : (u_lobe - ratio) / (1.f - ratio);
+            level[sp] = MixLevel{frame, ratio, {first_child, second_child}, first ? 1u : 0u};
+            sp++;
+            load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, first_child, frame, child, fr, cx.eta_i);
+            if (child.kind != LR_SURFACE_MIX || sp > kMixMaxDepth) { break; }
+            ratio = child.s0, first_child = child.x[0], second_child = child.x[1], frame = fr;
         }
     }
-    if (!nested) { bs = mix_leaf_sample<LV>(&cx, &child, &fr, wo, u_child, u_bsdf, importance); }
-    load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.x[1], frame, child, fr, cx.eta_i);
-    BsdfEval eb;
-    nested = false;
-    if constexpr (DEPTH > 0) {
-        if (child.kind == LR_SURFACE_MIX) {
-            eb = mix_evaluate<DEPTH - 1, LV>(cx, child, fr, wo, bs.wi, importance);
-            nested = true;
-        }
+    auto bs = mix_leaf_sample<LV>(&cx, &child, &fr, wo, u_lobe, u_bsdf, importance);
+    while (sp > 0) {
+        sp--;
+        const auto &node = level[sp];
+        load_lobe(cx.tb, cx.uv, cx.ng, cx.wo_pop, node.child[1], node.frame, child, fr, cx.eta_i);
+        const auto eb = child.kind == LR_SURFACE_MIX ? mix_evaluate<LV>(cx, child, fr, wo, bs.wi, importance) :
+                                                       mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, bs.wi, importance);
+        const auto m = node.next != 0u ? mix_blend(BsdfEval{bs.f, bs.pdf}, eb, node.ratio) : mix_blend(eb, BsdfEval{bs.f, bs.pdf}, node.ratio);
+        bs.f = m.f, bs.pdf = m.pdf;
+        if (!valid_sides(cx.ng, node.frame.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
     }
-    if (!nested) { eb = mix_leaf_evaluate<LV>(&cx, &child, &fr, wo, bs.wi, importance); }
-    auto m = first ? mix_blend(BsdfEval{bs.f, bs.pdf}, eb, ratio) : mix_blend(eb, BsdfEval{bs.f, bs.pdf}, ratio);
-    bs.f = m.f, bs.pdf = m.pdf;
-    if (!valid_sides(cx.ng, frame.n, wo, bs.wi)) { bs.f = mk3(0.f), bs.pdf = 0.f; }
     return bs;
 }
 
@@ -223,12 +262,12 @@ LR_D BsdfSample mix_sample(const MixCtx &cx, const DClosure &node, const Frame &
 template<int LV>
 __device__ __noinline__ BsdfEval layer_mix_evaluate(const LayerStack &L, bool is_top, f3 wo, f3 wi, bool importance) {
     const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
-    return mix_evaluate<kMixMaxDepth, LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, wi, importance);
+    return mix_evaluate<LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, wi, importance);
 }
 template<int LV>
 __device__ __noinline__ BsdfSample layer_mix_sample(const LayerStack &L, bool is_top, f3 wo, float uc, f2 u, bool importance) {
     const MixCtx cx{L.tb, L.uv, L.ng, L.p, L.wo_pop, is_top ? L.eta_i : L.eta_bottom};
-    return mix_sample<kMixMaxDepth, LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, uc, u, importance);
+    return mix_sample<LV>(cx, is_top ? L.top : L.bottom, is_top ? L.f_top : L.f_bottom, wo, uc, u, importance);
 }
 // a Layered surface as an interface of a Layered surface: LayeredSurfaceInstance::populate_closure (layered.cpp:478-500) of the
 // interface's record, with the eta_i the interface was populated with.  (Only the outermost level calls this: the inner stack's own
@@ -245,7 +284,7 @@ LR_HEAVY BsdfEval heavy_evaluate(const HeavyCtx *cxp, f3 wi) {
     auto &cx = *cxp;
     auto &c = cx.closure;
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:169-177
-        if (c.x[2] != 0u) { return mix_evaluate<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mix_ctx_of(cx), c, cx.shading, cx.wo, wi, false); }// a tree: the general interpreter
+        if (c.x[2] != 0u) { return mix_evaluate<(LAYERED && LR_NEST) ? kLayerLevels : 0>(mix_ctx_of(cx), c, cx.shading, cx.wo, wi, false); }// a tree: the general interpreter
         // the common case, two basic / Disney children, keeps the closure interpreter inline (the out-of-line leaves of the
         // general path cost C5 3 %)
         BsdfEval e[2];
@@ -276,8 +315,8 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
     r.eta = 1.f, r.has_eta = 0u;
     if (MIX && c.kind == LR_SURFACE_MIX && c.x[2] != 0u) {// a Mix tree
         const auto mx = mix_ctx_of(cx);
-        r.bs = mix_sample<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, cx.wo, u_lobe, u_bsdf, false);
-        r.has_eta = mix_eta<kMixMaxDepth, (LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, r.eta) ? 1u : 0u;
+        r.bs = mix_sample<(LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, cx.wo, u_lobe, u_bsdf, false);
+        r.has_eta = mix_eta<(LAYERED && LR_NEST) ? kLayerLevels : 0>(mx, c, cx.shading, r.eta) ? 1u : 0u;
         return r;
     }
     if (MIX && c.kind == LR_SURFACE_MIX) {// mix.cpp:178-196; the "sample b" branch samples A and evaluates B (reference quirk, kept)
@@ -305,7 +344,7 @@ LR_HEAVY HeavySample heavy_sample(const HeavyCtx *cxp, float u_lobe, f2 u_bsdf) 
         layer_stack<kLayerLevels - 1>(mx, c, cx.shading, layers);
         r.bs = layered_sample<kLayerLevels - 1>(layers, cx.wo, u_lobe, u_bsdf, false);
 #if LR_NEST
-        r.has_eta = node_eta<kMixMaxDepth, kLayerLevels - 1>(mx, c.x[1], cx.shading, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
+        r.has_eta = node_eta<kLayerLevels - 1>(mx, c.x[1], cx.shading, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
 #else
         r.has_eta = closure_eta(layers.bottom, r.eta) ? 1u : 0u;// LayeredSurfaceClosure::eta, layered.cpp:252
 #endif

@@ -636,7 +636,7 @@ public:
                 throw Error{"Mix surface with a null child is not supported. [" + d->location() + "]"};
             }
             children = {register_surface(a), register_surface(b)};
-            // nested Mix surfaces: the kernel interprets up to 3 levels below the root (dev_heavy.h: kMixMaxDepth); u[2] = depth.
+            // nested Mix surfaces: the kernels walk up to LR_MIX_MAX_DEPTH levels below the root (dev_heavy.h: kMixMaxDepth); u[2] = depth.
             // A Layered child is a leaf of the tree (its own interfaces may be Mix trees again, counted from zero); it sends the
             // Mix through the general interpreter (u[2] != 0), whose leaves know the Layered closure.
             auto depth_of = [&](uint32_t c) {
@@ -644,7 +644,9 @@ public:
                 return cs.kind == LR_SURFACE_MIX ? 1u + cs.u[2] : (cs.kind == LR_SURFACE_LAYERED ? 1u : 0u);
             };
             s.u[2] = std::max(depth_of(children[0]), depth_of(children[1]));
-            if (s.u[2] > 3u) { throw Error{"Mix surfaces nested more than 3 levels deep are not supported by the megakernel. [" + d->location() + "]"}; }
+            if (s.u[2] > static_cast<uint32_t>(LR_MIX_MAX_DEPTH)) {
+                throw Error{"Mix surfaces nested more than " + std::to_string(LR_MIX_MAX_DEPTH) + " levels deep are not supported by the megakernel. [" + d->location() + "]"};
+            }
             s.u[0] = children[0], s.u[1] = children[1];
             s.tex[0] = tex("ratio");
             wrappers = false;// NormalMapWrapper<MixSurface> only (mix.cpp:214-215)

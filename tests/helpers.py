@@ -51,6 +51,21 @@ MATERIALS = {
                    "Surface lx_c : Metal { eta { \"Cu\" } roughness : Constant { v { 0.3 } } } "
                    "Surface lx_bot : Mix { a { @lx_m } b { @lx_c } ratio : Constant { v { 0.7 } } } "
                    "Surface m : Layered { top { @lx_top } bottom { @lx_bot } thickness : Constant { v { 0.1 } } }",
+    # a Mix tree of six Mix levels (round 3: the kernels walk Mix trees with an explicit stack, lr_scene.h LR_MIX_MAX_DEPTH = 7), Mix nodes
+    # on both sides of their parents, a different leaf kind at every level
+    "mix_deep": "Surface md_a : Matte { Kd : Constant { v { 0.7, 0.2, 0.2 } } } "
+                "Surface md_b : Mirror { color : Constant { v { 0.9, 0.9, 0.9 } } roughness : Constant { v { 0.3 } } } "
+                "Surface md_c : Plastic { Kd : Constant { v { 0.2, 0.3, 0.8 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.5 } } } "
+                "Surface md_d : Glass { Kr : Constant { v { 0.9 } } Kt : Constant { v { 0.9 } } roughness : Constant { v { 0.2 } } eta : Constant { v { 1.5 } } } "
+                "Surface md_e : Metal { eta { \"Au\" } roughness : Constant { v { 0.25 } } } "
+                "Surface md_f : Disney { color : Constant { v { 0.5, 0.6, 0.7 } } roughness : Constant { v { 0.5 } } metallic : Constant { v { 0.3 } } } "
+                "Surface md_1 : Mix { a { @md_a } b { @md_b } ratio : Constant { v { 0.25 } } } "
+                "Surface md_2 : Mix { a { @md_d } b { @md_1 } ratio : Constant { v { 0.5 } } } "
+                "Surface md_3 : Mix { a { @md_2 } b { @md_c } ratio : Constant { v { 0.6 } } } "
+                "Surface md_s : Mix { a { @md_e } b { @md_f } ratio : Constant { v { 0.4 } } } "
+                "Surface md_4 : Mix { a { @md_3 } b { @md_s } ratio : Constant { v { 0.7 } } } "
+                "Surface md_5 : Mix { a { @md_b } b { @md_4 } ratio : Constant { v { 0.35 } } } "
+                "Surface m : Mix { a { @md_5 } b { @md_a } ratio : Constant { v { 0.8 } } }",
     # a Layered surface as the bottom interface of a Layered surface (a clear coat over a tinted coat over paint), round 3
     "layered_layered": "Surface ll_t : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } roughness : Constant { v { 0.1 } } eta : Constant { v { 1.5 } } } "
                        "Surface ll_t2 : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1, 0.8, 0.6 } } roughness : Constant { v { 0.3 } } eta : Constant { v { 1.3 } } } "
@@ -59,6 +74,14 @@ MATERIALS = {
                        "Surface m : Layered { top { @ll_t } bottom { @ll_in } thickness : Constant { v { 0.02 } } g : Constant { v { 0.2 } } albedo : Constant { v { 0.5, 0.6, 0.7 } } }",
     "metal": 'Surface m : Metal { eta { "Cu" } roughness : Constant { v { 0.3, 0.15 } } Kd : Constant { v { 0.9, 0.9, 0.9 } } }',
 }
+
+# rejected by the loader with a clear error: a Mix tree deeper than LR_MIX_MAX_DEPTH = 7 levels below its root
+def mix_too_deep():
+    text = "Surface mz_a : Matte { Kd : Constant { v { 0.7, 0.2, 0.2 } } } Surface mz_b : Mirror { color : Constant { v { 0.9 } } } Surface mz_0 : Mix { a { @mz_a } b { @mz_b } } "
+    for i in range(1, 8):
+        text += f"Surface mz_{i} : Mix {{ a {{ @mz_{i - 1} }} b {{ @mz_b }} }} "
+    return text + "Surface m : Mix { a { @mz_a } b { @mz_7 } }"
+
 
 # rejected by the loader with a clear error (the kernels bound their call graph: at most two Layered levels, lr_scene.h LR_LAYERED_MAX_LEVELS)
 LAYERED_THREE_DEEP = (MATERIALS["layered_layered"].replace("Surface m ", "Surface ll_mid ") +

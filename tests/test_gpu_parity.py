@@ -80,7 +80,8 @@ def test_golden_fixtures(renderer):
         assert _rel_l1(gpu, ref["film"]) < (1e-4 if "materials" not in name else 2e-3), name
 
 
-@pytest.mark.parametrize("material", ["oren", "mirror", "glass", "plastic", "metal", "disney", "disney_trans", "disney_thin", "mix", "mix_glass", "mix_nested"])
+@pytest.mark.parametrize("material", ["oren", "mirror", "glass", "plastic", "metal", "disney", "disney_trans", "disney_thin", "mix", "mix_glass", "mix_nested",
+                                      "mix_deep"])
 def test_each_closure_in_a_cornell_box(renderer, material):
     from helpers import MATERIALS
     extra = MATERIALS[material].replace("Surface m ", f"Surface {material} ") + "\n"

@@ -14,7 +14,7 @@ STOCHASTIC = ("layered", "layered_medium", "mix_layered", "layered_mix", "layere
 
 
 # (mix_nested: the inner Mix nodes take their "sample b" quirk branch for some lobe numbers; test_nested_mix_is_a_lerp_of_lerps pins it)
-@pytest.mark.parametrize("name", [m for m in MATERIALS if m not in STOCHASTIC and m != "mix_nested"])
+@pytest.mark.parametrize("name", [m for m in MATERIALS if m not in STOCHASTIC and m not in ("mix_nested", "mix_deep")])
 def test_sample_is_consistent_with_evaluate(name):
     probe = SurfaceProbe(material_scene(name))
     checked = 0
@@ -241,6 +241,15 @@ render { cameras { @cam } shapes { @quad, @q2, @q3, @q4 } integrator : MegaPath 
     assert np.allclose(wi_tree, wi_a, atol=1e-6)
     e_at = {name: evaluate(i, wo, wi_tree) for name, i in (("a", 1), ("b", 2), ("c", 3))}
     assert np.allclose([*f, pdf], 0.6 * (0.25 * e_at["a"] + 0.75 * e_at["b"]) + 0.4 * e_at["c"], rtol=1e-4, atol=1e-7)
+
+
+def test_mix_trees_up_to_seven_levels_deep():
+    from helpers import _PATCH, mix_too_deep
+    from luisarender_amd import Scene
+    view = material_scene("mix_deep").view()
+    assert max(view.surfaces[i].u[2] for i in range(view.surface_count) if view.surfaces[i].kind == 7) == 5  # the recorded depth of the root: five Mix levels below it (the old limit: 3)
+    with pytest.raises(Exception, match="Mix surfaces nested more than 7 levels deep"):
+        Scene.from_string(_PATCH.format(surface=mix_too_deep()))
 
 
 def test_layered_three_deep_is_rejected_with_a_clear_error():

@@ -270,7 +270,7 @@ def _mat_scene(material, **kw):
 
 
 @pytest.mark.parametrize("material", ["matte", "oren", "mirror", "glass", "plastic", "metal", "disney", "disney_trans", "disney_thin",
-                                      "mix", "mix_glass", "mix_nested"])
+                                      "mix", "mix_glass", "mix_nested", "mix_deep"])
 def test_li_each_closure_bit_exact(material):
     _compare_li(_mat_scene(material))
 
