@@ -168,10 +168,13 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
 
 /* Wavefront mode (round 3): a scene with Mix or Layered surfaces under the MegaPath integrator is rendered by a lean megakernel that
  * parks the paths reaching a Disney / Mix / Layered surface in HBM queues, a heavy-closure kernel that shades those vertices in full
- * waves of one closure kind, and a continuation pass of the megakernel -- alternating until the queues are empty.  The frame is cut
- * into slices of the sample range whose paths fit the queues.
- *   mode         0 = automatic (default), 1 = never: the all-in-one megakernel variants (A/B, tests)
- *   slice_paths  paths per slice = slots per queue (0 = default 2^25: ~10 GB of queues)
+ * waves of one closure kind, and a continuation pass of the megakernel -- alternating until the queues are empty.  The sample range
+ * is cut into slices of `slice_paths` paths of one nominal shard of the frame (tile_count / balance_shards tiles): a function of the
+ * frame and the caller's hint only, like the work items, so that films stay bit-identical under sharding and whatever memory is
+ * free; a call over more tiles than the queues can hold takes them group after group, which changes no bit.
+ *   mode         0 = automatic (default), 1 = never: the all-in-one megakernel variants (A/B, tests),
+ *                2 = automatic with queues of eight tiles (tests: the tile groups a GPU short of memory would use)
+ *   slice_paths  paths per slice (0 = default 2^28: 76 .. 89 GB of queues when a whole slice is in flight)
  * lrhip_last_variant reports LRHIP_FEAT_WAVEFRONT | the lean kernel's bits | the closure bits the heavy kernel served.          */
 #define LRHIP_FEAT_WAVEFRONT 1024u
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);

@@ -132,7 +132,7 @@ struct lrhip_ctx {
     // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
     DeviceBuffer wf_heavy, wf_cont, wf_counts, wf_accum;
     int heavy_blocks[20];// resident blocks per CU of each heavy-kernel variant (-1: not asked yet)
-    uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never
+    uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never, 2 = automatic with tiny tile groups (tests)
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
 };
 
@@ -885,21 +885,26 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto spp = p->spp_end - p->spp_begin;
     const auto pixel_count = ctx->width * ctx->height;
     const auto sampler_words = generic ? lrd::kWfSamplerWordsMax : 1u;
-    const auto paths_per_spp = static_cast<uint64_t>(tiles_in_range) * 64u;
-    // Slice size: every slice pays the latency of its last rounds (a handful of paths, one batch each), so slices are as large as
-    // the memory allows -- C5 at 512 spp: 356 / 404 / 442 Msamples/s with 2^25 / 2^26 / 2^27 paths per slice.  Default: a quarter of
-    // the free HBM, at most 2^28 paths; a path takes (3 queues x 15..18 words + 26..29 words) x 4 B = 284 .. 332 B, so on an idle
-    // MI355X that is ~250 M paths = 71 GB of the 288.
-    auto want_paths = static_cast<uint64_t>(ctx->wf_slice_paths);
-    if (want_paths == 0u) {
-        size_t free_bytes = 0u, total_bytes = 0u;
-        LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
-        const auto per_path = static_cast<uint64_t>(lrd::kWfKinds * (lrd::kWfHeavyWords + sampler_words) + lrd::kWfContWords + sampler_words) * sizeof(uint32_t);
-        want_paths = std::min<uint64_t>(1ull << 28u, std::max<uint64_t>(1ull << 20u, have / 4u / per_path));
-    }
-    const auto slice_spp = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(spp, want_paths / std::max<uint64_t>(paths_per_spp, 1u))));
-    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(paths_per_spp * slice_spp, (1ull << 31u) - 1u));
+    // Slice size: every slice pays the latency of its last rounds (a handful of paths, one batch each), so slices are large -- C5 at
+    // 512 spp: 356 / 404 / 442 / 472 Msamples/s with 2^25 / 2^26 / 2^27 / ~2^27.9 paths per slice.  A slice is 2^28 paths of ONE NOMINAL
+    // SHARD of the frame (tile_count / balance_shards tiles, like the chunking): its length in samples is a function of the frame and
+    // the caller's hint only -- never of the free memory or of the tile range of this call -- because the work items, and with
+    // them the order of the film's float sums, are cut per slice: every shard of a frame, and the unsharded frame rendered with the
+    // same hint, must cut them alike.  A path takes (3 queues x 15..18 words + 26..29 words) x 4 B = 284 .. 332 B: 2^28 of them are
+    // 76 .. 89 GB of the 288.  What the memory does decide is how many TILES go through the queues at a time (tile groups, below):
+    // a call over more tiles than fit -- the unsharded frame with a shard hint, a GPU with little memory left -- takes its tiles
+    // group after group with the same slices, which regroups nothing (items are per tile; parked paths add in fixed point).
+    const auto nominal_paths = ctx->wf_slice_paths != 0u ? static_cast<uint64_t>(ctx->wf_slice_paths) : (1ull << 28u);
+    const auto nominal_tiles = std::max<uint64_t>(1u, static_cast<uint64_t>(static_cast<double>(tile_count) / std::max(p->balance_shards, 1u) + 0.5));
+    const auto slice_spp = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(spp, nominal_paths / (nominal_tiles * 64u))));
+    const auto per_path = static_cast<uint64_t>(lrd::kWfKinds * (lrd::kWfHeavyWords + sampler_words) + lrd::kWfContWords + sampler_words) * sizeof(uint32_t);
+    size_t free_bytes = 0u, total_bytes = 0u;
+    LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+    const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
+    auto fit_paths = std::min<uint64_t>((1ull << 31u) - 1u, std::max<uint64_t>(1ull << 16u, have / 2u / per_path));// at most half of what is free
+    if (ctx->wf_mode == 2u) { fit_paths = 8ull * 64u * slice_spp; }// (tests: eight tiles at a time)
+    const auto group_tiles = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(tiles_in_range, fit_paths / (64ull * slice_spp))));
+    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, (1ull << 31u) - 1u));
     const auto heavy_words = static_cast<size_t>(lrd::kWfKinds) * (lrd::kWfHeavyWords + sampler_words) * capacity;
     const auto cont_words = static_cast<size_t>(lrd::kWfContWords + sampler_words) * capacity;
     if (auto r = ensure(ctx->wf_heavy, heavy_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
@@ -969,13 +974,17 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     auto item_scale = 1.25;
     if (ctx->diag_item_scale != 0.) { item_scale *= std::max(0.01, std::fabs(ctx->diag_item_scale)); }
     LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    for (auto g0 = 0u; g0 < tiles_in_range; g0 += group_tiles) {// tile groups: what fits the queues at a time (see above)
+    const auto group_count = std::min(group_tiles, tiles_in_range - g0);
+    args.tile_begin = p->tile_begin + g0 * p->tile_stride;
+    args.tile_end = std::min(p->tile_end, args.tile_begin + group_count * p->tile_stride);
     for (auto s0 = p->spp_begin; s0 < p->spp_end; s0 += slice_spp) {
         const auto s1 = std::min(p->spp_end, s0 + slice_spp);
         const auto n = s1 - s0;
         // ---- camera pass: samples [s0, s1) of every tile of the shard; heavy hits are parked
         const auto ck = chunking_of(n, shard_tiles, item_scale, ctx->diag_item_scale >= 0.);
         const auto chunk_count = ck.count;
-        args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = tiles_in_range * chunk_count;
+        args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = group_count * chunk_count;
         args.chunk_big_count = ck.big_count, args.chunk_big = ck.big, args.chunk_small = ck.small;
         args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_camera) * lrd::kBlockThreads;
         if (chunk_count > 1u) {
@@ -987,7 +996,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
         if (chunk_count > 1u) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
-                               args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
+                               args.partial, pixel_count, chunk_count, ctx->width, tiles_x, args.tile_begin, args.tile_end, p->tile_stride);
         }
         // ---- rounds: a path leaves a round either finished or parked again (one level deeper), so max_depth rounds empty the queues
         args.chunk_count = 1u, args.item_count = 0u;// (the continuation pass reads its item count from the device)
@@ -1003,6 +1012,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
             LR_HIP_CHECK(kVariants[vi_cont].launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, 2u * sizeof(uint32_t), ctx->stream));// (+ its work counter, next to it)
         }
+    }
     }
     hipLaunchKernelGGL(lrd::wf_resolve_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                        static_cast<unsigned long long *>(ctx->wf_accum.ptr), pixel_count, 1.0 / accum_scale);
@@ -1032,7 +1042,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // Wavefront mode (render_wavefront above) for every MegaPath scene that would otherwise land in an all-in-one variant with
     // out-of-line closures: Mix / Layered surfaces, and Disney together with an alpha test (no lean <Alpha | Disney> variant is
     // precompiled; such a scene ran at 433 Msamples/s on <60> where its Mix-holding sibling ran at 480 in wavefront mode).
-    if (ctx->wf_mode == 0u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+    if (ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
         const auto plain = pick_variant(ctx->features, false, generic_sampler);
         if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) {
@@ -1120,7 +1130,7 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
 }
 
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths) {
-    if (ctx == nullptr || mode > 1u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_wavefront: invalid argument"); }
+    if (ctx == nullptr || mode > 2u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_wavefront: invalid argument"); }
     ctx->wf_mode = mode, ctx->wf_slice_paths = slice_paths;
     return LRHIP_OK;
 }

@@ -126,10 +126,11 @@ class MegaPathRenderer:
         the work-item size; the library itself reads no environment variable"""
         self._check(self._lib.lrhip_set_diagnostics(self._ctx, force_features, item_scale))
 
-    def set_wavefront(self, enabled: bool = True, slice_paths: int = 0) -> None:
+    def set_wavefront(self, enabled: bool = True, slice_paths: int = 0, tiny_tile_groups: bool = False) -> None:
         """lrhip_set_wavefront: scenes with Mix / Layered surfaces render in wavefront mode by default (lean megakernel + heavy-closure
-        kernel + continuation pass); enabled=False keeps them on the all-in-one megakernel variants (A/B, tests)"""
-        self._check(self._lib.lrhip_set_wavefront(self._ctx, 0 if enabled else 1, slice_paths))
+        kernel + continuation pass); enabled=False keeps them on the all-in-one megakernel variants (A/B, tests); tiny_tile_groups
+        sends eight tiles through the queues at a time (tests: what a GPU short of memory does)"""
+        self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
 
     def close(self) -> None:
         if self._ctx:

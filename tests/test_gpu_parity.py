@@ -874,6 +874,18 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
         renderer.render(0, 16, sync=True)
         sliced = renderer.download(False)
         assert np.array_equal(sliced[..., 3], films[0][..., 3]) and np.allclose(sliced, films[0], rtol=2e-5, atol=1e-5)
+        # slices are cut by the frame (a nominal shard's tiles), not by the tile range of the call or by the free memory: the shards of
+        # the sliced frame still add up to it bit for bit, and so does the frame pushed through the queues eight tiles at a time
+        total = np.zeros_like(sliced)
+        for rank in range(3):
+            renderer.clear()
+            renderer.render(0, 16, rank=rank, world=3, sync=True)
+            total += renderer.download(False)
+        assert np.array_equal(total, sliced)
+        renderer.set_wavefront(True, slice_paths=256 * 144 * 3, tiny_tile_groups=True)
+        renderer.clear()
+        renderer.render(0, 16, sync=True)
+        assert np.array_equal(renderer.download(False), sliced)
         renderer.set_wavefront(False)
         renderer.clear()
         renderer.render(0, 16, sync=True)
