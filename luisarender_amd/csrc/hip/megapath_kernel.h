@@ -61,8 +61,12 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatVpt,
     // wavefront mode: the lean kernel that parks heavy hits (camera pass) and its continuation pass; picked by lrhip_render for scenes
     // with Mix / Layered surfaces, never by the superset search (they hold none of the closure bits)
+    kFeatWf,
+    kFeatEnv | kFeatWf,
     kFeatAlpha | kFeatWf,
     kFeatEnv | kFeatAlpha | kFeatWf,
+    kFeatWf | kFeatCont,
+    kFeatEnv | kFeatWf | kFeatCont,
     kFeatAlpha | kFeatWf | kFeatCont,
     kFeatEnv | kFeatAlpha | kFeatWf | kFeatCont,
 };

@@ -14,7 +14,11 @@
     X(636) X(637) X(638) X(639) /* everything + Mix / Layered nested in each other (kFeatNest) */ \
     X(252) X(253) X(254) X(255) /* everything + the sibling integrators Direct / Normal */ \
     X(256) X(257) X(258) X(259) /* the volumetric megakernel MegaVPTNaive (megavpt_kernel.h) */ \
-    X(1032) X(1033) X(1034) X(1035) /* wavefront mode, camera pass: lean + alpha test, parks heavy hits (kFeatWf) */ \
-    X(1036) X(1037) X(1038) X(1039) /* the same + environment */ \
-    X(3080) X(3081) X(3082) X(3083) /* wavefront mode, continuation pass (kFeatWf | kFeatCont) */ \
-    X(3084) X(3085) X(3086) X(3087) /* the same + environment */
+    X(1024) X(1025) X(1026) X(1027) /* wavefront mode, camera pass: the lean kernel that parks heavy hits (kFeatWf) */ \
+    X(1028) X(1029) X(1030) X(1031) /* + environment */ \
+    X(1032) X(1033) X(1034) X(1035) /* + alpha-tested traversal */ \
+    X(1036) X(1037) X(1038) X(1039) /* + environment + alpha test */ \
+    X(3072) X(3073) X(3074) X(3075) /* wavefront mode, continuation pass (kFeatWf | kFeatCont) */ \
+    X(3076) X(3077) X(3078) X(3079) /* + environment */ \
+    X(3080) X(3081) X(3082) X(3083) /* + alpha test */ \
+    X(3084) X(3085) X(3086) X(3087) /* + environment + alpha test */

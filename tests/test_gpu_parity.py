@@ -348,9 +348,10 @@ def test_kernel_variant_selection(renderer):
     renderer.upload(sc)
     renderer.render(0, 1, sync=True)
     assert renderer.last_variant() == 8  # alpha-tested traversal on the lean kernel
-    # Mix / Layered surfaces: wavefront mode -- the lean alpha kernel parks them for the heavy-closure kernel (lrhip.h: lrhip_set_wavefront)
-    assert variant("mix") == WF | 8 | 32
-    assert variant("layered") == WF | 8 | 16 | 64
+    # Mix / Layered surfaces: wavefront mode -- the lean kernel parks them for the heavy-closure kernel (lrhip.h: lrhip_set_wavefront);
+    # its alpha-tested form only where a surface may be non-opaque
+    assert variant("mix") == WF | 32
+    assert variant("layered") == WF | 16 | 64
     try:  # ... unless it is switched off: the all-in-one megakernel variants, next precompiled superset
         renderer.set_wavefront(False)
         assert variant("mix") == 60 and variant("layered") == 124
@@ -532,8 +533,8 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         "disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", tall_box_surface="disney_thin", extra_surfaces=mat("disney", "disney_thin")), 16),
         "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), 20),
         "mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha), WF | 8 | 32),
-        "layered": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium")), WF | 8 | 16 | 64),
-        "nested": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix")), WF | 8 | 16 | 32 | 64 | 512),
+        "layered": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium")), WF | 16 | 64),
+        "nested": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix")), WF | 16 | 32 | 64 | 512),
         "direct": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass")).replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 252),
         "vpt": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                 .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 256),
@@ -541,8 +542,8 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
         # the generic-sampler twins (| 2) of the variants that make real calls: every shipped binary of that kind is held to its
         # counting twin (they are the ones a compiler mishap has hit, Makefile: CALL_SAFE_FLAGS)
         "mix_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + alpha, sampler="Sobol"), WF | 8 | 32 | 2),
-        "layered_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium"), sampler="PCG32"), WF | 8 | 16 | 64 | 2),
-        "nested_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix"), sampler="PaddedSobol"), WF | 8 | 16 | 32 | 64 | 512 | 2),
+        "layered_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="layered_medium", extra_surfaces=mat("layered", "layered_medium"), sampler="PCG32"), WF | 16 | 64 | 2),
+        "nested_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="mix_layered", tall_box_surface="layered_mix", extra_surfaces=mat("mix_layered", "layered_mix"), sampler="PaddedSobol"), WF | 16 | 32 | 64 | 512 | 2),
         "direct_pcg": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PCG32").replace("integrator : MegaPath {", 'integrator : Direct { importance_sampling { "both" }'), 254),
         "vpt_pcg": (cornell_box(resolution=64, spp=8, extra_surfaces=FOG, short_box_surface="skin", sampler="PCG32").replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
                     .replace("render {", "render {\n  environment_medium { @fog }").replace("surface { @skin }", "surface { @skin } medium { @inner }"), 258),
@@ -841,7 +842,7 @@ def test_nested_mix_layered_only_in_megapath(renderer):
     text = cornell_box(resolution=32, spp=4, short_box_surface="mix_layered", extra_surfaces=extra)
     renderer.upload(Scene.from_string(text))
     renderer.render(0, 4, sync=True)
-    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64 | 512
+    assert renderer.last_variant() == WF | 16 | 32 | 64 | 512
     for integrator in ('Direct { importance_sampling { "both" }', "MegaVPTNaive {"):
         with pytest.raises(DeviceError, match="MegaPath integrator only"):
             renderer.upload(Scene.from_string(text.replace("integrator : MegaPath {", "integrator : " + integrator)))
@@ -860,7 +861,7 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
         renderer.clear()
         renderer.render(0, 16, sync=True)
         films.append(renderer.download(False))
-    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64
+    assert renderer.last_variant() == WF | 16 | 32 | 64  # (the stand-in at this size holds no alpha-tested surface)
     assert np.array_equal(films[0], films[1]) and np.isfinite(films[0]).all() and (films[0][..., 3] == 16).all()
     total = np.zeros_like(films[0])
     for rank in range(3):

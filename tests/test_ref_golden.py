@@ -31,10 +31,10 @@ DEVICE_TOL = {"cornell": 1e-5, "materials": 5e-4, "disney_mix_sobol": 5e-4, "thi
               "disney": 5e-4, "env_disney": 5e-4, "cornell_sobol": 1e-5, "layered": "blocks", "nested": "blocks", "layered_layered": "blocks",
               "env_combined_nested": 1e-4}
 # the smallest precompiled kernel variant each scene needs (lrhip.h LRHIP_FEAT_*; bit 0 = counters must be OFF here)
-VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {1024 | 8 | 16 | 32}, "thin_lens_plastic": {0}, "env_image": {4},
+VARIANT = {"cornell": {0}, "materials": {0}, "disney_mix_sobol": {1024 | 16 | 32}, "thin_lens_plastic": {0}, "env_image": {4},
            "env_combined": {4}, "direct_both": {252}, "vpt_fog_medium_box": {256}, "vpt_fog_env_medium_box": {256},
-           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {1024 | 8 | 16 | 64}, "nested": {1024 | 8 | 16 | 32 | 64 | 512},
-           "layered_layered": {1024 | 8 | 16 | 64 | 512},  # (the free-composition heavy kernels)
+           "disney": {16}, "env_disney": {20}, "cornell_sobol": {0}, "layered": {1024 | 16 | 64}, "nested": {1024 | 16 | 32 | 64 | 512},
+           "layered_layered": {1024 | 16 | 64 | 512},  # (the free-composition heavy kernels)
            "env_combined_nested": {60}}                        # (out-of-line environment code: a call-making variant, no wavefront mode)
 
 

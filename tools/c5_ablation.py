@@ -30,6 +30,7 @@ with tempfile.TemporaryDirectory() as tmp:
     cases["basic_no_alpha_no_nmap"] = replace(base, heavy + ["lace", "bumpy"])
     cases["basic_no_alpha_no_nmap_no_images"] = replace(base, heavy + ["lace", "bumpy", "oren", "plastic0", "floor_s"])
     cases["alpha_only"] = replace(base, heavy + ["bumpy", "oren", "plastic0", "floor_s"])
+    cases["heavy_no_alpha"] = replace(base, ["lace"])  # every heavy closure, no alpha-tested surface: the non-alpha wavefront kernels
     if len(sys.argv) > 2:
         cases = {k: v for k, v in cases.items() if k in sys.argv[2:]}
     r = MegaPathRenderer(0)
