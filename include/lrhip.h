@@ -179,6 +179,17 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
 #define LRHIP_FEAT_WAVEFRONT 1024u
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
 
+/* Scheduling of the lean megakernels (round 4).  The path-pool kernels (csrc/hip/megapool_kernel.h) give every wavefront 128 path
+ * slots in L2-resident records and let its lanes work through them -- full waves in the shading block, job turnover inside the
+ * traversal loop, work items overlapping inside a wave -- and accumulate the film in 64-bit fixed point, so that films are
+ * bit-reproducible under ANY sharding, grid size and work-item partition.  They serve every scene the lean kernels serve (basic
+ * closures and Disney inline, the wavefront-mode passes); a frame whose sums do not fit fixed point (film clamp x spp beyond 2^37, a
+ * non-finite clamp) and the variants with out-of-line closures / sibling integrators / media run on the one-path-per-lane kernels.
+ *   mode  0 = automatic (default), 1 = one path per lane everywhere (the round 1-3 kernels: A/B, tests)
+ * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
+#define LRHIP_FEAT_POOL 4096u
+int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);
+
 const char *lrhip_last_error(void);
 
 #ifdef __cplusplus

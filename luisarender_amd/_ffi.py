@@ -221,5 +221,6 @@ def hip_lib(path: str | None = None) -> C.CDLL:
         lib.lrhip_last_variant.argtypes = [C.c_void_p]
         lib.lrhip_set_diagnostics.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
         lib.lrhip_set_wavefront.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.lrhip_set_scheduler.argtypes = [C.c_void_p, C.c_uint32]
         lib._lr_ready = True
     return lib

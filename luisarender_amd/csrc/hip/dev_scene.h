@@ -139,6 +139,7 @@ struct WfArgs {
     uint32_t capacity;           // records per queue (>= paths of one slice: a path is parked at most once per round)
     unsigned long long *accum;   // fixed-point radiance sums [pixel][3] of the paths that finish outside their tile's wave
     float accum_scale;           // 2^k: radiance -> fixed point (the film gets accum / 2^k once per lrhip_render)
+    uint32_t count_at_flush;     // pool kernels (megapool_kernel.h): samples are counted when their wave leaves the work item; 0 = when they finish
 };
 
 struct DScene {
@@ -217,6 +218,7 @@ struct RenderArgs {
     // keep the drain at the end of an item (its last paths finish with most lanes idle) rare, small ones at the end keep the tail
     // of the launch (waves out of items while the last ones finish) short.  Uniform chunks: chunk_big_count = chunk_count.
     uint32_t chunk_big_count, chunk_big, chunk_small;
+    float4 *pool;          // pool kernels (megapool_kernel.h): path slots [wave][slot][quad], L2 / Infinity-Cache resident
 };
 
 // item number -> (tile of the range, chunk, sample range) under the chunking above

@@ -156,6 +156,164 @@ LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
 // Geometry::_alpha_skip (geometry.cpp:165-192), defined in dev_shade.h next to the texture code
 LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float u, float v);
 
+// What every step of a traversal loop needs of its wave: addresses that do not change over the call.
+struct TravLane {
+    const float4 *tris;
+    const char *node_bytes;
+    uint32_t quarter;          // byte offset of this lane's quarter of a packet (cooperative fetch below)
+    const float4 *mine;        // where this lane finds its own packet in the wave's staging area
+    LR_D static TravLane make(const DScene &scene, const TraversalStack &stack) {
+        const auto lane = threadIdx.x & 63u;
+        // load j: lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j into region j, float4 slot l.  Lane o therefore finds
+        // its own packet in region (o & 3), slots 4 (o >> 2) .. + 3, in order
+        return TravLane{reinterpret_cast<const float4 *>(scene.bvh_tris), reinterpret_cast<const char *>(scene.nodes), (lane & 3u) << 4u,
+                        stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u};
+    }
+};
+
+// ---- node step of the WAVE (every lane calls; `is_inner` lanes test the packet of tr.cur): cooperative packet fetch, quantised slab
+// tests, near -> far ordering, pushes.  `deep`: some lane may reach the HBM overflow area of the stack in this iteration.
+template<bool COUNT>
+LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(1))) const void global_void;
+    // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
+    // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
+    auto want = is_inner ? tr.cur : 0u;
+#define LR_FETCH(j) { \
+        const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, false)); /* quad_perm:[j,j,j,j] */ \
+        __builtin_amdgcn_global_load_lds((global_void *)(tl.node_bytes + ((w << 6u) | tl.quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
+    LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
+#undef LR_FETCH
+    __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const auto mine = tl.mine;
+    auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
+    const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + 3));// q3 = child[4] stays in LDS
+    if (is_inner) {
+        if (COUNT) { stats.nodes++; }
+#ifdef LR_PROBE_NODE
+        {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
+            float dummy = tr.t_min;
+#pragma unroll
+            for (auto i = 0; i < LR_PROBE_NODE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+            asm volatile("" ::"v"(dummy));
+        }
+#endif
+        // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
+        //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
+        // An EMPTY slot has inverted planes (lo 255, hi 0) and names the scene's sentinel leaf (a triangle nothing hits,
+        // lrhip.hip: quantise_node), so it needs no test of its own: it fails the slab test wherever the node has an extent
+        // and costs one wasted triangle test where it has none.
+        auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
+        auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
+        auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+        auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+        uint32_t key[4];
+        // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis.  (Bit selects on
+        // a per-ray sign mask, six v_bfi_b32 instead of three v_cmp + six v_cndmask, were measured in round 3 -- the issue-cost
+        // table has the second v_cndmask behind one v_cmp at ~14 cycles -- and changed nothing: 836.3 / 836.7 vs 834.8 / 836.3.)
+        auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
+        auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
+        auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
+#pragma unroll
+        for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
+            auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),
+                            vmax2(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
+            auto tf = vmin3(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by),
+                            vmin2(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
+            auto h = tn <= tf * 1.0000004f;
+            key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
+        }
+        // (the slot kept in the key as a byte offset, slot * 4 in four key bits, saves the shift: measured, no change)
+        auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
+        // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
+        cswap(key[0], key[1]);
+        cswap(key[2], key[3]);
+        cswap(key[0], key[2]);
+        cswap(key[1], key[3]);
+        cswap(key[1], key[2]);
+        // push far -> near so that the nearest is popped first; keep the nearest in `cur`
+        if (deep) {
+            if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
+            if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
+            if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
+        } else {
+            if (key[3] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[3])); }
+            if (key[2] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[2])); }
+            if (key[1] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[1])); }
+        }
+        if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
+        if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
+        else if (tr.sp > 0u) { tr.cur = deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp); }
+        else { tr.cur = kInvalid; }
+    }
+    // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
+    __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- leaf step of a lane standing at a leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds
+// one-triangle leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
+// of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
+// (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
+template<bool COUNT, bool ALPHA>
+LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats) {
+    auto found = false;
+    {
+        auto tb = tl.tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
+        auto a = tb[0], b = tb[1], c = tb[2];
+        if (COUNT) { stats.tris++; }
+#ifdef LR_PROBE_LEAF
+        {
+            float dummy = tr.t_min;
+#pragma unroll
+            for (auto i = 0; i < LR_PROBE_LEAF; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+            asm volatile("" ::"v"(dummy));
+        }
+#endif
+        auto flags = __float_as_uint(c.w);
+        f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+        auto pvec = cross(tr.d, e2);
+        auto det = dot(e1, pvec);
+#ifdef LR_EXACT_LEAF
+        auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
+#else
+        auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
+#endif
+        auto tvec = tr.o - p0;
+        auto u = dot(tvec, pvec) * inv_det;
+        auto qvec = cross(tvec, e1);
+        auto v = dot(tr.d, qvec) * inv_det;
+        auto t = dot(e2, qvec) * inv_det;
+        auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
+        if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
+            tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
+            tr.phase |= kPhasePendingAlpha;
+            ok = false;
+        }
+        if (ok) {
+            tr.t_max = t;
+            found = true;
+            if (tr.phase == kPhaseClosest) {
+                tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
+                tr.hit.u = u, tr.hit.v = v;
+                tr.hit.tri = tr.cur & ((1u << 27u) - 1u);
+            }
+        }
+    }
+    if (tr.phase == kPhaseShadow && found) {
+        tr.occluded = true;
+        tr.sp = 0u;// any-hit: drop the rest of the stack
+    }
+    if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
+        tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid;
+    }
+}
+
 // Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`
 // lanes have finished theirs.  A lane in kPhaseShadow that finishes switches to `next_closest`
 // (if has_next) without leaving the loop.  Must be called by all 64 lanes.
@@ -169,16 +327,7 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
 template<bool COUNT, bool ALPHA>
 LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravState &tr, bool has_next,
                       const Ray &next_closest, int refill, TraceStats &stats, bool idle_at_entry) {
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    typedef __attribute__((address_space(1))) const void global_void;
-    const auto lane = threadIdx.x & 63u;
-    const auto tris = reinterpret_cast<const float4 *>(scene.bvh_tris);
-    // load j: lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j into region j, float4 slot l.  Lane o therefore finds
-    // its own packet in region (o & 3), slots 4 (o >> 2) .. + 3, in order
-    const auto node_bytes = reinterpret_cast<const char *>(scene.nodes);
-    const auto quarter = (lane & 3u) << 4u;
-    const auto mine = stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u;
+    const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
@@ -188,139 +337,8 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
         // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
         const auto deep = __any(live && tr.sp + 3u > kStackLds);
-        if (__any(is_inner)) {
-            // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
-            // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
-            auto want = is_inner ? tr.cur : 0u;
-#define LR_FETCH(j) { \
-                const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, false)); /* quad_perm:[j,j,j,j] */ \
-                __builtin_amdgcn_global_load_lds((global_void *)(node_bytes + ((w << 6u) | quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
-            LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
-#undef LR_FETCH
-            __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
-            const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + 3));// q3 = child[4] stays in LDS
-            if (is_inner) {
-                if (COUNT) { stats.nodes++; }
-#ifdef LR_PROBE_NODE
-                {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
-                    float dummy = tr.t_min;
-#pragma unroll
-                    for (auto i = 0; i < LR_PROBE_NODE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
-                    asm volatile("" ::"v"(dummy));
-                }
-#endif
-                // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
-                //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
-                // An EMPTY slot has inverted planes (lo 255, hi 0) and names the scene's sentinel leaf (a triangle nothing hits,
-                // lrhip.hip: quantise_node), so it needs no test of its own: it fails the slab test wherever the node has an extent
-                // and costs one wasted triangle test where it has none.
-                auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
-                auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
-                auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
-                auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-                uint32_t key[4];
-                // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis.  (Bit selects on
-                // a per-ray sign mask, six v_bfi_b32 instead of three v_cmp + six v_cndmask, were measured in round 3 -- the issue-cost
-                // table has the second v_cndmask behind one v_cmp at ~14 cycles -- and changed nothing: 836.3 / 836.7 vs 834.8 / 836.3.)
-                auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
-                auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
-                auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
-#pragma unroll
-                for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
-                    auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),
-                                    vmax2(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
-                    auto tf = vmin3(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by),
-                                    vmin2(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
-                    auto h = tn <= tf * 1.0000004f;
-                    key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
-                }
-                // (the slot kept in the key as a byte offset, slot * 4 in four key bits, saves the shift: measured, no change)
-                auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
-                // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
-                cswap(key[0], key[1]);
-                cswap(key[2], key[3]);
-                cswap(key[0], key[2]);
-                cswap(key[1], key[3]);
-                cswap(key[1], key[2]);
-                // push far -> near so that the nearest is popped first; keep the nearest in `cur`
-                if (deep) {
-                    if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
-                    if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
-                    if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
-                } else {
-                    if (key[3] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[3])); }
-                    if (key[2] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[2])); }
-                    if (key[1] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[1])); }
-                }
-                if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
-                if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
-                else if (tr.sp > 0u) { tr.cur = deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp); }
-                else { tr.cur = kInvalid; }
-            }
-            // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
-            __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds one-triangle
-        // leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
-        // of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
-        // (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
-        if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
-            auto found = false;
-            {
-                auto tb = tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
-                auto a = tb[0], b = tb[1], c = tb[2];
-                if (COUNT) { stats.tris++; }
-#ifdef LR_PROBE_LEAF
-                {
-                    float dummy = tr.t_min;
-#pragma unroll
-                    for (auto i = 0; i < LR_PROBE_LEAF; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
-                    asm volatile("" ::"v"(dummy));
-                }
-#endif
-                auto flags = __float_as_uint(c.w);
-                f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-                auto pvec = cross(tr.d, e2);
-                auto det = dot(e1, pvec);
-#ifdef LR_EXACT_LEAF
-                auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
-#else
-                auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
-#endif
-                auto tvec = tr.o - p0;
-                auto u = dot(tvec, pvec) * inv_det;
-                auto qvec = cross(tvec, e1);
-                auto v = dot(tr.d, qvec) * inv_det;
-                auto t = dot(e2, qvec) * inv_det;
-                auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
-                if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
-                    tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
-                    tr.phase |= kPhasePendingAlpha;
-                    ok = false;
-                }
-                if (ok) {
-                    tr.t_max = t;
-                    found = true;
-                    if (tr.phase == kPhaseClosest) {
-                        tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
-                        tr.hit.u = u, tr.hit.v = v;
-                        tr.hit.tri = tr.cur & ((1u << 27u) - 1u);
-                    }
-                }
-            }
-            if (tr.phase == kPhaseShadow && found) {
-                tr.occluded = true;
-                tr.sp = 0u;// any-hit: drop the rest of the stack
-            }
-            if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
-                tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid;
-            }
-        }
+        if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
+        if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
         // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
         if (live && tr.cur == kInvalid) {
             if (tr.phase == kPhaseShadow && has_next) {

@@ -16,6 +16,8 @@ enum : uint32_t {
     // queues for the heavy-closure kernel (heavy_kernel.h) instead of shading them; kFeatCont = its continuation pass, whose work
     // items are the records the heavy kernel wrote (next ray + shadow ray) instead of camera samples
     kFeatWf = 1024u, kFeatCont = 2048u,
+    // round 4: the path-pool scheduler (megapool_kernel.h) instead of one path per lane; exists for the lean masks and the wavefront passes
+    kFeatPool = 4096u,
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 
@@ -32,22 +34,33 @@ LR_D void film_accumulate(float4 *pixel, f3 rgb, float clamp) {
     }
 }
 
+// Radiance -> 64-bit FIXED POINT (two's complement in an unsigned word: sums wrap exactly, so negative samples -- the Mitchell and
+// Lanczos filters have negative lobes, filter.cpp:49-64 weight = f / pdf -- add like any other; round 3 clamped them to zero).
+// `scale` is a power of two (WfArgs::accum_scale): the product is exact in fp64, the conversion rounds to nearest.
+LR_D unsigned long long radiance_to_fixed(float v, float scale) {
+    return static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(v) * static_cast<double>(scale)));
+}
+
 // The same for a path that finishes OUTSIDE the wave that owns its tile (a path that was parked at a heavy hit: it ends in the
-// continuation pass or in the heavy kernel, in whatever wave picked its record up).  The order of these adds is a race between
-// waves, so they are made order-independent: the radiance goes into 64-bit FIXED-POINT sums (integer atomics: associative, the
-// film stays bit-reproducible run to run and under any tile sharding) and the sample count into the film's own w (an integer below
-// 2^24: exact in fp32 in any order).  lrhip_render adds accum / scale to the film once, after the last round.
+// continuation pass or in the heavy kernel, in whatever wave picked its record up; round 4: a straggler of a work item its wave has
+// already left, megapool_kernel.h).  The order of these adds is a race between waves, so they are made order-independent: the
+// radiance goes into 64-bit FIXED-POINT sums (integer atomics: associative, the film stays bit-reproducible run to run and under
+// any tile sharding) and the sample count into the film's own w (an integer below 2^24: exact in fp32 in any order).
+// lrhip_render adds accum / scale to the film once, after the last round.
+// WfArgs::count_at_flush (the pool kernels): the wave that owned the sample's work item has already counted it when it left the
+// item; a REJECTED sample (NaN / Inf, color.cpp:110-113) takes its count back instead.
 LR_D void wf_film_accumulate(const DScene &scene, float4 *film, uint32_t pixel_index, f3 rgb, float clamp) {
     if (!(any_nan(rgb) || any_inf(rgb))) {
         auto threshold = clamp * fmaxf(1.f, 1.f);
         auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
         auto c = rgb * (threshold / fmaxf(strength, threshold));
         auto acc = scene.wf.accum + static_cast<size_t>(pixel_index) * 3u;
-        auto fixed = [&](float v) { return static_cast<unsigned long long>(static_cast<double>(fmaxf(v, 0.f)) * static_cast<double>(scene.wf.accum_scale) + 0.5); };
-        if (c.x != 0.f) { atomicAdd(acc + 0, fixed(c.x)); }
-        if (c.y != 0.f) { atomicAdd(acc + 1, fixed(c.y)); }
-        if (c.z != 0.f) { atomicAdd(acc + 2, fixed(c.z)); }
-        atomicAdd(&film[pixel_index].w, 1.f);
+        if (c.x != 0.f) { atomicAdd(acc + 0, radiance_to_fixed(c.x, scene.wf.accum_scale)); }
+        if (c.y != 0.f) { atomicAdd(acc + 1, radiance_to_fixed(c.y, scene.wf.accum_scale)); }
+        if (c.z != 0.f) { atomicAdd(acc + 2, radiance_to_fixed(c.z, scene.wf.accum_scale)); }
+        if (scene.wf.count_at_flush == 0u) { atomicAdd(&film[pixel_index].w, 1.f); }
+    } else if (scene.wf.count_at_flush != 0u) {
+        atomicAdd(&film[pixel_index].w, -1.f);
     }
 }
 
@@ -84,5 +97,16 @@ LR_D uint32_t wf_reserve(uint32_t *counter, unsigned long long mask, uint32_t la
     base = static_cast<uint32_t>(__shfl(static_cast<int>(base), static_cast<int>(leader)));
     return base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
+
+// Work distribution: ONE atomic counter over the item space (tiles x sample-chunks, tile-major).  The 4096 resident waves then work
+// on a moving front of ~300 neighbouring tiles, so every XCD's L2 already holds the front's BVH lines; per-XCD item ranges were
+// measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/r02b_ab_xcd_waves.txt).
+LR_D uint32_t next_item(uint32_t *counter, uint32_t item_count, uint32_t lane) {
+    uint32_t item = 0u;
+    if (lane == 0u) { item = atomicAdd(counter, 1u); }
+    item = __shfl(item, 0);
+    return item < item_count ? item : kInvalid;
+}
+
 
 }// namespace lrd

@@ -31,9 +31,10 @@ __global__ void wf_resolve_kernel(float4 *film, unsigned long long *accum, uint3
     auto a = accum + static_cast<size_t>(i) * 3u;
     if ((a[0] | a[1] | a[2]) == 0ull) { return; }
     auto v = film[i];
-    v.x += static_cast<float>(static_cast<double>(a[0]) * inv_scale);
-    v.y += static_cast<float>(static_cast<double>(a[1]) * inv_scale);
-    v.z += static_cast<float>(static_cast<double>(a[2]) * inv_scale);
+    // (signed sums: dev_wavefront.h radiance_to_fixed)
+    v.x += static_cast<float>(static_cast<double>(static_cast<long long>(a[0])) * inv_scale);
+    v.y += static_cast<float>(static_cast<double>(static_cast<long long>(a[1])) * inv_scale);
+    v.z += static_cast<float>(static_cast<double>(static_cast<long long>(a[2])) * inv_scale);
     film[i] = v;
     a[0] = 0ull, a[1] = 0ull, a[2] = 0ull;
 }

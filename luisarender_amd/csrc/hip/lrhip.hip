@@ -18,6 +18,7 @@
 
 #include "film_kernels.h"
 #include "megapath_kernel.h"
+#include "megapool_kernel.h"
 #include "variants.h"
 
 // one translation unit per precompiled megakernel variant (megapath_variant.hip, -DLR_VARIANT=<mask>); weak, so that
@@ -58,9 +59,11 @@ int find_variant(const VariantEntry *table, size_t n, uint32_t mask) {
     return -1;
 }
 
-// smallest precompiled superset of the scene's feature bits (+ the count / generic-sampler bits, which are exact)
-int pick_variant(uint32_t scene_features, bool count, bool generic) {
+// smallest precompiled superset of the scene's feature bits (+ the count / generic-sampler bits, which are exact) among the
+// variants of one scheduler: `pool` = the path-pool kernels of round 4 (megapool_kernel.h), otherwise the one-path-per-lane kernels
+int pick_variant(uint32_t scene_features, bool count, bool generic, bool pool = false) {
     for (uint32_t i = 0u; i < lrd::kSceneVariantCount; i++) {
+        if (((lrd::kSceneVariants[i] & lrd::kFeatPool) != 0u) != pool) { continue; }
         if ((lrd::kSceneVariants[i] & scene_features) == scene_features) {
             auto mask = lrd::kSceneVariants[i] | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
             for (uint32_t k = 0u; k < lrd::kSceneVariantCount * 4u; k++) {
@@ -131,9 +134,12 @@ struct lrhip_ctx {
     double diag_item_scale{0.};
     // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
     DeviceBuffer wf_heavy, wf_cont, wf_counts, wf_accum;
-    int heavy_blocks[20];// resident blocks per CU of each heavy-kernel variant (-1: not asked yet)
+    int heavy_blocks[sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0])];// resident blocks per CU of each heavy-kernel variant (-1: not asked yet)
     uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never, 2 = automatic with tiny tile groups (tests)
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
+    // round 4: the path-pool scheduler (megapool_kernel.h): slot records of every resident wave; lrhip_set_scheduler
+    DeviceBuffer pool;
+    uint32_t scheduler{0u};      // 0 = automatic (pool kernels where one exists for the scene and the fixed-point film can hold the frame), 1 = one path per lane (rounds 1-3)
 };
 
 namespace {
@@ -358,7 +364,7 @@ void lrhip_destroy(lrhip_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     release_scene(ctx);
     ctx->film_own.release(), ctx->converted.release(), ctx->partial.release();
-    ctx->spill.release(), ctx->wf_heavy.release(), ctx->wf_cont.release(), ctx->wf_counts.release(), ctx->wf_accum.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
+    ctx->spill.release(), ctx->wf_heavy.release(), ctx->wf_cont.release(), ctx->wf_counts.release(), ctx->wf_accum.release(), ctx->pool.release(), ctx->counters.release(), ctx->work_counter.release(), ctx->scene_record.release();
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
@@ -874,6 +880,32 @@ static Chunking chunking_of(uint32_t spp, double shard_tiles, double item_scale,
     return c;
 }
 
+// ---- fixed-point film sums (dev_wavefront.h: radiance_to_fixed; the pool kernels of round 4 and the parked paths of wavefront
+// mode).  One sample adds at most clamp x |shutter weight| per channel and a pixel takes at most `spp` of them in one lrhip_render; the
+// scale is the largest power of two that keeps that sum below 2^61, at most 2^40 (1e-12 of absolute resolution).  Returns log2 of the
+// scale, or -1 when fewer than kMinFixedBits fractional bits would be left -- a clamp used to switch clamping off (1e20, inf): such a
+// film cannot be held in 64-bit fixed point, and lrhip_render takes the float-accumulating kernels of rounds 1-3 instead.
+constexpr int kMinFixedBits = 24;
+int fixed_point_bits(float film_clamp, float shutter_weight, uint32_t spp) {
+    const auto bound = std::max(1.0, static_cast<double>(film_clamp) * std::max(1.0, std::fabs(static_cast<double>(shutter_weight)))) * std::max(1u, spp);
+    if (!std::isfinite(bound)) { return -1; }
+    const auto bits = std::min(40, 61 - static_cast<int>(std::ceil(std::log2(bound))));
+    return bits >= kMinFixedBits ? bits : -1;
+}
+// the frame's fixed-point sums [pixel][rgb], zero between renders (wf_resolve_kernel clears what it adds to the film)
+int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
+    const auto bytes = static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long);
+    if (ctx->wf_accum.bytes < bytes) {
+        if (auto r = ensure(ctx->wf_accum, bytes); r != LRHIP_OK) { return r; }
+        LR_HIP_CHECK(hipMemsetAsync(ctx->wf_accum.ptr, 0, bytes, ctx->stream));
+    }
+    return LRHIP_OK;
+}
+// slot records of the pool kernels: kPoolSlots x (8 | 9) float4 per resident wave (megapool_kernel.h)
+int ensure_pool(lrhip_ctx *ctx, uint32_t resident_blocks) {
+    return ensure(ctx->pool, static_cast<size_t>(resident_blocks) * lrd::kWavesPerBlock * lrd::kPoolSlots * lrd::pool_quads<true>() * sizeof(float4));
+}
+
 // ---- wavefront mode (dev_scene.h: WfArgs): a scene with Mix or Layered surfaces under the MegaPath integrator.  The frame is cut
 // into SLICES of the sample range whose paths fit the queues (a path is parked at most once per round, so a queue never needs more
 // slots than the slice has paths); per slice: the camera pass of the lean megakernel <.. | Wf> (its own work items, chunked by the
@@ -912,16 +944,10 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     if (ctx->wf_counts.ptr == nullptr) {
         if (auto r = ensure(ctx->wf_counts, lrd::kWfCounterWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     }
-    if (ctx->wf_accum.bytes < static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long)) {
-        if (auto r = ensure(ctx->wf_accum, static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long)); r != LRHIP_OK) { return r; }
-        LR_HIP_CHECK(hipMemsetAsync(ctx->wf_accum.ptr, 0, static_cast<size_t>(pixel_count) * 3u * sizeof(unsigned long long), ctx->stream));
-    }
-    // fixed point: one sample adds at most clamp x |shutter weight| per channel and a pixel takes at most `spp` of them in this call;
-    // the scale is the largest power of two that keeps that sum below 2^62 (and at most 2^40: 1e-12 of absolute resolution)
+    if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
     auto &scene = ctx->scene;
     scene.shutter_weight = (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f;
-    const auto bound = std::max(1.0, static_cast<double>(scene.film_clamp) * std::max(1.0, std::fabs(static_cast<double>(scene.shutter_weight)))) * std::max(1u, spp);
-    const auto scale_log2 = std::min(40, std::max(0, 61 - static_cast<int>(std::ceil(std::log2(bound)))));
+    const auto scale_log2 = fixed_point_bits(scene.film_clamp, scene.shutter_weight, spp);// (>= kMinFixedBits: lrhip_render checked)
     const auto accum_scale = std::ldexp(1.0, scale_log2);
     scene.wf.heavy = static_cast<uint32_t *>(ctx->wf_heavy.ptr), scene.wf.cont = static_cast<uint32_t *>(ctx->wf_cont.ptr);
     scene.wf.counts = static_cast<uint32_t *>(ctx->wf_counts.ptr), scene.wf.capacity = capacity;
@@ -929,8 +955,16 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     // kernels: the lean camera pass + continuation pass with the scene's environment / alpha needs, the heavy kernel with its nesting
     // (the alpha-tested traversal only where a surface may be non-opaque: the kitchen stand-in with its lace made opaque runs at 530.6
     // instead of 520.5 Msamples/s on the lean kernels without it, profiles/r03ar_wavefront_without_alpha_ab.txt)
-    const auto lean = (ctx->features & (lrd::kFeatEnv | lrd::kFeatAlpha)) | lrd::kFeatWf | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
+    auto lean = (ctx->features & (lrd::kFeatEnv | lrd::kFeatAlpha)) | lrd::kFeatWf | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
     const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
+    // round 4: both lean passes under the path-pool scheduler (megapool_kernel.h) where those kernels are in the library
+    auto pool = false;
+    if (ctx->scheduler != 1u) {
+        const auto a = find_variant(kVariants, n_variants, lean | lrd::kFeatPool), b = find_variant(kVariants, n_variants, lean | lrd::kFeatPool | lrd::kFeatCont);
+        pool = a >= 0 && b >= 0 && kVariants[a].launch != nullptr && kVariants[b].launch != nullptr;
+    }
+    if (pool) { lean |= lrd::kFeatPool; }
+    scene.wf.count_at_flush = pool ? 1u : 0u;
     const auto vi_camera = find_variant(kVariants, n_variants, lean), vi_cont = find_variant(kVariants, n_variants, lean | lrd::kFeatCont);
     const auto n_heavy = sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0]);
     int hi[lrd::kWfKinds];// the heavy kernel of each closure kind (Disney has no nested form)
@@ -961,6 +995,9 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const bool has_kind[lrd::kWfKinds] = {(ctx->features & lrd::kFeatDisney) != 0u, (ctx->features & lrd::kFeatMix) != 0u, (ctx->features & lrd::kFeatLayered) != 0u};
     const auto resident = ctx->cu_count * static_cast<uint32_t>(std::max(b_camera, b_cont));
     if (auto r = ensure(ctx->spill, static_cast<size_t>(resident) * lrd::kBlockThreads * lrd::kSpillEntries * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+    if (pool) {
+        if (auto r = ensure_pool(ctx, resident); r != LRHIP_OK) { return r; }
+    }
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
     LR_HIP_CHECK(hipMemcpyAsync(ctx->scene_record.ptr, &scene, sizeof(lrd::DScene), hipMemcpyHostToDevice, ctx->stream));
     const auto device_scene = static_cast<const lrd::DScene *>(ctx->scene_record.ptr);
@@ -970,6 +1007,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     args.tiles_x = tiles_x, args.tiles_y = tiles_y;
     args.work_counter = static_cast<uint32_t *>(ctx->work_counter.ptr);
     args.spill = static_cast<uint32_t *>(ctx->spill.ptr);
+    args.pool = static_cast<float4 *>(ctx->pool.ptr);
     args.counters = static_cast<lrd::DCounters *>(ctx->counters.ptr);
     const auto counts = static_cast<uint32_t *>(ctx->wf_counts.ptr);
     const auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
@@ -989,14 +1027,14 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = group_count * chunk_count;
         args.chunk_big_count = ck.big_count, args.chunk_big = ck.big, args.chunk_small = ck.small;
         args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_camera) * lrd::kBlockThreads;
-        if (chunk_count > 1u) {
+        if (chunk_count > 1u && !pool) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
             if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
             args.partial = static_cast<float4 *>(ctx->partial.ptr);
         }
         LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
         LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
         LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
-        if (chunk_count > 1u) {
+        if (chunk_count > 1u && !pool) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                                args.partial, pixel_count, chunk_count, ctx->width, tiles_x, args.tile_begin, args.tile_end, p->tile_stride);
         }
@@ -1044,7 +1082,9 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // Wavefront mode (render_wavefront above) for every MegaPath scene that would otherwise land in an all-in-one variant with
     // out-of-line closures: Mix / Layered surfaces, and Disney together with an alpha test (no lean <Alpha | Disney> variant is
     // precompiled; such a scene ran at 433 Msamples/s on <60> where its Mix-holding sibling ran at 480 in wavefront mode).
-    if (ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+    // (both need the film's fixed-point sums: a frame they cannot hold -- fixed_point_bits -- takes the float-accumulating kernels)
+    const auto fixed_bits = fixed_point_bits(ctx->scene.film_clamp, (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f, spp);
+    if (fixed_bits >= 0 && ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
         const auto plain = pick_variant(ctx->features, false, generic_sampler);
         if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) {
@@ -1074,10 +1114,6 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     args.total_threads = ctx->grid_blocks * lrd::kBlockThreads;
     args.counters = static_cast<lrd::DCounters *>(ctx->counters.ptr);
     auto pixel_count = ctx->width * ctx->height;
-    if (chunk_count > 1u) {
-        if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
-        args.partial = static_cast<float4 *>(ctx->partial.ptr);
-    }
     LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
     auto count = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
     auto generic = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;// generic-sampler instantiation
@@ -1087,6 +1123,13 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // anyway hold -- the ones with the Mix interpreter (the auxiliary and volumetric kernels are such variants already)
     if (ctx->env_tree && (features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) { features |= lrd::kFeatMix; }
     auto vi = pick_variant(features, count, generic);
+    // round 4: the path-pool scheduler (megapool_kernel.h) where a pool kernel is compiled for a scene the legacy search would have given
+    // a lean kernel (no out-of-line closures, no sibling integrator), and the fixed-point film can hold the frame
+    auto pool = false;
+    if (ctx->scheduler != 1u && fixed_bits >= 0 && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        const auto vp = pick_variant(features, count, generic, true);
+        if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { vi = vp, pool = true; }
+    }
     if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +
                                                  " was compiled into this library");
@@ -1098,7 +1141,19 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
+    if (chunk_count > 1u && !pool) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
+        if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
+        args.partial = static_cast<float4 *>(ctx->partial.ptr);
+    }
     auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
+    if (pool) {
+        if (auto r = ensure_pool(ctx, resident); r != LRHIP_OK) { return r; }
+        if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
+        args.pool = static_cast<float4 *>(ctx->pool.ptr);
+        ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
+        ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
+        ctx->scene.wf.count_at_flush = 1u;
+    }
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
@@ -1109,7 +1164,11 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;
-    if (chunk_count > 1u) {
+    if (pool) {// the frame's fixed-point sums join the film (and are cleared for the next call)
+        hipLaunchKernelGGL(lrd::wf_resolve_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
+                           static_cast<unsigned long long *>(ctx->wf_accum.ptr), pixel_count, std::ldexp(1.0, -fixed_bits));
+        LR_HIP_CHECK(hipGetLastError());
+    } else if (chunk_count > 1u) {
         hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                            args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
         LR_HIP_CHECK(hipGetLastError());
@@ -1128,6 +1187,12 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
     const auto tile_count = ((width + 7u) / 8u) * ((height + 7u) / 8u);
     const auto c = chunking_of(spp, static_cast<double>(tile_count) / std::max(balance_shards, 1u), 1.25, true);
     out[0] = c.count, out[1] = c.big_count, out[2] = c.big, out[3] = c.small;
+    return LRHIP_OK;
+}
+
+int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode) {
+    if (ctx == nullptr || mode > 1u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_scheduler: invalid argument"); }
+    ctx->scheduler = mode;
     return LRHIP_OK;
 }
 

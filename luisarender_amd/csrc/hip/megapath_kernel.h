@@ -69,6 +69,21 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatEnv | kFeatWf | kFeatCont,
     kFeatAlpha | kFeatWf | kFeatCont,
     kFeatEnv | kFeatAlpha | kFeatWf | kFeatCont,
+    // round 4: the same lean kernels under the path-pool scheduler (megapool_kernel.h); lrhip_render asks for them by the kFeatPool bit
+    kFeatPool,
+    kFeatPool | kFeatEnv,
+    kFeatPool | kFeatAlpha,
+    kFeatPool | kFeatEnv | kFeatAlpha,
+    kFeatPool | kFeatDisney,
+    kFeatPool | kFeatEnv | kFeatDisney,
+    kFeatPool | kFeatWf,
+    kFeatPool | kFeatEnv | kFeatWf,
+    kFeatPool | kFeatAlpha | kFeatWf,
+    kFeatPool | kFeatEnv | kFeatAlpha | kFeatWf,
+    kFeatPool | kFeatWf | kFeatCont,
+    kFeatPool | kFeatEnv | kFeatWf | kFeatCont,
+    kFeatPool | kFeatAlpha | kFeatWf | kFeatCont,
+    kFeatPool | kFeatEnv | kFeatAlpha | kFeatWf | kFeatCont,
 };
 constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVariants[0]);
 
@@ -105,16 +120,7 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #endif
 constexpr uint32_t min_waves_of(uint32_t f) { return (f & kFeatLayered) ? LR_WAVES_LAYERED : (f & kFeatMix) ? LR_WAVES_MIX : LR_MIN_WAVES; }
 
-// Work distribution: ONE atomic counter over the item space (tiles x sample-chunks, tile-major).  The 4096 resident waves then work
-// on a moving front of ~300 neighbouring tiles, so every XCD's L2 already holds the front's BVH lines; per-XCD item ranges were
-// measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/r02b_ab_xcd_waves.txt).
-LR_D uint32_t next_item(uint32_t *counter, uint32_t item_count, uint32_t lane) {
-    uint32_t item = 0u;
-    if (lane == 0u) { item = atomicAdd(counter, 1u); }
-    item = __shfl(item, 0);
-    return item < item_count ? item : kInvalid;
-}
-
+// (work distribution: dev_wavefront.h next_item)
 template<uint32_t F>
 __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kernel(DScenePtr scene_ptr, RenderArgs args) {
     const DScene &scene = *(const DScene *)scene_ptr;

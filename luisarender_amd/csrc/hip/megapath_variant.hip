@@ -9,6 +9,10 @@
 #if (LR_VARIANT) & 256// kFeatVpt: the volumetric megakernel
 #include "megavpt_kernel.h"
 #define LR_KERNEL megavpt_kernel
+#elif (LR_VARIANT) & 4096// kFeatPool: the path-pool scheduler (round 4)
+#include "megapath_kernel.h"
+#include "megapool_kernel.h"
+#define LR_KERNEL megapool_kernel
 #else
 #include "megapath_kernel.h"
 #define LR_KERNEL megapath_kernel

@@ -21,4 +21,11 @@
     X(3072) X(3073) X(3074) X(3075) /* wavefront mode, continuation pass (kFeatWf | kFeatCont) */ \
     X(3076) X(3077) X(3078) X(3079) /* + environment */ \
     X(3080) X(3081) X(3082) X(3083) /* + alpha test */ \
-    X(3084) X(3085) X(3086) X(3087) /* + environment + alpha test */
+    X(3084) X(3085) X(3086) X(3087) /* + environment + alpha test */ \
+    /* round 4: the path-pool scheduler (megapool_kernel.h, kFeatPool = 4096) for the lean masks ... */ \
+    X(4096) X(4097) X(4098) X(4099) X(4100) X(4101) X(4102) X(4103) X(4104) X(4105) X(4106) X(4107) \
+    X(4108) X(4109) X(4110) X(4111) X(4112) X(4113) X(4114) X(4115) X(4116) X(4117) X(4118) X(4119) \
+    /* ... the wavefront camera pass ... */ \
+    X(5120) X(5121) X(5122) X(5123) X(5124) X(5125) X(5126) X(5127) X(5128) X(5129) X(5130) X(5131) X(5132) X(5133) X(5134) X(5135) \
+    /* ... and the continuation pass */ \
+    X(7168) X(7169) X(7170) X(7171) X(7172) X(7173) X(7174) X(7175) X(7176) X(7177) X(7178) X(7179) X(7180) X(7181) X(7182) X(7183)

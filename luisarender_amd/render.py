@@ -3,6 +3,7 @@ torch is only used by callers that want the film in a tensor (bench.py, multi-GP
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -28,6 +29,8 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_create(device, C.byref(self._ctx)))
         self._scene = None
         self.width = self.height = 0
+        if os.environ.get("LRHIP_SCHEDULER") == "legacy":  # tools / A-B runs only, like LRHIP_LIB: the round 1-3 one-path-per-lane kernels
+            self.set_scheduler(False)
 
     def _check(self, rc: int) -> None:
         if rc != 0:
@@ -131,6 +134,11 @@ class MegaPathRenderer:
         kernel + continuation pass); enabled=False keeps them on the all-in-one megakernel variants (A/B, tests); tiny_tile_groups
         sends eight tiles through the queues at a time (tests: what a GPU short of memory does)"""
         self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
+
+    def set_scheduler(self, pool: bool = True) -> None:
+        """lrhip_set_scheduler: the lean kernels run under the path-pool scheduler of round 4 by default (128 path slots per wavefront,
+        fixed-point film sums); pool=False keeps every scene on the one-path-per-lane kernels of rounds 1-3 (A/B, tests)"""
+        self._check(self._lib.lrhip_set_scheduler(self._ctx, 0 if pool else 1))
 
     def close(self) -> None:
         if self._ctx:

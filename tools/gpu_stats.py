@@ -1,4 +1,4 @@
-"""SIMD-occupancy diagnostics of the megakernel on the bench workload (GPU box)."""
+"""SIMD-occupancy diagnostics of the megakernel on the bench workload (GPU box).  LRHIP_SCHEDULER=legacy: the round 1-3 kernels."""
 import sys, tempfile
 sys.path.insert(0, '.')
 from luisarender_amd import Scene

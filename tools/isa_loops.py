@@ -9,7 +9,7 @@ lines = open(sys.argv[1]).read().split('\n')
 addr, base = {}, None
 for i, l in enumerate(lines):
     m = re.match(r'([0-9a-f]{16}) <(.*)>:', l)
-    if m and ('megapath_kernel' in m.group(2) or 'megavpt_kernel' in m.group(2)):
+    if m and ('megapath_kernel' in m.group(2) or 'megapool_kernel' in m.group(2) or 'megavpt_kernel' in m.group(2)):
         base = int(m.group(1), 16)
     m = re.search(r'//\s+([0-9A-F]{12}):', l)
     if m:
