@@ -179,13 +179,19 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
 #define LRHIP_FEAT_WAVEFRONT 1024u
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
 
-/* Scheduling of the lean megakernels (round 4).  The path-pool kernels (csrc/hip/megapool_kernel.h) give every wavefront 128 path
- * slots in L2-resident records and let its lanes work through them -- full waves in the shading block, job turnover inside the
- * traversal loop, work items overlapping inside a wave -- and accumulate the film in 64-bit fixed point, so that films are
- * bit-reproducible under ANY sharding, grid size and work-item partition.  They serve every scene the lean kernels serve (basic
- * closures and Disney inline, the wavefront-mode passes); a frame whose sums do not fit fixed point (film clamp x spp beyond 2^37, a
- * non-finite clamp) and the variants with out-of-line closures / sibling integrators / media run on the one-path-per-lane kernels.
- *   mode  0 = automatic (default), 1 = one path per lane everywhere (the round 1-3 kernels: A/B, tests)
+/* Scheduling of the lean megakernels (round 4).  The path-pool kernels (csrc/hip/megapool_kernel.h) give every lane TWO path contexts:
+ * while one context's rays are traced the other waits -- for the shading block with its hit, or for the lane with the rays of its
+ * next job -- so that a lane whose job ends goes on with its other context inside the traversal loop (rays and hits in registers,
+ * the 64 bytes of path state in a per-thread record, the ray in flight parked in the LDS while the lane shades).  Work items overlap
+ * inside a wave and the film is summed in 64-bit fixed point: bit-reproducible under ANY sharding, grid size and work-item
+ * partition.  Measured on MI355X (profiles/r04_*): lane utilisation of the traversal loop 0.56 -> 0.91, of the shading block 0.47 ->
+ * 0.61, films equal to the one-path-per-lane kernels' to 8e-8 -- and 11 % SLOWER at four waves per SIMD (the second context's
+ * registers push the shading block into scratch spills, whose traffic evicts the reused BVH levels from the 32 KB vector L1: a node
+ * step takes 4200 cycles instead of 2100), 11 % faster at three.  So they are an option, not the default.  They serve every scene
+ * the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes); a frame whose sums do not fit fixed point
+ * (film clamp x spp beyond 2^37, a non-finite clamp), paths deeper than 65535, and the variants with out-of-line closures / sibling
+ * integrators / media always run on the one-path-per-lane kernels.
+ *   mode  0 = automatic (today: one path per lane), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u
 int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);

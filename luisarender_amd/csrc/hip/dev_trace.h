@@ -245,7 +245,9 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
             if (key[2] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[2])); }
             if (key[1] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[1])); }
         }
+#ifndef LR_TRACE_PROBE
         if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
+#endif
         if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
         else if (tr.sp > 0u) { tr.cur = deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp); }
         else { tr.cur = kInvalid; }
@@ -265,6 +267,7 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
     auto found = false;
     {
         auto tb = tl.tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
+        // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
         auto a = tb[0], b = tb[1], c = tb[2];
         if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF
@@ -330,7 +333,12 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
     for (;;) {
+#ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
+        if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u; }
+        const auto probe_t0 = __builtin_readcyclecounter();
+#else
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
+#endif
         auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
         auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
         // one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in this iteration
@@ -338,7 +346,13 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
         const auto deep = __any(live && tr.sp + 3u > kStackLds);
         if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
+#ifdef LR_TRACE_PROBE
+        const auto probe_t1 = __builtin_readcyclecounter();
+#endif
         if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+#ifdef LR_TRACE_PROBE
+        const auto probe_t2 = __builtin_readcyclecounter();
+#endif
         // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
         if (live && tr.cur == kInvalid) {
             if (tr.phase == kPhaseShadow && has_next) {
@@ -349,6 +363,12 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             }
         }
         auto in_flight = __ballot(tr.phase != kPhaseIdle);
+#ifdef LR_TRACE_PROBE
+        if (COUNT && (threadIdx.x & 63u) == 0u) {
+            stats.nodes_empty += static_cast<uint32_t>(probe_t1 - probe_t0);
+            stats.steps_starved += static_cast<uint32_t>(__builtin_readcyclecounter() - probe_t2);
+        }
+#endif
         if (in_flight == 0ull) { break; }
         if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
         auto finished = __ballot(tr.phase == kPhaseIdle && !idle_at_entry);

@@ -36,9 +36,11 @@ LR_D void film_accumulate(float4 *pixel, f3 rgb, float clamp) {
 
 // Radiance -> 64-bit FIXED POINT (two's complement in an unsigned word: sums wrap exactly, so negative samples -- the Mitchell and
 // Lanczos filters have negative lobes, filter.cpp:49-64 weight = f / pdf -- add like any other; round 3 clamped them to zero).
-// `scale` is a power of two (WfArgs::accum_scale): the product is exact in fp64, the conversion rounds to nearest.
+// `scale` is a power of two (WfArgs::accum_scale): the product is exact, the conversion rounds to nearest.
 LR_D unsigned long long radiance_to_fixed(float v, float scale) {
-    return static_cast<unsigned long long>(__double2ll_rn(static_cast<double>(v) * static_cast<double>(scale)));
+    // (the product is exact -- a power of two -- and rintf leaves an integer-valued float: the conversion truncates nothing.  In fp32
+    // throughout: the fp64 form cost the pool kernel 24 spilled VGPRs in the middle of its shading block)
+    return static_cast<unsigned long long>(static_cast<long long>(rintf(v * scale)));
 }
 
 // The same for a path that finishes OUTSIDE the wave that owns its tile (a path that was parked at a heavy hit: it ends in the

@@ -102,7 +102,10 @@ struct DeviceBuffer {
 // chunking (and therefore the fp32 summation order of the film) is identical on every GPU
 constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
 constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
-constexpr uint32_t kMaxBlocksPerCu = 8u; // resident 256-thread blocks per CU the persistent grid may use
+#ifndef LR_MAX_BLOCKS_PER_CU
+#define LR_MAX_BLOCKS_PER_CU 8
+#endif
+constexpr uint32_t kMaxBlocksPerCu = LR_MAX_BLOCKS_PER_CU; // resident 256-thread blocks per CU the persistent grid may use (-D: A/B builds)
 
 }// namespace
 
@@ -139,7 +142,7 @@ struct lrhip_ctx {
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
     // round 4: the path-pool scheduler (megapool_kernel.h): slot records of every resident wave; lrhip_set_scheduler
     DeviceBuffer pool;
-    uint32_t scheduler{0u};      // 0 = automatic (pool kernels where one exists for the scene and the fixed-point film can hold the frame), 1 = one path per lane (rounds 1-3)
+    uint32_t scheduler{0u};      // lrhip_set_scheduler: 0 = automatic (today: one path per lane everywhere), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
 };
 
 namespace {
@@ -959,12 +962,13 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
     // round 4: both lean passes under the path-pool scheduler (megapool_kernel.h) where those kernels are in the library
     auto pool = false;
-    if (ctx->scheduler != 1u) {
+    if (ctx->scheduler == 2u) {
         const auto a = find_variant(kVariants, n_variants, lean | lrd::kFeatPool), b = find_variant(kVariants, n_variants, lean | lrd::kFeatPool | lrd::kFeatCont);
         pool = a >= 0 && b >= 0 && kVariants[a].launch != nullptr && kVariants[b].launch != nullptr;
     }
     if (pool) { lean |= lrd::kFeatPool; }
-    scene.wf.count_at_flush = pool ? 1u : 0u;
+    scene.wf.count_at_flush = pool && LR_POOL_OVERLAP ? 1u : 0u;
+    const auto pool_film = pool && LR_POOL_OVERLAP;// the camera pass sums its tiles into the frame's fixed-point sums: no partial planes
     const auto vi_camera = find_variant(kVariants, n_variants, lean), vi_cont = find_variant(kVariants, n_variants, lean | lrd::kFeatCont);
     const auto n_heavy = sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0]);
     int hi[lrd::kWfKinds];// the heavy kernel of each closure kind (Disney has no nested form)
@@ -1027,14 +1031,14 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         args.spp_begin = s0, args.spp_end = s1, args.chunk_count = chunk_count, args.item_count = group_count * chunk_count;
         args.chunk_big_count = ck.big_count, args.chunk_big = ck.big, args.chunk_small = ck.small;
         args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_camera) * lrd::kBlockThreads;
-        if (chunk_count > 1u && !pool) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
+        if (chunk_count > 1u && !pool_film) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
             if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
             args.partial = static_cast<float4 *>(ctx->partial.ptr);
         }
         LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
         LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
         LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
-        if (chunk_count > 1u && !pool) {
+        if (chunk_count > 1u && !pool_film) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                                args.partial, pixel_count, chunk_count, ctx->width, tiles_x, args.tile_begin, args.tile_end, p->tile_stride);
         }
@@ -1126,7 +1130,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // round 4: the path-pool scheduler (megapool_kernel.h) where a pool kernel is compiled for a scene the legacy search would have given
     // a lean kernel (no out-of-line closures, no sibling integrator), and the fixed-point film can hold the frame
     auto pool = false;
-    if (ctx->scheduler != 1u && fixed_bits >= 0 && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+    if (ctx->scheduler == 2u && fixed_bits >= 0 && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto vp = pick_variant(features, count, generic, true);
         if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { vi = vp, pool = true; }
     }
@@ -1141,18 +1145,21 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
-    if (chunk_count > 1u && !pool) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
+    const auto pool_film = pool && LR_POOL_OVERLAP;
+    if (chunk_count > 1u && !pool_film) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
         if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
         args.partial = static_cast<float4 *>(ctx->partial.ptr);
     }
     auto blocks = std::min(resident, (args.item_count + 3u) / 4u);
     if (pool) {
         if (auto r = ensure_pool(ctx, resident); r != LRHIP_OK) { return r; }
-        if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
         args.pool = static_cast<float4 *>(ctx->pool.ptr);
-        ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
-        ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
-        ctx->scene.wf.count_at_flush = 1u;
+        if (LR_POOL_OVERLAP) {// the frame's fixed-point sums (megapool_kernel.h: FILM)
+            if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
+            ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
+            ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
+            ctx->scene.wf.count_at_flush = 1u;
+        }
     }
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns
@@ -1164,7 +1171,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;
-    if (pool) {// the frame's fixed-point sums join the film (and are cleared for the next call)
+    if (pool_film) {// the frame's fixed-point sums join the film (and are cleared for the next call)
         hipLaunchKernelGGL(lrd::wf_resolve_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                            static_cast<unsigned long long *>(ctx->wf_accum.ptr), pixel_count, std::ldexp(1.0, -fixed_bits));
         LR_HIP_CHECK(hipGetLastError());
@@ -1191,7 +1198,7 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
 }
 
 int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode) {
-    if (ctx == nullptr || mode > 1u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_scheduler: invalid argument"); }
+    if (ctx == nullptr || mode > 2u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_scheduler: invalid argument"); }
     ctx->scheduler = mode;
     return LRHIP_OK;
 }

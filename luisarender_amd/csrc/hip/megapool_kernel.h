@@ -1,24 +1,33 @@
-// megapool_kernel.h — round 4: the persistent-threads megakernel with a PATH POOL per wavefront.
+// megapool_kernel.h — round 4: the persistent-threads megakernel with a PATH POOL: two path contexts per lane.
 //
 // megapath_kernel.h (rounds 1-3) binds one path to one lane: a lane whose ray has finished waits, idle, until enough of its
 // neighbours have finished too (the refill threshold), and the shading block then runs for the ~half of the wave that has
 // something to shade.  Measured on the C2 stand-in (profiles/r03am_*): 56 % of the traversal loop's lane-steps and 47 % of the
 // shading block's lanes did useful work while the VALU pipes were ~full -- the machine was busy computing masked-off lanes.
 //
-// Here a wave owns kPoolSlots = 128 PATH SLOTS -- twice its lanes -- whose state lives in a wave-private 16 KB record array in
-// global memory (one 128-byte line per slot: rays to trace, throughput, radiance, sampler position, hit), i.e. in L2 / Infinity
-// Cache, and lanes are workers:
-//   * a slot with rays to trace (its shadow ray and / or its next path segment: one JOB) waits in the wave's RAY QUEUE, a slot whose
-//     job is done waits in the SHADE QUEUE; both are FIFOs of slot numbers in LDS, filled and drained with ballot + prefix counts
-//     (wave-private: no atomics);
-//   * in the traversal loop a lane that finishes its job RETIRES it (hit -> slot, slot -> shade queue) and takes the next job off
-//     the ray queue without leaving the loop, in batches of LR_POOL_REFILL lanes; the loop is left when the ray queue is dry and
-//     lanes begin to idle -- by then at least 64 slots wait in the shade queue (128 slots - at most 64 in flight);
-//   * the shading block takes 64 slots off the shade queue -- a FULL wave, whatever the lanes' own rays are doing (a lane keeps its
-//     ray in flight in its registers while it shades another slot's vertex) -- and every slot leaves it with a new job: the path's
-//     next rays, or the first ray of the next sample of the work item (path regeneration, as before).
-// The scheduling model (tools/sched_model.py, calibrated on the round-3 counters): lane utilisation of the traversal loop 0.70 -> 0.95,
-// of the shading block 0.63 -> 1.0, cost per job 0.89 -> 0.65.
+// Here a wave holds 128 paths, two CONTEXTS per lane.  While one context's rays are traced the other one waits -- for the shading
+// block with its hit, or for the lane with the rays of its next job -- and when a lane's job ends it switches to its other
+// context's rays INSIDE the traversal loop, registers to registers:
+//   * what the traversal loop needs of a waiting context -- the job's rays (shadow ray + next path segment, 15 words) or its hit (4
+//     words) -- lives in REGISTERS.  The loop runs in ~75 of the kernel's 128 VGPRs (the shading block sets the allocation), so
+//     the second context costs the loop nothing, and a job turnover is a handful of v_mov: no memory, no LDS, no queue;
+//   * what only the shading block needs of a path -- throughput, radiance, NEE term, bsdf pdf, depth, sampler position, pixel: 16
+//     words -- lives in a per-thread record in global memory, [context][quad][thread]: four coalesced 16-byte loads when the
+//     context is shaded, four stores when it leaves, ONE round trip per shading batch;
+//   * the wave leaves the traversal loop when LR_POOL_SHADE_LANES lanes hold a context to shade (or LR_POOL_IDLE_LANES of them have
+//     nothing left to trace); a lane shades ONE context per batch, its ray in flight parked in the packet staging area of the
+//     LDS (idle outside the traversal loop) so that the shading block keeps its registers.
+// The scheduling model (tools/sched_model.py, calibrated on the round-3 counters: it reproduces their 0.70 / 0.63 lane utilisation of
+// the traversal loop / the shading block without the item drain) gives 0.92 / 0.76 and 0.79 of the cost per job.
+//
+// MEASURED AND NOT KEPT (profiles/r04a-c_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
+// shade queues of slot numbers in LDS, lanes fetching their next job from the ray queue inside the loop.  It filled the lanes (0.93 /
+// 0.79, 23 % fewer VALU instructions per sample, films equal to 6e-8) and was no faster: C2 830 against 854 Msamples/s at 256 spp,
+// C1 2420 against 4820.  Every job turnover read and wrote slot records whose lines the 4 MiB L2 of an XCD had long dropped (8 MiB of
+// slots per XCD, the BVH streaming through): 2.4 TB/s of extra fabric traffic, and -- loads return in order -- every one of those
+// reads held up the whole wave's next packet fetch (wave cycles waiting 0.50 -> 0.63).  Requesting the rays an iteration ahead
+// (+5 %), full-line stores through the LDS (-4 %), non-temporal hints (-29 %), fewer waves (-19 %) did not change the picture: the
+// rays must not leave the chip.
 //
 // FILM.  With lanes no longer bound to pixels and WORK ITEMS OVERLAPPING inside a wave (when an item's sample queue runs dry the wave
 // takes the next item at once; the old item's last paths finish beside the new item's first -- no drain), the order of a pixel's
@@ -31,7 +40,7 @@
 // (NaN / Inf, color.cpp:110-113) takes its count back.
 //
 // The estimator is the reference's MegakernelPathTracingInstance::Li (src/integrators/mega_path.cpp:49-156) exactly as in
-// megapath_kernel.h -- the shading block below is that file's, reading a slot instead of the lane's registers -- and the wavefront-mode
+// megapath_kernel.h -- the shading block below is that file's, working on a context instead of the lane -- and the wavefront-mode
 // roles of that kernel (kFeatWf camera pass: heavy hits parked for heavy_kernel.h; kFeatCont: continuation records instead of
 // camera samples) carry over unchanged.
 #pragma once
@@ -42,132 +51,162 @@ namespace lrd {
 #ifndef LR_MIN_WAVES
 #define LR_MIN_WAVES 4
 #endif
-#ifndef LR_POOL_SLOTS
-#define LR_POOL_SLOTS 128
+#ifndef LR_POOL_CONTEXTS
+#define LR_POOL_CONTEXTS 2   // path contexts per lane.  1 = the round 1-3 scheduling (one path per lane, its state in registers) with this
+#endif                       // kernel's overlapping work items and fixed-point film: no second context, no state records, no LDS parking
+#if LR_POOL_CONTEXTS == 1
+#define LR_POOL_SINGLE 1
 #endif
-#ifndef LR_POOL_REFILL
-#define LR_POOL_REFILL 8   // idle lanes that trigger a retire + fetch round inside the traversal loop
+#ifndef LR_POOL_OVERLAP
+#define LR_POOL_OVERLAP 1    // 1: work items overlap inside a wave and the film is summed in fixed point (FILM above); 0: a wave finishes its
+#endif                       // item before it takes the next and sums its tile in fp32 like the round 1-3 kernel (deterministic: see below)
+#ifndef LR_POOL_SHADE_LANES
+#define LR_POOL_SHADE_LANES (LR_POOL_CONTEXTS == 1 ? 64 : 56)// lanes with a context to shade that end the traversal loop
 #endif
-#ifndef LR_POOL_MIN_READY
-#define LR_POOL_MIN_READY 16// (tail of a launch, pool no longer full) slots that must wait for shading before the traversal loop is left for them
+#ifndef LR_POOL_IDLE_LANES
+#define LR_POOL_IDLE_LANES (LR_POOL_CONTEXTS == 1 ? 40 : 16) // ... or lanes with a context to shade and nothing left to trace
 #endif
-constexpr uint32_t kPoolSlots = LR_POOL_SLOTS;
-static_assert((kPoolSlots & (kPoolSlots - 1u)) == 0u && kPoolSlots >= 64u && kPoolSlots <= 256u, "slots per wave: a power of two, one byte");
+constexpr uint32_t kPoolSlots = 128u;// paths per wave: two contexts per lane
 
-// ---- slot record: kPoolQuads x float4 (lean sampler: one 128-byte line)
-//   0  shadow o.xyz | shadow t_max          1  shadow d.xyz | pixel index (frame)
-//   2  next ray o.xyz | t_max               3  next ray d.xyz | t_min
-//   4  nee.xyz | pdf_bsdf                   5  beta.xyz | depth (16) | pixel in tile (6) << 16 | job had shadow << 22 | closest << 23
-//   6  Li.xyz | sampler word 0              7  hit: tri | occluded << 31 (miss: tri = 0x7fffffff), u, v | work item of the path
-//   8  sampler words 1-3 (generic sampler only)
-// Quads 0-3 are what a lane reads when it takes the job (both rays in ONE format), 7.xyz what it writes when it retires it.
-constexpr uint32_t kPoolMiss = 0x7fffffffu;
+// ---- path state of one context in global memory: kPoolQuads float4 at [context][quad][thread]
+//   0  nee.xyz | pdf_bsdf        1  beta.xyz | depth (16) | pixel in tile (6) << 16
+//   2  Li.xyz | sampler word 0   3  pixel index (frame) | work item of the path | sampler words 1-2
+//   4  sampler word 3 (generic sampler only)
 template<bool GENERIC>
-constexpr uint32_t pool_quads() { return GENERIC ? 9u : 8u; }
-// job word (ray queue entry, lane register): slot | rays still to trace
-enum : uint32_t { kJobSlotMask = 0xffu, kJobShadow = 1u << 8u, kJobClosest = 1u << 9u, kNoJob = 0xffffffffu };
+constexpr uint32_t pool_quads() { return GENERIC ? 5u : 4u; }
 
-struct PoolWave {// the wave's queues (wave-uniform: SGPRs); heads run free, entries live at (index & (kPoolSlots - 1))
-    uint32_t rq_head, rq_count;// ray queue: slots with a job
-    uint32_t sq_head, sq_count;// shade queue: slots whose job is done
+// ---- one of a lane's two path contexts as the traversal loop sees it (registers)
+enum : uint32_t {
+    kCtxShadow = 1u, kCtxClosest = 2u,     // rays of the job still to trace
+    kCtxHadShadow = 4u, kCtxHadClosest = 8u,// what the job held (the shading block consumes the results accordingly)
+    kCtxDone = 16u,                        // the job is traced: hit / occluded are valid, the context waits for the shading block
+    kCtxOccluded = 32u,
+    kCtxSide = 64u,                        // which of the thread's two state records belongs to this context
+    kCtxOpen = 128u,                       // holds a path (else: empty, takes the next sample)
 };
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
+struct PathCtx {
+    f3 so, sd;        // shadow ray (t_min 0)
+    float s_tmax;
+    f3 no, nd;        // the path's next segment; kept until the shading block reads them back as the segment that was traced
+    float n_tmin, n_tmax;
+    uint32_t tri;     // hit of the segment (kInvalid: miss)
+    float u, v;
+    uint32_t flags;
+};
+// the first ray of a context's job into the lane's traversal state
+LR_D void ctx_start(PathCtx &c, TravState &tr) {
+    if ((c.flags & kCtxShadow) != 0u) {
+        tr.o = c.so, tr.d = c.sd, tr.t_min = 0.f, tr.t_max = c.s_tmax;
+        tr.phase = kPhaseShadow;
+        c.flags &= ~kCtxShadow;
+    } else {
+        tr.o = c.no, tr.d = c.nd, tr.t_min = c.n_tmin, tr.t_max = c.n_tmax;
+        tr.phase = kPhaseClosest;
+        c.flags &= ~kCtxClosest;
+    }
+    tr.cur = 0u, tr.sp = 0u;// root
+    tr.hit.tri = kInvalid, tr.hit.u = 0.f, tr.hit.v = 0.f;
+    tr.occluded = false;
+}
+
+// field by field: a `c ? a : b` on the structs selects an ADDRESS and pins both contexts in scratch memory
+LR_D PathCtx ctx_select(bool second, const PathCtx &a, const PathCtx &b) {
+    auto f = [&](float x, float y) { return second ? y : x; };
+    auto f3s = [&](f3 x, f3 y) { return mk3(f(x.x, y.x), f(x.y, y.y), f(x.z, y.z)); };
+    PathCtx r;
+    r.so = f3s(a.so, b.so), r.sd = f3s(a.sd, b.sd), r.s_tmax = f(a.s_tmax, b.s_tmax);
+    r.no = f3s(a.no, b.no), r.nd = f3s(a.nd, b.nd), r.n_tmin = f(a.n_tmin, b.n_tmin), r.n_tmax = f(a.n_tmax, b.n_tmax);
+    r.tri = second ? b.tri : a.tri, r.u = f(a.u, b.u), r.v = f(a.v, b.v);
+    r.flags = second ? b.flags : a.flags;
+    return r;
+}
 
 LR_D uint32_t lane_rank(unsigned long long mask) {// lanes of `mask` below this one
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-// Retire + fetch round of the traversal loop.  Every idle lane whose job is complete writes the hit into its slot and queues the slot
-// for shading; with FETCH every idle lane without a job then takes the next one off the ray queue and starts its first ray.
-template<uint32_t QUADS, bool FETCH>
-LR_D void pool_refill(TravState &tr, uint32_t &job, Ray &next, f3 &inv, float4 *slots, lds_u16 *rq, lds_u8 *sq, PoolWave &pw) {
-    const auto idle = tr.phase == kPhaseIdle;
-    const auto retire = idle && job != kNoJob;// (a lane goes idle only when no ray of its job is left, see pool_trace)
-    const auto rmask = __ballot(retire);
-    if (rmask != 0ull) {
-        if (retire) {
-            const auto slot = job & kJobSlotMask;
-            auto out = reinterpret_cast<uint32_t *>(slots + slot * QUADS + 7u);
-            out[0] = (tr.hit.tri & kPoolMiss) | (tr.occluded ? 0x80000000u : 0u);// (kInvalid & kPoolMiss = kPoolMiss)
-            out[1] = __float_as_uint(tr.hit.u), out[2] = __float_as_uint(tr.hit.v);
-            sq[(pw.sq_head + pw.sq_count + lane_rank(rmask)) & (kPoolSlots - 1u)] = static_cast<uint8_t>(slot);
-            job = kNoJob;
-        }
-        pw.sq_count += static_cast<uint32_t>(__popcll(rmask));
-    }
-    if (FETCH && pw.rq_count != 0u) {
-        const auto wmask = __ballot(idle);// (every idle lane is without a job now)
-        const auto n = min(static_cast<uint32_t>(__popcll(wmask)), pw.rq_count);
-        if (idle && lane_rank(wmask) < n) {
-            job = rq[(pw.rq_head + lane_rank(wmask)) & (kPoolSlots - 1u)];
-            const auto s = slots + (job & kJobSlotMask) * QUADS;
-            const auto shadow_first = (job & kJobShadow) != 0u;
-            const auto first = s + (shadow_first ? 0u : 2u);
-            const auto qa = first[0], qb = first[1];
-            tr.o = mk3(qa.x, qa.y, qa.z), tr.t_max = qa.w;
-            tr.d = mk3(qb.x, qb.y, qb.z), tr.t_min = shadow_first ? 0.f : qb.w;
-            if (shadow_first && (job & kJobClosest) != 0u) {// the path's next segment follows the shadow ray inside the loop
-                const auto qc = s[2], qd = s[3];
-                next.o = mk3(qc.x, qc.y, qc.z), next.t_max = qc.w;
-                next.d = mk3(qd.x, qd.y, qd.z), next.t_min = qd.w;
-            }
-            tr.cur = 0u, tr.sp = 0u;// root
-            tr.phase = shadow_first ? kPhaseShadow : kPhaseClosest;
-            job &= shadow_first ? ~kJobShadow : ~kJobClosest;
-            tr.hit.tri = kInvalid, tr.hit.u = 0.f, tr.hit.v = 0.f;
-            tr.occluded = false;
-            inv = safe_inverse(tr.d);
-        }
-        pw.rq_head += n, pw.rq_count -= n;
-    }
+// The lane's two contexts are `a` and `b`; `sel` names the CURRENT one (0: a, 1: b) -- the context whose ray the lane traces -- and the
+// other one waits.  (Contexts are never moved: a switch flips `sel`; what the loop touches of them it touches under a branch per context.)
+constexpr uint32_t kCtxRays = kCtxShadow | kCtxClosest;
+// flags of a context that the shading block has work for: a traced job, or (while the launch has samples left) no path at all
+LR_D bool ctx_shadeable(uint32_t flags, bool samples_left) {
+#ifdef LR_POOL_SINGLE// (experiment: the second context never takes a path -- the round 1-3 scheduling in this kernel's clothes)
+    if ((flags & kCtxSide) != 0u) { samples_left = false; }
+#endif
+    return (flags & kCtxDone) != 0u || (samples_left && (flags & kCtxOpen) == 0u);
+}
+// whether the shading block is due: enough lanes hold a context for it, or enough of them have nothing left to trace, or nothing is in
+// flight at all.  Only an idle lane's current context can be shaded.
+LR_D bool pool_shade_due(uint32_t phase, uint32_t cur_flags, uint32_t oth_flags, bool samples_left) {
+    const auto idle = phase == kPhaseIdle;
+    const auto s = __ballot(ctx_shadeable(oth_flags, samples_left) || (idle && ctx_shadeable(cur_flags, samples_left)));
+    if (s == 0ull) { return false; }
+    const auto idle_mask = __ballot(idle);
+    return static_cast<uint32_t>(__popcll(s)) >= static_cast<uint32_t>(LR_POOL_SHADE_LANES) ||
+           static_cast<uint32_t>(__popcll(s & idle_mask)) >= static_cast<uint32_t>(LR_POOL_IDLE_LANES) || idle_mask == ~0ull;
 }
 
-// The traversal loop of the pool kernel: dev_trace.h's node and leaf steps, with job turnover inside the loop.  Returns when the ray
-// queue is dry and LR_POOL_REFILL lanes have nothing to do while enough slots wait for shading, or when nothing is left to trace
-// (ALPHA: also when a lane holds a candidate hit for the alpha test, dev_shade.h: resolve_pending_alpha).  Must be called by all 64 lanes.
-template<bool COUNT, bool ALPHA, uint32_t QUADS>
-LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, uint32_t &job, Ray &next, float4 *slots, lds_u16 *rq,
-                     lds_u8 *sq, PoolWave &pw, TraceStats &stats) {
+// The traversal loop of the pool kernel: dev_trace.h's node and leaf steps; a lane whose job ends switches to its other context's
+// rays without leaving the loop.  Returns when the shading block is due or nothing is in flight (ALPHA: also when a lane holds a
+// candidate hit for the alpha test, dev_shade.h: resolve_pending_alpha).  Must be called by all 64 lanes.
+template<bool COUNT, bool ALPHA>
+LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &a, PathCtx &b, uint32_t &sel, bool samples_left,
+                     TraceStats &stats) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");// the slots and queue entries the shading block wrote
     for (;;) {
-        {// ---- job turnover, LR_POOL_REFILL lanes at a time
-            const auto idle = tr.phase == kPhaseIdle;
-            if (static_cast<uint32_t>(__popcll(__ballot(idle))) >= static_cast<uint32_t>(LR_POOL_REFILL) && (pw.rq_count != 0u || __any(idle && job != kNoJob))) {
-                pool_refill<QUADS, true>(tr, job, next, inv, slots, rq, sq, pw);
-            }
-        }
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
-            stats.steps_starved += tr.phase == kPhaseIdle && pw.rq_count == 0u ? 1u : 0u;// idle with nothing to fetch
+#ifndef LR_TRACE_PROBE
+            stats.steps_starved += tr.phase == kPhaseIdle && ((a.flags | b.flags) & kCtxOpen) == 0u ? 1u : 0u;// no path left to hold
+#endif
         }
         const auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
         const auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
         const auto deep = __any(live && tr.sp + 3u > kStackLds);
+#ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
+        const auto probe_t0 = __builtin_readcyclecounter();
+#endif
         if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
+#ifdef LR_TRACE_PROBE
+        const auto probe_t1 = __builtin_readcyclecounter();
+#endif
         if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
-        // ---- ray finished: the job's next ray, or idle (retired at the next turnover)
+#ifdef LR_TRACE_PROBE
+        const auto probe_t2 = __builtin_readcyclecounter();
+#endif
+        // ---- ray finished: the job's next ray, the other context's job, or idle
         if (live && tr.cur == kInvalid) {
-            if (tr.phase == kPhaseShadow && (job & kJobClosest) != 0u) {
-                trav_begin(tr, next, kPhaseClosest);
-                job &= ~kJobClosest;
-                inv = safe_inverse(tr.d);
+            auto cf = sel != 0u ? b.flags : a.flags;
+            const auto of = sel != 0u ? a.flags : b.flags;
+            if (tr.phase == kPhaseShadow) {
+                if (tr.occluded) { cf |= kCtxOccluded; }
+            } else if (sel != 0u) {
+                b.tri = tr.hit.tri, b.u = tr.hit.u, b.v = tr.hit.v;
             } else {
-                tr.phase = kPhaseIdle;
+                a.tri = tr.hit.tri, a.u = tr.hit.u, a.v = tr.hit.v;
+            }
+            tr.phase = kPhaseIdle;
+            const auto complete = (cf & kCtxRays) == 0u;
+            if (complete) { cf |= kCtxDone; }
+            if (sel != 0u) { b.flags = cf; } else { a.flags = cf; }
+            if (complete && (of & kCtxRays) != 0u) { sel ^= 1u; }// on to the other context's job
+            if (((sel != 0u ? b.flags : a.flags) & kCtxRays) != 0u) {
+                if (sel != 0u) { ctx_start(b, tr); } else { ctx_start(a, tr); }
+                inv = safe_inverse(tr.d);
             }
         }
-        if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
-        if (pw.rq_count == 0u) {
-            const auto idle_mask = __ballot(tr.phase == kPhaseIdle);
-            if (idle_mask == ~0ull) { break; }// nothing in flight, nothing to fetch
-            const auto ready = pw.sq_count + static_cast<uint32_t>(__popcll(__ballot(tr.phase == kPhaseIdle && job != kNoJob)));
-            if (static_cast<uint32_t>(__popcll(idle_mask)) >= static_cast<uint32_t>(LR_POOL_REFILL) && ready >= static_cast<uint32_t>(LR_POOL_MIN_READY)) { break; }
+#ifdef LR_TRACE_PROBE
+        if (COUNT && (threadIdx.x & 63u) == 0u) {
+            const auto probe_t3 = __builtin_readcyclecounter();
+            stats.nodes_empty += static_cast<uint32_t>(probe_t1 - probe_t0);
+            stats.steps_starved += static_cast<uint32_t>(probe_t3 - probe_t2);
         }
+#endif
+        if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        if (__ballot(tr.phase != kPhaseIdle) == 0ull) { break; }
+        if (pool_shade_due(tr.phase, sel != 0u ? b.flags : a.flags, sel != 0u ? a.flags : b.flags, samples_left)) { break; }
     }
-    pool_refill<QUADS, false>(tr, job, next, inv, slots, rq, sq, pw);// retire what has finished
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
 template<uint32_t F>
@@ -183,18 +222,22 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     constexpr uint32_t QUADS = pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
+#if LR_POOL_OVERLAP
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
-    __shared__ uint16_t s_rq[kWavesPerBlock * kPoolSlots];
-    __shared__ uint8_t s_sq[kWavesPerBlock * kPoolSlots];
+#else
+    __shared__ float4 s_film[CONT ? 1u : kWavesPerBlock * 64u];// per-wave tile accumulators (sum r, g, b, n)
+#endif
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
     const auto wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6u);
     TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + wave_in_block * kStageWave};
-    const auto film_tile = s_film + (CONT ? 0u : wave_in_block * 192u);
-    const auto rq = (lds_u16 *)(s_rq + wave_in_block * kPoolSlots);
-    const auto sq = (lds_u8 *)(s_sq + wave_in_block * kPoolSlots);
-    const auto slots = args.pool + static_cast<size_t>(blockIdx.x * kWavesPerBlock + wave_in_block) * (kPoolSlots * QUADS);
+    const auto film_tile = s_film + (CONT ? 0u : wave_in_block * (LR_POOL_OVERLAP ? 192u : 64u));
+    // path state of this thread's two contexts: quad q of context c at args.pool[(c * QUADS + q) * total_threads + gtid]
+    const auto state_of = [&](uint32_t side, uint32_t quad) { return args.pool + static_cast<size_t>(side * QUADS + quad) * args.total_threads + gtid; };
+    // (as 16-byte quads.  Word by word -- no register tuples for the allocator to place -- was tried: 46 -> 60 spilled VGPRs)
+    const auto state_load = [&](uint32_t side, uint32_t quad) { return *state_of(side, quad); };
+    const auto state_store = [&](uint32_t side, uint32_t quad, float4 v) { *state_of(side, quad) = v; };
     DCounters local{};
     const auto t_wave = COUNT ? __builtin_readcyclecounter() : 0ull;
 
@@ -210,20 +253,31 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     auto items_left = true;
     auto q_next = 0u, q_total = 0u;// the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * item_records + k)
     auto s_begin = 0u, s_count = 0u, tx = 0u, ty = 0u;
-    PoolWave pw{0u, 0u, 0u, 0u};
-    auto next_fresh = 0u;          // slots [next_fresh, kPoolSlots) have never held a path
+#if LR_POOL_OVERLAP
     if (!CONT) { film_tile[lane * 3u] = 0ull, film_tile[lane * 3u + 1u] = 0ull, film_tile[lane * 3u + 2u] = 0ull; }
-    // ---- the lane as a traversal worker: its ray in flight, the job (slot) it belongs to
+#else
+    if (!CONT) { film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    auto chunk = 0u;// the item's sample chunk (its partial plane)
+#endif
+    // ---- the lane: its ray in flight, the context the ray belongs to (`cur`) and the lane's other context (`oth`)
     TravState tr{};
     tr.phase = kPhaseIdle;
-    uint32_t job = kNoJob;
-    Ray next{};// the job's path segment waiting behind its shadow ray
+    PathCtx ca{}, cb{};
+    ca.flags = 0u, cb.flags = kCtxSide;
+    auto sel = 0u;
+#if LR_POOL_CONTEXTS == 1// the lane's one path: its state stays in registers
+    PathSampler<PCG> sampler{};
+    f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
+    auto pdf_bsdf = 1e16f;
+    auto dp = 0u, pixel_index = 0u, path_item = kInvalid;// dp: depth | pixel in tile << 16
+#endif
 
     // the wave leaves its work item: the tile's sums join the frame's, every sample of the item is counted
     auto flush_tile = [&]() {
         if (CONT || item == kInvalid) { return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#if LR_POOL_OVERLAP
         const auto a0 = film_tile[lane * 3u], a1 = film_tile[lane * 3u + 1u], a2 = film_tile[lane * 3u + 2u];
         film_tile[lane * 3u] = 0ull, film_tile[lane * 3u + 1u] = 0ull, film_tile[lane * 3u + 2u] = 0ull;
         const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
@@ -235,59 +289,125 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             if (a2 != 0ull) { atomicAdd(acc + 2, a2); }
             if (s_count != 0u) { atomicAdd(&args.film[index].w, static_cast<float>(s_count)); }
         }
+#else
+        // lane l adds pixel l of the tile to the film (or stores this chunk's partial plane), megapath_kernel.h
+        const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
+        const auto acc = film_tile[lane];
+        film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wx < scene.camera.width && wy < scene.camera.height) {
+            const auto index = wy * scene.camera.width + wx;
+            if (args.chunk_count == 1u) {
+                auto f = args.film[index];
+                f.x += acc.x, f.y += acc.y, f.z += acc.z, f.w += acc.w;
+                args.film[index] = f;
+            } else {
+                args.partial[static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + index] = acc;
+            }
+        }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
-    auto after_trace = true;
+    // the wave's next work item (the tile of the one it leaves goes to the film first)
+    auto take_item = [&]() {
+        flush_tile();
+        item = next_item(CONT ? scene.wf.counts + kWfWorkCont : args.work_counter, item_count, lane);
+        q_next = 0u, q_total = 0u, s_count = 0u;
+        if (item == kInvalid) {
+            items_left = false;
+            return;
+        }
+        if (CONT) {
+            q_total = min(item_records, cont_total - item * item_records);
+        } else {
+            const auto range = item_range(args, item);
+            const auto tile = args.tile_begin + range.tile_index * args.tile_stride;
+            ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
+            s_begin = range.s_begin, s_count = range.s_end > range.s_begin ? range.s_end - range.s_begin : 0u;
+            q_total = s_count * 64u;
+#if !LR_POOL_OVERLAP
+            chunk = range.chunk;
+#endif
+        }
+    };
+
     for (;;) {
-        // ==== (A) shading batches: while a full wave of slots waits (or, after the traversal loop gave up, whatever waits)
+        // ==== (A) shading batches, while they are due (pool_shade_due: enough lanes hold a context to shade)
         for (;;) {
-            const auto fresh = (items_left || q_next < q_total) ? kPoolSlots - next_fresh : 0u;
-            const auto shadeable = pw.sq_count + fresh;
-            if (!(shadeable >= 64u || (shadeable != 0u && after_trace))) { break; }
-            after_trace = false;
+            const auto samples_left = (LR_POOL_OVERLAP && items_left) || q_next < q_total;
+            if (!pool_shade_due(tr.phase, sel != 0u ? cb.flags : ca.flags, sel != 0u ? ca.flags : cb.flags, samples_left)) { break; }
             const auto t_shade = COUNT ? __builtin_readcyclecounter() : 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");// what the traversal loop retired
-            // ---- up to 64 slots off the shade queue, one per lane
-            const auto n_sq = min(pw.sq_count, 64u);
-            auto slot = kInvalid;
-            if (lane < n_sq) { slot = sq[(pw.sq_head + lane) & (kPoolSlots - 1u)]; }
-            pw.sq_head += n_sq, pw.sq_count -= n_sq;
-            // ---- the slot's path
+#if LR_POOL_CONTEXTS == 1
+            // ---- one context per lane: the lanes without a ray in flight take part (round 1-3 scheduling)
+            const PathCtx oth = ca;
+            const auto mine = tr.phase == kPhaseIdle && ctx_shadeable(ca.flags, samples_left);
+            Ray ray{}, shadow{};
+#else
+            // ---- the context this lane shades is its OTHER one; an idle lane whose other context has nothing for the shading block
+            // offers its current one
+            if (tr.phase == kPhaseIdle && !ctx_shadeable(sel != 0u ? ca.flags : cb.flags, samples_left)) { sel ^= 1u; }
+            const PathCtx oth = ctx_select(sel == 0u, ca, cb), curc = ctx_select(sel != 0u, ca, cb);
+            // (a context that waits with the rays of its job is none of the shading block's business)
+#ifdef LR_POOL_SINGLE
+            const auto mine = (oth.flags & kCtxDone) != 0u || ((oth.flags & kCtxOpen) == 0u && (oth.flags & kCtxSide) == 0u);
+#else
+            const auto mine = (oth.flags & kCtxDone) != 0u || (oth.flags & kCtxOpen) == 0u;
+#endif
+            // ---- Of the lane's two contexts the shading block needs the traced segment and the hit of the one it shades (when it is
+            // `mine`), and it produces that context's next rays in `shadow` / `ray`.  Everything else must leave the registers the
+            // shading block is allocated in (314 spilled VGPRs otherwise): ONE context's rays wait in the packet staging area of the
+            // LDS (idle outside the traversal loop; 16 words per lane, [quad][lane]) -- the current context's, normally -- and where the
+            // other context is not `mine` but waits with rays of its own, those wait in the LDS and the current context's sit in
+            // `shadow` / `ray`, which such a lane does not write.  Origin and direction of the ray in flight are one of those rays.
+            const PathCtx lds_ctx = ctx_select(!mine, curc, oth);
+            {
+                const auto stage = stack.stage;
+                stage[lane] = make_float4(lds_ctx.so.x, lds_ctx.so.y, lds_ctx.so.z, lds_ctx.s_tmax);
+                stage[64u + lane] = make_float4(lds_ctx.sd.x, lds_ctx.sd.y, lds_ctx.sd.z, lds_ctx.n_tmin);
+                stage[128u + lane] = make_float4(lds_ctx.no.x, lds_ctx.no.y, lds_ctx.no.z, lds_ctx.n_tmax);
+                stage[192u + lane] = make_float4(lds_ctx.nd.x, lds_ctx.nd.y, lds_ctx.nd.z, 0.f);
+                asm volatile("" ::: "memory");// (the values must not be forwarded to the loads at the end of the block: they are to LEAVE the registers)
+            }
+            // one hit besides the shaded context's is alive in a lane: the running one of the ray in flight, or the current context's
+            // finished one (an idle lane); a context that waits with its rays has none
+            const auto keep_tri = tr.phase != kPhaseIdle ? tr.hit.tri : curc.tri;
+            const auto keep_u = tr.phase != kPhaseIdle ? tr.hit.u : curc.u, keep_v = tr.phase != kPhaseIdle ? tr.hit.v : curc.v;
+            // (one register: traversal phase 0-2, occluded 3, sel 4, stack depth 5-11, flags of the context in the LDS 12-19, of the current one 20-27)
+            const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (sel << 4u) | (tr.sp << 5u) | (lds_ctx.flags << 12u) | (curc.flags << 20u);
+            // ---- the context's path
             PathSampler<PCG> sampler{};
             Ray ray{}, shadow{};
+            if (!mine) {
+                shadow.o = curc.so, shadow.d = curc.sd, shadow.t_min = 0.f, shadow.t_max = curc.s_tmax;
+                ray.o = curc.no, ray.d = curc.nd, ray.t_min = curc.n_tmin, ray.t_max = curc.n_tmax;
+            }
             f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
             auto pdf_bsdf = 1e16f;
-            auto depth = 0u, pixel_index = 0u, pix = 0u, path_item = kInvalid;
-            auto path_open = false, traced_shadow = false, traced_closest = false, occluded = false;
-            f3 ro = mk3(0.f), rd = mk3(0.f);// the path segment the job traced
-            auto hit_tri = kPoolMiss;
-            auto hit_u = 0.f, hit_v = 0.f;
-            if (slot != kInvalid) {
-                const auto s = slots + slot * QUADS;
-                const auto q2 = s[2], q3 = s[3], q4 = s[4], q5 = s[5], q6 = s[6], q7 = s[7];
-                pixel_index = reinterpret_cast<const uint32_t *>(s + 1u)[3];
-                ro = mk3(q2.x, q2.y, q2.z), rd = mk3(q3.x, q3.y, q3.z);
-                nee = mk3(q4.x, q4.y, q4.z), pdf_bsdf = q4.w;
-                beta = mk3(q5.x, q5.y, q5.z);
-                const auto packed = __float_as_uint(q5.w);
-                depth = packed & 0xffffu, pix = (packed >> 16u) & 63u;
-                traced_shadow = (packed & (1u << 22u)) != 0u, traced_closest = (packed & (1u << 23u)) != 0u;
-                Li = mk3(q6.x, q6.y, q6.z);
+            auto dp = 0u, pixel_index = 0u, path_item = kInvalid;// dp: depth | pixel in tile << 16 (one register across the block)
+#endif
+            const auto side = (oth.flags & kCtxSide) != 0u ? 1u : 0u;
+            auto path_open = (oth.flags & kCtxDone) != 0u;// (else: an empty context, or one that is not `mine`)
+            const auto traced_shadow = path_open && (oth.flags & kCtxHadShadow) != 0u, traced_closest = path_open && (oth.flags & kCtxHadClosest) != 0u;
+            const auto occluded = (oth.flags & kCtxOccluded) != 0u;
+            const auto ro = oth.no, rd = oth.nd;// the path segment the job traced
+            const auto hit_tri = oth.tri;
+            const auto hit_u = oth.u, hit_v = oth.v;
+#if LR_POOL_CONTEXTS == 2
+            if (path_open) {
+                const auto q0 = state_load(side, 0u), q1 = state_load(side, 1u), q2 = state_load(side, 2u), q3 = state_load(side, 3u);
+                nee = mk3(q0.x, q0.y, q0.z), pdf_bsdf = q0.w;
+                beta = mk3(q1.x, q1.y, q1.z);
+                const auto packed = __float_as_uint(q1.w);
+                dp = packed & 0x3fffffu;
+                Li = mk3(q2.x, q2.y, q2.z);
+                pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
                 uint32_t words[kWfSamplerWordsMax];
-                words[0] = __float_as_uint(q6.w);
-                if (PCG) {
-                    const auto q8 = s[QUADS - 1u];
-                    words[1] = __float_as_uint(q8.x), words[2] = __float_as_uint(q8.y), words[3] = __float_as_uint(q8.z);
-                }
+                words[0] = __float_as_uint(q2.w), words[1] = __float_as_uint(q3.z), words[2] = __float_as_uint(q3.w);
+                words[3] = PCG ? __float_as_uint(state_load(side, QUADS - 1u).x) : 0u;
                 sampler.restore(scene, words);
-                const auto h = __float_as_uint(q7.x);
-                hit_tri = h & kPoolMiss, occluded = (h >> 31u) != 0u;
-                hit_u = q7.y, hit_v = q7.z;
-                path_item = __float_as_uint(q7.w);
-                path_open = true;
             }
+#endif
             auto want_shadow = false, want_closest = false;
             unsigned long long t_closure_sum = 0ull;// (COUNT: wave cycles inside the closure section of this batch; lanes agree)
             auto park_kind = kInvalid;// WF: closure kind (0 Disney, 1 Mix, 2 Layered) of the heavy surface this path just reached
@@ -298,7 +418,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 if (traced_closest) {// one iteration of the reference's depth loop, mega_path.cpp:63-154
                     if (COUNT) { local.shade_busy++; }
                     const auto wo = -rd;
-                    const auto hit_valid = hit_tri != kPoolMiss;
+                    const auto hit_valid = hit_tri != kInvalid;
                     if (!hit_valid && scene.env_kind != kEnvNone) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
                         f3 L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
                         auto pdf = kInvPi * 0.25f;
@@ -366,7 +486,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         }
                         if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
                         auto alive = !(beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f);
-                        const auto rr = depth + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
+                        const auto rr = (dp & 0xffffu) + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
                         auto u_rr = 0.f;
                         if (rr) { u_rr = sampler.next_1d(); }// (drawn before the closure in the reference: same stream position)
                         if (alive) {
@@ -376,8 +496,8 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                                 else { beta *= q < scene.rr_threshold ? 1.0f / q : 1.f; }
                             }
                         }
-                        depth++;
-                        want_closest = alive && depth < scene.max_depth;
+                        dp++;// (depth < 65536: lrhip_render sends deeper paths to the round 1-3 kernels)
+                        want_closest = alive && (dp & 0xffffu) < scene.max_depth;
                         if (COUNT) { t_closure_sum += __builtin_readcyclecounter() - t_closure; }
                     }
                 }
@@ -394,7 +514,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             q.put3(out, 0u, rd);
                             q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
                             q.put3(out, 6u, beta), q.put3(out, 9u, Li);
-                            q.put(out, 12u, pixel_index), q.put(out, 13u, depth);
+                            q.put(out, 12u, pixel_index), q.put(out, 13u, dp & 0xffffu);
                             uint32_t words[kWfSamplerWordsMax];
                             sampler.save(words);
 #pragma unroll
@@ -406,57 +526,39 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             }
             if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
                 const auto rgb = Li * scene.shutter_weight;
+#if !LR_POOL_OVERLAP
+                if (CONT) { wf_film_accumulate(scene, args.film, pixel_index, rgb, scene.film_clamp); }
+                else { film_accumulate(film_tile + (dp >> 16u), rgb, scene.film_clamp); }// (every path of the wave belongs to its one work item: the tile, in fp32, in the wave's own order)
+#else
                 if (CONT || path_item != item) {// (its wave has left the path's work item: the frame's sums directly)
                     wf_film_accumulate(scene, args.film, pixel_index, rgb, scene.film_clamp);
                 } else if (!(any_nan(rgb) || any_inf(rgb))) {// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) into the tile
                     const auto threshold = scene.film_clamp * fmaxf(1.f, 1.f);
                     const auto strength = fmaxf(fmaxf(fmaxf(fabsf(rgb.x), fabsf(rgb.y)), fabsf(rgb.z)), 0.f);
                     const auto c = rgb * (threshold / fmaxf(strength, threshold));
-                    const auto px_sums = film_tile + pix * 3u;
+                    const auto px_sums = film_tile + (dp >> 16u) * 3u;
                     if (c.x != 0.f) { atomicAdd(px_sums + 0, radiance_to_fixed(c.x, scene.wf.accum_scale)); }
                     if (c.y != 0.f) { atomicAdd(px_sums + 1, radiance_to_fixed(c.y, scene.wf.accum_scale)); }
                     if (c.z != 0.f) { atomicAdd(px_sums + 2, radiance_to_fixed(c.z, scene.wf.accum_scale)); }
                 } else {// rejected: the flush counts every sample of the item
                     atomicAdd(&args.film[pixel_index].w, -1.f);
                 }
+#endif
                 path_open = false;
             }
-            // ==== (A') path regeneration: slots without a path take the next samples of the item's queue, in lane order; lanes that
-            // got no slot off the shade queue open the pool's unused slots (start of the launch)
+            // ==== (A') path regeneration: contexts without a path take the next samples of the item's queue, in lane order
             const auto t_regen = COUNT ? __builtin_readcyclecounter() : 0ull;
             if (COUNT) {// (the closure section is timed by the lanes that ran it: lane 0 reports the wave's figure)
                 for (auto off = 32; off > 0; off >>= 1) { t_closure_sum = max(t_closure_sum, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(t_closure_sum), off))); }
             }
-            if (next_fresh < kPoolSlots && (items_left || q_next < q_total)) {
-                const auto mask = __ballot(slot == kInvalid);
-                if (mask != 0ull) {
-                    const auto s = next_fresh + lane_rank(mask);
-                    if (slot == kInvalid && s < kPoolSlots) { slot = s; }
-                    next_fresh = min(kPoolSlots, next_fresh + static_cast<uint32_t>(__popcll(mask)));
-                }
-            }
-            auto need = !path_open && slot != kInvalid;
+            auto need = mine && !path_open;// (a context without a path: it takes the next sample, if the launch has one left)
             for (;;) {
                 const auto mask = __ballot(need);
                 if (mask == 0ull) { break; }
                 if (q_next >= q_total) {// the item's queue is dry: on to the next item, the old one's paths finish beside the new one's
+                    if (!LR_POOL_OVERLAP || !items_left) { break; }// (no overlap: the item's last paths drain, the main loop takes the next item)
+                    take_item();
                     if (!items_left) { break; }
-                    flush_tile();
-                    item = next_item(CONT ? scene.wf.counts + kWfWorkCont : args.work_counter, item_count, lane);
-                    q_next = 0u, q_total = 0u, s_count = 0u;
-                    if (item == kInvalid) {
-                        items_left = false;
-                        break;
-                    }
-                    if (CONT) {
-                        q_total = min(item_records, cont_total - item * item_records);
-                    } else {
-                        const auto range = item_range(args, item);
-                        const auto tile = args.tile_begin + range.tile_index * args.tile_stride;
-                        ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
-                        s_begin = range.s_begin, s_count = range.s_end > range.s_begin ? range.s_end - range.s_begin : 0u;
-                        q_total = s_count * 64u;
-                    }
                     continue;
                 }
                 const auto avail = q_total - q_next;
@@ -474,7 +576,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         pdf_bsdf = q.getf(rec, 22u);
                         pixel_index = q.get(rec, 23u);
                         const auto packed = q.get(rec, 24u);
-                        depth = packed & 0xffffu;
+                        dp = packed & 0xffffu;
                         want_shadow = (packed & (1u << 16u)) != 0u, want_closest = (packed & (1u << 17u)) != 0u;
                         uint32_t words[kWfSamplerWordsMax];
 #pragma unroll
@@ -482,7 +584,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         sampler.restore(scene, words);
                         path_open = true, need = false;
                     } else {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
-                        pix = k & 63u;
+                        const auto pix = k & 63u;
                         const auto px = tx * 8u + (pix & 7u), py = ty * 8u + (pix >> 3u);
                         if (px < scene.camera.width && py < scene.camera.height) {// (a pixel beyond the frame's edge has no samples: the lane asks again)
                             pixel_index = py * scene.camera.width + px;
@@ -495,7 +597,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             beta = mk3(weight);
                             Li = mk3(0.f), nee = mk3(0.f);
                             pdf_bsdf = 1e16f;
-                            depth = 0u;
+                            dp = pix << 16u;
                             path_open = true, want_shadow = false, want_closest = true, need = false;
                             if (COUNT) { local.paths++; }
                         }
@@ -503,33 +605,64 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 }
                 q_next += min(static_cast<uint32_t>(__popcll(mask)), avail);
             }
-            // ---- every slot that goes on: its state back into the record, the slot into the ray queue
+            // ---- every context that goes on: its path state back into the record, its job's rays into the context
             const auto t_launch = COUNT ? __builtin_readcyclecounter() : 0ull;
             const auto go = path_open && (want_shadow || want_closest);
             if (go) {
-                const auto s = slots + slot * QUADS;
+#if LR_POOL_CONTEXTS == 2
                 uint32_t words[kWfSamplerWordsMax] = {0u, 0u, 0u, 0u};
                 sampler.save(words);
-                s[0] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, shadow.t_max);
-                s[1] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, __uint_as_float(pixel_index));
-                s[2] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.t_max);
-                s[3] = make_float4(ray.d.x, ray.d.y, ray.d.z, ray.t_min);
-                s[4] = make_float4(nee.x, nee.y, nee.z, pdf_bsdf);
-                s[5] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((depth & 0xffffu) | (pix << 16u) | (want_shadow ? 1u << 22u : 0u) | (want_closest ? 1u << 23u : 0u)));
-                s[6] = make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0]));
-                s[7] = make_float4(__uint_as_float(kPoolMiss), 0.f, 0.f, __uint_as_float(path_item));
-                if (PCG) { s[QUADS - 1u] = make_float4(__uint_as_float(words[1]), __uint_as_float(words[2]), __uint_as_float(words[3]), 0.f); }
+                state_store(side, 0u, make_float4(nee.x, nee.y, nee.z, pdf_bsdf));
+                state_store(side, 1u, make_float4(beta.x, beta.y, beta.z, __uint_as_float(dp)));
+                state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
+                state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2])));
+                if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
+#endif
                 if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
             }
-            {
-                const auto mask = __ballot(go);
-                if (go) {
-                    rq[(pw.rq_head + pw.rq_count + lane_rank(mask)) & (kPoolSlots - 1u)] =
-                        static_cast<uint16_t>(slot | (want_shadow ? kJobShadow : 0u) | (want_closest ? kJobClosest : 0u));
-                }
-                pw.rq_count += static_cast<uint32_t>(__popcll(mask));
+#if LR_POOL_CONTEXTS == 1
+            if (mine) {// the context's next job (or none: its path ended and no sample was left), started at once: the lane is idle
+                ca.so = shadow.o, ca.sd = shadow.d, ca.s_tmax = shadow.t_max;
+                ca.no = ray.o, ca.nd = ray.d, ca.n_tmin = ray.t_min, ca.n_tmax = ray.t_max;
+                ca.tri = kInvalid, ca.u = 0.f, ca.v = 0.f;
+                ca.flags = go ? kCtxOpen | (want_shadow ? kCtxShadow | kCtxHadShadow : 0u) | (want_closest ? kCtxClosest | kCtxHadClosest : 0u) : 0u;
+                if (go) { ctx_start(ca, tr); }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
+            // ---- the contexts come back: one from the LDS, one from shadow / ray (the shaded context's new job, or -- not `mine` -- the
+            // current context as it was), and with the current one origin and direction of the ray in flight
+            {
+                PathCtx back, regs;
+                const auto stage = stack.stage;
+                asm volatile("" ::: "memory");
+                const auto p0 = stage[lane], p1 = stage[64u + lane], p2 = stage[128u + lane], p3 = stage[192u + lane];
+                back.so = mk3(p0.x, p0.y, p0.z), back.s_tmax = p0.w;
+                back.sd = mk3(p1.x, p1.y, p1.z), back.n_tmin = p1.w;
+                back.no = mk3(p2.x, p2.y, p2.z), back.n_tmax = p2.w;
+                back.nd = mk3(p3.x, p3.y, p3.z);
+                back.flags = (keep_word >> 12u) & 0xffu, back.tri = keep_tri, back.u = keep_u, back.v = keep_v;
+                tr.hit.tri = keep_tri, tr.hit.u = keep_u, tr.hit.v = keep_v;
+                tr.phase = keep_word & 7u, tr.occluded = (keep_word & 8u) != 0u;
+                tr.sp = (keep_word >> 5u) & 127u, sel = (keep_word >> 4u) & 1u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                regs.so = shadow.o, regs.sd = shadow.d, regs.s_tmax = shadow.t_max;
+                regs.no = ray.o, regs.nd = ray.d, regs.n_tmin = ray.t_min, regs.n_tmax = ray.t_max;
+                // the shaded context: its new job, or empty (its path ended, or was parked, and no sample was left for it)
+                const auto shaded_flags = (side != 0u ? kCtxSide : 0u) |
+                                          (go ? kCtxOpen | (want_shadow ? kCtxShadow | kCtxHadShadow : 0u) | (want_closest ? kCtxClosest | kCtxHadClosest : 0u) : 0u);
+                regs.flags = mine ? shaded_flags : (keep_word >> 20u) & 0xffu;
+                regs.tri = mine ? kInvalid : keep_tri, regs.u = mine ? 0.f : keep_u, regs.v = mine ? 0.f : keep_v;
+                const PathCtx cur_new = ctx_select(!mine, back, regs), oth_new = ctx_select(mine, back, regs);
+                if ((tr.phase & 3u) == kPhaseShadow) { tr.o = cur_new.so, tr.d = cur_new.sd, tr.t_min = 0.f; }
+                else { tr.o = cur_new.no, tr.d = cur_new.nd, tr.t_min = cur_new.n_tmin; }
+                if (sel != 0u) { cb = cur_new, ca = oth_new; } else { ca = cur_new, cb = oth_new; }
+            }
+            // ---- an idle lane starts on the job its context was just given
+            if (tr.phase == kPhaseIdle && ((sel != 0u ? ca.flags : cb.flags) & kCtxRays) != 0u) {
+                sel ^= 1u;
+                if (sel != 0u) { ctx_start(cb, tr); } else { ctx_start(ca, tr); }
+            }
+#endif
             if (COUNT) {
                 if (lane == 0u) {
                     const auto t_end = __builtin_readcyclecounter();
@@ -540,17 +673,21 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 local.shade_calls++;
             }
         }
-        if (pw.rq_count == 0u && pw.sq_count == 0u && !__any(tr.phase != kPhaseIdle || job != kNoJob)) { break; }// every slot of the pool is out of samples
-        // ==== (B) traverse: jobs turn over inside the loop until the ray queue is dry
+        if (!__any(tr.phase != kPhaseIdle)) {// nothing in flight and nothing to shade: every context of the wave is out of samples
+            if (LR_POOL_OVERLAP || !items_left) { break; }
+            take_item();// (no overlap: the item is complete)
+            if (!items_left) { break; }
+            continue;
+        }
+        // ==== (B) traverse: lanes switch to their other context's job inside the loop
         TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
-            pool_trace<COUNT, ALPHA, QUADS>(scene, stack, tr, job, next, slots, rq, sq, pw, ts);
+            pool_trace<COUNT, ALPHA>(scene, stack, tr, ca, cb, sel, (LR_POOL_OVERLAP && items_left) || q_next < q_total, ts);
             if (!ALPHA) { break; }
             if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
             resolve_pending_alpha(scene, stack, tr);
         }
-        after_trace = true;
         if (COUNT) {
             if (lane == 0u) { local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
             local.nodes_visited += ts.nodes, local.tris_tested += ts.tris, local.nodes_empty += ts.nodes_empty;

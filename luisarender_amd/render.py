@@ -29,8 +29,8 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_create(device, C.byref(self._ctx)))
         self._scene = None
         self.width = self.height = 0
-        if os.environ.get("LRHIP_SCHEDULER") == "legacy":  # tools / A-B runs only, like LRHIP_LIB: the round 1-3 one-path-per-lane kernels
-            self.set_scheduler(False)
+        if os.environ.get("LRHIP_SCHEDULER") in ("legacy", "pool"):  # tools / A-B runs only, like LRHIP_LIB
+            self.set_scheduler(os.environ["LRHIP_SCHEDULER"] == "pool")
 
     def _check(self, rc: int) -> None:
         if rc != 0:
@@ -135,10 +135,11 @@ class MegaPathRenderer:
         sends eight tiles through the queues at a time (tests: what a GPU short of memory does)"""
         self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
 
-    def set_scheduler(self, pool: bool = True) -> None:
-        """lrhip_set_scheduler: the lean kernels run under the path-pool scheduler of round 4 by default (128 path slots per wavefront,
-        fixed-point film sums); pool=False keeps every scene on the one-path-per-lane kernels of rounds 1-3 (A/B, tests)"""
-        self._check(self._lib.lrhip_set_scheduler(self._ctx, 0 if pool else 1))
+    def set_scheduler(self, pool: bool | None = None) -> None:
+        """lrhip_set_scheduler: None = automatic (the one-path-per-lane kernels, which are the faster ones on every measured scene),
+        False = the same, explicitly; True = the path-pool kernels of round 4 (two path contexts per lane, fixed-point film sums,
+        overlapping work items) where one exists for the scene -- measured, documented, and not the default"""
+        self._check(self._lib.lrhip_set_scheduler(self._ctx, 0 if pool is None else (2 if pool else 1)))
 
     def close(self) -> None:
         if self._ctx:

@@ -6,13 +6,17 @@ from luisarender_amd.render import MegaPathRenderer
 from luisarender_amd.scenes import generate_room_scene
 from luisarender_amd.scenes.configs import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-workload = sys.argv[2] if len(sys.argv) > 2 else "c2"   # c2 | c3 | c4 | c5 (the bench's stand-ins, at 1024 x 1024 / 1280 x 720)
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"   # c1 | c2 | c3 | c4 | c5 (the bench's stand-ins, at 1024 x 1024 / 1280 x 720)
 with tempfile.TemporaryDirectory() as tmp:
-    gen = {"c2": lambda: generate_room_scene(tmp, resolution=(1024, 1024), spp=spp),
+    gen = {"c1": lambda: None, "c2": lambda: generate_room_scene(tmp, resolution=(1024, 1024), spp=spp),
            "c3": lambda: generate_bedroom_scene(tmp, resolution=(1280, 720), spp=spp),
            "c4": lambda: generate_camera_scene(tmp, resolution=(1280, 720), spp=spp),
            "c5": lambda: generate_kitchen_scene(tmp, resolution=(1280, 720), spp=spp)}[workload]
-    sc = Scene.load(gen())
+    if workload == 'c1':
+        from luisarender_amd.scenes import cornell_box
+        sc = Scene.from_string(cornell_box(resolution=512, spp=spp, depth=8))
+    else:
+        sc = Scene.load(gen())
     r = MegaPathRenderer(0)
     r.upload(sc)
     r.render(0, spp, counters=True, sync=True)

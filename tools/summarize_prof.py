@@ -9,7 +9,7 @@ import os
 import sqlite3
 import sys
 
-KERNEL = "%megapath_kernel%"
+KERNEL = "%megap%_kernel%"
 
 
 def main():
