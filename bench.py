@@ -62,7 +62,11 @@ ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 3909.0, "c3": 11125.0, "c4"
 # VALU issue rates calibrated on the box (tools/valu_peak.hip -> profiles/r02_valu_peak.json): cycles a SIMD needs per wave64
 # instruction with >= 2 waves resident: v_fma_f32 / v_add_u32 2.3-2.6, v_max_f32 / v_cvt_f32_ubyte / v_pk_fma_f32 4.1-4.3
 VALU_CYCLES_PER_WAVE_INSTR = (2.4, 4.2)
+# ... and the kernel's own mix priced with that table: tools/isa_census.py on the lean kernel's traversal loop (where two thirds of the
+# instructions are issued) gives 807 issue cycles for 247 VALU instructions (profiles/r03_isa_census.txt) = 3.27 cycles per instruction
+VALU_CYCLES_PER_WAVE_INSTR_MIX = 3.27
 SHADER_CLOCK_HZ = 2.4e9
+L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth, MI355X_MICROARCH.md (4 MiB per XCD, 32 MiB aggregate, ~34.5 TB/s)
 METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
@@ -118,7 +122,7 @@ def device_parity(scene, local_rank, cpu_frame, spp):
     h, w = gpu.shape[:2]
     y0, x0 = max(0, (h - 512) // 2), max(0, (w - 512) // 2)
     out["flip"] = M.flip(gpu[y0:y0 + 512, x0:x0 + 512, :3], cpu_frame[y0:y0 + 512, x0:x0 + 512, :3])
-    out.update({"samples": int(h * w * spp), "spp": spp, "kernel": f"lrd::megapath_kernel<{variant}u>", "finite": bool(np.isfinite(gpu).all()),
+    out.update({"samples": int(h * w * spp), "spp": spp, "kernel": kernel_name(variant), "finite": bool(np.isfinite(gpu).all()),
                 "against": "the CPU oracle's frame of the same samples (the oracle is bit-equal to the reference's own code: tests/test_oracle_vs_ref.py, "
                            "tests/test_ref_golden.py); rmse = per-pixel L2 of the converted linear RGB, flip = LDR-FLIP restated in oracle/image_metrics.py "
                            "(clip + sRGB), on the central 512 x 512"})
@@ -134,9 +138,24 @@ def path_statistics(scene, local_rank, spp=4):
     c = r.counters()
     r.close()
     paths = max(c["paths"], 1)
+    # what the kernel itself asks the memory system for, per sample: 64 B per BVH packet, 48 B per triangle test, one 128-byte shading
+    # record per surface hit, and per light sample the light's triangle (alias entry 8 B + shading-point gather 128 B)
+    requested = (64.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 128.0 * c["surface_hits"] + 136.0 * c["nee_samples"]) / paths
     return {"rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
             "shadow_rays_per_sample": c["shadow_rays"] / paths, "mean_path_length": c["path_length_sum"] / paths,
-            "nodes_per_ray": c["nodes_visited"] / max(c["closest_rays"] + c["shadow_rays"], 1), "spp": spp}
+            "nodes_per_ray": c["nodes_visited"] / max(c["closest_rays"] + c["shadow_rays"], 1), "spp": spp,
+            "nodes_per_sample": c["nodes_visited"] / paths, "tris_per_sample": c["tris_tested"] / paths,
+            "surface_hits_per_sample": c["surface_hits"] / paths, "nee_samples_per_sample": c["nee_samples"] / paths,
+            "requested_bytes_per_sample": requested,
+            "lanes": {"trace": c["trace_steps_busy"] / max(c["trace_steps"], 1), "trace_starved": c["trace_steps_starved"] / max(c["trace_steps"], 1),
+                      "shade": c["shade_busy"] / max(c["shade_calls"], 1),
+                      "note": "lane utilisation from the counting twin of the kernel at %d spp: trace = lane-steps of the traversal loop with a ray in flight / all lane-steps; "
+                              "shade = lanes with a hit to shade / lanes of a shading batch; trace_starved = lane-steps idle because the work item had no sample left" % spp}}
+
+
+def kernel_name(variant: int) -> str:
+    """symbol of the megakernel variant lrhip_last_variant names (include/lrhip.h LRHIP_FEAT_*): the pool kernels are another template"""
+    return f"lrd::megapool_kernel<{variant}u>" if variant & 4096 else f"lrd::megapath_kernel<{variant}u>"
 
 
 def source_hash() -> str:
@@ -189,7 +208,7 @@ def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
     return out
 
 
-def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None, sampler="Independent"):
+def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None, sampler="Independent", warmup_spp=None):
     """times `steps` frames of one workload -> (value Msamples/s, ms_per_step, kernel_ms, variant, scene, res, spp, desc)"""
     import numpy as np
     import torch
@@ -228,10 +247,10 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
     torch.cuda.synchronize()
     reduce_ms = []
 
-    def step():
+    def step(n=None):
         film.zero_()
         torch.cuda.synchronize()  # film clear is on torch's stream, the megakernel on the context's stream
-        renderer.render(0, spp, rank=rank, world=world, balance_shards=world)
+        renderer.render(0, n or spp, rank=rank, world=world, balance_shards=world)
         if reducer is not None or world > 1:
             renderer.synchronize()  # (one host round trip per step: it separates the collective's time from the kernel's)
             t = time.perf_counter()
@@ -252,7 +271,7 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        step()
+        step(warmup_spp)  # (warmup_spp: the extra configurations warm up -- allocations, code load -- on a few samples of their frame)
     reduce_ms.clear()
     barrier()
     t0 = time.perf_counter()
@@ -266,7 +285,17 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
         t = torch.tensor([elapsed, mean_kernel_ms, -mean_kernel_ms, mean_reduce_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, mean_kernel_ms = float(t[0]), float(t[1])
+        # what every rank actually saw -- its device, and the size / rank of ITS communicator as RCCL reports them (lrhip_comm_info) -- gathered to
+        # rank 0: the line itself says whether the collective spanned the N ranks the launcher started
+        mine = reducer.info() if reducer is not None else None
+        seen = torch.tensor([rank, local_rank, torch.cuda.current_device(), mine["ranks"] if mine else -1, mine["rank"] if mine else -1,
+                             mine["device"] if mine else -1, dist.get_world_size()], dtype=torch.int64, device=f"cuda:{local_rank}")
+        gathered = [torch.zeros_like(seen) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, seen)
+        ranks_seen = [dict(zip(("rank", "local_rank", "hip_device", "comm_ranks", "comm_rank", "comm_device", "process_group_size"), (int(x) for x in g.tolist()))) for g in gathered]
         info = {"kernel_ms_max_over_ranks": float(t[1]), "kernel_ms_min_over_ranks": -float(t[2]), "reduce_ms": float(t[3]),
+                "ranks": ranks_seen, "rccl_saw_all_ranks": all(r["comm_ranks"] == world for r in ranks_seen) if reducer is not None else None,
+                "distinct_devices": len({r["hip_device"] for r in ranks_seen}),
                 "reduce_bytes": res[0] * res[1] * 16, "note": "reduce_ms = host time from the end of the slowest rank's megakernel to the end of the collective (waiting for stragglers included)"}
         # The reduced film must BE the frame: rank 0 renders the first 8 tile rows (64 pixel rows, every rank owns tiles there) on its
         # own with the same balance_shards and compares them bit for bit with what the collective delivered.  A wrong collective
@@ -376,15 +405,22 @@ def main():
                         pass
             traffic = pmc["hbm_bytes_per_sample"] * launch_samples if pmc and pmc.get("hbm_bytes_per_sample") else None
             achieved = traffic / (mean_kernel_ms * 1e-3) / 1e9 if traffic else None
+            stats = out.get("path_statistics")
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                # What bounds lrd::megapath_kernel is VALU issue, jointly with the latency of its dependent gathers (DESIGN.md section 5;
+                # round 4 measured it directly: with the lanes of the traversal loop filled from 0.56 to 0.91 the kernel issued 14-23 %
+                # fewer VALU instructions and was no faster -- profiles/r04_pool_*).  The contract's HBM figures stay: `achieved` /
+                # `frac` / `traffic` are the MEASURED memory traffic over the kernel's duration (FETCH_SIZE counts Infinity-Cache hits too:
+                # an upper bound on HBM traffic); one number per roof follows in `valu`, `lanes`, `l2`.
+                "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic, "traffic_source": pmc_source,
-                "kernel": f"lrd::megapath_kernel<{variant}u>", "kernel_ms": mean_kernel_ms,
+                "kernel": kernel_name(variant), "kernel_ms": mean_kernel_ms,
                 "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_gbps": algorithmic_gbps,
                 "algorithmic_frac_of_hbm_peak": algorithmic_gbps / HBM_PEAK_GBPS,
-                "note": "achieved / frac = MEASURED HBM traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE) over the kernel's HIP-event duration; "
-                        "algorithmic_* = the canonical-BVH2 byte count of SURVEY 8(d), most of which L2 / LDS serve on chip (it may exceed "
-                        "the HBM peak and is not a traffic figure); the kernel is bound by VALU issue + memory latency, see `valu` and DESIGN.md 5",
+                "note": "achieved / frac = MEASURED memory traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) over the kernel's HIP-event "
+                        "duration; algorithmic_* = the canonical-BVH2 byte count of SURVEY 8(d), most of which L1 / L2 / LDS serve on chip (it may exceed "
+                        "the HBM peak and is not a traffic figure); valu.issue_frac = the VALU pipes' occupancy, lanes = how many of the issued lanes "
+                        "did useful work, l2 = the kernel's own requests against the L2's bandwidth",
             }
             if pmc and pmc.get("valu_wave_instr_per_sample"):
                 instr = pmc["valu_wave_instr_per_sample"] * launch_samples
@@ -392,26 +428,48 @@ def main():
                 simds = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
                 simd_cycles = simds * mean_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
                 out["roofline"]["valu"] = {
-                    "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"],
-                    "issue_frac_if_all_full_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[0] / simd_cycles,
-                    "issue_frac_if_all_quarter_rate": instr * VALU_CYCLES_PER_WAVE_INSTR[1] / simd_cycles,
-                    "calibration": "profiles/r03_valu_peak.json (tools/valu_peak2.hip, 64 opcodes): 2.4 cycles per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every "
-                                   "min / max / cvt / cmp / cndmask / shift / packed op, 8.2 per transcendental; the kernel's mix lies between (tools/isa_census.py prices its loops)",
+                    "issue_frac": instr * VALU_CYCLES_PER_WAVE_INSTR_MIX / simd_cycles,
+                    "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"], "wave_instr_per_launch": instr,
+                    "cycles_per_wave_instr": VALU_CYCLES_PER_WAVE_INSTR_MIX, "simds": simds, "shader_clock_hz": SHADER_CLOCK_HZ, "simd_cycles_per_launch": simd_cycles,
+                    "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the kernel's own "
+                                   "opcode mix priced with the issue costs measured on the box (profiles/r03_valu_peak.json, tools/valu_peak2.hip, 64 opcodes: 2.4 cycles "
+                                   "per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every min / max / cvt / cmp / cndmask / shift / packed op, 8.2 per "
+                                   "transcendental): 807 cycles for the 247 VALU instructions of the traversal loop (profiles/r03_isa_census.txt, tools/isa_census.py)",
+                }
+                counters = pmc.get("counters") or {}
+                if counters.get("SQ_ACTIVE_INST_VALU") and counters.get("SQ_WAVE_CYCLES"):
+                    out["roofline"]["valu"]["pmc_active_inst_valu_over_wave_cycles"] = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
+            if stats:
+                out["roofline"]["lanes"] = stats["lanes"]
+                req_gbps = stats["requested_bytes_per_sample"] * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
+                out["roofline"]["l2"] = {
+                    "frac": req_gbps / L2_PEAK_GBPS, "requested_gbps": req_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s",
+                    "requested_bytes_per_sample": stats["requested_bytes_per_sample"],
+                    "note": "the kernel's own requests per sample from its counters (path_statistics: 64 B x nodes + 48 B x triangle tests + 128 B x surface hits "
+                            "+ 136 B x light samples) x samples / kernel time, against the aggregate L2 bandwidth (MI355X_MICROARCH.md); the vector L1 serves "
+                            "part of them (the BVH's top levels), so this is an upper bound on L2 traffic",
                 }
             if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None:
                 extra = []
-                # (workload, steps, spp, CPU leg, sampler): C1 = BASELINE configs[0] whole; C4 = the 8-GPU configuration's 1-GPU number;
-                # C2 once more with the sampler class + filter the reference's converter writes for the README scenes
-                # (tools/tungsten2luisa.py:373-412 there: a low-discrepancy sampler, Gaussian r = 1 -- the stand-in's filter already)
-                for w, steps, spp_o, with_cpu, sampler in (("c1", 3, None, True, "Independent"), ("c3", 2, 1024, False, "Independent"),
-                                                           ("c4", 2, 64, False, "Independent"), ("c5", 1, 512, False, "Independent"),
-                                                           ("c2", 3, 256, False, "PaddedSobol")):
-                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler)
-                    e = {"workload": d, "sampler": sampler, "spp_timed": sp, "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
-                         "kernel": f"lrd::megapath_kernel<{var}u>", "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
-                    if with_cpu:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration
-                        e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _, (cpu_frame, cpu_spp) = cpu_baseline(sc, r, 30.0, full_spp=sp)
+                # Every other BASELINE configuration AT ITS STATED SIZE on this GPU (round 4; round 3 timed them at reduced spp), each with
+                # its own oracle leg on a bounded sample and the parity of the device against it: C1 = configs[0] whole (+ the reference's
+                # own code beside it), C3 at 4096 spp, C4 = the 8-GPU configuration's 1-GPU number at 1024 spp, C5 at 2048 of its 65 536 spp
+                # (>= 1024; the Independent sampler's throughput is spp-invariant beyond the item drain), and C2
+                # once more with the sampler class + filter the reference's converter writes for the README scenes
+                # (tools/tungsten2luisa.py:373-412 there: a low-discrepancy sampler, Gaussian r = 1 -- the stand-in's filter already).
+                # (workload, timed steps, spp (None = the configuration's), seconds of oracle, whole configuration on the CPU, sampler)
+                for w, steps, spp_o, cpu_s, whole, sampler in (("c1", 3, None, 30.0, True, "Independent"), ("c3", 1, None, 8.0, False, "Independent"),
+                                                               ("c4", 1, None, 10.0, False, "Independent"), ("c5", 1, BENCH_SPP_CAP["c5"], 8.0, False, "Independent"),
+                                                               ("c2", 1, None, 0.0, False, "PaddedSobol")):
+                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler, warmup_spp=None if w == "c1" else 8)
+                    e = {"workload": d, "sampler": sampler, "spp_timed": sp, "spp_config": WORKLOADS[w][2], "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
+                         "kernel_ms": kms, "kernel": kernel_name(var), "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
+                    if cpu_s > 0.0:
+                        e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _, (cpu_frame, cpu_spp) = cpu_baseline(sc, r, cpu_s, full_spp=sp if whole else None)
                         e["parity"] = device_parity(sc, local_rank, cpu_frame, cpu_spp)
+                    else:  # (the same frame and estimator as the headline line, another sampler: its parity is the twin tests', tests/test_gpu_parity.py)
+                        e["parity"] = None
+                    if whole:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration --
                         # and the REFERENCE'S OWN code beside it (oracle/_ref, one thread, a bounded sample of the same frame); absent
                         # where oracle/_ref was not built
                         # (in a child process: libref.so brings its own operator new and the reference's symbols)

@@ -132,6 +132,9 @@ int lrhip_comm_unique_id(unsigned char id[LRHIP_COMM_ID_BYTES]);
 int lrhip_comm_init_rank(lrhip_ctx *ctx, int world, int rank, const unsigned char id[LRHIP_COMM_ID_BYTES], void **comm);
 int lrhip_comm_init_all(int count, const int *devices, void **comms);
 int lrhip_comm_destroy(void *comm);
+/* what a communicator actually spans: out = { ranks (ncclCommCount), this rank (ncclCommUserRank), its HIP device (ncclCommCuDevice) } --
+ * so that a host (bench.py's multi_gpu block) can say from its own output whether RCCL saw the N ranks it was launched with */
+int lrhip_comm_info(void *comm, int out[3]);
 
 int lrhip_get_counters(lrhip_ctx *ctx, lrhip_counters *out); /* summed since upload; synchronises */
 /* HIP-event time of the megakernel launches of the last lrhip_render call, in ms; synchronises */

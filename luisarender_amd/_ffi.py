@@ -207,6 +207,7 @@ def hip_lib(path: str | None = None) -> C.CDLL:
         lib.lrhip_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         lib.lrhip_comm_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         lib.lrhip_comm_destroy.argtypes = [C.c_void_p]
+        lib.lrhip_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.lrhip_device_count.argtypes = [C.POINTER(C.c_int)]
         lib.lrhip_bind_film.argtypes = [C.c_void_p, C.c_void_p]
         lib.lrhip_film_clear.argtypes = [C.c_void_p]

@@ -1244,6 +1244,9 @@ struct Rccl {
     int (*reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t){nullptr};
     int (*group_start)(){nullptr};
     int (*group_end)(){nullptr};
+    int (*comm_count)(void *, int *){nullptr};// (optional: lrhip_comm_info)
+    int (*comm_user_rank)(void *, int *){nullptr};
+    int (*comm_device)(void *, int *){nullptr};
     bool ok{false};
     Rccl() {
         auto lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -1256,6 +1259,9 @@ struct Rccl {
         reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
         group_start = reinterpret_cast<decltype(group_start)>(dlsym(lib, "ncclGroupStart"));
         group_end = reinterpret_cast<decltype(group_end)>(dlsym(lib, "ncclGroupEnd"));
+        comm_count = reinterpret_cast<decltype(comm_count)>(dlsym(lib, "ncclCommCount"));
+        comm_user_rank = reinterpret_cast<decltype(comm_user_rank)>(dlsym(lib, "ncclCommUserRank"));
+        comm_device = reinterpret_cast<decltype(comm_device)>(dlsym(lib, "ncclCommCuDevice"));
         ok = get_unique_id && comm_init_rank && comm_init_all && comm_destroy && reduce && group_start && group_end;
     }
 };
@@ -1302,6 +1308,17 @@ int lrhip_comm_destroy(void *comm) {
     if (comm == nullptr) { return LRHIP_OK; }
     if (!rccl().ok) { return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_destroy: librccl.so could not be loaded"); }
     if (auto rc = rccl().comm_destroy(comm); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommDestroy failed with code " + std::to_string(rc)); }
+    return LRHIP_OK;
+}
+
+int lrhip_comm_info(void *comm, int out[3]) {
+    if (comm == nullptr || out == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_comm_info: NULL argument"); }
+    if (!rccl().ok || !rccl().comm_count || !rccl().comm_user_rank || !rccl().comm_device) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_comm_info: librccl.so (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) could not be loaded");
+    }
+    if (auto rc = rccl().comm_count(comm, out + 0); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommCount failed with code " + std::to_string(rc)); }
+    if (auto rc = rccl().comm_user_rank(comm, out + 1); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommUserRank failed with code " + std::to_string(rc)); }
+    if (auto rc = rccl().comm_device(comm, out + 2); rc != 0) { return fail(LRHIP_ERROR_DEVICE, "ncclCommCuDevice failed with code " + std::to_string(rc)); }
     return LRHIP_OK;
 }
 

@@ -57,6 +57,10 @@ class FilmReducer:
         if self.comm is not None:
             self.renderer.film_reduce(self.comm, dst)
 
+    def info(self) -> dict | None:
+        """ranks / rank / device as RCCL itself reports them for this communicator (lrhip_comm_info); None without one"""
+        return self.renderer.comm_info(self.comm) if self.comm is not None else None
+
     def close(self) -> None:
         if self.comm is not None:
             self.renderer.comm_destroy(self.comm)

@@ -109,6 +109,12 @@ class MegaPathRenderer:
         """sum-reduce of the bound film to `root` over RCCL, in stream order behind the renders (lrhip_film_reduce)"""
         self._check(self._lib.lrhip_film_reduce(self._ctx, comm, root))
 
+    def comm_info(self, comm) -> dict:
+        """lrhip_comm_info: what the communicator spans -- ranks, this rank, its device"""
+        out = (C.c_int * 3)()
+        self._check(self._lib.lrhip_comm_info(comm, out))
+        return {"ranks": int(out[0]), "rank": int(out[1]), "device": int(out[2])}
+
     def comm_destroy(self, comm) -> None:
         self._check(self._lib.lrhip_comm_destroy(comm))
 

@@ -899,6 +899,37 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
     assert np.array_equal(mono[..., 3], films[0][..., 3]) and err < 2e-2 and abs(films[0][..., :3].mean() - mono[..., :3].mean()) / mono[..., :3].mean() < 2e-3
 
 
+def test_wavefront_mode_keeps_negative_samples(renderer, tmp_path):
+    """Mitchell and Lanczos filters have negative lobes: the filter weight (f / pdf, filter.cpp:49-64) and with it a sample's radiance can
+    be negative.  A path that finishes outside its tile's wave adds in fixed point, and round 3 clamped those adds at zero -- brighter
+    frames in wavefront mode only.  Signed adds now: wavefront mode and the all-in-one kernel (plain float adds, like the reference's
+    ColorFilmInstance::_accumulate) render the same frame, negative pixels included."""
+    path = generate_kitchen_scene(str(tmp_path), resolution=(192, 108), spp=12, target_triangles=40_000)
+    text = open(path).read()
+    assert "filter : Gaussian { radius { 1 } }" in text
+    mitchell = tmp_path / "kitchen_mitchell.luisa"
+    mitchell.write_text(text.replace("filter : Gaussian { radius { 1 } }", "filter : Mitchell { radius { 2 } }"))
+    sc = Scene.load(str(mitchell))
+    renderer.upload(sc)
+    renderer.render(0, 12, sync=True)
+    wave = renderer.download(False)
+    assert (renderer.last_variant() & WF) != 0
+    try:
+        renderer.set_wavefront(False)
+        renderer.clear()
+        renderer.render(0, 12, sync=True)
+        mono = renderer.download(False)
+        assert (renderer.last_variant() & WF) == 0
+    finally:
+        renderer.set_wavefront(True)
+    neg = mono[..., :3] < 0.0
+    print(f"Mitchell r = 2: {int(neg.sum())} negative channel sums of {neg.size}; wavefront vs all-in-one rel-L1 {_rel_l1(wave, mono):.2e}")
+    assert neg.sum() > 0  # (the scene does produce negative sums: what round 3 lost)
+    assert np.array_equal(wave[..., 3], mono[..., 3])
+    assert abs(wave[..., :3].mean() - mono[..., :3].mean()) / abs(mono[..., :3].mean()) < 2e-3 and _rel_l1(wave, mono) < 2e-2
+    assert abs(wave[..., :3][neg].sum() - mono[..., :3][neg].sum()) <= 0.05 * abs(mono[..., :3][neg].sum()) + 1e-3
+
+
 def test_c_abi_rejects_closure_trees_the_interpreters_cannot_walk(renderer):
     """lrhip_upload_scene walks every Mix / Layered tree itself: what the C++ loader refuses -- more than two
     Layered levels on a path through the interfaces, a Mix tree whose recorded depth (u[2]) is not its depth, a cycle -- is an

@@ -1,0 +1,188 @@
+"""GPU tests of the path-pool scheduler of round 4 (csrc/hip/megapool_kernel.h, lrhip_set_scheduler mode 2): two path contexts per lane,
+work items overlapping inside a wave, the film summed in 64-bit fixed point.
+
+The pool kernels run the SAME shading block on the same random numbers as the one-path-per-lane kernels, so a path's value is the same to
+the last bit; what differs is the ORDER in which a pixel's samples are added -- fp32 adds in the wave's own order there, integer adds
+here -- i.e. the last bits of a sum.  The one-path-per-lane kernels are held against the oracle (and through it the reference's own code) by
+tests/test_gpu_parity.py and tests/test_ref_golden.py; these tests hold the pool kernels against them, against the oracle directly on the
+Cornell box, and check what the fixed-point film promises: bit-identical frames run to run, under any sharding AND any work-item partition."""
+import numpy as np
+import pytest
+
+from luisarender_amd import Scene
+from luisarender_amd.scenes import cornell_box, generate_kitchen_scene, generate_room_scene
+from oracle.check import Oracle
+
+pytestmark = pytest.mark.gpu
+POOL, WF = 4096, 1024  # LRHIP_FEAT_POOL, LRHIP_FEAT_WAVEFRONT
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    from luisarender_amd.render import MegaPathRenderer
+    r = MegaPathRenderer(0)
+    yield r
+    r.close()
+
+
+def _rel_l1(a, b):
+    return float(np.abs(a[..., :3] - b[..., :3]).sum() / max(np.abs(b[..., :3]).sum(), 1e-20))
+
+
+def _both(renderer, scene, spp, counters=False):
+    out = {}
+    try:
+        for name, pool in (("lane", False), ("pool", True)):
+            renderer.set_scheduler(pool)
+            renderer.upload(scene)
+            renderer.render(0, spp, counters=counters, sync=True)
+            out[name] = (renderer.download(False), renderer.last_variant(), renderer.counters() if counters else None)
+    finally:
+        renderer.set_scheduler(None)
+    return out
+
+
+DISNEY = ('Surface paint : Disney { color : Constant { v { 0.8, 0.3, 0.2 } } metallic { 0.3 } roughness { 0.35 } clearcoat { 0.5 } '
+          'sheen { 0.3 } specular_trans { 0.2 } }\n')
+GLASS = 'Surface crystal : Glass { Kr : Constant { v { 0.95, 0.95, 0.95 } } Kt : Constant { v { 0.9, 0.95, 0.9 } } eta { "bk7" } roughness { 0.1 } }\n'
+
+
+@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "pcg", "mitchell", "rr"])
+def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(renderer, case):
+    kw = dict(resolution=96, spp=24)
+    if case == "glass":
+        kw.update(extra_surfaces=GLASS, short_box_surface="crystal")
+    elif case == "disney":
+        kw.update(extra_surfaces=DISNEY, tall_box_surface="paint")
+    elif case == "sobol":
+        kw.update(sampler="Sobol")
+    elif case == "pcg":
+        kw.update(sampler="PCG32")
+    elif case == "mitchell":
+        kw.update(filter_impl="Mitchell", filter_radius=2.0)  # negative lobes: negative samples (signed fixed-point adds)
+    elif case == "rr":
+        kw.update(rr_depth=2, depth=12)
+    scene = Scene.from_string(cornell_box(**kw))
+    out = _both(renderer, scene, 24, counters=True)
+    (lane, v_lane, c_lane), (pool, v_pool, c_pool) = out["lane"], out["pool"]
+    assert (v_pool & POOL) != 0 and (v_lane & POOL) == 0 and (v_pool & ~POOL) == v_lane, (v_lane, v_pool)
+    assert np.isfinite(pool).all() and np.array_equal(pool[..., 3], lane[..., 3])
+    # the same paths: every counter of the path topology is EQUAL (not close: same kernel code per vertex, same random numbers)
+    for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nee_samples", "path_length_sum", "nodes_visited", "tris_tested"):
+        assert c_pool[k] == c_lane[k], (k, c_pool[k], c_lane[k])
+    err = _rel_l1(pool, lane)
+    print(f"{case}: pool vs one-path-per-lane rel-L1 {err:.2e}; pool lanes trace {c_pool['trace_steps_busy'] / c_pool['trace_steps']:.2f} "
+          f"(one path per lane {c_lane['trace_steps_busy'] / c_lane['trace_steps']:.2f})")
+    assert err < 1e-6  # fp32 sum in the wave's order vs exact integer sum rounded once: ~spp * 2^-24
+    assert np.allclose(pool[..., :3], lane[..., :3], rtol=2e-5, atol=1e-6)
+
+
+def test_pool_kernels_against_the_oracle(renderer):
+    scene = Scene.from_string(cornell_box(resolution=128, spp=16))
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(scene)
+        renderer.render(0, 16, counters=True, sync=True)
+        gpu, gc = renderer.download(False), renderer.counters()
+        assert renderer.last_variant() == (POOL | 1)
+    finally:
+        renderer.set_scheduler(None)
+    cpu, cc = Oracle(scene).render(0, 16)
+    assert gc["paths"] == cc["paths"]
+    for k in ("closest_rays", "surface_hits", "nee_samples", "path_length_sum"):
+        assert abs(gc[k] - cc[k]) <= max(1, 1e-5 * cc[k]), (k, gc[k], cc[k])
+    assert np.array_equal(gpu[..., 3], cpu[..., 3]) and _rel_l1(gpu, cpu) < 1e-4  # (the bars of test_gpu_parity.py::test_cornell_same_paths_and_image)
+
+
+def test_pool_films_are_bit_identical_under_any_sharding_and_any_work_item_partition(renderer, tmp_path):
+    """Integer sums are associative: the frame does not depend on the order of its adds -- not on the run, not on how tiles are dealt
+    to GPUs, and (what rounds 1-3 could not offer) not on how the frame is cut into work items: shards rendered with DIFFERENT
+    balance_shards hints and item sizes still add up to the unsharded frame bit for bit."""
+    scene = Scene.load(generate_room_scene(str(tmp_path), target_triangles=40_000, resolution=(200, 120), spp=12))  # (ragged: 200 x 120 is 25 x 15 tiles)
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(scene)
+        frames = []
+        for _ in range(2):
+            renderer.clear()
+            renderer.render(0, 12, sync=True)
+            frames.append(renderer.download(False))
+        assert (renderer.last_variant() & POOL) != 0
+        assert np.array_equal(frames[0], frames[1]) and np.isfinite(frames[0]).all() and (frames[0][..., 3] == 12).all()
+        for world, hint, scale in ((3, 3, 0.0), (4, 1, 0.0), (2, 8, 0.3), (5, 2, 4.0)):
+            renderer.set_diagnostics(item_scale=scale)
+            total = np.zeros_like(frames[0])
+            for rank in range(world):
+                renderer.clear()
+                renderer.render(0, 12, rank=rank, world=world, balance_shards=hint, sync=True)
+                total += renderer.download(False)
+            assert np.array_equal(total, frames[0]), (world, hint, scale)
+        renderer.set_diagnostics()
+        # progressive calls: each call's sums are rounded to fp32 once when they join the film
+        renderer.clear()
+        renderer.render(0, 5, sync=True)
+        renderer.render(5, 12, sync=True)
+        two = renderer.download(False)
+        assert np.array_equal(two[..., 3], frames[0][..., 3]) and np.allclose(two, frames[0], rtol=1e-6, atol=1e-7)
+    finally:
+        renderer.set_diagnostics()
+        renderer.set_scheduler(None)
+
+
+def test_pool_kernels_in_wavefront_mode(renderer, tmp_path):
+    """Mix / Layered scenes: the lean camera pass and the continuation pass as pool kernels around the same heavy-closure kernels."""
+    scene = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16, target_triangles=60_000))
+    out = _both(renderer, scene, 16)
+    (lane, v_lane, _), (pool, v_pool, _) = out["lane"], out["pool"]
+    assert v_lane == (WF | 16 | 32 | 64) and v_pool == (v_lane | POOL)
+    err = _rel_l1(pool, lane)
+    print(f"wavefront mode, pool vs one-path-per-lane lean kernels: rel-L1 {err:.2e}")
+    assert np.array_equal(pool[..., 3], lane[..., 3]) and (pool[..., 3] == 16).all() and np.isfinite(pool).all()
+    assert err < 1e-6
+    try:  # bit-identical run to run and under sharding, like everything that adds in fixed point
+        renderer.set_scheduler(True)
+        renderer.upload(scene)
+        total = np.zeros_like(pool)
+        for rank in range(3):
+            renderer.clear()
+            renderer.render(0, 16, rank=rank, world=3, sync=True)
+            total += renderer.download(False)
+        assert np.array_equal(total, pool)
+    finally:
+        renderer.set_scheduler(None)
+
+
+def test_frames_that_do_not_fit_fixed_point_take_the_float_kernels(renderer, tmp_path):
+    """A film clamp used to switch clamping off (1e20) leaves no fractional bits in 64-bit fixed point: the pool kernels -- and wavefront
+    mode, whose parked paths add in fixed point -- step aside for the float-accumulating kernels instead of quantising the frame
+    (round 3 rendered such a wavefront frame in whole integers)."""
+    big = Scene.from_string(cornell_box(resolution=64, spp=8).replace("film : Color {", "film : Color { clamp { 1e20 }"))
+    ref = Scene.from_string(cornell_box(resolution=64, spp=8).replace("film : Color {", "film : Color { clamp { 1e6 }"))
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(big)
+        renderer.render(0, 8, sync=True)
+        a = renderer.download(False)
+        assert (renderer.last_variant() & POOL) == 0
+        renderer.upload(ref)
+        renderer.render(0, 8, sync=True)
+        b = renderer.download(False)
+        assert (renderer.last_variant() & POOL) != 0  # 1e6 x 8 spp still leaves 38 fractional bits
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6)  # (nothing in a Cornell box reaches either clamp)
+    finally:
+        renderer.set_scheduler(None)
+    kitchen = generate_kitchen_scene(str(tmp_path), resolution=(128, 72), spp=8, target_triangles=30_000)
+    text = open(kitchen).read().replace("film : Color {", "film : Color { clamp { 1e20 }")
+    path = tmp_path / "kitchen_noclamp.luisa"
+    path.write_text(text)
+    renderer.upload(Scene.load(str(path)))
+    renderer.render(0, 8, sync=True)
+    f = renderer.download(False)
+    assert (renderer.last_variant() & WF) == 0 and np.isfinite(f).all() and (f[..., 3] == 8).all()
+    assert float(np.abs(f[..., :3] - np.round(f[..., :3])).max()) > 1e-3  # not whole numbers
+
+
+def test_scheduler_argument_is_checked(renderer):
+    import ctypes as C
+    assert renderer._lib.lrhip_set_scheduler(renderer._ctx, 3) != 0 and b"lrhip_set_scheduler" in renderer._lib.lrhip_last_error()
+    assert renderer._lib.lrhip_set_scheduler(C.c_void_p(), 0) != 0
