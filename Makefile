@@ -71,17 +71,19 @@ hip: $(LIBDIR)/liblrhip.so
 # test_gpu_parity.py::test_volumetric_megakernel); with contraction it renders the lamp-lit fog scenes 30 % darker than the
 # reference's own code does (measured, round 2).  It is a feature row, not the benchmarked path.
 VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize
-# The variants that make REAL CALLS (out-of-line closures: every mask with Mix, Layered or the volumetric kernel) are built with
-# -mllvm -amdgpu-spill-sgpr-to-vgpr=0.  With the default (SGPRs spilled into lanes of a VGPR) those kernels come out miscompiled
-# or not depending on unrelated code, flags and the register budget: NaN / lost samples in <124> at 3 waves per SIMD in round 1, fine
-# after round 2's changes, broken again without the SLP vectorizer, <124> (not <125>) non-deterministic at 4 waves after one more
-# change -- each time bit-identical to the good builds with this flag.  Some scenes pass on a broken binary (the kitchen parity test
-# did), so tests cannot establish that a fast build is sound; the flag removes the mechanism.  Cost: kitchen stand-in 275 -> 256
-# Msamples/s, <60> 350 -> 298 (profiles/r02f_ab_compiler_flags.txt).  The lean variants keep the default: their one call is the texture
-# callback of load_lobe (dev_math.h: LR_TEX_LAMBDA; profiles/r03s_sgpr_spill_repro.txt: every lean binary is bit-identical with and without the flag).
-CALL_MASKS := 60 61 62 63 124 125 126 127 636 637 638 639 252 253 254 255 256 257 258 259
+# EVERY variant is built with -mllvm -amdgpu-spill-sgpr-to-vgpr=0.  With the default (SGPRs spilled into lanes of a VGPR) the kernels that
+# make REAL CALLS (out-of-line closures: every mask with Mix, Layered or the volumetric kernel) come out miscompiled or not depending on
+# unrelated code, flags and the register budget: NaN / lost samples in <124> at 3 waves per SIMD in round 1, fine after round 2's changes,
+# broken again without the SLP vectorizer, <124> (not <125>) non-deterministic at 4 waves after one more change -- each time
+# bit-identical to the good builds with this flag.  Some scenes pass on a broken binary (the kitchen parity test did), so tests cannot
+# establish that a fast build is sound; the flag removes the mechanism.  Cost: kitchen stand-in 275 -> 256 Msamples/s, <60> 350 -> 298
+# (profiles/r02f_ab_compiler_flags.txt).  Round 4: the LEAN variants too -- since round 3 they make a real call of their own
+# (the texture callback of load_lobe, dev_math.h: LR_TEX_LAMBDA, is out of line) and spill SGPRs, i.e. they hold exactly the
+# ingredients; no binary of theirs was ever caught wrong (profiles/r03s_sgpr_spill_repro.txt: bit-identical with and without the
+# flag), but the same was true of <124> for two rounds.  Cost, same box: C2 782.3 -> 777.0, C3 809.6 -> 803.4, C4 875.6 -> 876.2
+# Msamples/s at 64 spp, films bit-identical (profiles/r04_ab_call_safe_lean.txt).
 CALL_SAFE_FLAGS ?= -mllvm -amdgpu-spill-sgpr-to-vgpr=0
-variant_flags = $(if $(filter 256 257 258 259,$(1)),$(VPT_HIPFLAGS),$(HIPFLAGS)) $(if $(filter $(CALL_MASKS),$(1)),$(CALL_SAFE_FLAGS),)
+variant_flags = $(if $(filter 256 257 258 259,$(1)),$(VPT_HIPFLAGS),$(HIPFLAGS)) $(CALL_SAFE_FLAGS)
 $(OBJDIR)/variant_%.o: $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(call variant_flags,$*) -DLR_VARIANT=$* -c -o $@ $(HIPDIR)/megapath_variant.hip

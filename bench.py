@@ -122,6 +122,25 @@ def device_parity(scene, local_rank, cpu_frame, spp):
     h, w = gpu.shape[:2]
     y0, x0 = max(0, (h - 512) // 2), max(0, (w - 512) // 2)
     out["flip"] = M.flip(gpu[y0:y0 + 512, x0:x0 + 512, :3], cpu_frame[y0:y0 + 512, x0:x0 + 512, :3])
+    # ... and against the oracle on the DEVICE'S OWN GEOMETRY (oracle_bvh.h baked-geometry mode: the fp32 world-space triangles the host bakes,
+    # not the reference's object-space ones), central window, same samples: what is left is the kernel's arithmetic alone
+    try:
+        from oracle.check import Oracle
+        rect = (x0, y0, min(x0 + 512, w), min(y0 + 512, h))
+        baked = Oracle(scene, bake_instances=True)
+        sub, _ = baked.render(0, spp, rect=rect)
+        ref = baked.convert(sub)[rect[1]:rect[3], rect[0]:rect[2], :3]
+        dev = gpu[rect[1]:rect[3], rect[0]:rect[2], :3]
+        obj = cpu_frame[rect[1]:rect[3], rect[0]:rect[2], :3]
+        out["parity_same_geometry"] = {"rel_l1": float(np.abs(dev - ref).sum() / max(np.abs(ref).sum(), 1e-30)),
+                                       "bias": float((dev.mean() - ref.mean()) / max(ref.mean(), 1e-30)), "window": list(rect), "spp": spp,
+                                       # the scene's own sensitivity: the oracle against itself across the two geometry modes (same algorithm, same samples,
+                                       # hit points that differ in their last bit) -- the device cannot be closer to either than they are to each other
+                                       "oracle_vs_oracle_rel_l1": float(np.abs(ref - obj).sum() / max(np.abs(obj).sum(), 1e-30)),
+                                       "device_vs_object_space_oracle_rel_l1_same_window": float(np.abs(dev - obj).sum() / max(np.abs(obj).sum(), 1e-30)),
+                                       "against": "the CPU oracle intersecting the fp32 world-space triangles the host bakes for the device (test infrastructure), same samples"}
+    except Exception as e:  # noqa: BLE001
+        out["parity_same_geometry"] = {"error": str(e)}
     out.update({"samples": int(h * w * spp), "spp": spp, "kernel": kernel_name(variant), "finite": bool(np.isfinite(gpu).all()),
                 "against": "the CPU oracle's frame of the same samples (the oracle is bit-equal to the reference's own code: tests/test_oracle_vs_ref.py, "
                            "tests/test_ref_golden.py); rmse = per-pixel L2 of the converted linear RGB, flip = LDR-FLIP restated in oracle/image_metrics.py "

@@ -12,6 +12,8 @@
 #include <cstddef>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include <functional>
@@ -102,6 +104,7 @@ struct DeviceBuffer {
 // chunking (and therefore the fp32 summation order of the film) is identical on every GPU
 constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
 constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
+constexpr uint64_t kWfQueueBudget = 96ull << 30u;// bytes the queues of wavefront mode may take (of 288 GB)
 #ifndef LR_MAX_BLOCKS_PER_CU
 #define LR_MAX_BLOCKS_PER_CU 8
 #endif
@@ -170,6 +173,9 @@ void release_scene(lrhip_ctx *ctx) {
     for (auto &b : ctx->scene_buffers) { b.release(); }
     ctx->scene_buffers.clear();
     ctx->scene_ready = false;
+    // the queues of wavefront mode and the pool kernels' state records are sized for the scene (and the memory free at the time): a new
+    // scene starts without them (76-89 GB kept until lrhip_destroy starved later allocations on the same GPU)
+    ctx->wf_heavy.release(), ctx->wf_cont.release(), ctx->pool.release();
 }
 
 // 3x3 inverse-transpose, same arithmetic as luisa::inverse(float3x3) + transpose (geometry.cpp:378)
@@ -565,7 +571,21 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
             // C-ABI caller gets the same answer here instead of silently wrong shading: at most LR_LAYERED_MAX_LEVELS Layered surfaces on
             // a path through the interfaces, Mix trees at most kMixMaxDepth levels deep with u[2] = that depth, no cycles.
             std::string bad;
+            // (memoised per (surface, Layered levels above it): subtrees shared between parents -- a DAG from a C-ABI caller -- are walked
+            // once, not once per path to them; a surface met again while it is still being walked is a cycle)
+            std::map<std::pair<uint32_t, uint32_t>, int> memo;
+            std::set<std::pair<uint32_t, uint32_t>> walking;
+            std::function<int(uint32_t, uint32_t, uint32_t)> depth_of_inner;
             std::function<int(uint32_t, uint32_t, uint32_t)> depth_of = [&](uint32_t tag, uint32_t budget, uint32_t layered_above) -> int {
+                const auto key = std::make_pair(tag, layered_above);
+                if (auto it = memo.find(key); it != memo.end()) { return it->second; }
+                if (!walking.insert(key).second) { bad = "a Mix / Layered tree that is cyclic or deeper than the interpreter reaches"; return 0; }
+                const auto d = depth_of_inner(tag, budget, layered_above);
+                walking.erase(key);
+                if (bad.empty()) { memo.emplace(key, d); }
+                return d;
+            };
+            depth_of_inner = [&](uint32_t tag, uint32_t budget, uint32_t layered_above) -> int {
                 auto &c = s->surfaces[tag];
                 if (budget == 0u) { bad = "a Mix / Layered tree that is cyclic or deeper than the interpreter reaches"; return 0; }
                 if (c.kind == LR_SURFACE_LAYERED) {
@@ -936,7 +956,8 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     size_t free_bytes = 0u, total_bytes = 0u;
     LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
     const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
-    auto fit_paths = std::min<uint64_t>((1ull << 31u) - 1u, std::max<uint64_t>(1ull << 16u, have / 2u / per_path));// at most half of what is free
+    // at most half of what is free, and at most kWfQueueBudget: the 2^28-path default slice needs 76-89 GB, more buys nothing
+    auto fit_paths = std::min<uint64_t>((1ull << 31u) - 1u, std::max<uint64_t>(1ull << 16u, std::min<uint64_t>(have / 2u, kWfQueueBudget) / per_path));
     if (ctx->wf_mode == 2u) { fit_paths = 8ull * 64u * slice_spp; }// (tests: eight tiles at a time)
     const auto group_tiles = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(tiles_in_range, fit_paths / (64ull * slice_spp))));
     const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, (1ull << 31u) - 1u));

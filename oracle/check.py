@@ -34,6 +34,7 @@ def oracle_lib() -> C.CDLL:
         lib.oracle_create.argtypes = [C.POINTER(_ffi.Scene)]
         lib.oracle_destroy.argtypes = [C.c_void_p]
         lib.oracle_set_shutter_weight.argtypes = [C.c_void_p, f32]
+        lib.oracle_set_bake.argtypes = [C.c_void_p, C.c_int]
         lib.oracle_render.argtypes = [C.c_void_p, u32, u32, u32, u32, u32, u32, C.c_int, C.c_void_p,
                                       C.POINTER(OracleCounters)]
         lib.oracle_film_convert.argtypes = [C.POINTER(_ffi.Scene), C.c_void_p, C.c_void_p]
@@ -63,12 +64,16 @@ def oracle_lib() -> C.CDLL:
 
 
 class Oracle:
-    def __init__(self, scene: Scene, camera: int = 0):
+    def __init__(self, scene: Scene, camera: int = 0, bake_instances: bool = False):
+        """bake_instances: intersect the fp32 WORLD-space triangles the host bakes for the device (lr_scene.accel.triangles) instead of the
+        reference's object-space triangles behind the instance transform -- isolates the kernel from that design choice (oracle_bvh.h)"""
         self._lib = oracle_lib()
         self._scene = scene
         self._view = scene.view(camera)
         self._ctx = self._lib.oracle_create(C.byref(self._view))
         self.width, self.height = int(self._view.camera.width), int(self._view.camera.height)
+        if bake_instances and self._lib.oracle_set_bake(self._ctx, 1) != 0:
+            raise RuntimeError("oracle: the scene view holds no baked triangles (acceleration structure not built)")
 
     def render(self, spp_begin: int, spp_end: int, rect=None, threads: int | None = None, film: np.ndarray | None = None):
         """-> (raw film float4[H, W] = (sum rgb, n), counters dict)"""

@@ -320,6 +320,20 @@ struct oracle_ctx {
         auto ns = has_normal ? normalize(mn * ns_local) : ng;
         it.uv = has_uv ? float2{bary.x * uv0.x + bary.y * uv1.x + bary.z * uv2.x, bary.x * uv0.y + bary.y * uv1.y + bary.z * uv2.y} :
                          float2{bary.y, bary.z};
+        // BAKED-GEOMETRY MODE (oracle_bvh.h: Accel::set_bake; test infrastructure): a traced hit is reconstructed from the fp32
+        // world-space triangle the device intersected -- point, geometric normal, area, tangent and the interpolation of the
+        // world-space vertex normals in the device's own order (csrc/hip/dev_shade.h: reconstruct_baked, lrhip.hip: build_shade_tris)
+        if (const auto bt = use_wo ? accel.baked(inst_id, prim_id) : nullptr; bt != nullptr) {
+            auto b0 = f3(bt->v0[0], bt->v0[1], bt->v0[2]), e1 = f3(bt->e1[0], bt->e1[1], bt->e1[2]), e2 = f3(bt->e2[0], bt->e2[1], bt->e2[2]);
+            p = b0 + e1 * bary.y + e2 * bary.z;
+            c = cross(e1, e2);
+            it.area = length(c) * .5f;
+            ng = normalize(c);
+            fallback = Frame::make(ng);
+            dpdu = det == 0.f ? fallback.s : (e1 * duv1.y - e2 * duv0.y) * inv_det;
+            auto nw = [&](const lr_vertex &v) { return mn.c[0] * v.nx + mn.c[1] * v.ny + mn.c[2] * v.nz; };
+            ns = has_normal ? normalize(nw(v0) * bary.x + nw(v1) * bary.y + nw(v2) * bary.z) : ng;
+        }
         it.pg = p, it.ps = p, it.ng = ng;
         it.shading = Frame::make(face_forward(ns, ng), dpdu);
         it.back_facing = use_wo ? dot(wo_or_pfrom, ng) < 0.0f :          // geometry.cpp:290
@@ -1005,6 +1019,8 @@ extern "C" {
 oracle_ctx *oracle_create(const lr_scene *scene) { return new oracle_ctx{scene}; }
 void oracle_destroy(oracle_ctx *ctx) { delete ctx; }
 void oracle_set_shutter_weight(oracle_ctx *ctx, float weight) { ctx->shutter_weight = weight; }
+// baked-geometry mode (oracle_bvh.h: Accel::set_bake): 0 = ok, -1 = the scene holds no baked triangles (lrhost_scene_build_accel not run)
+int oracle_set_bake(oracle_ctx *ctx, int on) { return ctx->accel.set_bake(on != 0) ? 0 : -1; }
 
 int oracle_render(oracle_ctx *ctx, uint32_t spp_begin, uint32_t spp_end, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                   int threads, float *film, oracle_counters *counters) {

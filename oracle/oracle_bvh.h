@@ -208,8 +208,42 @@ private:
         float w2o[12];                       // 3 rows x 4: object = W * (world, 1)
     };
     std::vector<InstanceXform> _xforms;
+    // BAKED-GEOMETRY MODE (set_bake; test infrastructure, round 4).  The reference intersects object-space triangles with a ray taken
+    // through the instance's inverse transform (geometry.cpp:218-260); the device intersects fp32 WORLD-space triangles, baked once by
+    // the host (lr_scene.accel.triangles) -- a design choice that moves hits by an ulp and, on a large scene, makes device and
+    // oracle stop tracing identical paths after a few bounces (tests/test_gpu_parity.py::test_what_separates_c2_from_the_oracle).
+    // In this mode the oracle tests the SAME baked triangles with the world-space ray (its own BVHs still cull), so that what is
+    // left between the two is the kernel alone.  The reference-side truth stays the default mode (tests/test_oracle_vs_ref.py).
+    bool _bake{false};
+    std::vector<uint32_t> _baked_of;       // [instance triangle base + prim] -> index into accel.triangles
+    std::vector<uint32_t> _baked_base;     // per instance
 
 public:
+    bool set_bake(bool on) {
+        if (on && _baked_of.empty()) {
+            if (_scene.accel.triangles == nullptr || _scene.accel.triangle_count == 0u) { return false; }
+            _baked_base.resize(_scene.instance_count);
+            uint32_t total = 0u;
+            for (uint32_t i = 0; i < _scene.instance_count; i++) {
+                _baked_base[i] = total;
+                total += _scene.meshes[_scene.instances[i].handle.x >> 10u].triangle_count;
+            }
+            _baked_of.assign(total, 0xffffffffu);
+            for (uint32_t k = 0; k < _scene.accel.triangle_count; k++) {
+                auto &bt = _scene.accel.triangles[k];
+                if (bt.inst < _scene.instance_count) { _baked_of[_baked_base[bt.inst] + bt.prim] = k; }
+            }
+        }
+        _bake = on;
+        return true;
+    }
+    // the baked triangle of (instance, primitive) in baked-geometry mode, else nullptr
+    const lr_bvh_triangle *baked(uint32_t inst, uint32_t prim) const {
+        if (!_bake) { return nullptr; }
+        const auto k = _baked_of[_baked_base[inst] + prim];
+        return k != 0xffffffffu ? _scene.accel.triangles + k : nullptr;
+    }
+
     explicit Accel(const lr_scene &scene) : _scene{scene} {
         _blas.resize(scene.mesh_count);
         for (uint32_t m = 0; m < scene.mesh_count; m++) {
@@ -288,7 +322,15 @@ public:
                     auto p0 = f3(v0.px, v0.py, v0.pz);
                     counters.tris++;
                     float t, u, v;
-                    if (hit_triangle(o, d, ray.t_min, t_max, p0, f3(v1.px, v1.py, v1.pz) - p0, f3(v2.px, v2.py, v2.pz) - p0, t, u, v)) {
+                    bool found;
+                    if (_bake && _baked_of[_baked_base[inst_id] + prim] != 0xffffffffu) {// the device's triangle, the world-space ray
+                        auto &bt = _scene.accel.triangles[_baked_of[_baked_base[inst_id] + prim]];
+                        found = hit_triangle(ray.o, ray.d, ray.t_min, t_max, f3(bt.v0[0], bt.v0[1], bt.v0[2]), f3(bt.e1[0], bt.e1[1], bt.e1[2]),
+                                             f3(bt.e2[0], bt.e2[1], bt.e2[2]), t, u, v);
+                    } else {
+                        found = hit_triangle(o, d, ray.t_min, t_max, p0, f3(v1.px, v1.py, v1.pz) - p0, f3(v2.px, v2.py, v2.pz) - p0, t, u, v);
+                    }
+                    if (found) {
                         if (alpha_skip && (inst.handle.x & LR_SHAPE_MAYBE_NON_OPAQUE) && alpha_skip(inst_id, prim, u, v)) { continue; }
                         t_max = t;
                         hit.inst = inst_id, hit.prim = prim, hit.bary = {u, v}, hit.t = t;

@@ -17,6 +17,15 @@ from luisarender_amd.scenes import (cornell_box, generate_bedroom_scene, generat
 
 pytestmark = pytest.mark.gpu
 
+# Bars of the headline-scene comparisons: TWICE what was measured on MI355X in round 4 (profiles/r04_parity_bars.txt), for the device against
+# the oracle and against the oracle on the device's own baked geometry (_same_geometry).  Round 3 asserted 2e-2 against measured 3e-3 ...
+# 9e-3: a regression that doubled the error would have passed.
+C2_SMALL_BAR, C2_SMALL_SAME_BAR = 1.0e-2, 1.0e-2   # measured 5.1e-3
+C3_SMALL_BAR, C3_SMALL_SAME_BAR = 7e-3, 7e-3         # measured 3.5e-3
+C2_FULL_BAR, C2_FULL_SAME_BAR = 1.7e-2, 1.7e-2       # measured 8.5e-3 (central 256 x 256, 8 spp)
+FULL_BAR = {"c3": 2.6e-2, "c4": 4.5e-3}               # measured 1.29e-2 (2 spp), 2.2e-3 (1 spp)
+FULL_SAME_BAR = {"c3": 2.6e-2, "c4": 4.5e-3}
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -30,6 +39,24 @@ def renderer():
 
 def _rel_l1(a, b):
     return float(np.abs(a[..., :3] - b[..., :3]).sum() / max(np.abs(b[..., :3]).sum(), 1e-20))
+
+
+def _same_geometry(scene, spp, film, rect=None, cpu=None):
+    """rel-L1 / relative mean difference of a device film against the oracle in BAKED-GEOMETRY mode (oracle_bvh.h: the oracle intersects the
+    very fp32 world-space triangles the host bakes for the device, not the reference's object-space ones): what separates the KERNEL
+    from the oracle once the design choice of baking is taken out -- the kernel's own arithmetic (fma contraction, hardware rcp,
+    quantised BVH4 visiting order).  The reference-side truth is the default oracle, pinned in tests/test_oracle_vs_ref.py."""
+    sub, _ = Oracle(scene, bake_instances=True).render(0, spp, rect=rect)
+    if rect is not None:
+        x0, y0, x1, y1 = rect
+        film, sub = film[y0:y1, x0:x1], sub[y0:y1, x0:x1]
+        cpu = cpu[y0:y1, x0:x1] if cpu is not None and cpu.shape != sub.shape else cpu
+    # the scene's own sensitivity: the oracle against ITSELF in the other geometry mode -- the same algorithm, the same samples, hit points
+    # that differ in their last bit.  On the large stand-ins (near-specular chains: GGX alpha 1e-4 mirrors, smooth glass, fixtures of
+    # centimetres) that last bit decides after a few bounces which triangle a path meets next; what the device is apart from either
+    # oracle cannot be smaller than what the two oracles are apart from each other.
+    floor = _rel_l1(sub, cpu) if cpu is not None else float("nan")
+    return _rel_l1(film, sub), abs(float(film[..., :3].mean()) - float(sub[..., :3].mean())) / float(sub[..., :3].mean()), floor
 
 
 def _render_both(renderer, scene, spp):
@@ -277,8 +304,10 @@ def test_bathroom_class_instanced_scene(renderer, tmp_path):
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
     # Tolerance: GPU and oracle trace the same paths except where fp32 rounding flips a discrete decision
     # (lobe pick, RR, alias slot) on the smooth-shaded GGX fixtures; a flipped path changes its pixel by O(1)
-    # at 4 spp.  Measured: ~1e-4 of the rays differ, rel-L1 4.7e-3, mean 3e-5.  Bars: rel-L1 < 2e-2, mean < 2e-3.
-    assert _rel_l1(gpu, cpu) < 2e-2
+    # at 4 spp.  Measured: ~1e-4 of the rays differ, rel-L1 4.7e-3, mean 3e-5.  Bars (round 4: twice the measured values, not 2e-2).
+    err, same = _rel_l1(gpu, cpu), _same_geometry(sc, 4, gpu, cpu=cpu)
+    print(f"c2 at 192 x 192: rel-L1 {err:.3e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
+    assert err < C2_SMALL_BAR and same[0] < C2_SMALL_SAME_BAR
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 2e-3
 
 
@@ -296,7 +325,9 @@ def test_bedroom_class_scene(renderer, tmp_path):
     assert renderer.last_variant() == 4 | 1  # LRHIP_FEAT_ENVIRONMENT | COUNT: nothing else is compiled in
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
-    assert _rel_l1(gpu, cpu) < 2e-2
+    err, same = _rel_l1(gpu, cpu), _same_geometry(sc, 16, gpu, cpu=cpu)
+    print(f"c3 at 256 x 144: rel-L1 {err:.3e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
+    assert err < C3_SMALL_BAR and same[0] < C3_SMALL_SAME_BAR
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 2e-3
 
 
@@ -429,7 +460,11 @@ def test_full_size_c2_properties(renderer, tmp_path):
     # Same seeded paths; specular chains through alpha = 1e-4 GGX lobes amplify fp32 rounding differences (fma
     # contraction, hardware division) into per-pixel differences without bias.  Measured: mean 1e-4, rel-L1 8e-3.
     fast = _rel_l1(a, b)
-    assert abs(a.mean() - b.mean()) / b.mean() < 2e-3 and fast < 2e-2
+    same = _same_geometry(sc, 8, film, rect=(384, 384, 640, 640), cpu=sub)
+    print(f"c2 full size, central 256 x 256 at 8 spp: rel-L1 {fast:.3e}, mean {abs(a.mean() - b.mean()) / b.mean():.2e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; "
+          f"oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
+    assert abs(a.mean() - b.mean()) / b.mean() < 2e-3 and fast < C2_FULL_BAR
+    assert same[0] < C2_FULL_SAME_BAR and same[1] < 1e-3
 
 
 def test_what_separates_c2_from_the_oracle(tmp_path):
@@ -476,15 +511,15 @@ def test_what_separates_c2_from_the_oracle(tmp_path):
 
 @pytest.mark.parametrize("config", ["c3", "c4", "c5"])
 def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
-    """BASELINE C3 / C4 / C5 stand-ins at their FULL resolution (1280x720 / 3840x2160 / 1280x720, depth 16; 150 k triangles
-    instead of 0.6 - 1 M so that building three scenes costs seconds of the GPU box, not minutes), a few spp, with the SHIPPED kernels <4> / <20> / <124> (counters off): size-independent properties -- every pixel got its
+    """BASELINE C3 / C4 / C5 stand-ins at their FULL resolution AND the bench's own triangle counts (1280x720 / 3840x2160 / 1280x720, depth
+    16, 0.6 M / 1 M / 0.6 M triangles: round 4 -- round 3 ran 150 k), 1-2 spp, with the SHIPPED kernels <4> / <20> / wavefront (counters off): size-independent properties -- every pixel got its
     samples, no NaN / Inf, per-sample clamp honoured -- and the oracle's estimate on a window of the frame (same seeded paths;
     C5 holds Layered and alpha-tested surfaces, statistical by construction: 8x8 block means there)."""
-    gen, res, spp, variant, rect = {"c3": (generate_bedroom_scene, (1280, 720), 4, 4, (512, 232, 768, 488)),
-                                    "c4": (generate_camera_scene, (3840, 2160), 2, 20, (1792, 952, 2048, 1208)),
-                                    "c5": (generate_kitchen_scene, (1280, 720), 8, WF | 8 | 16 | 32 | 64, (512, 232, 768, 488))}[config]
+    gen, res, spp, variant, rect = {"c3": (generate_bedroom_scene, (1280, 720), 2, 4, (512, 232, 768, 488)),
+                                    "c4": (generate_camera_scene, (3840, 2160), 1, 20, (1792, 952, 2048, 1208)),
+                                    "c5": (generate_kitchen_scene, (1280, 720), 2, WF | 8 | 16 | 32 | 64, (512, 232, 768, 488))}[config]
     kw = {"texture_size": 1024} if config == "c4" else {}
-    sc = Scene.load(gen(str(tmp_path), resolution=res, spp=spp, target_triangles=150_000, **kw))
+    sc = Scene.load(gen(str(tmp_path), resolution=res, spp=spp, **kw))  # (the generator's default triangle count = the bench's)
     renderer.upload(sc)
     renderer.render(0, spp, counters=False, sync=True)
     assert renderer.last_variant() == variant
@@ -501,8 +536,11 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
         print(f"{config}: block rel-L1 {err:.3e}, mean {abs(g.mean() - c.mean()) / c.mean():.2e}")
         assert err < 8e-2 and abs(g.mean() - c.mean()) / c.mean() < 1e-2
     else:
-        print(f"{config}: rel-L1 {_rel_l1(a, b):.3e}, mean {abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean():.2e}")
-        assert _rel_l1(a, b) < 2e-2 and abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 2e-3
+        same = _same_geometry(sc, spp, film, rect=rect, cpu=sub)
+        print(f"{config}: rel-L1 {_rel_l1(a, b):.3e}, mean {abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean():.2e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; "
+              f"oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
+        assert _rel_l1(a, b) < FULL_BAR[config] and abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 4e-3  # (1-2 spp of a 65 k-pixel window: the means are noisy)
+        assert same[0] < FULL_SAME_BAR[config] and same[1] < 6e-3
 
 
 @pytest.mark.parametrize("case", ["lean", "environment", "alpha", "env_alpha", "disney", "env_disney", "mix_alpha", "layered", "nested", "direct", "vpt", "sobol",
@@ -1017,3 +1055,54 @@ def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
             assert err < 3e-3, (force, err)
     finally:
         renderer.set_diagnostics()
+
+
+def test_two_contexts_driven_from_two_host_threads_render_one_frame(tmp_path):
+    """The C++ host's multi-GPU model (plugin_megapath.cpp: one context + one host thread per GPU) on ONE device: two lrhip_ctx on
+    device 0, driven concurrently from two host threads, render complementary tile shards of a frame; their films, added, are bit-equal
+    to one context's full frame (same balance_shards).  Exercises what a second rank exercises short of RCCL: per-context state
+    (streams, work counters, spill areas, scene records), two persistent grids sharing the CUs, the free-memory-sized queues of
+    wavefront mode under contention, and the thread-local error string."""
+    import threading
+    from luisarender_amd.render import DeviceError, MegaPathRenderer
+    scenes = {"lean": Scene.load(generate_room_scene(str(tmp_path / "room"), target_triangles=60_000, resolution=(256, 160), spp=8)),
+              "wavefront": Scene.load(generate_kitchen_scene(str(tmp_path / "kitchen"), resolution=(192, 112), spp=8, target_triangles=40_000))}
+    for name, sc in scenes.items():
+        single = MegaPathRenderer(0)
+        single.upload(sc)
+        single.render(0, 8, balance_shards=2, sync=True)
+        full = single.download(False)
+        single.close()
+        films, errors, messages = [None, None], [], [None, None]
+        barrier = threading.Barrier(2)
+
+        def work(rank):
+            try:
+                r = MegaPathRenderer(0)
+                r.upload(sc)
+                barrier.wait()
+                for _ in range(3):  # (several rounds: the two grids meet in different phases)
+                    r.clear()
+                    r.render(0, 8, rank=rank, world=2, balance_shards=2, sync=True)
+                films[rank] = r.download(False)
+                # an error of THIS thread's context: its text must not leak into (or come from) the other thread
+                try:
+                    r.render(5, 3, rank=rank, world=2)
+                except DeviceError as e:
+                    messages[rank] = str(e)
+                barrier.wait()
+                r.close()
+            except Exception as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+                barrier.abort()
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert all(m is not None and "spp" in m for m in messages), messages
+        total = films[0] + films[1]
+        assert np.isfinite(total).all() and (total[..., 3] == 8).all(), name
+        assert np.array_equal(total, full), name
