@@ -148,7 +148,7 @@ def device_parity(scene, local_rank, cpu_frame, spp):
     return out
 
 
-def path_statistics(scene, local_rank, spp=4):
+def path_statistics(scene, local_rank, spp=64):
     """rays per sample and mean path length from the device counters of a short counting render (the COUNT twin of the kernel)"""
     from luisarender_amd.render import MegaPathRenderer
     r = MegaPathRenderer(local_rank)

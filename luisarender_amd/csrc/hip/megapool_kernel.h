@@ -551,7 +551,12 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             if (COUNT) {// (the closure section is timed by the lanes that ran it: lane 0 reports the wave's figure)
                 for (auto off = 32; off > 0; off >>= 1) { t_closure_sum = max(t_closure_sum, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(t_closure_sum), off))); }
             }
+            // The loop below only HANDS OUT sample numbers (it is a loop because the wave may walk into its next work item half way through
+            // the batch, and because a pixel beyond the frame's edge has no samples: such a lane asks again); the work of starting a path
+            // follows it once.  (With the camera code inside the loop the register allocator took the whole shading block for a cold one.)
             auto need = mine && !path_open;// (a context without a path: it takes the next sample, if the launch has one left)
+            auto got = false;
+            auto new_k = 0u, new_item = kInvalid, new_px = 0u, new_py = 0u, new_s = 0u;
             for (;;) {
                 const auto mask = __ballot(need);
                 if (mask == 0ull) { break; }
@@ -565,45 +570,48 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 const auto rank = lane_rank(mask);
                 if (need && rank < avail) {
                     const auto k = q_next + rank;
-                    if (CONT) {// a path comes back from the heavy kernel: as if this slot's vertex had just been shaded
-                        const auto rec = item * item_records + k;
-                        const auto &q = cont_queue;
-                        ray.o = q.get3(rec, 0u), ray.d = q.get3(rec, 3u);
-                        ray.t_min = 0.f, ray.t_max = kFloatMax;
-                        shadow.o = q.get3(rec, 6u), shadow.d = q.get3(rec, 9u);
-                        shadow.t_min = 0.f, shadow.t_max = q.getf(rec, 12u);
-                        nee = q.get3(rec, 13u), beta = q.get3(rec, 16u), Li = q.get3(rec, 19u);
-                        pdf_bsdf = q.getf(rec, 22u);
-                        pixel_index = q.get(rec, 23u);
-                        const auto packed = q.get(rec, 24u);
-                        dp = packed & 0xffffu;
-                        want_shadow = (packed & (1u << 16u)) != 0u, want_closest = (packed & (1u << 17u)) != 0u;
-                        uint32_t words[kWfSamplerWordsMax];
-#pragma unroll
-                        for (auto w = 0u; w < SAMPLER_WORDS; w++) { words[w] = q.get(rec, kWfContWords + w); }
-                        sampler.restore(scene, words);
-                        path_open = true, need = false;
-                    } else {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
-                        const auto pix = k & 63u;
-                        const auto px = tx * 8u + (pix & 7u), py = ty * 8u + (pix >> 3u);
-                        if (px < scene.camera.width && py < scene.camera.height) {// (a pixel beyond the frame's edge has no samples: the lane asks again)
-                            pixel_index = py * scene.camera.width + px;
-                            path_item = item;
-                            sampler.start(scene, px, py, s_begin + (k >> 6u));
-                            const auto u_filter = sampler.next_pixel_2d();
-                            const auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
-                            float weight;
-                            camera_ray(scene, scene.filter, px, py, u_filter, u_lens, ray, weight);
-                            beta = mk3(weight);
-                            Li = mk3(0.f), nee = mk3(0.f);
-                            pdf_bsdf = 1e16f;
-                            dp = pix << 16u;
-                            path_open = true, want_shadow = false, want_closest = true, need = false;
-                            if (COUNT) { local.paths++; }
-                        }
+                    const auto px = tx * 8u + (k & 7u), py = ty * 8u + ((k >> 3u) & 7u);
+                    if (CONT || (px < scene.camera.width && py < scene.camera.height)) {
+                        new_k = k, new_item = item, new_px = px, new_py = py, new_s = s_begin + (k >> 6u);
+                        got = true, need = false;
                     }
                 }
                 q_next += min(static_cast<uint32_t>(__popcll(mask)), avail);
+            }
+            if (got) {
+                if (CONT) {// a path comes back from the heavy kernel: as if this context's vertex had just been shaded
+                    const auto rec = new_item * item_records + new_k;
+                    const auto &q = cont_queue;
+                    ray.o = q.get3(rec, 0u), ray.d = q.get3(rec, 3u);
+                    ray.t_min = 0.f, ray.t_max = kFloatMax;
+                    shadow.o = q.get3(rec, 6u), shadow.d = q.get3(rec, 9u);
+                    shadow.t_min = 0.f, shadow.t_max = q.getf(rec, 12u);
+                    nee = q.get3(rec, 13u), beta = q.get3(rec, 16u), Li = q.get3(rec, 19u);
+                    pdf_bsdf = q.getf(rec, 22u);
+                    pixel_index = q.get(rec, 23u);
+                    const auto packed = q.get(rec, 24u);
+                    dp = packed & 0xffffu;
+                    want_shadow = (packed & (1u << 16u)) != 0u, want_closest = (packed & (1u << 17u)) != 0u;
+                    uint32_t words[kWfSamplerWordsMax];
+#pragma unroll
+                    for (auto w = 0u; w < SAMPLER_WORDS; w++) { words[w] = q.get(rec, kWfContWords + w); }
+                    sampler.restore(scene, words);
+                    path_open = true;
+                } else {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
+                    pixel_index = new_py * scene.camera.width + new_px;
+                    path_item = new_item;
+                    sampler.start(scene, new_px, new_py, new_s);
+                    const auto u_filter = sampler.next_pixel_2d();
+                    const auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};
+                    float weight;
+                    camera_ray(scene, scene.filter, new_px, new_py, u_filter, u_lens, ray, weight);
+                    beta = mk3(weight);
+                    Li = mk3(0.f), nee = mk3(0.f);
+                    pdf_bsdf = 1e16f;
+                    dp = (new_k & 63u) << 16u;
+                    path_open = true, want_shadow = false, want_closest = true;
+                    if (COUNT) { local.paths++; }
+                }
             }
             // ---- every context that goes on: its path state back into the record, its job's rays into the context
             const auto t_launch = COUNT ? __builtin_readcyclecounter() : 0ull;

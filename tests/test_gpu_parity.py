@@ -24,7 +24,7 @@ C2_SMALL_BAR, C2_SMALL_SAME_BAR = 1.0e-2, 1.0e-2   # measured 5.1e-3
 C3_SMALL_BAR, C3_SMALL_SAME_BAR = 7e-3, 7e-3         # measured 3.5e-3
 C2_FULL_BAR, C2_FULL_SAME_BAR = 1.7e-2, 1.7e-2       # measured 8.5e-3 (central 256 x 256, 8 spp)
 FULL_BAR = {"c3": 2.6e-2, "c4": 4.5e-3}               # measured 1.29e-2 (2 spp), 2.2e-3 (1 spp)
-FULL_SAME_BAR = {"c3": 2.6e-2, "c4": 4.5e-3}
+FULL_SAME_BAR = {"c3": 2.9e-2, "c4": 4.5e-3}             # measured 1.43e-2, 1.9e-3
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -308,6 +308,7 @@ def test_bathroom_class_instanced_scene(renderer, tmp_path):
     err, same = _rel_l1(gpu, cpu), _same_geometry(sc, 4, gpu, cpu=cpu)
     print(f"c2 at 192 x 192: rel-L1 {err:.3e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
     assert err < C2_SMALL_BAR and same[0] < C2_SMALL_SAME_BAR
+    assert err < 2.0 * same[2] and same[0] < 2.0 * same[2]  # no further from either oracle than they are from each other (measured: 1.05 x, 0.94 x)
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 2e-3
 
 
@@ -465,6 +466,7 @@ def test_full_size_c2_properties(renderer, tmp_path):
           f"oracle vs oracle (object-space vs baked geometry): {same[2]:.3e}")
     assert abs(a.mean() - b.mean()) / b.mean() < 2e-3 and fast < C2_FULL_BAR
     assert same[0] < C2_FULL_SAME_BAR and same[1] < 1e-3
+    assert fast < 2.0 * same[2] and same[0] < 2.0 * same[2]  # (measured: 0.98 x, 0.97 x the oracle-vs-oracle distance)
 
 
 def test_what_separates_c2_from_the_oracle(tmp_path):
