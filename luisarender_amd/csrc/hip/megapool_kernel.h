@@ -222,6 +222,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     constexpr uint32_t QUADS = pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
+#if LR_POOL_CONTEXTS == 2
+    // what a lane keeps of its ray in flight across the shading block: five words, [word][thread] (the LDS the 11-entry stack leaves, see below)
+    __shared__ uint32_t s_park[5u * kBlockThreads];
+    static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile the pool variants with LR_STACK_LDS <= 11");
+#endif
 #if LR_POOL_OVERLAP
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
 #else
@@ -366,15 +371,23 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 stage[lane] = make_float4(lds_ctx.so.x, lds_ctx.so.y, lds_ctx.so.z, lds_ctx.s_tmax);
                 stage[64u + lane] = make_float4(lds_ctx.sd.x, lds_ctx.sd.y, lds_ctx.sd.z, lds_ctx.n_tmin);
                 stage[128u + lane] = make_float4(lds_ctx.no.x, lds_ctx.no.y, lds_ctx.no.z, lds_ctx.n_tmax);
-                stage[192u + lane] = make_float4(lds_ctx.nd.x, lds_ctx.nd.y, lds_ctx.nd.z, 0.f);
+                // SIX more words leave the registers -- what is left of the ray in flight: its hit so far (one hit besides the shaded context's
+                // is alive in a lane: the running one, or an idle lane's current context's finished one; a context that waits with its rays
+                // has none), t_max, the node it stands at, and one word of small things (traversal phase 0-2, occluded 3, sel 4, stack depth
+                // 5-11, flags of the context in the LDS 12-19, of the current one 20-27).  With these six in registers the block spills 37
+                // VGPRs on its hot path, without them 12 off it (round 4, the measurement behind section 4.1c of DESIGN.md): they are the
+                // difference between a traversal loop with and without its L1.  One goes into the spare word of the staging area, five
+                // into the LDS the pool kernels' stack gives up (11 entries per lane instead of 16).
+                const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (sel << 4u) | (tr.sp << 5u) | (lds_ctx.flags << 12u) | (curc.flags << 20u);
+                stage[192u + lane] = make_float4(lds_ctx.nd.x, lds_ctx.nd.y, lds_ctx.nd.z, __uint_as_float(keep_word));
+                const auto park = s_park + tid;
+                park[0u * kBlockThreads] = tr.phase != kPhaseIdle ? tr.hit.tri : curc.tri;
+                park[1u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.u : curc.u);
+                park[2u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.v : curc.v);
+                park[3u * kBlockThreads] = __float_as_uint(tr.t_max);
+                park[4u * kBlockThreads] = tr.cur;
                 asm volatile("" ::: "memory");// (the values must not be forwarded to the loads at the end of the block: they are to LEAVE the registers)
             }
-            // one hit besides the shaded context's is alive in a lane: the running one of the ray in flight, or the current context's
-            // finished one (an idle lane); a context that waits with its rays has none
-            const auto keep_tri = tr.phase != kPhaseIdle ? tr.hit.tri : curc.tri;
-            const auto keep_u = tr.phase != kPhaseIdle ? tr.hit.u : curc.u, keep_v = tr.phase != kPhaseIdle ? tr.hit.v : curc.v;
-            // (one register: traversal phase 0-2, occluded 3, sel 4, stack depth 5-11, flags of the context in the LDS 12-19, of the current one 20-27)
-            const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (sel << 4u) | (tr.sp << 5u) | (lds_ctx.flags << 12u) | (curc.flags << 20u);
             // ---- the context's path
             PathSampler<PCG> sampler{};
             Ray ray{}, shadow{};
@@ -648,6 +661,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 back.sd = mk3(p1.x, p1.y, p1.z), back.n_tmin = p1.w;
                 back.no = mk3(p2.x, p2.y, p2.z), back.n_tmax = p2.w;
                 back.nd = mk3(p3.x, p3.y, p3.z);
+                const auto keep_word = __float_as_uint(p3.w);
+                const auto park = s_park + tid;
+                const auto keep_tri = park[0u * kBlockThreads];
+                const auto keep_u = __uint_as_float(park[1u * kBlockThreads]), keep_v = __uint_as_float(park[2u * kBlockThreads]);
+                tr.t_max = __uint_as_float(park[3u * kBlockThreads]), tr.cur = park[4u * kBlockThreads];
                 back.flags = (keep_word >> 12u) & 0xffu, back.tri = keep_tri, back.u = keep_u, back.v = keep_v;
                 tr.hit.tri = keep_tri, tr.hit.u = keep_u, tr.hit.v = keep_v;
                 tr.phase = keep_word & 7u, tr.occluded = (keep_word & 8u) != 0u;
