@@ -269,6 +269,9 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
         auto tb = tl.tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
         // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
         auto a = tb[0], b = tb[1], c = tb[2];
+#ifdef LR_LEAF_FULL_QUADS// (a kernel that never reads hit.inst / hit.prim gets two 12-byte loads here: keep them 16-byte ones)
+        asm volatile("" ::"v"(a.w), "v"(b.w));
+#endif
         if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF
         {

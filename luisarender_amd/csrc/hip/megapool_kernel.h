@@ -51,20 +51,18 @@ namespace lrd {
 #ifndef LR_MIN_WAVES
 #define LR_MIN_WAVES 4
 #endif
-#ifndef LR_POOL_CONTEXTS
-#define LR_POOL_CONTEXTS 2   // path contexts per lane.  1 = the round 1-3 scheduling (one path per lane, its state in registers) with this
-#endif                       // kernel's overlapping work items and fixed-point film: no second context, no state records, no LDS parking
-#if LR_POOL_CONTEXTS == 1
-#define LR_POOL_SINGLE 1
-#endif
+// -DLR_POOL_SINGLE: the lane's second context never takes a path (a diagnostic: this kernel's machinery under the round 1-3 scheduling)
 #ifndef LR_POOL_OVERLAP
 #define LR_POOL_OVERLAP 1    // 1: work items overlap inside a wave and the film is summed in fixed point (FILM above); 0: a wave finishes its
 #endif                       // item before it takes the next and sums its tile in fp32 like the round 1-3 kernel (deterministic: see below)
 #ifndef LR_POOL_SHADE_LANES
-#define LR_POOL_SHADE_LANES (LR_POOL_CONTEXTS == 1 ? 64 : 56)// lanes with a context to shade that end the traversal loop
+#define LR_POOL_SHADE_LANES 56// lanes with a context to shade that end the traversal loop
 #endif
 #ifndef LR_POOL_IDLE_LANES
-#define LR_POOL_IDLE_LANES (LR_POOL_CONTEXTS == 1 ? 40 : 16) // ... or lanes with a context to shade and nothing left to trace
+#define LR_POOL_IDLE_LANES 16 // ... or lanes with a context to shade and nothing left to trace
+#endif
+#ifndef LR_POOL_RAY_INIT
+#define LR_POOL_RAY_INIT if (!mine)
 #endif
 constexpr uint32_t kPoolSlots = 128u;// paths per wave: two contexts per lane
 
@@ -109,24 +107,23 @@ LR_D void ctx_start(PathCtx &c, TravState &tr) {
     tr.occluded = false;
 }
 
-// field by field: a `c ? a : b` on the structs selects an ADDRESS and pins both contexts in scratch memory
-LR_D PathCtx ctx_select(bool second, const PathCtx &a, const PathCtx &b) {
-    auto f = [&](float x, float y) { return second ? y : x; };
-    auto f3s = [&](f3 x, f3 y) { return mk3(f(x.x, y.x), f(x.y, y.y), f(x.z, y.z)); };
-    PathCtx r;
-    r.so = f3s(a.so, b.so), r.sd = f3s(a.sd, b.sd), r.s_tmax = f(a.s_tmax, b.s_tmax);
-    r.no = f3s(a.no, b.no), r.nd = f3s(a.nd, b.nd), r.n_tmin = f(a.n_tmin, b.n_tmin), r.n_tmax = f(a.n_tmax, b.n_tmax);
-    r.tri = second ? b.tri : a.tri, r.u = f(a.u, b.u), r.v = f(a.v, b.v);
-    r.flags = second ? b.flags : a.flags;
-    return r;
+// The lane's two contexts are `cur` -- the one whose ray the lane traces (or traced last) -- and `oth`, the one that waits.  A lane
+// that goes on to its other context's job EXCHANGES the two: seventeen v_swap_b32, no copy through a third register, no per-field
+// select on a "which one" bit in the loop (the first form of this kernel: 60 instructions per turnover where this one has 20).
+LR_D void swap_words(float &x, float &y) { asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+LR_D void swap_words(uint32_t &x, uint32_t &y) { asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
+LR_D void ctx_swap(PathCtx &a, PathCtx &b) {
+    swap_words(a.so.x, b.so.x), swap_words(a.so.y, b.so.y), swap_words(a.so.z, b.so.z), swap_words(a.s_tmax, b.s_tmax);
+    swap_words(a.sd.x, b.sd.x), swap_words(a.sd.y, b.sd.y), swap_words(a.sd.z, b.sd.z);
+    swap_words(a.no.x, b.no.x), swap_words(a.no.y, b.no.y), swap_words(a.no.z, b.no.z), swap_words(a.n_tmin, b.n_tmin);
+    swap_words(a.nd.x, b.nd.x), swap_words(a.nd.y, b.nd.y), swap_words(a.nd.z, b.nd.z), swap_words(a.n_tmax, b.n_tmax);
+    swap_words(a.tri, b.tri), swap_words(a.u, b.u), swap_words(a.v, b.v), swap_words(a.flags, b.flags);
 }
 
 LR_D uint32_t lane_rank(unsigned long long mask) {// lanes of `mask` below this one
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-// The lane's two contexts are `a` and `b`; `sel` names the CURRENT one (0: a, 1: b) -- the context whose ray the lane traces -- and the
-// other one waits.  (Contexts are never moved: a switch flips `sel`; what the loop touches of them it touches under a branch per context.)
 constexpr uint32_t kCtxRays = kCtxShadow | kCtxClosest;
 // flags of a context that the shading block has work for: a traced job, or (while the launch has samples left) no path at all
 LR_D bool ctx_shadeable(uint32_t flags, bool samples_left) {
@@ -150,15 +147,14 @@ LR_D bool pool_shade_due(uint32_t phase, uint32_t cur_flags, uint32_t oth_flags,
 // rays without leaving the loop.  Returns when the shading block is due or nothing is in flight (ALPHA: also when a lane holds a
 // candidate hit for the alpha test, dev_shade.h: resolve_pending_alpha).  Must be called by all 64 lanes.
 template<bool COUNT, bool ALPHA>
-LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &a, PathCtx &b, uint32_t &sel, bool samples_left,
-                     TraceStats &stats) {
+LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &cur, PathCtx &oth, bool samples_left, TraceStats &stats) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
     for (;;) {
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
 #ifndef LR_TRACE_PROBE
-            stats.steps_starved += tr.phase == kPhaseIdle && ((a.flags | b.flags) & kCtxOpen) == 0u ? 1u : 0u;// no path left to hold
+            stats.steps_starved += tr.phase == kPhaseIdle && ((cur.flags | oth.flags) & kCtxOpen) == 0u ? 1u : 0u;// no path left to hold
 #endif
         }
         const auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
@@ -176,23 +172,20 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         const auto probe_t2 = __builtin_readcyclecounter();
 #endif
         // ---- ray finished: the job's next ray, the other context's job, or idle
-        if (live && tr.cur == kInvalid) {
-            auto cf = sel != 0u ? b.flags : a.flags;
-            const auto of = sel != 0u ? a.flags : b.flags;
+        const auto ended = live && tr.cur == kInvalid;
+        if (ended) {
             if (tr.phase == kPhaseShadow) {
-                if (tr.occluded) { cf |= kCtxOccluded; }
-            } else if (sel != 0u) {
-                b.tri = tr.hit.tri, b.u = tr.hit.u, b.v = tr.hit.v;
+                if (tr.occluded) { cur.flags |= kCtxOccluded; }
             } else {
-                a.tri = tr.hit.tri, a.u = tr.hit.u, a.v = tr.hit.v;
+                cur.tri = tr.hit.tri, cur.u = tr.hit.u, cur.v = tr.hit.v;
             }
             tr.phase = kPhaseIdle;
-            const auto complete = (cf & kCtxRays) == 0u;
-            if (complete) { cf |= kCtxDone; }
-            if (sel != 0u) { b.flags = cf; } else { a.flags = cf; }
-            if (complete && (of & kCtxRays) != 0u) { sel ^= 1u; }// on to the other context's job
-            if (((sel != 0u ? b.flags : a.flags) & kCtxRays) != 0u) {
-                if (sel != 0u) { ctx_start(b, tr); } else { ctx_start(a, tr); }
+            if ((cur.flags & kCtxRays) == 0u) {// the job is complete: on to the other context's, if it waits with one
+                cur.flags |= kCtxDone;
+                if ((oth.flags & kCtxRays) != 0u) { ctx_swap(cur, oth); }
+            }
+            if ((cur.flags & kCtxRays) != 0u) {
+                ctx_start(cur, tr);
                 inv = safe_inverse(tr.d);
             }
         }
@@ -204,8 +197,15 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         }
 #endif
         if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        // (what the shading block has to do only changes when a lane runs out of rays: the test is skipped otherwise -- +1.9 % on C2.
+        // LR_POOL_EXIT_TEST 1 looks whenever a ray ends, also where its lane went straight on to its other context's job)
+#if !defined(LR_POOL_EXIT_TEST) || LR_POOL_EXIT_TEST == 2
+        if (!__any(live && tr.phase == kPhaseIdle)) { continue; }
+#elif LR_POOL_EXIT_TEST == 1
+        if (!__any(ended)) { continue; }
+#endif
         if (__ballot(tr.phase != kPhaseIdle) == 0ull) { break; }
-        if (pool_shade_due(tr.phase, sel != 0u ? b.flags : a.flags, sel != 0u ? a.flags : b.flags, samples_left)) { break; }
+        if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
 }
 
@@ -222,11 +222,9 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     constexpr uint32_t QUADS = pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
-#if LR_POOL_CONTEXTS == 2
     // what a lane keeps of its ray in flight across the shading block: five words, [word][thread] (the LDS the 11-entry stack leaves, see below)
     __shared__ uint32_t s_park[5u * kBlockThreads];
     static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile the pool variants with LR_STACK_LDS <= 11");
-#endif
 #if LR_POOL_OVERLAP
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
 #else
@@ -267,15 +265,8 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     // ---- the lane: its ray in flight, the context the ray belongs to (`cur`) and the lane's other context (`oth`)
     TravState tr{};
     tr.phase = kPhaseIdle;
-    PathCtx ca{}, cb{};
-    ca.flags = 0u, cb.flags = kCtxSide;
-    auto sel = 0u;
-#if LR_POOL_CONTEXTS == 1// the lane's one path: its state stays in registers
-    PathSampler<PCG> sampler{};
-    f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
-    auto pdf_bsdf = 1e16f;
-    auto dp = 0u, pixel_index = 0u, path_item = kInvalid;// dp: depth | pixel in tile << 16
-#endif
+    PathCtx cur{}, oth{};
+    cur.flags = 0u, oth.flags = kCtxSide;
 
     // the wave leaves its work item: the tile's sums join the frame's, every sample of the item is counted
     auto flush_tile = [&]() {
@@ -341,49 +332,40 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
         // ==== (A) shading batches, while they are due (pool_shade_due: enough lanes hold a context to shade)
         for (;;) {
             const auto samples_left = (LR_POOL_OVERLAP && items_left) || q_next < q_total;
-            if (!pool_shade_due(tr.phase, sel != 0u ? cb.flags : ca.flags, sel != 0u ? ca.flags : cb.flags, samples_left)) { break; }
+            if (!pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
             const auto t_shade = COUNT ? __builtin_readcyclecounter() : 0ull;
-#if LR_POOL_CONTEXTS == 1
-            // ---- one context per lane: the lanes without a ray in flight take part (round 1-3 scheduling)
-            const PathCtx oth = ca;
-            const auto mine = tr.phase == kPhaseIdle && ctx_shadeable(ca.flags, samples_left);
-            Ray ray{}, shadow{};
-#else
             // ---- the context this lane shades is its OTHER one; an idle lane whose other context has nothing for the shading block
             // offers its current one
-            if (tr.phase == kPhaseIdle && !ctx_shadeable(sel != 0u ? ca.flags : cb.flags, samples_left)) { sel ^= 1u; }
-            const PathCtx oth = ctx_select(sel == 0u, ca, cb), curc = ctx_select(sel != 0u, ca, cb);
+            if (tr.phase == kPhaseIdle && !ctx_shadeable(oth.flags, samples_left)) { ctx_swap(cur, oth); }
             // (a context that waits with the rays of its job is none of the shading block's business)
 #ifdef LR_POOL_SINGLE
             const auto mine = (oth.flags & kCtxDone) != 0u || ((oth.flags & kCtxOpen) == 0u && (oth.flags & kCtxSide) == 0u);
 #else
             const auto mine = (oth.flags & kCtxDone) != 0u || (oth.flags & kCtxOpen) == 0u;
 #endif
-            // ---- Of the lane's two contexts the shading block needs the traced segment and the hit of the one it shades (when it is
-            // `mine`), and it produces that context's next rays in `shadow` / `ray`.  Everything else must leave the registers the
-            // shading block is allocated in (314 spilled VGPRs otherwise): ONE context's rays wait in the packet staging area of the
-            // LDS (idle outside the traversal loop; 16 words per lane, [quad][lane]) -- the current context's, normally -- and where the
-            // other context is not `mine` but waits with rays of its own, those wait in the LDS and the current context's sit in
-            // `shadow` / `ray`, which such a lane does not write.  Origin and direction of the ray in flight are one of those rays.
-            const PathCtx lds_ctx = ctx_select(!mine, curc, oth);
+            // ---- Of the lane's two contexts the shading block needs the traced segment and the hit of the one it shades, and it
+            // produces that context's next rays in `shadow` / `ray` (which start as the rays the context holds: where it is not `mine`
+            // they come out as they went in).  Everything else must leave the registers the shading block is allocated in (314 spilled
+            // VGPRs otherwise): the CURRENT context's rays -- origin and direction of the ray in flight are among them -- wait in the
+            // packet staging area of the LDS (idle outside the traversal loop; 16 words per lane, [quad][lane]).
             {
                 const auto stage = stack.stage;
-                stage[lane] = make_float4(lds_ctx.so.x, lds_ctx.so.y, lds_ctx.so.z, lds_ctx.s_tmax);
-                stage[64u + lane] = make_float4(lds_ctx.sd.x, lds_ctx.sd.y, lds_ctx.sd.z, lds_ctx.n_tmin);
-                stage[128u + lane] = make_float4(lds_ctx.no.x, lds_ctx.no.y, lds_ctx.no.z, lds_ctx.n_tmax);
+                stage[lane] = make_float4(cur.so.x, cur.so.y, cur.so.z, cur.s_tmax);
+                stage[64u + lane] = make_float4(cur.sd.x, cur.sd.y, cur.sd.z, cur.n_tmin);
+                stage[128u + lane] = make_float4(cur.no.x, cur.no.y, cur.no.z, cur.n_tmax);
                 // SIX more words leave the registers -- what is left of the ray in flight: its hit so far (one hit besides the shaded context's
-                // is alive in a lane: the running one, or an idle lane's current context's finished one; a context that waits with its rays
-                // has none), t_max, the node it stands at, and one word of small things (traversal phase 0-2, occluded 3, sel 4, stack depth
-                // 5-11, flags of the context in the LDS 12-19, of the current one 20-27).  With these six in registers the block spills 37
-                // VGPRs on its hot path, without them 12 off it (round 4, the measurement behind section 4.1c of DESIGN.md): they are the
-                // difference between a traversal loop with and without its L1.  One goes into the spare word of the staging area, five
-                // into the LDS the pool kernels' stack gives up (11 entries per lane instead of 16).
-                const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (sel << 4u) | (tr.sp << 5u) | (lds_ctx.flags << 12u) | (curc.flags << 20u);
-                stage[192u + lane] = make_float4(lds_ctx.nd.x, lds_ctx.nd.y, lds_ctx.nd.z, __uint_as_float(keep_word));
+                // is alive in a lane: the running one, or an idle lane's current context's finished one), t_max, the node it stands at, and
+                // one word of small things (traversal phase 0-2, occluded 3, stack depth 5-11, flags of the current context 12-19, of the
+                // other one 20-27).  With these six in registers the block spills 37 VGPRs on its hot path, without them 12 off it (round 4,
+                // the measurement behind section 4.1c of DESIGN.md): they are the difference between a traversal loop with and without its
+                // L1.  One goes into the spare word of the staging area, five into the LDS the pool kernels' stack gives up (11 entries
+                // per lane instead of 16).
+                const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (tr.sp << 5u) | (cur.flags << 12u) | (oth.flags << 20u);
+                stage[192u + lane] = make_float4(cur.nd.x, cur.nd.y, cur.nd.z, __uint_as_float(keep_word));
                 const auto park = s_park + tid;
-                park[0u * kBlockThreads] = tr.phase != kPhaseIdle ? tr.hit.tri : curc.tri;
-                park[1u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.u : curc.u);
-                park[2u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.v : curc.v);
+                park[0u * kBlockThreads] = tr.phase != kPhaseIdle ? tr.hit.tri : cur.tri;
+                park[1u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.u : cur.u);
+                park[2u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.v : cur.v);
                 park[3u * kBlockThreads] = __float_as_uint(tr.t_max);
                 park[4u * kBlockThreads] = tr.cur;
                 asm volatile("" ::: "memory");// (the values must not be forwarded to the loads at the end of the block: they are to LEAVE the registers)
@@ -391,14 +373,13 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             // ---- the context's path
             PathSampler<PCG> sampler{};
             Ray ray{}, shadow{};
-            if (!mine) {
-                shadow.o = curc.so, shadow.d = curc.sd, shadow.t_min = 0.f, shadow.t_max = curc.s_tmax;
-                ray.o = curc.no, ray.d = curc.nd, ray.t_min = curc.n_tmin, ray.t_max = curc.n_tmax;
+            LR_POOL_RAY_INIT {
+                shadow.o = oth.so, shadow.d = oth.sd, shadow.t_min = 0.f, shadow.t_max = oth.s_tmax;
+                ray.o = oth.no, ray.d = oth.nd, ray.t_min = oth.n_tmin, ray.t_max = oth.n_tmax;
             }
             f3 beta = mk3(0.f), Li = mk3(0.f), nee = mk3(0.f);
             auto pdf_bsdf = 1e16f;
             auto dp = 0u, pixel_index = 0u, path_item = kInvalid;// dp: depth | pixel in tile << 16 (one register across the block)
-#endif
             const auto side = (oth.flags & kCtxSide) != 0u ? 1u : 0u;
             auto path_open = (oth.flags & kCtxDone) != 0u;// (else: an empty context, or one that is not `mine`)
             const auto traced_shadow = path_open && (oth.flags & kCtxHadShadow) != 0u, traced_closest = path_open && (oth.flags & kCtxHadClosest) != 0u;
@@ -406,7 +387,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             const auto ro = oth.no, rd = oth.nd;// the path segment the job traced
             const auto hit_tri = oth.tri;
             const auto hit_u = oth.u, hit_v = oth.v;
-#if LR_POOL_CONTEXTS == 2
             if (path_open) {
                 const auto q0 = state_load(side, 0u), q1 = state_load(side, 1u), q2 = state_load(side, 2u), q3 = state_load(side, 3u);
                 nee = mk3(q0.x, q0.y, q0.z), pdf_bsdf = q0.w;
@@ -420,7 +400,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 words[3] = PCG ? __float_as_uint(state_load(side, QUADS - 1u).x) : 0u;
                 sampler.restore(scene, words);
             }
-#endif
             auto want_shadow = false, want_closest = false;
             unsigned long long t_closure_sum = 0ull;// (COUNT: wave cycles inside the closure section of this batch; lanes agree)
             auto park_kind = kInvalid;// WF: closure kind (0 Disney, 1 Mix, 2 Layered) of the heavy surface this path just reached
@@ -630,7 +609,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             const auto t_launch = COUNT ? __builtin_readcyclecounter() : 0ull;
             const auto go = path_open && (want_shadow || want_closest);
             if (go) {
-#if LR_POOL_CONTEXTS == 2
                 uint32_t words[kWfSamplerWordsMax] = {0u, 0u, 0u, 0u};
                 sampler.save(words);
                 state_store(side, 0u, make_float4(nee.x, nee.y, nee.z, pdf_bsdf));
@@ -638,57 +616,43 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
                 state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2])));
                 if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
-#endif
                 if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
             }
-#if LR_POOL_CONTEXTS == 1
-            if (mine) {// the context's next job (or none: its path ended and no sample was left), started at once: the lane is idle
-                ca.so = shadow.o, ca.sd = shadow.d, ca.s_tmax = shadow.t_max;
-                ca.no = ray.o, ca.nd = ray.d, ca.n_tmin = ray.t_min, ca.n_tmax = ray.t_max;
-                ca.tri = kInvalid, ca.u = 0.f, ca.v = 0.f;
-                ca.flags = go ? kCtxOpen | (want_shadow ? kCtxShadow | kCtxHadShadow : 0u) | (want_closest ? kCtxClosest | kCtxHadClosest : 0u) : 0u;
-                if (go) { ctx_start(ca, tr); }
-            }
-#else
-            // ---- the contexts come back: one from the LDS, one from shadow / ray (the shaded context's new job, or -- not `mine` -- the
-            // current context as it was), and with the current one origin and direction of the ray in flight
+            // ---- the contexts come back: the current one from the LDS, and with it origin and direction of the ray in flight; the other
+            // one from shadow / ray (the shaded context's new job, or -- not `mine` -- the rays it waits with)
             {
-                PathCtx back, regs;
                 const auto stage = stack.stage;
                 asm volatile("" ::: "memory");
                 const auto p0 = stage[lane], p1 = stage[64u + lane], p2 = stage[128u + lane], p3 = stage[192u + lane];
-                back.so = mk3(p0.x, p0.y, p0.z), back.s_tmax = p0.w;
-                back.sd = mk3(p1.x, p1.y, p1.z), back.n_tmin = p1.w;
-                back.no = mk3(p2.x, p2.y, p2.z), back.n_tmax = p2.w;
-                back.nd = mk3(p3.x, p3.y, p3.z);
+                cur.so = mk3(p0.x, p0.y, p0.z), cur.s_tmax = p0.w;
+                cur.sd = mk3(p1.x, p1.y, p1.z), cur.n_tmin = p1.w;
+                cur.no = mk3(p2.x, p2.y, p2.z), cur.n_tmax = p2.w;
+                cur.nd = mk3(p3.x, p3.y, p3.z);
                 const auto keep_word = __float_as_uint(p3.w);
                 const auto park = s_park + tid;
                 const auto keep_tri = park[0u * kBlockThreads];
                 const auto keep_u = __uint_as_float(park[1u * kBlockThreads]), keep_v = __uint_as_float(park[2u * kBlockThreads]);
                 tr.t_max = __uint_as_float(park[3u * kBlockThreads]), tr.cur = park[4u * kBlockThreads];
-                back.flags = (keep_word >> 12u) & 0xffu, back.tri = keep_tri, back.u = keep_u, back.v = keep_v;
+                cur.flags = (keep_word >> 12u) & 0xffu, cur.tri = keep_tri, cur.u = keep_u, cur.v = keep_v;
                 tr.hit.tri = keep_tri, tr.hit.u = keep_u, tr.hit.v = keep_v;
                 tr.phase = keep_word & 7u, tr.occluded = (keep_word & 8u) != 0u;
-                tr.sp = (keep_word >> 5u) & 127u, sel = (keep_word >> 4u) & 1u;
+                tr.sp = (keep_word >> 5u) & 127u;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                regs.so = shadow.o, regs.sd = shadow.d, regs.s_tmax = shadow.t_max;
-                regs.no = ray.o, regs.nd = ray.d, regs.n_tmin = ray.t_min, regs.n_tmax = ray.t_max;
+                oth.so = shadow.o, oth.sd = shadow.d, oth.s_tmax = shadow.t_max;
+                oth.no = ray.o, oth.nd = ray.d, oth.n_tmin = ray.t_min, oth.n_tmax = ray.t_max;
+                oth.tri = kInvalid, oth.u = 0.f, oth.v = 0.f;// (a context that waits with its rays has no hit yet)
                 // the shaded context: its new job, or empty (its path ended, or was parked, and no sample was left for it)
                 const auto shaded_flags = (side != 0u ? kCtxSide : 0u) |
                                           (go ? kCtxOpen | (want_shadow ? kCtxShadow | kCtxHadShadow : 0u) | (want_closest ? kCtxClosest | kCtxHadClosest : 0u) : 0u);
-                regs.flags = mine ? shaded_flags : (keep_word >> 20u) & 0xffu;
-                regs.tri = mine ? kInvalid : keep_tri, regs.u = mine ? 0.f : keep_u, regs.v = mine ? 0.f : keep_v;
-                const PathCtx cur_new = ctx_select(!mine, back, regs), oth_new = ctx_select(mine, back, regs);
-                if ((tr.phase & 3u) == kPhaseShadow) { tr.o = cur_new.so, tr.d = cur_new.sd, tr.t_min = 0.f; }
-                else { tr.o = cur_new.no, tr.d = cur_new.nd, tr.t_min = cur_new.n_tmin; }
-                if (sel != 0u) { cb = cur_new, ca = oth_new; } else { ca = cur_new, cb = oth_new; }
+                oth.flags = mine ? shaded_flags : (keep_word >> 20u) & 0xffu;
+                if ((tr.phase & 3u) == kPhaseShadow) { tr.o = cur.so, tr.d = cur.sd, tr.t_min = 0.f; }
+                else { tr.o = cur.no, tr.d = cur.nd, tr.t_min = cur.n_tmin; }
             }
             // ---- an idle lane starts on the job its context was just given
-            if (tr.phase == kPhaseIdle && ((sel != 0u ? ca.flags : cb.flags) & kCtxRays) != 0u) {
-                sel ^= 1u;
-                if (sel != 0u) { ctx_start(cb, tr); } else { ctx_start(ca, tr); }
+            if (tr.phase == kPhaseIdle && (oth.flags & kCtxRays) != 0u) {
+                ctx_swap(cur, oth);
+                ctx_start(cur, tr);
             }
-#endif
             if (COUNT) {
                 if (lane == 0u) {
                     const auto t_end = __builtin_readcyclecounter();
@@ -709,7 +673,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
         TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
-            pool_trace<COUNT, ALPHA>(scene, stack, tr, ca, cb, sel, (LR_POOL_OVERLAP && items_left) || q_next < q_total, ts);
+            pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, (LR_POOL_OVERLAP && items_left) || q_next < q_total, ts);
             if (!ALPHA) { break; }
             if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
             resolve_pending_alpha(scene, stack, tr);
