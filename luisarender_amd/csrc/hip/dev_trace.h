@@ -262,11 +262,27 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // one-triangle leaves (accel.cpp): with the wave's lanes at different depths a leaf loop runs for the longest leaf
 // of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
 // (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
-template<bool COUNT, bool ALPHA>
-LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats) {
+//
+// LEAF BATCHING (round 4, LR_LEAF_BATCH > 0).  With one-triangle leaves a ray takes one leaf step per six node steps, so in a loop
+// that runs "node step, then leaf step" every iteration the leaf step works for 0.13 of the lanes that have a ray -- and costs 2050
+// cycles of the iteration's 5100 (section probes, profiles/r04c).  A lane that arrives at a leaf therefore POSTPONES it: it keeps the
+// leaf in a register (`leaf`) and goes on with the next entry of its stack; the wave runs the leaf step when LR_LEAF_BATCH lanes hold a
+// postponed leaf (or no lane has an inner node left), and a lane that reaches a second leaf before that waits.  A lane's leaves are
+// still tested in the order it found them, so hits (and ties) come out as before; what changes is that the boxes between a postponed
+// leaf and its test are culled against the t_max of before that test: a few more node visits, the same results.  Outside the loop
+// nothing is postponed: trav_unpostpone puts the lane back where it stood (the entry it went on with returns to the stack).
+// MEASURED, and OFF by default: a model of the loop with the probes' section costs promised 1.16-1.29x on the traversal; on the box
+// (C2, 256 spp, Msamples/s) the pool kernel went 898 -> 889 / 891 / 875 / 835 / 767 at LR_LEAF_BATCH 12 / 16 / 24 / 32 / 40 and the
+// one-path-per-lane kernel 850 -> 820 / 804 / 720 / 569 / 497 (profiles/r04d_leaf_batching.txt): same films, same rays, 0.5 % fewer
+// boxes, steps per ray 20.8 against the minimum of 19.6 -- the lanes do not wait long, the iterations simply do not get cheaper.  The
+// leaf step's price is its triangle fetch's latency, which the other three waves of the SIMD cover; the instructions it saves are
+// fewer than the ballots, the extra pop and the longer live ranges that batching adds to EVERY iteration.
+template<bool COUNT, bool ALPHA, bool POSTPONED = false>
+LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats, uint32_t *leaf = nullptr) {
     auto found = false;
+    const auto ref = POSTPONED ? *leaf : tr.cur;
     {
-        auto tb = tl.tris + static_cast<size_t>(tr.cur & ((1u << 27u) - 1u)) * 3u;
+        auto tb = tl.tris + static_cast<size_t>(ref & ((1u << 27u) - 1u)) * 3u;
         // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
         auto a = tb[0], b = tb[1], c = tb[2];
 #ifdef LR_LEAF_FULL_QUADS// (a kernel that never reads hit.inst / hit.prim gets two 12-byte loads here: keep them 16-byte ones)
@@ -307,17 +323,52 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
             if (tr.phase == kPhaseClosest) {
                 tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
                 tr.hit.u = u, tr.hit.v = v;
-                tr.hit.tri = tr.cur & ((1u << 27u) - 1u);
+                tr.hit.tri = ref & ((1u << 27u) - 1u);
             }
         }
     }
     if (tr.phase == kPhaseShadow && found) {
         tr.occluded = true;
         tr.sp = 0u;// any-hit: drop the rest of the stack
+        if (POSTPONED) { tr.cur = kInvalid; }
     }
     if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
+        if (POSTPONED) { *leaf = kInvalid; }
+        else { tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid; }
+    }
+}
+
+#ifndef LR_LEAF_BATCH
+#define LR_LEAF_BATCH 0// lanes with a postponed leaf that make the wave run the leaf step; 0: a leaf step every iteration (rounds 1-3)
+#endif
+// a lane that stands at a leaf and has none postponed keeps it for later and goes on with its stack
+LR_D void trav_postpone(const TraversalStack &stack, TravState &tr, uint32_t &leaf, bool live, bool deep) {
+    if (live && leaf == kInvalid && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
+        leaf = tr.cur;
         tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid;
     }
+}
+// ... and back (on the way out of a traversal loop): the lane stands at its postponed leaf, where it went on to is the top of its stack
+LR_D void trav_unpostpone(const TraversalStack &stack, TravState &tr, uint32_t &leaf) {
+    if (leaf != kInvalid) {
+        if (tr.cur != kInvalid) { stack.push(tr.sp++, tr.cur); }
+        tr.cur = leaf;
+        leaf = kInvalid;
+    }
+}
+// one iteration's leaf work of the wave; returns with `leaf` tested where the wave's leaf step was due
+template<bool COUNT, bool ALPHA>
+LR_D void trav_leaves(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &leaf, bool live, bool deep, TraceStats &stats) {
+#if LR_LEAF_BATCH > 0
+    trav_postpone(stack, tr, leaf, live, deep);
+    const auto holds = live && leaf != kInvalid;
+    const auto waiting = __ballot(holds);
+    if (waiting == 0ull) { return; }
+    if (static_cast<uint32_t>(__popcll(waiting)) < static_cast<uint32_t>(LR_LEAF_BATCH) && __any(live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u)) { return; }
+    if (holds) { trav_leaf_step<COUNT, ALPHA, true>(stack, tl, tr, deep, stats, &leaf); }
+#else
+    if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+#endif
 }
 
 // Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`
@@ -335,6 +386,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                       const Ray &next_closest, int refill, TraceStats &stats, bool idle_at_entry) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
+    auto leaf = kInvalid;// the lane's postponed leaf (LEAF BATCHING above)
     for (;;) {
 #ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u; }
@@ -352,12 +404,12 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
 #endif
-        if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+        trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t2 = __builtin_readcyclecounter();
 #endif
         // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
-        if (live && tr.cur == kInvalid) {
+        if (live && tr.cur == kInvalid && leaf == kInvalid) {
             if (tr.phase == kPhaseShadow && has_next) {
                 trav_begin(tr, next_closest, kPhaseClosest);
                 inv = safe_inverse(tr.d);
@@ -377,6 +429,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         auto finished = __ballot(tr.phase == kPhaseIdle && !idle_at_entry);
         if (__popcll(finished) >= refill) { break; }
     }
+    trav_unpostpone(stack, tr, leaf);
 }
 
 }// namespace lrd

@@ -145,7 +145,7 @@ struct lrhip_ctx {
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
     // round 4: the path-pool scheduler (megapool_kernel.h): slot records of every resident wave; lrhip_set_scheduler
     DeviceBuffer pool;
-    uint32_t scheduler{0u};      // lrhip_set_scheduler: 0 = automatic (today: one path per lane everywhere), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
+    uint32_t scheduler{0u};      // lrhip_set_scheduler: 0 = automatic (wants_pool below), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
 };
 
 namespace {
@@ -924,6 +924,15 @@ int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
     }
     return LRHIP_OK;
 }
+// Which scheduler a frame of this scene runs under (lrhip_set_scheduler).  Automatic: the pool kernels, except on scenes so small that
+// a ray is a handful of traversal steps -- there the pool kernel's costlier shading block (path state through global memory, the
+// current context through the LDS) is not paid back by fuller traversal steps.  Measured in round 4 at the bench's sizes (kernel
+// time, pool / one path per lane): Cornell box, 32 triangles, 0.86; C2 1.5 M triangles 1.05 (256 spp) ... 1.005 (1024 spp); C3 1.12;
+// C4 1.02; C5 (wavefront mode) 1.08 (profiles/r04_final_schedulers.txt).
+constexpr uint32_t kPoolAutoTriangles = 4096u;
+bool wants_pool(const lrhip_ctx *ctx) {
+    return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= kPoolAutoTriangles);
+}
 // slot records of the pool kernels: kPoolSlots x (8 | 9) float4 per resident wave (megapool_kernel.h)
 int ensure_pool(lrhip_ctx *ctx, uint32_t resident_blocks) {
     return ensure(ctx->pool, static_cast<size_t>(resident_blocks) * lrd::kWavesPerBlock * lrd::kPoolSlots * lrd::pool_quads<true>() * sizeof(float4));
@@ -983,7 +992,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
     // round 4: both lean passes under the path-pool scheduler (megapool_kernel.h) where those kernels are in the library
     auto pool = false;
-    if (ctx->scheduler == 2u) {
+    if (wants_pool(ctx)) {
         const auto a = find_variant(kVariants, n_variants, lean | lrd::kFeatPool), b = find_variant(kVariants, n_variants, lean | lrd::kFeatPool | lrd::kFeatCont);
         pool = a >= 0 && b >= 0 && kVariants[a].launch != nullptr && kVariants[b].launch != nullptr;
     }
@@ -1151,7 +1160,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // round 4: the path-pool scheduler (megapool_kernel.h) where a pool kernel is compiled for a scene the legacy search would have given
     // a lean kernel (no out-of-line closures, no sibling integrator), and the fixed-point film can hold the frame
     auto pool = false;
-    if (ctx->scheduler == 2u && fixed_bits >= 0 && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+    if (wants_pool(ctx) && fixed_bits >= 0 && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto vp = pick_variant(features, count, generic, true);
         if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { vi = vp, pool = true; }
     }

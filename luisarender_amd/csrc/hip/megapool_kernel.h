@@ -150,6 +150,7 @@ template<bool COUNT, bool ALPHA>
 LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &cur, PathCtx &oth, bool samples_left, TraceStats &stats) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
+    auto leaf = kInvalid;// the lane's postponed leaf (dev_trace.h: LEAF BATCHING)
     for (;;) {
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
@@ -167,12 +168,12 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
 #endif
-        if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+        trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t2 = __builtin_readcyclecounter();
 #endif
         // ---- ray finished: the job's next ray, the other context's job, or idle
-        const auto ended = live && tr.cur == kInvalid;
+        const auto ended = live && tr.cur == kInvalid && leaf == kInvalid;
         if (ended) {
             if (tr.phase == kPhaseShadow) {
                 if (tr.occluded) { cur.flags |= kCtxOccluded; }
@@ -207,6 +208,7 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         if (__ballot(tr.phase != kPhaseIdle) == 0ull) { break; }
         if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
+    trav_unpostpone(stack, tr, leaf);
 }
 
 template<uint32_t F>

@@ -17,6 +17,13 @@ from luisarender_amd.scenes import (cornell_box, generate_bedroom_scene, generat
 
 pytestmark = pytest.mark.gpu
 
+
+def _variant(renderer):
+    """the frame's kernel variant without the scheduler bit (LRHIP_FEAT_POOL): which scheduler a scene gets is lrhip.hip: wants_pool's
+    business (tests/test_gpu_pool.py holds the two against each other), which closures / traversal / sampler code it needs is these tests'"""
+    return renderer.last_variant() & ~4096
+
+
 # Bars of the headline-scene comparisons: TWICE what was measured on MI355X in round 4 (profiles/r04_parity_bars.txt), for the device against
 # the oracle and against the oracle on the device's own baked geometry (_same_geometry).  Round 3 asserted 2e-2 against measured 3e-3 ...
 # 9e-3: a regression that doubled the error would have passed.
@@ -241,7 +248,7 @@ def test_image_and_directional_environments(renderer, tmp_path, kind):
     sc = Scene.from_string(ENV_SCENE.format(env=env, spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
     if kind.startswith("combined_nested"):
-        assert renderer.last_variant() & 96 and not renderer.last_variant() & 1024, renderer.last_variant()  # out-of-line environment code, no wavefront mode
+        assert _variant(renderer) & 96 and not _variant(renderer) & 1024, _variant(renderer)  # out-of-line environment code, no wavefront mode
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
     assert cpu[..., :3].mean() > 0.01
@@ -323,7 +330,7 @@ def test_bedroom_class_scene(renderer, tmp_path):
     closest rays differ (texel-edge flips of the lat-long lookup, rough-glass lobe picks)."""
     sc = Scene.load(generate_bedroom_scene(str(tmp_path), resolution=(256, 144), spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
-    assert renderer.last_variant() == 4 | 1  # LRHIP_FEAT_ENVIRONMENT | COUNT: nothing else is compiled in
+    assert _variant(renderer) == 4 | 1  # LRHIP_FEAT_ENVIRONMENT | COUNT: nothing else is compiled in
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
     err, same = _rel_l1(gpu, cpu), _same_geometry(sc, 16, gpu, cpu=cpu)
@@ -338,7 +345,7 @@ def test_camera_class_scene(renderer, tmp_path):
     Measured: rel-L1 4.2e-4, mean 6e-5, 1 closest ray of 419 k differs."""
     sc = Scene.load(generate_camera_scene(str(tmp_path), resolution=(256, 144), spp=8, texture_size=1024))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 8)
-    assert renderer.last_variant() == 4 | 16 | 1
+    assert _variant(renderer) == 4 | 16 | 1
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
     assert _rel_l1(gpu, cpu) < 5e-3
@@ -352,7 +359,7 @@ def test_kitchen_class_scene(renderer, tmp_path):
     block rel-L1 2.1e-2, mean 2e-5, closest rays 1 810 464 vs 1 810 586."""
     sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
-    assert renderer.last_variant() == WF | 8 | 16 | 32 | 64 | 1  # wavefront mode: lean alpha kernel + Disney / Mix / Layered in the heavy kernel + COUNT
+    assert _variant(renderer) == WF | 8 | 16 | 32 | 64 | 1  # wavefront mode: lean alpha kernel + Disney / Mix / Layered in the heavy kernel + COUNT
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-3 * cc["closest_rays"]
     g, c = _blocks(gpu), _blocks(cpu)
@@ -369,7 +376,7 @@ def test_kernel_variant_selection(renderer):
         sc = Scene.from_string(cornell_box(resolution=16, spp=1, short_box_surface="probe" if material else "white", extra_surfaces=extra, **kw))
         renderer.upload(sc)
         renderer.render(0, 1, sync=True)
-        return renderer.last_variant()
+        return _variant(renderer)
 
     assert variant(None) == 0
     assert variant(None, sampler="Sobol") == 2
@@ -379,7 +386,7 @@ def test_kernel_variant_selection(renderer):
     sc = Scene.from_string(cornell_box(resolution=16, spp=1, short_box_surface="probe", extra_surfaces=cut))
     renderer.upload(sc)
     renderer.render(0, 1, sync=True)
-    assert renderer.last_variant() == 8  # alpha-tested traversal on the lean kernel
+    assert _variant(renderer) == 8  # alpha-tested traversal on the lean kernel
     # Mix / Layered surfaces: wavefront mode -- the lean kernel parks them for the heavy-closure kernel (lrhip.h: lrhip_set_wavefront);
     # its alpha-tested form only where a surface may be non-opaque
     assert variant("mix") == WF | 32
@@ -500,7 +507,7 @@ def test_what_separates_c2_from_the_oracle(tmp_path):
             r = MegaPathRenderer(0, lib_path=lib)
             r.upload(sc)
             r.render(0, 8, counters=False, sync=True)
-            assert r.last_variant() == 0
+            assert _variant(r) == 0
             g = r.download(False)
             r.close()
             assert np.array_equal(g[..., 3], c[..., 3])
@@ -524,7 +531,7 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
     sc = Scene.load(gen(str(tmp_path), resolution=res, spp=spp, **kw))  # (the generator's default triangle count = the bench's)
     renderer.upload(sc)
     renderer.render(0, spp, counters=False, sync=True)
-    assert renderer.last_variant() == variant
+    assert _variant(renderer) == variant
     film = renderer.download(False)
     assert film.shape == (res[1], res[0], 4) and np.isfinite(film).all()
     assert (film[..., 3] <= spp).all() and (film[..., 3] == spp).mean() > 0.999  # (a NaN sample is rejected by the film, color.cpp:111)
@@ -593,7 +600,7 @@ def test_shipped_kernels_equal_their_counting_twins(renderer, tmp_path, case):
     for count in (True, False):
         renderer.upload(sc)
         renderer.render(0, 8, counters=count, sync=True)
-        assert renderer.last_variant() == (variant | (1 if count else 0)), (case, renderer.last_variant())
+        assert _variant(renderer) == (variant | (1 if count else 0)), (case, _variant(renderer))
         films.append(renderer.download(converted=False))
     a, b = films
     assert a[..., :3].sum() > 0 and np.isfinite(b).all() and np.array_equal(a[..., 3], b[..., 3]), case
@@ -637,7 +644,7 @@ def test_sibling_integrators(renderer, integrator):
     text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
     sc = Scene.from_string(text)
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
-    assert renderer.last_variant() == 252 | 1
+    assert _variant(renderer) == 252 | 1
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-4 * cc["closest_rays"]
     assert np.abs(cpu[..., :3]).mean() > 0.01 and _rel_l1(gpu, cpu) < 1e-3, integrator
@@ -704,7 +711,7 @@ def test_volumetric_megakernel(renderer, case):
     sc = Scene.from_string(text)
     assert sc.view().integrator.kind == 3 and sc.view().medium_count == {"vacuum": 0, "fog_env": 1, "fog_lamp_and_medium_box": 2}[case]
     gpu, gc, cpu, cc = _render_both(renderer, sc, 64)
-    assert renderer.last_variant() == 256 | 1
+    assert _variant(renderer) == 256 | 1
     # NaN samples of the lottery are rejected by the film on both sides, not necessarily the same ones
     assert np.isfinite(gpu).all() and np.abs(gpu[..., 3] - cpu[..., 3]).max() <= 8 and abs(gpu[..., 3].sum() - cpu[..., 3].sum()) <= 2e-3 * cpu[..., 3].sum()
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 5e-3 * cc["closest_rays"]
@@ -882,7 +889,7 @@ def test_nested_mix_layered_only_in_megapath(renderer):
     text = cornell_box(resolution=32, spp=4, short_box_surface="mix_layered", extra_surfaces=extra)
     renderer.upload(Scene.from_string(text))
     renderer.render(0, 4, sync=True)
-    assert renderer.last_variant() == WF | 16 | 32 | 64 | 512
+    assert _variant(renderer) == WF | 16 | 32 | 64 | 512
     for integrator in ('Direct { importance_sampling { "both" }', "MegaVPTNaive {"):
         with pytest.raises(DeviceError, match="MegaPath integrator only"):
             renderer.upload(Scene.from_string(text.replace("integrator : MegaPath {", "integrator : " + integrator)))
@@ -901,7 +908,7 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
         renderer.clear()
         renderer.render(0, 16, sync=True)
         films.append(renderer.download(False))
-    assert renderer.last_variant() == WF | 16 | 32 | 64  # (the stand-in at this size holds no alpha-tested surface)
+    assert _variant(renderer) == WF | 16 | 32 | 64  # (the stand-in at this size holds no alpha-tested surface)
     assert np.array_equal(films[0], films[1]) and np.isfinite(films[0]).all() and (films[0][..., 3] == 16).all()
     total = np.zeros_like(films[0])
     for rank in range(3):
@@ -930,7 +937,7 @@ def test_wavefront_mode_is_deterministic_shardable_and_agrees_with_the_all_in_on
         renderer.set_wavefront(False)
         renderer.clear()
         renderer.render(0, 16, sync=True)
-        assert renderer.last_variant() == 124
+        assert _variant(renderer) == 124
         mono = renderer.download(False)
     finally:
         renderer.set_wavefront(True)
@@ -953,13 +960,13 @@ def test_wavefront_mode_keeps_negative_samples(renderer, tmp_path):
     renderer.upload(sc)
     renderer.render(0, 12, sync=True)
     wave = renderer.download(False)
-    assert (renderer.last_variant() & WF) != 0
+    assert (_variant(renderer) & WF) != 0
     try:
         renderer.set_wavefront(False)
         renderer.clear()
         renderer.render(0, 12, sync=True)
         mono = renderer.download(False)
-        assert (renderer.last_variant() & WF) == 0
+        assert (_variant(renderer) & WF) == 0
     finally:
         renderer.set_wavefront(True)
     neg = mono[..., :3] < 0.0
@@ -1039,7 +1046,7 @@ def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
     generic = 0 if sampler == "Independent" else 2
     renderer.upload(sc)
     renderer.render(0, 8, counters=False, sync=True)
-    assert renderer.last_variant() == generic
+    assert _variant(renderer) == generic
     base = renderer.download(converted=False)
     try:
         for force in (4, 8, 12, 16, 20, 60, 124):
@@ -1048,7 +1055,7 @@ def test_every_scene_feature_variant_renders_the_same_frame(renderer, sampler):
             for _ in range(2):
                 renderer.upload(sc)
                 renderer.render(0, 8, counters=False, sync=True)
-                assert renderer.last_variant() == (force | generic), (force, renderer.last_variant())
+                assert _variant(renderer) == (force | generic), (force, _variant(renderer))
                 films.append(renderer.download(converted=False))
             assert np.array_equal(films[0], films[1]), force
             assert np.array_equal(films[0][..., 3], base[..., 3]) and np.isfinite(films[0]).all(), force

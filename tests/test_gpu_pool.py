@@ -68,8 +68,12 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
     assert (v_pool & POOL) != 0 and (v_lane & POOL) == 0 and (v_pool & ~POOL) == v_lane, (v_lane, v_pool)
     assert np.isfinite(pool).all() and np.array_equal(pool[..., 3], lane[..., 3])
     # the same paths: every counter of the path topology is EQUAL (not close: same kernel code per vertex, same random numbers)
-    for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nee_samples", "path_length_sum", "nodes_visited", "tris_tested"):
+    for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nee_samples", "path_length_sum"):
         assert c_pool[k] == c_lane[k], (k, c_pool[k], c_lane[k])
+    # ... and the traversal work agrees to the few boxes a postponed leaf lets through (dev_trace.h: LEAF BATCHING -- which boxes a ray
+    # visits between a leaf and its test depends on when the WAVE runs its leaf step, i.e. on the other lanes)
+    for k in ("nodes_visited", "tris_tested"):
+        assert abs(c_pool[k] - c_lane[k]) <= 0.05 * c_lane[k], (k, c_pool[k], c_lane[k])
     err = _rel_l1(pool, lane)
     print(f"{case}: pool vs one-path-per-lane rel-L1 {err:.2e}; pool lanes trace {c_pool['trace_steps_busy'] / c_pool['trace_steps']:.2f} "
           f"(one path per lane {c_lane['trace_steps_busy'] / c_lane['trace_steps']:.2f})")
