@@ -173,10 +173,9 @@ struct TravLane {
 
 // ---- node step of the WAVE (every lane calls; `is_inner` lanes test the packet of tr.cur): cooperative packet fetch, quantised slab
 // tests, near -> far ordering, pushes.  `deep`: some lane may reach the HBM overflow area of the stack in this iteration.
-template<bool COUNT>
-LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
+// the fetch half of the node step: the packets of the lanes at inner nodes are on their way into the wave's staging area
+LR_D void trav_node_fetch(const TraversalStack &stack, const TravLane &tl, const TravState &tr, bool is_inner) {
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef __attribute__((address_space(1))) const void global_void;
     // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
     // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
@@ -186,9 +185,21 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         __builtin_amdgcn_global_load_lds((global_void *)(tl.node_bytes + ((w << 6u) | tl.quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
     LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
 #undef LR_FETCH
-    __builtin_amdgcn_s_waitcnt(0);// vmcnt(0): the four packets are in LDS
+}
+// every load of the iteration has landed: the packets are in the LDS (and the triangles of the lanes at leaves in their registers)
+LR_D void trav_fetch_wait() {
+    __builtin_amdgcn_s_waitcnt(0);// vmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template<bool COUNT, bool FETCHED = false>
+LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    if (!FETCHED) {
+        trav_node_fetch(stack, tl, tr, is_inner);
+        trav_fetch_wait();
+    }
     const auto mine = tl.mine;
     auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
     const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + 3));// q3 = child[4] stays in LDS
@@ -277,14 +288,20 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // boxes, steps per ray 20.8 against the minimum of 19.6 -- the lanes do not wait long, the iterations simply do not get cheaper.  The
 // leaf step's price is its triangle fetch's latency, which the other three waves of the SIMD cover; the instructions it saves are
 // fewer than the ballots, the extra pop and the longer live ranges that batching adds to EVERY iteration.
+struct LeafTriangle { float4 a, b, c; };
+LR_D LeafTriangle trav_leaf_fetch(const TravLane &tl, uint32_t ref) {
+    auto tb = tl.tris + static_cast<size_t>(ref & ((1u << 27u) - 1u)) * 3u;
+    // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
+    return LeafTriangle{tb[0], tb[1], tb[2]};
+}
 template<bool COUNT, bool ALPHA, bool POSTPONED = false>
-LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats, uint32_t *leaf = nullptr) {
+LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats, uint32_t *leaf = nullptr,
+                         const LeafTriangle *fetched = nullptr) {
     auto found = false;
     const auto ref = POSTPONED ? *leaf : tr.cur;
     {
-        auto tb = tl.tris + static_cast<size_t>(ref & ((1u << 27u) - 1u)) * 3u;
-        // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
-        auto a = tb[0], b = tb[1], c = tb[2];
+        const auto tri = fetched != nullptr ? *fetched : trav_leaf_fetch(tl, ref);
+        auto a = tri.a, b = tri.b, c = tri.c;
 #ifdef LR_LEAF_FULL_QUADS// (a kernel that never reads hit.inst / hit.prim gets two 12-byte loads here: keep them 16-byte ones)
         asm volatile("" ::"v"(a.w), "v"(b.w));
 #endif
@@ -356,6 +373,31 @@ LR_D void trav_unpostpone(const TraversalStack &stack, TravState &tr, uint32_t &
         leaf = kInvalid;
     }
 }
+// ONE ITERATION of a traversal loop for the wave (LR_FUSED_FETCH, round 4): every lane with a ray stands at an inner node or at a leaf, and
+// both kinds of step begin with a dependent gather -- the node's packet, the leaf's triangle.  Rounds 1-3 ran "node step, then leaf
+// step": two round trips to memory in a row, the second one (1450-2050 cycles by the section probes, for 80 VALU instructions) on
+// behalf of the 0.13 of the lanes that stand at a leaf.  Here both gathers are issued up front and waited for ONCE; then the leaf
+// lanes test their triangle and the node lanes their packet.
+// MEASURED, and OFF by default (profiles/r04e_fused_fetch.txt, Msamples/s with / without): one path per lane C2 861 / 853 (256 spp),
+// 908 / 895 (1024), C3 810 / 803, C4 894 / 881, C5 421 / 417 -- but the Cornell box 3410 / 3757; the pool kernels C2 892 / 898, C3 890 /
+// 897, C4 904 / 898, C5 447 / 449, Cornell 3018 / 3230.  One per cent on the kernels that no longer run the large scenes, nothing on the
+// ones that do: the wave's own round trips are not what the loop waits for -- the SIMD's other three waves cover them either way.
+#ifndef LR_FUSED_FETCH
+#define LR_FUSED_FETCH 0
+#endif
+template<bool COUNT, bool ALPHA>
+LR_D void trav_step_fused(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool live, bool deep, TraceStats &stats) {
+    const auto is_inner = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u;
+    const auto is_leaf = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u;
+    const auto any_inner = __any(is_inner);
+    if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
+    LeafTriangle tri;
+    if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
+    trav_fetch_wait();
+    if (is_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats, nullptr, &tri); }
+    if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, inv, is_inner, deep, stats); }
+}
+
 // one iteration's leaf work of the wave; returns with `leaf` tested where the wave's leaf step was due
 template<bool COUNT, bool ALPHA>
 LR_D void trav_leaves(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &leaf, bool live, bool deep, TraceStats &stats) {
@@ -366,6 +408,12 @@ LR_D void trav_leaves(const TraversalStack &stack, const TravLane &tl, TravState
     if (waiting == 0ull) { return; }
     if (static_cast<uint32_t>(__popcll(waiting)) < static_cast<uint32_t>(LR_LEAF_BATCH) && __any(live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u)) { return; }
     if (holds) { trav_leaf_step<COUNT, ALPHA, true>(stack, tl, tr, deep, stats, &leaf); }
+#elif defined(LR_LEAF_WAIT) && LR_LEAF_WAIT > 1// (the plain form: lanes at a leaf WAIT until LR_LEAF_WAIT of them do, or no lane has an inner node to go on with)
+    const auto at_leaf = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u;
+    const auto n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
+    if (n_leaf == 0u) { return; }
+    if (n_leaf < static_cast<uint32_t>(LR_LEAF_WAIT) && __any(live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u)) { return; }
+    if (at_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
 #else
     if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
 #endif
@@ -400,11 +448,17 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
         // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
         const auto deep = __any(live && tr.sp + 3u > kStackLds);
+#if LR_FUSED_FETCH && LR_LEAF_BATCH == 0
+        trav_step_fused<COUNT, ALPHA>(stack, tl, tr, inv, live, deep, stats);
+#else
         if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
+#endif
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
 #endif
+#if !(LR_FUSED_FETCH && LR_LEAF_BATCH == 0)
         trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
+#endif
 #ifdef LR_TRACE_PROBE
         const auto probe_t2 = __builtin_readcyclecounter();
 #endif

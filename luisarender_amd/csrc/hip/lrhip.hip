@@ -519,7 +519,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (s->accel.triangle_count >= (1u << 27u) - 1u || s->accel.node_count >= (1u << 26u)) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 2^27 - 2 BVH triangles or 2^26 - 1 BVH packets");
     }
-    if (ctx->bvh_depth * 3u > 11u + lrd::kSpillEntries) {// (11: the smallest LDS stack of any variant, the pool kernels')
+    if (ctx->bvh_depth * 3u > 11u + lrd::kSpillEntries) {// (11: the pool kernels' 16 LDS entries less the five words a lane parks on top of its stack across the shading block)
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");
     }

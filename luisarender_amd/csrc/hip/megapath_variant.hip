@@ -10,8 +10,8 @@
 #include "megavpt_kernel.h"
 #define LR_KERNEL megavpt_kernel
 #elif (LR_VARIANT) & 4096// kFeatPool: the path-pool scheduler (round 4)
-#ifndef LR_STACK_LDS
-#define LR_STACK_LDS 11// (the pool kernels give five of the sixteen LDS stack entries per lane to what a lane keeps across the shading block, megapool_kernel.h)
+#if defined(LR_POOL_PARK_ON_STACK) && LR_POOL_PARK_ON_STACK == 0 && !defined(LR_STACK_LDS)
+#define LR_STACK_LDS 11// (such pool kernels give five of the sixteen LDS stack entries per lane to what a lane keeps across the shading block, megapool_kernel.h)
 #endif
 #include "megapath_kernel.h"
 #include "megapool_kernel.h"

@@ -61,6 +61,16 @@ namespace lrd {
 #ifndef LR_POOL_IDLE_LANES
 #define LR_POOL_IDLE_LANES 16 // ... or lanes with a context to shade and nothing left to trace
 #endif
+#ifndef LR_POOL_TURNOVER_LANES
+// A ray that ended waits until this many lanes have one (or no lane has anything left to traverse): the turnover code of the loop --
+// results into the context, exchange of the contexts, the next ray into the traversal state, 1 / d -- then runs once for all of them,
+// every seventh iteration or so instead of in seven of ten.  C2, 256 spp: 918 Msamples/s at 1 (no waiting), 924 at 5 (on the build
+// before), 955 at 8, 954 at 12, 945 at 16, 916 at 24 (profiles/r04f_turnover_and_stack.txt).
+#define LR_POOL_TURNOVER_LANES 8
+#endif
+#ifndef LR_POOL_PARK_ON_STACK
+#define LR_POOL_PARK_ON_STACK 1// the five parked words of the ray in flight go on top of the lane's traversal stack (0: an LDS area of their own, LR_STACK_LDS <= 11)
+#endif
 #ifndef LR_POOL_RAY_INIT
 #define LR_POOL_RAY_INIT if (!mine)
 #endif
@@ -164,17 +174,29 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
 #ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         const auto probe_t0 = __builtin_readcyclecounter();
 #endif
+#if LR_FUSED_FETCH && LR_LEAF_BATCH == 0
+        trav_step_fused<COUNT, ALPHA>(stack, tl, tr, inv, live, deep, stats);
+#else
         if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
+#endif
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
 #endif
+#if !(LR_FUSED_FETCH && LR_LEAF_BATCH == 0)
         trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
+#endif
 #ifdef LR_TRACE_PROBE
         const auto probe_t2 = __builtin_readcyclecounter();
 #endif
         // ---- ray finished: the job's next ray, the other context's job, or idle
         const auto ended = live && tr.cur == kInvalid && leaf == kInvalid;
-        if (ended) {
+#if LR_POOL_TURNOVER_LANES > 1
+        const auto n_ended = static_cast<uint32_t>(__popcll(__ballot(ended)));
+        const auto turnover = n_ended >= static_cast<uint32_t>(LR_POOL_TURNOVER_LANES) || (n_ended != 0u && !__any(live && tr.cur != kInvalid));
+#else
+        constexpr auto turnover = true;
+#endif
+        if (ended && turnover) {
             if (tr.phase == kPhaseShadow) {
                 if (tr.occluded) { cur.flags |= kCtxOccluded; }
             } else {
@@ -224,9 +246,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     constexpr uint32_t QUADS = pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
-    // what a lane keeps of its ray in flight across the shading block: five words, [word][thread] (the LDS the 11-entry stack leaves, see below)
+#if LR_POOL_PARK_ON_STACK == 0
+    // what a lane keeps of its ray in flight across the shading block: five words, [word][thread] (the LDS an 11-entry stack leaves, see below)
     __shared__ uint32_t s_park[5u * kBlockThreads];
-    static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile the pool variants with LR_STACK_LDS <= 11");
+    static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile such pool variants with LR_STACK_LDS <= 11");
+#endif
 #if LR_POOL_OVERLAP
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
 #else
@@ -364,12 +388,20 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 // per lane instead of 16).
                 const auto keep_word = (tr.phase & 7u) | (tr.occluded ? 8u : 0u) | (tr.sp << 5u) | (cur.flags << 12u) | (oth.flags << 20u);
                 stage[192u + lane] = make_float4(cur.nd.x, cur.nd.y, cur.nd.z, __uint_as_float(keep_word));
+#if LR_POOL_PARK_ON_STACK// ... on top of the lane's own traversal stack (the entries above sp; beyond the LDS part: the overflow area in HBM)
+                stack.push(tr.sp + 0u, tr.phase != kPhaseIdle ? tr.hit.tri : cur.tri);
+                stack.push(tr.sp + 1u, __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.u : cur.u));
+                stack.push(tr.sp + 2u, __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.v : cur.v));
+                stack.push(tr.sp + 3u, __float_as_uint(tr.t_max));
+                stack.push(tr.sp + 4u, tr.cur);
+#else
                 const auto park = s_park + tid;
                 park[0u * kBlockThreads] = tr.phase != kPhaseIdle ? tr.hit.tri : cur.tri;
                 park[1u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.u : cur.u);
                 park[2u * kBlockThreads] = __float_as_uint(tr.phase != kPhaseIdle ? tr.hit.v : cur.v);
                 park[3u * kBlockThreads] = __float_as_uint(tr.t_max);
                 park[4u * kBlockThreads] = tr.cur;
+#endif
                 asm volatile("" ::: "memory");// (the values must not be forwarded to the loads at the end of the block: they are to LEAVE the registers)
             }
             // ---- the context's path
@@ -631,14 +663,20 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 cur.no = mk3(p2.x, p2.y, p2.z), cur.n_tmax = p2.w;
                 cur.nd = mk3(p3.x, p3.y, p3.z);
                 const auto keep_word = __float_as_uint(p3.w);
+                tr.phase = keep_word & 7u, tr.occluded = (keep_word & 8u) != 0u;
+                tr.sp = (keep_word >> 5u) & 127u;
+#if LR_POOL_PARK_ON_STACK
+                const auto keep_tri = stack.pop(tr.sp + 0u);
+                const auto keep_u = __uint_as_float(stack.pop(tr.sp + 1u)), keep_v = __uint_as_float(stack.pop(tr.sp + 2u));
+                tr.t_max = __uint_as_float(stack.pop(tr.sp + 3u)), tr.cur = stack.pop(tr.sp + 4u);
+#else
                 const auto park = s_park + tid;
                 const auto keep_tri = park[0u * kBlockThreads];
                 const auto keep_u = __uint_as_float(park[1u * kBlockThreads]), keep_v = __uint_as_float(park[2u * kBlockThreads]);
                 tr.t_max = __uint_as_float(park[3u * kBlockThreads]), tr.cur = park[4u * kBlockThreads];
+#endif
                 cur.flags = (keep_word >> 12u) & 0xffu, cur.tri = keep_tri, cur.u = keep_u, cur.v = keep_v;
                 tr.hit.tri = keep_tri, tr.hit.u = keep_u, tr.hit.v = keep_v;
-                tr.phase = keep_word & 7u, tr.occluded = (keep_word & 8u) != 0u;
-                tr.sp = (keep_word >> 5u) & 127u;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 oth.so = shadow.o, oth.sd = shadow.d, oth.s_tmax = shadow.t_max;
                 oth.no = ray.o, oth.nd = ray.d, oth.n_tmin = ray.t_min, oth.n_tmax = ray.t_max;
