@@ -385,7 +385,8 @@ def main():
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)" if args.sampler == "Independent" else args.sampler,
                            "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
-                           "collective": getattr(run_workload, "collective", None)},
+                           "collective": getattr(run_workload, "collective", None),
+                           "scheduler": "path pool, two contexts per lane (megapool_kernel.h)" if variant & 4096 else "one path per lane (megapath_kernel.h)"},
             }
             if args.spp is not None or args.sampler != "Independent":
                 out["config"]["note"] = "spp / sampler overridden: not the headline configuration"
@@ -426,9 +427,10 @@ def main():
             achieved = traffic / (mean_kernel_ms * 1e-3) / 1e9 if traffic else None
             stats = out.get("path_statistics")
             out["roofline"] = {
-                # What bounds lrd::megapath_kernel is VALU issue, jointly with the latency of its dependent gathers (DESIGN.md section 5;
-                # round 4 measured it directly: with the lanes of the traversal loop filled from 0.56 to 0.91 the kernel issued 14-23 %
-                # fewer VALU instructions and was no faster -- profiles/r04_pool_*).  The contract's HBM figures stay: `achieved` /
+                # What bounds the megakernel (lrd::megapool_kernel on the large scenes since round 4, lrd::megapath_kernel on the small ones)
+                # is VALU issue, jointly with the latency of its dependent gathers (DESIGN.md sections 4.1c and 5: filling the lanes of
+                # the traversal loop from 0.56 to 0.9 paid only once the scheduler's own instructions -- spills, turnovers -- were off
+                # the loop's hot path).  The contract's HBM figures stay: `achieved` /
                 # `frac` / `traffic` are the MEASURED memory traffic over the kernel's duration (FETCH_SIZE counts Infinity-Cache hits too:
                 # an upper bound on HBM traffic); one number per roof follows in `valu`, `lanes`, `l2`.
                 "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -2,7 +2,7 @@
 """A/B of the two schedulers of the lean kernels on the bench's stand-ins (GPU box): the path-pool kernels of round 4 against the
 one-path-per-lane kernels of rounds 1-3 -- kernel time (HIP events), Msamples/s, and how far the two films are apart.
     python tools/ab_sched.py <spp> [c2 c3 c4 c5 ...]      (LRHIP_LIB selects an experimental build of the library)"""
-import sys, tempfile, time
+import os, sys, tempfile, time
 sys.path.insert(0, '.')
 import numpy as np
 from luisarender_amd import Scene
@@ -25,6 +25,8 @@ for wl in workloads:
         for sched in ("legacy", "pool"):
             r = MegaPathRenderer(0)
             r.set_scheduler(sched == "pool")
+            if os.environ.get("LR_ITEM_SCALE"):
+                r.set_diagnostics(item_scale=float(os.environ["LR_ITEM_SCALE"]))
             r.upload(sc)
             r.render(0, min(spp, 4), sync=True)  # warm-up (allocations, code load)
             r.clear()
