@@ -187,14 +187,14 @@ int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
  * next job -- so that a lane whose job ends goes on with its other context inside the traversal loop (rays and hits in registers,
  * the 64 bytes of path state in a per-thread record, the ray in flight parked in the LDS while the lane shades).  Work items overlap
  * inside a wave and the film is summed in 64-bit fixed point: bit-reproducible under ANY sharding, grid size and work-item
- * partition.  Measured on MI355X (profiles/r04_*): lane utilisation of the traversal loop 0.56 -> 0.91, of the shading block 0.47 ->
- * 0.61, films equal to the one-path-per-lane kernels' to 8e-8 -- and 11 % SLOWER at four waves per SIMD (the second context's
- * registers push the shading block into scratch spills, whose traffic evicts the reused BVH levels from the 32 KB vector L1: a node
- * step takes 4200 cycles instead of 2100), 11 % faster at three.  So they are an option, not the default.  They serve every scene
- * the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes); a frame whose sums do not fit fixed point
- * (film clamp x spp beyond 2^37, a non-finite clamp), paths deeper than 65535, and the variants with out-of-line closures / sibling
- * integrators / media always run on the one-path-per-lane kernels.
- *   mode  0 = automatic (today: one path per lane), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
+ * partition.  Measured on MI355X (profiles/r04_final_*): lane utilisation of the traversal loop 0.56 -> 0.91, of the shading block
+ * 0.47 -> 0.63, films equal to the one-path-per-lane kernels' to 8e-8, and 5 .. 18 % faster on every scene but the smallest ones
+ * (a Cornell box: 13 % slower -- a ray is a handful of steps there and the pool's costlier shading block is not paid back).  They
+ * serve every scene the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes); a frame whose sums do
+ * not fit fixed point (film clamp x spp beyond 2^37, a non-finite clamp), paths deeper than 65535, and the variants with
+ * out-of-line closures / sibling integrators / media always run on the one-path-per-lane kernels.
+ *   mode  0 = automatic: the pool kernels on scenes of 4096 BVH triangles or more, one path per lane below;
+ *         1 = one path per lane; 2 = the pool kernels wherever one exists for the scene
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u
 int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);

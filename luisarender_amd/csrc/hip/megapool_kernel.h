@@ -9,18 +9,23 @@
 // block with its hit, or for the lane with the rays of its next job -- and when a lane's job ends it switches to its other
 // context's rays INSIDE the traversal loop, registers to registers:
 //   * what the traversal loop needs of a waiting context -- the job's rays (shadow ray + next path segment, 15 words) or its hit (4
-//     words) -- lives in REGISTERS.  The loop runs in ~75 of the kernel's 128 VGPRs (the shading block sets the allocation), so
-//     the second context costs the loop nothing, and a job turnover is a handful of v_mov: no memory, no LDS, no queue;
+//     words) -- lives in REGISTERS, in fixed roles: `cur` is the context whose ray the lane traces, `oth` the one that waits, and a
+//     lane that goes on to its other context's job EXCHANGES the two with 19 v_swap_b32: no memory, no LDS, no queue.  Rays that
+//     ended wait until LR_POOL_TURNOVER_LANES lanes have one: the turnover code then runs once for all of them;
 //   * what only the shading block needs of a path -- throughput, radiance, NEE term, bsdf pdf, depth, sampler position, pixel: 16
 //     words -- lives in a per-thread record in global memory, [context][quad][thread]: four coalesced 16-byte loads when the
 //     context is shaded, four stores when it leaves, ONE round trip per shading batch;
 //   * the wave leaves the traversal loop when LR_POOL_SHADE_LANES lanes hold a context to shade (or LR_POOL_IDLE_LANES of them have
-//     nothing left to trace); a lane shades ONE context per batch, its ray in flight parked in the packet staging area of the
-//     LDS (idle outside the traversal loop) so that the shading block keeps its registers.
-// The scheduling model (tools/sched_model.py, calibrated on the round-3 counters: it reproduces their 0.70 / 0.63 lane utilisation of
-// the traversal loop / the shading block without the item drain) gives 0.92 / 0.76 and 0.79 of the cost per job.
+//     nothing left to trace); a lane shades ONE context per batch -- its other one -- and EVERYTHING ELSE LEAVES THE REGISTERS for the
+//     duration of the block: the current context's rays go to the packet staging area of the LDS (idle outside the traversal
+//     loop), what is left of the ray in flight (hit so far, t_max, node, phase / stack depth) on top of the lane's own traversal
+//     stack.  This is what makes the scheme pay: with those six words in registers the block spilled 37 VGPRs on its hot path, the
+//     scratch traffic evicted the BVH's top levels from the 32 KB vector L1, and a node step took 4200 cycles instead of 2100
+//     (profiles/r04c_*, r04g_*).
+// Measured (profiles/r04_final_schedulers.txt, pool / one path per lane, Msamples/s): C2 966 / 898, C3 949 / 803, C4 936 / 882, C5 459 /
+// 418; a Cornell box 3268 / 3766 -- lrhip.hip: wants_pool picks this kernel from 4096 triangles up.
 //
-// MEASURED AND NOT KEPT (profiles/r04a-c_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
+// MEASURED AND NOT KEPT (profiles/r04a_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
 // shade queues of slot numbers in LDS, lanes fetching their next job from the ray queue inside the loop.  It filled the lanes (0.93 /
 // 0.79, 23 % fewer VALU instructions per sample, films equal to 6e-8) and was no faster: C2 830 against 854 Msamples/s at 256 spp,
 // C1 2420 against 4820.  Every job turnover read and wrote slot records whose lines the 4 MiB L2 of an XCD had long dropped (8 MiB of

@@ -142,9 +142,9 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
 
     def set_scheduler(self, pool: bool | None = None) -> None:
-        """lrhip_set_scheduler: None = automatic (the one-path-per-lane kernels, which are the faster ones on every measured scene),
-        False = the same, explicitly; True = the path-pool kernels of round 4 (two path contexts per lane, fixed-point film sums,
-        overlapping work items) where one exists for the scene -- measured, documented, and not the default"""
+        """lrhip_set_scheduler: None = automatic (the path-pool kernels of round 4 -- two path contexts per lane, fixed-point film sums,
+        overlapping work items -- on scenes of 4096 BVH triangles or more, the one-path-per-lane kernels below), False = one path per
+        lane everywhere, True = the pool kernels wherever one exists for the scene"""
         self._check(self._lib.lrhip_set_scheduler(self._ctx, 0 if pool is None else (2 if pool else 1)))
 
     def close(self) -> None:
