@@ -30,8 +30,8 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.h) $(wildcard include/*.h)
 HIP_SRC := $(HIPDIR)/lrhip.hip
 HIP_HDR := $(wildcard $(HIPDIR)/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean hip-variant variant-lib ref ieee
-all: host oracle hip cli ieee
+.PHONY: all host hip oracle cli clean hip-variant variant-lib ref ieee shallow
+all: host oracle hip cli ieee shallow
 
 # oracle/_ref: the reference's OWN sources compiled in place against the scalar LuisaCompute stand-in of oracle/ref_shim
 # (test infrastructure: pins oracle/ to the reference; needs /root/reference, so only where the reference tree exists)
@@ -115,6 +115,14 @@ variant-lib: $(OBJDIR)/lrhip.o $(VARIANT_OBJ)
 ieee: $(LIBDIR)/variants/liblrhip_ieee.so
 $(LIBDIR)/variants/liblrhip_ieee.so: $(HIP_SRC) $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
 	$(MAKE) --no-print-directory hip-variant NAME=ieee HIPFLAGS='$(VPT_HIPFLAGS) -DLR_EXACT_LEAF=1' DEFS= VARIANT_MASKS='0 1' HEAVY_MASKS=
+
+# The lean kernels of both schedulers once more with a FOUR-entry LDS traversal stack: every ray of every scene goes through the HBM
+# overflow area of the stack (dev_trace.h: TraversalStack::push / pop beyond kStackLds, the wave-level `deep` paths of the node step,
+# and the words a pool kernel parks on top of a lane's stack across the shading block).  TEST INFRASTRUCTURE: its frames must equal the
+# shipped library's bit for bit (tests/test_gpu_pool.py::test_the_overflow_area_of_the_traversal_stack).
+shallow: $(LIBDIR)/variants/liblrhip_shallow.so
+$(LIBDIR)/variants/liblrhip_shallow.so: $(HIP_SRC) $(HIPDIR)/megapath_variant.hip $(HIP_HDR) Makefile
+	$(MAKE) --no-print-directory hip-variant NAME=shallow DEFS='-DLR_STACK_LDS=4' VARIANT_MASKS='0 1 4096 4097' HEAVY_MASKS=
 
 cli: $(BINDIR)/luisa-render-cli
 $(BINDIR)/luisa-render-cli: $(HOSTDIR)/cli.cpp $(HOSTDIR)/plugin_megapath.cpp $(LIBDIR)/liblrhost.so $(HOST_HDR)

@@ -190,3 +190,35 @@ def test_scheduler_argument_is_checked(renderer):
     import ctypes as C
     assert renderer._lib.lrhip_set_scheduler(renderer._ctx, 3) != 0 and b"lrhip_set_scheduler" in renderer._lib.lrhip_last_error()
     assert renderer._lib.lrhip_set_scheduler(C.c_void_p(), 0) != 0
+
+
+def test_the_overflow_area_of_the_traversal_stack(tmp_path):
+    """`make shallow`: the lean kernels of both schedulers with a four-entry LDS stack, so that EVERY ray goes through the HBM overflow
+    area (push / pop beyond the LDS part, the wave-level `deep` paths, the five words a pool kernel parks on top of a lane's stack
+    across the shading block -- which the shipped sixteen entries reach on a few rays of a few scenes only).  Same traversal order,
+    same sums: the frames must be the shipped library's bit for bit."""
+    import os
+    from luisarender_amd import _ffi as ffi
+    from luisarender_amd.render import MegaPathRenderer
+    lib = os.path.join(ffi.LIB_DIR, "variants", "liblrhip_shallow.so")
+    assert os.path.exists(lib), "make shallow (python __graft_entry__.py builds it)"
+    scenes = [Scene.from_string(cornell_box(resolution=96, spp=8)),
+              Scene.load(generate_room_scene(str(tmp_path), target_triangles=60_000, resolution=(160, 96), spp=6))]
+    for scene, spp in zip(scenes, (8, 6)):
+        frames = {}
+        for build, path in (("shipped", None), ("shallow", lib)):
+            r = MegaPathRenderer(0, lib_path=path) if path else MegaPathRenderer(0)
+            try:
+                for pool in (False, True):
+                    r.set_scheduler(pool)
+                    r.upload(scene)
+                    r.render(0, spp, counters=True, sync=True)
+                    assert bool(r.last_variant() & POOL) == pool
+                    frames[build, pool] = (r.download(False), r.counters())
+            finally:
+                r.close()
+        for pool in (False, True):
+            (a, ca), (b, cb) = frames["shipped", pool], frames["shallow", pool]
+            assert np.array_equal(a, b), (pool, _rel_l1(b, a))
+            for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nodes_visited", "tris_tested"):
+                assert ca[k] == cb[k], (pool, k)
