@@ -78,10 +78,15 @@ LR_D float balance(float f_pdf, float g_pdf) {// balance_heuristic, sampling.cpp
 struct WfQueue {
     uint32_t *base;
     uint32_t capacity;
-    LR_D void put(uint32_t slot, uint32_t field, uint32_t v) const { base[static_cast<size_t>(field) * capacity + slot] = v; }
+    // field-major columns: a column's address is wave-uniform (SGPRs), the slot a 32-bit byte offset on top of it (capacity <= 2^30,
+    // lrhip.hip) -- one global access with scalar base per field instead of 64-bit address arithmetic per field and lane
+    LR_D uint32_t *at(uint32_t slot, uint32_t field) const {
+        return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(base + static_cast<size_t>(field) * capacity) + (slot << 2u));
+    }
+    LR_D void put(uint32_t slot, uint32_t field, uint32_t v) const { *at(slot, field) = v; }
     LR_D void put(uint32_t slot, uint32_t field, float v) const { put(slot, field, __float_as_uint(v)); }
     LR_D void put3(uint32_t slot, uint32_t field, f3 v) const { put(slot, field, v.x), put(slot, field + 1u, v.y), put(slot, field + 2u, v.z); }
-    LR_D uint32_t get(uint32_t slot, uint32_t field) const { return base[static_cast<size_t>(field) * capacity + slot]; }
+    LR_D uint32_t get(uint32_t slot, uint32_t field) const { return *at(slot, field); }
     LR_D float getf(uint32_t slot, uint32_t field) const { return __uint_as_float(get(slot, field)); }
     LR_D f3 get3(uint32_t slot, uint32_t field) const { return mk3(getf(slot, field), getf(slot, field + 1u), getf(slot, field + 2u)); }
 };

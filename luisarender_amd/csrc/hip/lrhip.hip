@@ -966,10 +966,11 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
     const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
     // at most half of what is free, and at most kWfQueueBudget: the 2^28-path default slice needs 76-89 GB, more buys nothing
-    auto fit_paths = std::min<uint64_t>((1ull << 31u) - 1u, std::max<uint64_t>(1ull << 16u, std::min<uint64_t>(have / 2u, kWfQueueBudget) / per_path));
+    auto fit_paths = std::min<uint64_t>(1ull << 30u,// (dev_wavefront.h: a slot's byte offset inside a queue column is 32 bits)
+                                         std::max<uint64_t>(1ull << 16u, std::min<uint64_t>(have / 2u, kWfQueueBudget) / per_path));
     if (ctx->wf_mode == 2u) { fit_paths = 8ull * 64u * slice_spp; }// (tests: eight tiles at a time)
     const auto group_tiles = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(tiles_in_range, fit_paths / (64ull * slice_spp))));
-    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, (1ull << 31u) - 1u));
+    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, 1ull << 30u));
     const auto heavy_words = static_cast<size_t>(lrd::kWfKinds) * (lrd::kWfHeavyWords + sampler_words) * capacity;
     const auto cont_words = static_cast<size_t>(lrd::kWfContWords + sampler_words) * capacity;
     if (auto r = ensure(ctx->wf_heavy, heavy_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
@@ -997,8 +998,8 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         pool = a >= 0 && b >= 0 && kVariants[a].launch != nullptr && kVariants[b].launch != nullptr;
     }
     if (pool) { lean |= lrd::kFeatPool; }
-    scene.wf.count_at_flush = pool && LR_POOL_OVERLAP ? 1u : 0u;
-    const auto pool_film = pool && LR_POOL_OVERLAP;// the camera pass sums its tiles into the frame's fixed-point sums: no partial planes
+    scene.wf.count_at_flush = pool ? 1u : 0u;
+    const auto pool_film = pool;// the camera pass sums its tiles into the frame's fixed-point sums: no partial planes
     const auto vi_camera = find_variant(kVariants, n_variants, lean), vi_cont = find_variant(kVariants, n_variants, lean | lrd::kFeatCont);
     const auto n_heavy = sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0]);
     int hi[lrd::kWfKinds];// the heavy kernel of each closure kind (Disney has no nested form)
@@ -1175,7 +1176,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     }
     auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
     args.total_threads = resident * lrd::kBlockThreads;
-    const auto pool_film = pool && LR_POOL_OVERLAP;
+    const auto pool_film = pool;
     if (chunk_count > 1u && !pool_film) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
         if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
         args.partial = static_cast<float4 *>(ctx->partial.ptr);
@@ -1184,12 +1185,11 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (pool) {
         if (auto r = ensure_pool(ctx, resident); r != LRHIP_OK) { return r; }
         args.pool = static_cast<float4 *>(ctx->pool.ptr);
-        if (LR_POOL_OVERLAP) {// the frame's fixed-point sums (megapool_kernel.h: FILM)
-            if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
-            ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
-            ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
-            ctx->scene.wf.count_at_flush = 1u;
-        }
+        // the frame's fixed-point sums (megapool_kernel.h: FILM)
+        if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
+        ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
+        ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
+        ctx->scene.wf.count_at_flush = 1u;
     }
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns

@@ -57,9 +57,6 @@ namespace lrd {
 #define LR_MIN_WAVES 4
 #endif
 // -DLR_POOL_SINGLE: the lane's second context never takes a path (a diagnostic: this kernel's machinery under the round 1-3 scheduling)
-#ifndef LR_POOL_OVERLAP
-#define LR_POOL_OVERLAP 1    // 1: work items overlap inside a wave and the film is summed in fixed point (FILM above); 0: a wave finishes its
-#endif                       // item before it takes the next and sums its tile in fp32 like the round 1-3 kernel (deterministic: see below)
 #ifndef LR_POOL_SHADE_LANES
 #define LR_POOL_SHADE_LANES 56// lanes with a context to shade that end the traversal loop
 #endif
@@ -256,17 +253,13 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     __shared__ uint32_t s_park[5u * kBlockThreads];
     static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile such pool variants with LR_STACK_LDS <= 11");
 #endif
-#if LR_POOL_OVERLAP
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
-#else
-    __shared__ float4 s_film[CONT ? 1u : kWavesPerBlock * 64u];// per-wave tile accumulators (sum r, g, b, n)
-#endif
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
     const auto wave_in_block = __builtin_amdgcn_readfirstlane(tid >> 6u);
     TraversalStack stack{s_stack + tid, args.spill + gtid, args.total_threads, s_stage + wave_in_block * kStageWave};
-    const auto film_tile = s_film + (CONT ? 0u : wave_in_block * (LR_POOL_OVERLAP ? 192u : 64u));
+    const auto film_tile = s_film + (CONT ? 0u : wave_in_block * 192u);
     // path state of this thread's two contexts: quad q of context c at args.pool[(c * QUADS + q) * total_threads + gtid]
     const auto state_of = [&](uint32_t side, uint32_t quad) { return args.pool + static_cast<size_t>(side * QUADS + quad) * args.total_threads + gtid; };
     // (as 16-byte quads.  Word by word -- no register tuples for the allocator to place -- was tried: 46 -> 60 spilled VGPRs)
@@ -287,12 +280,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     auto items_left = true;
     auto q_next = 0u, q_total = 0u;// the item's sample queue: k = 64 * (s - s_begin) + pixel_in_tile (CONT: record item * item_records + k)
     auto s_begin = 0u, s_count = 0u, tx = 0u, ty = 0u;
-#if LR_POOL_OVERLAP
     if (!CONT) { film_tile[lane * 3u] = 0ull, film_tile[lane * 3u + 1u] = 0ull, film_tile[lane * 3u + 2u] = 0ull; }
-#else
-    if (!CONT) { film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    auto chunk = 0u;// the item's sample chunk (its partial plane)
-#endif
     // ---- the lane: its ray in flight, the context the ray belongs to (`cur`) and the lane's other context (`oth`)
     TravState tr{};
     tr.phase = kPhaseIdle;
@@ -304,7 +292,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
         if (CONT || item == kInvalid) { return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#if LR_POOL_OVERLAP
         const auto a0 = film_tile[lane * 3u], a1 = film_tile[lane * 3u + 1u], a2 = film_tile[lane * 3u + 2u];
         film_tile[lane * 3u] = 0ull, film_tile[lane * 3u + 1u] = 0ull, film_tile[lane * 3u + 2u] = 0ull;
         const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
@@ -316,22 +303,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             if (a2 != 0ull) { atomicAdd(acc + 2, a2); }
             if (s_count != 0u) { atomicAdd(&args.film[index].w, static_cast<float>(s_count)); }
         }
-#else
-        // lane l adds pixel l of the tile to the film (or stores this chunk's partial plane), megapath_kernel.h
-        const auto wx = tx * 8u + (lane & 7u), wy = ty * 8u + (lane >> 3u);
-        const auto acc = film_tile[lane];
-        film_tile[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wx < scene.camera.width && wy < scene.camera.height) {
-            const auto index = wy * scene.camera.width + wx;
-            if (args.chunk_count == 1u) {
-                auto f = args.film[index];
-                f.x += acc.x, f.y += acc.y, f.z += acc.z, f.w += acc.w;
-                args.film[index] = f;
-            } else {
-                args.partial[static_cast<size_t>(chunk) * scene.camera.width * scene.camera.height + index] = acc;
-            }
-        }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
@@ -353,18 +324,16 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             ty = tile / args.tiles_x, tx = (tile - ty * args.tiles_x + ty) % args.tiles_x;// row ty is rotated by ty (lrhip.h)
             s_begin = range.s_begin, s_count = range.s_end > range.s_begin ? range.s_end - range.s_begin : 0u;
             q_total = s_count * 64u;
-#if !LR_POOL_OVERLAP
-            chunk = range.chunk;
-#endif
         }
     };
 
     for (;;) {
         // ==== (A) shading batches, while they are due (pool_shade_due: enough lanes hold a context to shade)
         for (;;) {
-            const auto samples_left = (LR_POOL_OVERLAP && items_left) || q_next < q_total;
+            const auto samples_left = items_left || q_next < q_total;
             if (!pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
             const auto t_shade = COUNT ? __builtin_readcyclecounter() : 0ull;
+            if (ALPHA) { tr.pend_t = 0.f, tr.pend_u = 0.f, tr.pend_v = 0.f; }// (no candidate waits for its alpha test out here: three registers the block need not carry)
             // ---- the context this lane shades is its OTHER one; an idle lane whose other context has nothing for the shading block
             // offers its current one
             if (tr.phase == kPhaseIdle && !ctx_shadeable(oth.flags, samples_left)) { ctx_swap(cur, oth); }
@@ -478,6 +447,28 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         const auto kind = scene.closures[(it.tags >> 12u) & 4095u].kind;
                         if (kind >= LR_SURFACE_DISNEY) { park_kind = kind - LR_SURFACE_DISNEY, has_surface = false; }
                     }
+                    if (WF) {// ---- park (at once: the hit and the direction die here instead of living through the closure code below -- 25 -> 15
+                        // spilled VGPRs in the camera pass): one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
+                        if (__any(park_kind != kInvalid)) {
+#pragma unroll
+                            for (auto k = 0u; k < kWfKinds; k++) {
+                                const auto mask = __ballot(park_kind == k);
+                                if (mask == 0ull) { continue; }
+                                const auto out = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
+                                if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
+                                    const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
+                                    q.put3(out, 0u, rd);
+                                    q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
+                                    q.put3(out, 6u, beta), q.put3(out, 9u, Li);
+                                    q.put(out, 12u, pixel_index), q.put(out, 13u, dp & 0xffffu);
+                                    uint32_t words[kWfSamplerWordsMax];
+                                    sampler.save(words);
+#pragma unroll
+                                    for (auto w = 0u; w < SAMPLER_WORDS; w++) { q.put(out, kWfHeavyWords + w, words[w]); }
+                                }
+                            }
+                        }
+                    }
                     if (has_surface) {
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
@@ -533,34 +524,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     }
                 }
             }
-            if (WF) {// ---- park: one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
-                if (__any(park_kind != kInvalid)) {
-#pragma unroll
-                    for (auto k = 0u; k < kWfKinds; k++) {
-                        const auto mask = __ballot(park_kind == k);
-                        if (mask == 0ull) { continue; }
-                        const auto out = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
-                        if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
-                            const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
-                            q.put3(out, 0u, rd);
-                            q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
-                            q.put3(out, 6u, beta), q.put3(out, 9u, Li);
-                            q.put(out, 12u, pixel_index), q.put(out, 13u, dp & 0xffffu);
-                            uint32_t words[kWfSamplerWordsMax];
-                            sampler.save(words);
-#pragma unroll
-                            for (auto w = 0u; w < SAMPLER_WORDS; w++) { q.put(out, kWfHeavyWords + w, words[w]); }
-                        }
-                    }
-                }
+            if (WF) {
                 if (park_kind != kInvalid) { path_open = false; }// (it goes on elsewhere: nothing to accumulate here)
             }
             if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
                 const auto rgb = Li * scene.shutter_weight;
-#if !LR_POOL_OVERLAP
-                if (CONT) { wf_film_accumulate(scene, args.film, pixel_index, rgb, scene.film_clamp); }
-                else { film_accumulate(film_tile + (dp >> 16u), rgb, scene.film_clamp); }// (every path of the wave belongs to its one work item: the tile, in fp32, in the wave's own order)
-#else
                 if (CONT || path_item != item) {// (its wave has left the path's work item: the frame's sums directly)
                     wf_film_accumulate(scene, args.film, pixel_index, rgb, scene.film_clamp);
                 } else if (!(any_nan(rgb) || any_inf(rgb))) {// ColorFilmInstance::_accumulate (color.cpp:107-130, effective_spp = 1) into the tile
@@ -574,7 +542,6 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 } else {// rejected: the flush counts every sample of the item
                     atomicAdd(&args.film[pixel_index].w, -1.f);
                 }
-#endif
                 path_open = false;
             }
             // ==== (A') path regeneration: contexts without a path take the next samples of the item's queue, in lane order
@@ -592,7 +559,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 const auto mask = __ballot(need);
                 if (mask == 0ull) { break; }
                 if (q_next >= q_total) {// the item's queue is dry: on to the next item, the old one's paths finish beside the new one's
-                    if (!LR_POOL_OVERLAP || !items_left) { break; }// (no overlap: the item's last paths drain, the main loop takes the next item)
+                    if (!items_left) { break; }
                     take_item();
                     if (!items_left) { break; }
                     continue;
@@ -708,17 +675,12 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 local.shade_calls++;
             }
         }
-        if (!__any(tr.phase != kPhaseIdle)) {// nothing in flight and nothing to shade: every context of the wave is out of samples
-            if (LR_POOL_OVERLAP || !items_left) { break; }
-            take_item();// (no overlap: the item is complete)
-            if (!items_left) { break; }
-            continue;
-        }
+        if (!__any(tr.phase != kPhaseIdle)) { break; }// nothing in flight and nothing to shade: every context of the wave is out of samples
         // ==== (B) traverse: lanes switch to their other context's job inside the loop
         TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
-            pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, (LR_POOL_OVERLAP && items_left) || q_next < q_total, ts);
+            pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, items_left || q_next < q_total, ts);
             if (!ALPHA) { break; }
             if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
             resolve_pending_alpha(scene, stack, tr);
