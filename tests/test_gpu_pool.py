@@ -47,7 +47,11 @@ DISNEY = ('Surface paint : Disney { color : Constant { v { 0.8, 0.3, 0.2 } } met
 GLASS = 'Surface crystal : Glass { Kr : Constant { v { 0.95, 0.95, 0.95 } } Kt : Constant { v { 0.9, 0.95, 0.9 } } eta { "bk7" } roughness { 0.1 } }\n'
 
 
-@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "pcg", "mitchell", "rr"])
+ALPHA = ('Texture holes : Checkerboard { on : Constant { v { 1 } } off : Constant { v { 0.2 } } scale { 3 } }\n'
+         'Surface cutout : Matte { Kd : Constant { v { 0.7, 0.6, 0.2 } } alpha { @holes } }\n')
+
+
+@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "pcg", "mitchell", "rr", "alpha", "environment"])
 def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(renderer, case):
     kw = dict(resolution=96, spp=24)
     if case == "glass":
@@ -62,7 +66,12 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
         kw.update(filter_impl="Mitchell", filter_radius=2.0)  # negative lobes: negative samples (signed fixed-point adds)
     elif case == "rr":
         kw.update(rr_depth=2, depth=12)
-    scene = Scene.from_string(cornell_box(**kw))
+    elif case == "alpha":  # the alpha-tested traversal: candidates parked for the test outside the loop, beside lanes that wait for a turnover
+        kw.update(extra_surfaces=ALPHA, short_box_surface="cutout")
+    text = cornell_box(**kw)
+    if case == "environment":  # the <environment> variants: rays that leave through the open front are lit
+        text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
+    scene = Scene.from_string(text)
     out = _both(renderer, scene, 24, counters=True)
     (lane, v_lane, c_lane), (pool, v_pool, c_pool) = out["lane"], out["pool"]
     assert (v_pool & POOL) != 0 and (v_lane & POOL) == 0 and (v_pool & ~POOL) == v_lane, (v_lane, v_pool)
