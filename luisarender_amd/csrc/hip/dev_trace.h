@@ -229,6 +229,10 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
         auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
         auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
+        // (round 4, two more forms of these selects, after profiles/r04h_cndmask_forms.json priced a v_cndmask_b32_e32 right behind another
+        // one at 19 cycles: one v_swap_b32 under EXEC per axis -- compare, s_and_saveexec, branch, swap, restore -- lost 2.7 % (965 -> 939);
+        // per-ray sign masks in SGPRs, remade at every turnover, and six v_cndmask_b32_e64 on them, no compare: 961 vs 961, the
+        // one-path-per-lane kernel 841 vs 848.  Here each pair sits right behind its own v_cmp, which is the cheap case)
 #pragma unroll
         for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
             auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),

@@ -105,13 +105,18 @@ struct PathCtx {
 };
 // the first ray of a context's job into the lane's traversal state
 LR_D void ctx_start(PathCtx &c, TravState &tr) {
+    // (written so that the compiler moves under EXEC instead of selecting: eight v_cndmask_b32_e32 in a row on one VCC cost 19 cycles
+    // EACH on this chip -- tools/valu_peak2.hip, profiles/r04h_cndmask_forms.json: 18.7 back to back, 2.2 with other VALU work
+    // between them, 4.2 in the VOP3 form -- and a job turnover was mostly that: C2 956 -> 965 Msamples/s)
+    tr.o = c.no, tr.d = c.nd, tr.t_min = c.n_tmin, tr.t_max = c.n_tmax;
+    tr.phase = kPhaseClosest;
     if ((c.flags & kCtxShadow) != 0u) {
+        asm volatile("");
         tr.o = c.so, tr.d = c.sd, tr.t_min = 0.f, tr.t_max = c.s_tmax;
         tr.phase = kPhaseShadow;
         c.flags &= ~kCtxShadow;
     } else {
-        tr.o = c.no, tr.d = c.nd, tr.t_min = c.n_tmin, tr.t_max = c.n_tmax;
-        tr.phase = kPhaseClosest;
+        asm volatile("");
         c.flags &= ~kCtxClosest;
     }
     tr.cur = 0u, tr.sp = 0u;// root
