@@ -926,9 +926,9 @@ int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
 }
 // Which scheduler a frame of this scene runs under (lrhip_set_scheduler).  Automatic: the pool kernels, except on scenes so small that
 // a ray is a handful of traversal steps -- there the pool kernel's costlier shading block (path state through global memory, the
-// current context through the LDS) is not paid back by fuller traversal steps.  Measured in round 4 at the bench's sizes (kernel
-// time, pool / one path per lane): Cornell box, 32 triangles, 0.86; C2 1.5 M triangles 1.05 (256 spp) ... 1.005 (1024 spp); C3 1.12;
-// C4 1.02; C5 (wavefront mode) 1.08 (profiles/r04_final_schedulers.txt).
+// current context through the LDS) is not paid back by fuller traversal steps.  Measured in round 4 at the bench's scenes (kernel
+// time, one path per lane / pool, profiles/r04_final_schedulers.txt): Cornell box, 32 triangles, 0.88; C2 1.5 M triangles 1.08 (1024
+// spp) ... 1.12 (256 spp); C3 1.18; C4 1.06; C5 (wavefront mode) 1.10.
 constexpr uint32_t kPoolAutoTriangles = 4096u;
 bool wants_pool(const lrhip_ctx *ctx) {
     return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= kPoolAutoTriangles);

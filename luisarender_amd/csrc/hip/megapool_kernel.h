@@ -22,8 +22,9 @@
 //     stack.  This is what makes the scheme pay: with those six words in registers the block spilled 37 VGPRs on its hot path, the
 //     scratch traffic evicted the BVH's top levels from the 32 KB vector L1, and a node step took 4200 cycles instead of 2100
 //     (profiles/r04c_*, r04g_*).
-// Measured (profiles/r04_final_schedulers.txt, pool / one path per lane, Msamples/s): C2 966 / 898, C3 949 / 803, C4 936 / 882, C5 459 /
-// 418; a Cornell box 3268 / 3766 -- lrhip.hip: wants_pool picks this kernel from 4096 triangles up.
+// Measured (profiles/r04_final_schedulers.txt, kernel time of the one-path-per-lane kernel / this one, same build, same box): C2 1.08
+// at 1024 spp, C3 1.18, C4 1.06, C5 (wavefront mode) 1.10 at 64 spp; a Cornell box 0.88 -- lrhip.hip: wants_pool picks this kernel
+// from 4096 triangles up.
 //
 // MEASURED AND NOT KEPT (profiles/r04a_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
 // shade queues of slot numbers in LDS, lanes fetching their next job from the ray queue inside the loop.  It filled the lanes (0.93 /
