@@ -92,15 +92,13 @@ constexpr int kChains = 8, kUnroll = 32;
     X(75, "v_cmp vcc + s_mov sgpr, vcc + 2 x v_cndmask e64 on the copy (per VALU instruction)", "v_cmp_lt_f32 vcc, %0, %2\n\ts_mov_b64 s[40:41], vcc\n\tv_cndmask_b32_e64 %0, %0, %3, s[40:41]\n\tv_cndmask_b32_e64 %0, %3, %0, s[40:41]") \
     X(76, "v_cndmask_b32_e64 with vcc as the explicit mask operand (vcc set once per trip)", "v_cndmask_b32_e64 %0, %0, %2, vcc") \
     X(77, "v_cndmask_b32 vcc + 3 x v_fma (vcc set once per trip; per instruction)", "v_cndmask_b32 %0, %0, %2, vcc\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %0, %0, %2, %3") \
-    X(78, "v_mov_b32 under a narrowed EXEC: s_and_saveexec + v_mov + s_or exec (per VALU instruction)", "s_and_saveexec_b64 s[40:41], %4\n\tv_mov_b32 %0, %2\n\ts_or_b64 exec, exec, s[40:41]") \
-    X(79, "s_and_saveexec + 4 x v_mov + s_or exec (per VALU instruction)", "s_and_saveexec_b64 s[40:41], %4\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %0, %3\n\ts_or_b64 exec, exec, s[40:41]") \
-    X(80, "v_cndmask_b32_e64 sgpr mask x 4 on one mask (per instruction)", "v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %0, %3, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %3, %4\n\tv_cndmask_b32_e64 %0, %2, %0, %4")
-constexpr int kOps = 81;
+    X(78, "v_cndmask_b32_e64 sgpr mask x 4 on one mask (per instruction)", "v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %0, %3, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %3, %4\n\tv_cndmask_b32_e64 %0, %2, %0, %4")
+constexpr int kOps = 79;
 constexpr int instr_per_asm(int idx) {
-    return idx == 19 || idx == 65 || idx == 66 || idx == 69 ? 2 : (idx == 64 || idx == 70 || idx == 75 ? 3 : (idx == 71 || idx == 72 || idx == 73 || idx == 77 || idx == 79 || idx == 80 ? 4 : (idx == 74 ? 7 : 1)));
+    return idx == 19 || idx == 65 || idx == 66 || idx == 69 ? 2 : (idx == 64 || idx == 70 || idx == 75 ? 3 : (idx == 71 || idx == 72 || idx == 73 || idx == 77 || idx == 78 ? 4 : (idx == 74 ? 7 : 1)));
 }
 // (an asm statement that clobbers SGPRs makes the compiler put an s_nop behind it: only the opcodes that write one declare it)
-constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62 || idx == 64 || idx == 65 || idx == 66 || (idx >= 70 && idx <= 75) || idx == 78 || idx == 79; }
+constexpr bool writes_sgpr(int idx) { return idx == 17 || idx == 18 || idx == 19 || idx == 34 || idx == 54 || idx == 61 || idx == 62 || idx == 64 || idx == 65 || idx == 66 || (idx >= 70 && idx <= 75); }
 
 template<int KIND>
 __global__ __launch_bounds__(64) void valu_kernel(float *out, int trips, float seed) {
