@@ -193,7 +193,7 @@ int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
  * serve every scene the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes); a frame whose sums do
  * not fit fixed point (film clamp x spp beyond 2^37, a non-finite clamp), paths deeper than 65535, and the variants with
  * out-of-line closures / sibling integrators / media always run on the one-path-per-lane kernels.
- *   mode  0 = automatic: the pool kernels on scenes of 4096 BVH triangles or more, one path per lane below;
+ *   mode  0 = automatic: the pool kernels on scenes of 65536 BVH triangles or more (they break even at 50-60 thousand), one path per lane below;
  *         1 = one path per lane; 2 = the pool kernels wherever one exists for the scene
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u

@@ -929,7 +929,9 @@ int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
 // current context through the LDS) is not paid back by fuller traversal steps.  Measured in round 4 at the bench's scenes (kernel
 // time, one path per lane / pool, profiles/r04_final_schedulers.txt): Cornell box, 32 triangles, 0.88; C2 1.5 M triangles 1.08 (1024
 // spp) ... 1.12 (256 spp); C3 1.18; C4 1.06; C5 (wavefront mode) 1.10.
-constexpr uint32_t kPoolAutoTriangles = 4096u;
+// A room scene swept over its triangle count (profiles/r04i_scheduler_crossover.txt): 0.88 at 2-5 thousand triangles, 0.93 at 12, 0.96 at
+// 30, 1.06 at 100, 1.20 at 400 thousand.
+constexpr uint32_t kPoolAutoTriangles = 65536u;
 bool wants_pool(const lrhip_ctx *ctx) {
     return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= kPoolAutoTriangles);
 }
