@@ -482,7 +482,7 @@ def main():
                 for w, steps, spp_o, cpu_s, whole, sampler in (("c1", 3, None, 30.0, True, "Independent"), ("c3", 1, None, 8.0, False, "Independent"),
                                                                ("c4", 1, None, 10.0, False, "Independent"), ("c5", 1, BENCH_SPP_CAP["c5"], 8.0, False, "Independent"),
                                                                ("c2", 1, None, 0.0, False, "PaddedSobol")):
-                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler, warmup_spp=None if w == "c1" else 8)
+                    v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler, warmup_spp=None if w in ("c1", "c5") else 8)  # (C5: wavefront mode sizes its queues by the frame's spp -- a warm-up on fewer samples leaves a 76-89 GB allocation inside the timed step)
                     e = {"workload": d, "sampler": sampler, "spp_timed": sp, "spp_config": WORKLOADS[w][2], "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
                          "kernel_ms": kms, "kernel": kernel_name(var), "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
                     if cpu_s > 0.0:
