@@ -62,7 +62,7 @@ def main():
     base = None
     for l in lines:
         m = re.match(r"([0-9a-f]{16}) <(.*)>:", l)
-        if m and ("megapath_kernel" in m.group(2) or "megavpt_kernel" in m.group(2) or "heavy_kernel" in m.group(2)):
+        if m and any(k in m.group(2) for k in ("megapath_kernel", "megapool_kernel", "megavpt_kernel", "heavy_kernel")):
             base = int(m.group(1), 16)
     addr = {o[1]: i for i, o in enumerate(ops) if o}
 
