@@ -9,6 +9,20 @@
 
 #define LR_HD __host__ __device__ __forceinline__
 #define LR_D __device__ __forceinline__
+// Wave votes on a BOOL (round 5).  HIP's __any / __ballot take an int: the compiler materialises the predicate in a VGPR and compares
+// it with zero again (v_cndmask_b32_e64 v, 0, 1, s[..] + v_cmp_ne_u32 s[..], 0, v -- two half-rate VALU instructions per vote, five votes
+// per iteration of the traversal loop: 42 of its ~960 issue cycles).  The ballot builtin takes the lane mask the compare already
+// produced (LR_VOTE_BUILTIN=0 restores the library forms for A/B).
+#ifndef LR_VOTE_BUILTIN
+#define LR_VOTE_BUILTIN 1
+#endif
+#if LR_VOTE_BUILTIN
+__device__ __forceinline__ unsigned long long lr_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lr_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+#else
+__device__ __forceinline__ unsigned long long lr_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ bool lr_any(bool p) { return __any(p) != 0; }
+#endif
 // Out-of-line device functions.  LR_HEAVY: the Disney / Mix / Layered path of the variants that hold Mix or Layered
 // (dev_heavy.h) is always a real call.  LR_CALL: the texture lookup and the environment evaluate / sample are real
 // calls only in those same variants (one copy instead of one per use: -60 % code, fewer spills in the main loop);

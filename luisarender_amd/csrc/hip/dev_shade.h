@@ -722,7 +722,7 @@ LR_D void trace_until_refill(const DScene &scene, const TraversalStack &stack, T
     for (;;) {
         trace_steps<COUNT, ALPHA>(scene, stack, tr, has_next, next_closest, refill, stats, idle_at_entry);
         if (!ALPHA) { break; }
-        if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        if (!lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
         resolve_pending_alpha(scene, stack, tr);
     }
 }

@@ -157,19 +157,60 @@ LR_D void trav_begin(TravState &tr, const Ray &r, uint32_t phase) {
 LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float u, float v);
 
 // What every step of a traversal loop needs of its wave: addresses that do not change over the call.
+//
+// THE LOOP'S OWN BOOKKEEPING (round 5).  The pipes are full (SQ_ACTIVE_INST_VALU 0.998, round 4), so what an iteration costs is its VALU
+// issue cycles, and of the ~960 a pool iteration took, ~110 were not arithmetic of the walk at all:
+//   * every wave vote on a COMPOUND predicate (`live && x`) made the compiler materialise the predicate in a VGPR and compare it with
+//     zero again (v_cndmask_b32_e64 v, 0, 1, s[..] + v_cmp_ne_u32: 8.4 cycles, five of them per iteration).  Inside the loops a lane's state
+//     is therefore carried by `cur` alone, so that every vote is ONE compare:  (int) cur >= 0  the lane stands at an inner node,
+//     (int) cur < -2  at a leaf,  cur == kInvalid (-1)  its ray has ended (the job's next ray / the turnover is due),  cur == kCurIdle (-2)
+//     it has no ray.  `phase` still says shadow / closest (and parked, ALPHA) -- it is read where a ray ends, not in every iteration;
+//   * the stack pointer is the LDS BYTE ADDRESS of the next free entry (`spb`, entries 1 KiB apart: [entry][lane]) instead of an entry
+//     index: a push is a store and a full-rate v_add, a pop a v_add and a load -- five half-rate v_lshl_add_u32 per iteration gone -- and
+//     "is the stack empty" / "could a node step reach the HBM overflow area" are compares against two wave-uniform bounds (SGPRs): a
+//     lane's offset within an entry row is < 1 KiB, so spb - (address of the wave's first lane) orders like the entry index;
+//   * the four packet addresses of the cooperative fetch are one shift and four v_or_b32 with a DPP quad_perm operand (half rate, one
+//     instruction each) instead of four v_mov_b32 dpp + four v_lshl_or_b32.
+// Same walk, same order of every lane's operations: films and counters are bit-identical to round 4's (tests/test_gpu_pool.py twins).
+constexpr uint32_t kCurIdle = 0xfffffffeu;
+constexpr uint32_t kStackStride = kBlockThreads * 4u;// bytes between two entries of a lane's LDS stack
 struct TravLane {
     const float4 *tris;
     const char *node_bytes;
     uint32_t quarter;          // byte offset of this lane's quarter of a packet (cooperative fetch below)
     const float4 *mine;        // where this lane finds its own packet in the wave's staging area
+    uint32_t lds_base;         // LDS byte address of entry 0 of this lane's stack
+    uint32_t s_empty, s_deep;  // wave-uniform: spb > s_empty <=> the stack holds an entry; spb > s_deep <=> sp + 3 > kStackLds
     LR_D static TravLane make(const DScene &scene, const TraversalStack &stack) {
         const auto lane = threadIdx.x & 63u;
         // load j: lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j into region j, float4 slot l.  Lane o therefore finds
         // its own packet in region (o & 3), slots 4 (o >> 2) .. + 3, in order
+        const auto base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((TraversalStack::lds_u32 *)stack.lds));
+        const auto first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base - lane * 4u)));// (whatever lane is first: the wave's row origin)
+        static_assert(kStackLds >= 3u, "the wave-level overflow test assumes at least three LDS entries");
         return TravLane{reinterpret_cast<const float4 *>(scene.bvh_tris), reinterpret_cast<const char *>(scene.nodes), (lane & 3u) << 4u,
-                        stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u};
+                        stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u, base,
+                        first + 252u, first + (kStackLds - 3u) * kStackStride + 252u};
     }
+    LR_D uint32_t spb_of(uint32_t sp) const { return lds_base + sp * kStackStride; }
+    LR_D uint32_t sp_of(uint32_t spb) const { return (spb - lds_base) / kStackStride; }
 };
+// stack accesses by byte address (entries known to lie in LDS), and the general forms (`deep` iterations: the entry may be in the overflow area)
+LR_D void spb_store(uint32_t spb, uint32_t v) { *(TraversalStack::lds_u32 *)static_cast<uintptr_t>(spb) = v; }
+LR_D uint32_t spb_load(uint32_t spb) { return *(TraversalStack::lds_u32 *)static_cast<uintptr_t>(spb); }
+LR_D void trav_push(const TraversalStack &stack, const TravLane &tl, uint32_t &spb, uint32_t v, bool deep) {
+    if (deep) { stack.push(tl.sp_of(spb), v); }
+    else { spb_store(spb, v); }
+    spb += kStackStride;
+}
+LR_D uint32_t trav_pop(const TraversalStack &stack, const TravLane &tl, uint32_t &spb, bool deep) {// the next entry, kInvalid if there is none
+    auto v = kInvalid;
+    if (spb > tl.s_empty) {
+        spb -= kStackStride;
+        v = deep ? stack.pop(tl.sp_of(spb)) : spb_load(spb);
+    }
+    return v;
+}
 
 // ---- node step of the WAVE (every lane calls; `is_inner` lanes test the packet of tr.cur): cooperative packet fetch, quantised slab
 // tests, near -> far ordering, pushes.  `deep`: some lane may reach the HBM overflow area of the stack in this iteration.
@@ -179,21 +220,21 @@ LR_D void trav_node_fetch(const TraversalStack &stack, const TravLane &tl, const
     typedef __attribute__((address_space(1))) const void global_void;
     // ---- cooperative packet fetch: 4 coalesced dwordx4 loads -> LDS (global_load_lds_dwordx4: no trip through the VGPRs)
     // -> 4 ds_read_b128 per lane.  Four consecutive lanes read one 64-byte packet: 16 lines per instruction, not 64
-    auto want = is_inner ? tr.cur : 0u;
+    const auto want = (is_inner ? tr.cur : 0u) << 6u;
 #define LR_FETCH(j) { \
-        const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, false)); /* quad_perm:[j,j,j,j] */ \
-        __builtin_amdgcn_global_load_lds((global_void *)(tl.node_bytes + ((w << 6u) | tl.quarter)), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
+        const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, true)) | tl.quarter; /* quad_perm:[j,j,j,j] */ \
+        __builtin_amdgcn_global_load_lds((global_void *)(tl.node_bytes + w), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
     LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
 #undef LR_FETCH
 }
-// every load of the iteration has landed: the packets are in the LDS (and the triangles of the lanes at leaves in their registers)
+// every load of the iteration has landed: the packets are in the LDS
 LR_D void trav_fetch_wait() {
     __builtin_amdgcn_s_waitcnt(0);// vmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template<bool COUNT, bool FETCHED = false>
-LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
+LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     if (!FETCHED) {
@@ -248,24 +289,21 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         cswap(key[0], key[1]);
         cswap(key[2], key[3]);
         cswap(key[0], key[2]);
+#if !defined(LR_SORT_COMPARATORS) || LR_SORT_COMPARATORS >= 4// (experiment: 3 = the nearest child first, the others as they fall; tools/bvh_sim.cpp BVH_SIM_PARTIAL_SORT: +1.05 % steps per ray on C2)
         cswap(key[1], key[3]);
+#endif
+#if !defined(LR_SORT_COMPARATORS) || LR_SORT_COMPARATORS >= 5
         cswap(key[1], key[2]);
-        // push far -> near so that the nearest is popped first; keep the nearest in `cur`
-        if (deep) {
-            if (key[3] != kInvalid) { stack.push(tr.sp++, ref_of(key[3])); }
-            if (key[2] != kInvalid) { stack.push(tr.sp++, ref_of(key[2])); }
-            if (key[1] != kInvalid) { stack.push(tr.sp++, ref_of(key[1])); }
-        } else {
-            if (key[3] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[3])); }
-            if (key[2] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[2])); }
-            if (key[1] != kInvalid) { stack.push_lds(tr.sp++, ref_of(key[1])); }
-        }
+#endif
+        // push far -> near so that the nearest is popped first; keep the nearest in `cur` (a valid key is a non-negative float's bits)
+        if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, ref_of(key[3]), deep); }
+        if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, ref_of(key[2]), deep); }
+        if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, ref_of(key[1]), deep); }
 #ifndef LR_TRACE_PROBE
         if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
 #endif
-        if (key[0] != kInvalid) { tr.cur = ref_of(key[0]); }
-        else if (tr.sp > 0u) { tr.cur = deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp); }
-        else { tr.cur = kInvalid; }
+        if (static_cast<int>(key[0]) >= 0) { tr.cur = ref_of(key[0]); }
+        else { tr.cur = trav_pop(stack, tl, spb, deep); }
     }
     // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
     __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
@@ -278,37 +316,26 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
 // (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
 //
-// LEAF BATCHING (round 4, LR_LEAF_BATCH > 0).  With one-triangle leaves a ray takes one leaf step per six node steps, so in a loop
-// that runs "node step, then leaf step" every iteration the leaf step works for 0.13 of the lanes that have a ray -- and costs 2050
-// cycles of the iteration's 5100 (section probes, profiles/r04c).  A lane that arrives at a leaf therefore POSTPONES it: it keeps the
-// leaf in a register (`leaf`) and goes on with the next entry of its stack; the wave runs the leaf step when LR_LEAF_BATCH lanes hold a
-// postponed leaf (or no lane has an inner node left), and a lane that reaches a second leaf before that waits.  A lane's leaves are
-// still tested in the order it found them, so hits (and ties) come out as before; what changes is that the boxes between a postponed
-// leaf and its test are culled against the t_max of before that test: a few more node visits, the same results.  Outside the loop
-// nothing is postponed: trav_unpostpone puts the lane back where it stood (the entry it went on with returns to the stack).
-// MEASURED, and OFF by default: a model of the loop with the probes' section costs promised 1.16-1.29x on the traversal; on the box
-// (C2, 256 spp, Msamples/s) the pool kernel went 898 -> 889 / 891 / 875 / 835 / 767 at LR_LEAF_BATCH 12 / 16 / 24 / 32 / 40 and the
-// one-path-per-lane kernel 850 -> 820 / 804 / 720 / 569 / 497 (profiles/r04d_leaf_batching.txt): same films, same rays, 0.5 % fewer
-// boxes, steps per ray 20.8 against the minimum of 19.6 -- the lanes do not wait long, the iterations simply do not get cheaper.  The
-// leaf step's price is its triangle fetch's latency, which the other three waves of the SIMD cover; the instructions it saves are
-// fewer than the ballots, the extra pop and the longer live ranges that batching adds to EVERY iteration.
+// MEASURED IN ROUND 4 AND NOT KEPT (the code is gone in round 5; profiles/r04d_leaf_batching.txt, r04e_fused_fetch.txt):
+//   * leaf batching -- a lane that arrives at a leaf keeps it in a register, goes on with its stack, and the wave runs the leaf step when
+//     12 ... 40 lanes hold one: the pool kernel 898 -> 889 / 891 / 875 / 835 / 767 Msamples/s, the one-path kernel 850 -> 820 ... 497; lanes
+//     simply WAITING at their leaf until 12 of them do: +0.6 %;
+//   * fused fetch -- the node packets and the leaf triangles of an iteration requested together and waited for once: +-1 %.
+// The leaf step's price is its triangle fetch's latency, which the SIMD's other three waves cover; the instructions such schemes save
+// are fewer than the votes, extra pops and longer live ranges they add to EVERY iteration.
 struct LeafTriangle { float4 a, b, c; };
 LR_D LeafTriangle trav_leaf_fetch(const TravLane &tl, uint32_t ref) {
     auto tb = tl.tris + static_cast<size_t>(ref & ((1u << 27u) - 1u)) * 3u;
     // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
     return LeafTriangle{tb[0], tb[1], tb[2]};
 }
-template<bool COUNT, bool ALPHA, bool POSTPONED = false>
-LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, bool deep, TraceStats &stats, uint32_t *leaf = nullptr,
-                         const LeafTriangle *fetched = nullptr) {
+template<bool COUNT, bool ALPHA>
+LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats, const LeafTriangle *fetched = nullptr) {
     auto found = false;
-    const auto ref = POSTPONED ? *leaf : tr.cur;
+    const auto ref = tr.cur;
     {
         const auto tri = fetched != nullptr ? *fetched : trav_leaf_fetch(tl, ref);
         auto a = tri.a, b = tri.b, c = tri.c;
-#ifdef LR_LEAF_FULL_QUADS// (a kernel that never reads hit.inst / hit.prim gets two 12-byte loads here: keep them 16-byte ones)
-        asm volatile("" ::"v"(a.w), "v"(b.w));
-#endif
         if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF
         {
@@ -350,76 +377,41 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
     }
     if (tr.phase == kPhaseShadow && found) {
         tr.occluded = true;
-        tr.sp = 0u;// any-hit: drop the rest of the stack
-        if (POSTPONED) { tr.cur = kInvalid; }
+        spb = tl.lds_base;// any-hit: drop the rest of the stack
     }
     if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
-        if (POSTPONED) { *leaf = kInvalid; }
-        else { tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid; }
+        tr.cur = trav_pop(stack, tl, spb, deep);
     }
 }
 
-#ifndef LR_LEAF_BATCH
-#define LR_LEAF_BATCH 0// lanes with a postponed leaf that make the wave run the leaf step; 0: a leaf step every iteration (rounds 1-3)
-#endif
-// a lane that stands at a leaf and has none postponed keeps it for later and goes on with its stack
-LR_D void trav_postpone(const TraversalStack &stack, TravState &tr, uint32_t &leaf, bool live, bool deep) {
-    if (live && leaf == kInvalid && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) {
-        leaf = tr.cur;
-        tr.cur = tr.sp > 0u ? (deep ? stack.pop(--tr.sp) : stack.pop_lds(--tr.sp)) : kInvalid;
-    }
-}
-// ... and back (on the way out of a traversal loop): the lane stands at its postponed leaf, where it went on to is the top of its stack
-LR_D void trav_unpostpone(const TraversalStack &stack, TravState &tr, uint32_t &leaf) {
-    if (leaf != kInvalid) {
-        if (tr.cur != kInvalid) { stack.push(tr.sp++, tr.cur); }
-        tr.cur = leaf;
-        leaf = kInvalid;
-    }
-}
-// ONE ITERATION of a traversal loop for the wave (LR_FUSED_FETCH, round 4): every lane with a ray stands at an inner node or at a leaf, and
-// both kinds of step begin with a dependent gather -- the node's packet, the leaf's triangle.  Rounds 1-3 ran "node step, then leaf
-// step": two round trips to memory in a row, the second one (1450-2050 cycles by the section probes, for 80 VALU instructions) on
-// behalf of the 0.13 of the lanes that stand at a leaf.  Here both gathers are issued up front and waited for ONCE; then the leaf
-// lanes test their triangle and the node lanes their packet.
-// MEASURED, and OFF by default (profiles/r04e_fused_fetch.txt, Msamples/s with / without): one path per lane C2 861 / 853 (256 spp),
-// 908 / 895 (1024), C3 810 / 803, C4 894 / 881, C5 421 / 417 -- but the Cornell box 3410 / 3757; the pool kernels C2 892 / 898, C3 890 /
-// 897, C4 904 / 898, C5 447 / 449, Cornell 3018 / 3230.  One per cent on the kernels that no longer run the large scenes, nothing on the
-// ones that do: the wave's own round trips are not what the loop waits for -- the SIMD's other three waves cover them either way.
+// ONE ITERATION's walk for the wave: the lanes at inner nodes test their packets, the lanes at leaves their triangles.
+// LR_FUSED_FETCH (experiment, round 4: +-1 %; kept measurable in round 5, where the loop's instruction count is a fifth lower): both
+// gathers of an iteration -- node packets and leaf triangles -- are requested up front and waited for ONCE; a lane that arrives at a leaf
+// in the node step tests it in the NEXT iteration.
 #ifndef LR_FUSED_FETCH
 #define LR_FUSED_FETCH 0
 #endif
 template<bool COUNT, bool ALPHA>
-LR_D void trav_step_fused(const TraversalStack &stack, const TravLane &tl, TravState &tr, f3 inv, bool live, bool deep, TraceStats &stats) {
-    const auto is_inner = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u;
-    const auto is_leaf = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u;
-    const auto any_inner = __any(is_inner);
+LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, TraceStats &stats) {
+    const auto is_inner = static_cast<int>(tr.cur) >= 0;
+    // one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in this iteration
+    // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
+    // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
+    const auto deep = lr_any(spb > tl.s_deep);
+#if LR_FUSED_FETCH
+    const auto is_leaf = static_cast<int>(tr.cur) < static_cast<int>(kCurIdle);
+    const auto any_inner = lr_any(is_inner);
     if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
     LeafTriangle tri;
     if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
     trav_fetch_wait();
-    if (is_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats, nullptr, &tri); }
-    if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, inv, is_inner, deep, stats); }
-}
-
-// one iteration's leaf work of the wave; returns with `leaf` tested where the wave's leaf step was due
-template<bool COUNT, bool ALPHA>
-LR_D void trav_leaves(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &leaf, bool live, bool deep, TraceStats &stats) {
-#if LR_LEAF_BATCH > 0
-    trav_postpone(stack, tr, leaf, live, deep);
-    const auto holds = live && leaf != kInvalid;
-    const auto waiting = __ballot(holds);
-    if (waiting == 0ull) { return; }
-    if (static_cast<uint32_t>(__popcll(waiting)) < static_cast<uint32_t>(LR_LEAF_BATCH) && __any(live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u)) { return; }
-    if (holds) { trav_leaf_step<COUNT, ALPHA, true>(stack, tl, tr, deep, stats, &leaf); }
-#elif defined(LR_LEAF_WAIT) && LR_LEAF_WAIT > 1// (the plain form: lanes at a leaf WAIT until LR_LEAF_WAIT of them do, or no lane has an inner node to go on with)
-    const auto at_leaf = live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u;
-    const auto n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
-    if (n_leaf == 0u) { return; }
-    if (n_leaf < static_cast<uint32_t>(LR_LEAF_WAIT) && __any(live && tr.cur != kInvalid && (tr.cur & kLeafFlag) == 0u)) { return; }
-    if (at_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+    if (is_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats, &tri); }
+    if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
 #else
-    if (live && tr.cur != kInvalid && (tr.cur & kLeafFlag) != 0u) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, deep, stats); }
+    if (lr_any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
+    if (static_cast<int>(tr.cur) < static_cast<int>(kCurIdle)) {// at a leaf (ALPHA: a lane that parks a candidate stays at it, and the wave leaves the loop)
+        trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats);
+    }
 #endif
 }
 
@@ -438,7 +430,13 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
                       const Ray &next_closest, int refill, TraceStats &stats, bool idle_at_entry) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
-    auto leaf = kInvalid;// the lane's postponed leaf (LEAF BATCHING above)
+    auto spb = tl.spb_of(tr.sp);
+    if (tr.phase == kPhaseIdle) { tr.cur = kCurIdle; }// (the loop reads a lane's state off `cur`: see TravLane)
+    const auto fresh = ~lr_ballot(idle_at_entry);// lanes that came with a ray: the ones whose end the caller counts
+    {// (nothing in flight, or -- back from an alpha test -- enough rays ended already: the tests at the loop's end, which only run when a ray ends)
+        const auto idle = lr_ballot(tr.cur == kCurIdle);
+        if (idle == ~0ull || __popcll(idle & fresh) >= refill) { return; }
+    }
     for (;;) {
 #ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u; }
@@ -446,48 +444,36 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
 #else
         if (COUNT) { stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u, stats.steps_starved += idle_at_entry ? 1u : 0u; }
 #endif
-        auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
-        auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
-        // one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in this iteration
-        // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
-        // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
-        const auto deep = __any(live && tr.sp + 3u > kStackLds);
-#if LR_FUSED_FETCH && LR_LEAF_BATCH == 0
-        trav_step_fused<COUNT, ALPHA>(stack, tl, tr, inv, live, deep, stats);
-#else
-        if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
-#endif
+        trav_iteration<COUNT, ALPHA>(stack, tl, tr, spb, inv, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
 #endif
-#if !(LR_FUSED_FETCH && LR_LEAF_BATCH == 0)
-        trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
-#endif
 #ifdef LR_TRACE_PROBE
         const auto probe_t2 = __builtin_readcyclecounter();
-#endif
-        // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle
-        if (live && tr.cur == kInvalid && leaf == kInvalid) {
-            if (tr.phase == kPhaseShadow && has_next) {
-                trav_begin(tr, next_closest, kPhaseClosest);
-                inv = safe_inverse(tr.d);
-            } else {
-                tr.phase = kPhaseIdle;
-            }
-        }
-        auto in_flight = __ballot(tr.phase != kPhaseIdle);
-#ifdef LR_TRACE_PROBE
         if (COUNT && (threadIdx.x & 63u) == 0u) {
             stats.nodes_empty += static_cast<uint32_t>(probe_t1 - probe_t0);
             stats.steps_starved += static_cast<uint32_t>(__builtin_readcyclecounter() - probe_t2);
         }
 #endif
-        if (in_flight == 0ull) { break; }
-        if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
-        auto finished = __ballot(tr.phase == kPhaseIdle && !idle_at_entry);
-        if (__popcll(finished) >= refill) { break; }
+        if (ALPHA && lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle.  (Nothing the tests below look at changes
+        // in an iteration in which no ray ended.)
+        const auto ended = tr.cur == kInvalid;
+        if (!lr_any(ended)) { continue; }
+        if (ended) {
+            if (tr.phase == kPhaseShadow && has_next) {
+                trav_begin(tr, next_closest, kPhaseClosest);
+                inv = safe_inverse(tr.d);
+                spb = tl.lds_base;
+            } else {
+                tr.phase = kPhaseIdle, tr.cur = kCurIdle;
+            }
+        }
+        const auto idle = lr_ballot(tr.cur == kCurIdle);
+        if (idle == ~0ull) { break; }
+        if (__popcll(idle & fresh) >= refill) { break; }
     }
-    trav_unpostpone(stack, tr, leaf);
+    tr.sp = tl.sp_of(spb);
 }
 
 }// namespace lrd

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_HEAVY_WAVES) void heavy_kernel(DS
         }
         // ---- the paths that go on: continuation records, one atomic per wave
         const auto go_on = want_shadow || want_closest;
-        const auto mask = __ballot(go_on);
+        const auto mask = lr_ballot(go_on);
         if (mask != 0ull) {
             const auto out = wf_reserve(scene.wf.counts + kWfCountCont, mask, lane);
             if (go_on && out < scene.wf.capacity) {

@@ -205,9 +205,9 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
 #endif
                     heavy_hit = (flags & LR_SHAPE_HAS_SURFACE) != 0u && scene.closures[(tags >> 12u) & 4095u].kind >= LR_SURFACE_DISNEY;
                 }
-                const auto heavy_lanes = __popcll(__ballot(heavy_hit));
+                const auto heavy_lanes = __popcll(lr_ballot(heavy_hit));
                 if (heavy_lanes > 0 && heavy_lanes < HEAVY_BATCH) {
-                    const auto others = __any(tr.phase != kPhaseIdle || (ready && !heavy_hit) || (tr.phase == kPhaseIdle && !path_open && q_next < q_total));
+                    const auto others = lr_any(tr.phase != kPhaseIdle || (ready && !heavy_hit) || (tr.phase == kPhaseIdle && !path_open && q_next < q_total));
                     parked = heavy_hit && others;
                 }
             }
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                 }
             }
             if (WF) {// ---- park: one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
-                if (__any(park_kind != kInvalid)) {
+                if (lr_any(park_kind != kInvalid)) {
 #pragma unroll
                     for (auto k = 0u; k < kWfKinds; k++) {
-                        const auto mask = __ballot(park_kind == k);
+                        const auto mask = lr_ballot(park_kind == k);
                         if (mask == 0ull) { continue; }
                         const auto slot = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
                         if (park_kind == k && slot < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
             }
             {
                 const auto need = tr.phase == kPhaseIdle && !path_open;
-                const auto mask = __ballot(need);
+                const auto mask = lr_ballot(need);
                 const auto k = q_next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32u), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
                 q_next = min(q_next + static_cast<uint32_t>(__popcll(mask)), q_total);
                 if (CONT) {
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
                 }
             }
-            if (!__any(tr.phase != kPhaseIdle)) {
-                if (PARK_HEAVY && __any(parked)) { continue; }// parked paths are left: shade them now
+            if (!lr_any(tr.phase != kPhaseIdle)) {
+                if (PARK_HEAVY && lr_any(parked)) { continue; }// parked paths are left: shade them now
                 break;// every lane of the tile is out of samples
             }
             // ==== (B) traverse until `refill` lanes have results to shade

@@ -74,6 +74,9 @@ namespace lrd {
 #ifndef LR_POOL_PARK_ON_STACK
 #define LR_POOL_PARK_ON_STACK 1// the five parked words of the ray in flight go on top of the lane's traversal stack (0: an LDS area of their own, LR_STACK_LDS <= 11)
 #endif
+#ifndef LR_POOL_STATE_LEAN
+#define LR_POOL_STATE_LEAN 0
+#endif
 #ifndef LR_POOL_RAY_INIT
 #define LR_POOL_RAY_INIT if (!mine)
 #endif
@@ -154,9 +157,9 @@ LR_D bool ctx_shadeable(uint32_t flags, bool samples_left) {
 // flight at all.  Only an idle lane's current context can be shaded.
 LR_D bool pool_shade_due(uint32_t phase, uint32_t cur_flags, uint32_t oth_flags, bool samples_left) {
     const auto idle = phase == kPhaseIdle;
-    const auto s = __ballot(ctx_shadeable(oth_flags, samples_left) || (idle && ctx_shadeable(cur_flags, samples_left)));
+    const auto s = lr_ballot(ctx_shadeable(oth_flags, samples_left) || (idle && ctx_shadeable(cur_flags, samples_left)));
     if (s == 0ull) { return false; }
-    const auto idle_mask = __ballot(idle);
+    const auto idle_mask = lr_ballot(idle);
     return static_cast<uint32_t>(__popcll(s)) >= static_cast<uint32_t>(LR_POOL_SHADE_LANES) ||
            static_cast<uint32_t>(__popcll(s & idle_mask)) >= static_cast<uint32_t>(LR_POOL_IDLE_LANES) || idle_mask == ~0ull;
 }
@@ -168,7 +171,8 @@ template<bool COUNT, bool ALPHA>
 LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &cur, PathCtx &oth, bool samples_left, TraceStats &stats) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
-    auto leaf = kInvalid;// the lane's postponed leaf (dev_trace.h: LEAF BATCHING)
+    auto spb = tl.spb_of(tr.sp);
+    if (tr.phase == kPhaseIdle) { tr.cur = kCurIdle; }// (inside the loop a lane's state is read off `cur`: dev_trace.h, TravLane)
     for (;;) {
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
@@ -176,41 +180,34 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
             stats.steps_starved += tr.phase == kPhaseIdle && ((cur.flags | oth.flags) & kCtxOpen) == 0u ? 1u : 0u;// no path left to hold
 #endif
         }
-        const auto live = ALPHA ? (tr.phase == kPhaseShadow || tr.phase == kPhaseClosest) : tr.phase != kPhaseIdle;// (not parked)
-        const auto is_inner = live && tr.cur != kInvalid && !(tr.cur & kLeafFlag);
-        const auto deep = __any(live && tr.sp + 3u > kStackLds);
-#ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: node step -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
+#ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: the iteration's walk -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         const auto probe_t0 = __builtin_readcyclecounter();
 #endif
-#if LR_FUSED_FETCH && LR_LEAF_BATCH == 0
-        trav_step_fused<COUNT, ALPHA>(stack, tl, tr, inv, live, deep, stats);
-#else
-        if (__any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, inv, is_inner, deep, stats); }
-#endif
+        trav_iteration<COUNT, ALPHA>(stack, tl, tr, spb, inv, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
+        const auto probe_t2 = probe_t1;
 #endif
-#if !(LR_FUSED_FETCH && LR_LEAF_BATCH == 0)
-        trav_leaves<COUNT, ALPHA>(stack, tl, tr, leaf, live, deep, stats);
-#endif
+        if (ALPHA && lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        // ---- rays that ended: the job's next ray, the other context's job, or idle -- once LR_POOL_TURNOVER_LANES lanes wait with one, or no
+        // lane has anything left to traverse.  (Nothing below changes in an iteration without a turnover: the exit tests run behind one.)
+        const auto ended = tr.cur == kInvalid;
+        const auto n_ended = static_cast<uint32_t>(__popcll(lr_ballot(ended)));
 #ifdef LR_TRACE_PROBE
-        const auto probe_t2 = __builtin_readcyclecounter();
+        if (COUNT && (threadIdx.x & 63u) == 0u) {
+            stats.nodes_empty += static_cast<uint32_t>(probe_t1 - probe_t0);
+            stats.steps_starved += static_cast<uint32_t>(__builtin_readcyclecounter() - probe_t2);
+        }
 #endif
-        // ---- ray finished: the job's next ray, the other context's job, or idle
-        const auto ended = live && tr.cur == kInvalid && leaf == kInvalid;
-#if LR_POOL_TURNOVER_LANES > 1
-        const auto n_ended = static_cast<uint32_t>(__popcll(__ballot(ended)));
-        const auto turnover = n_ended >= static_cast<uint32_t>(LR_POOL_TURNOVER_LANES) || (n_ended != 0u && !__any(live && tr.cur != kInvalid));
-#else
-        constexpr auto turnover = true;
-#endif
-        if (ended && turnover) {
+        if (n_ended == 0u) { continue; }
+        if (n_ended < static_cast<uint32_t>(LR_POOL_TURNOVER_LANES) && lr_any(tr.cur < kCurIdle)) { continue; }
+        if (ended) {
             if (tr.phase == kPhaseShadow) {
                 if (tr.occluded) { cur.flags |= kCtxOccluded; }
             } else {
                 cur.tri = tr.hit.tri, cur.u = tr.hit.u, cur.v = tr.hit.v;
             }
-            tr.phase = kPhaseIdle;
+            tr.phase = kPhaseIdle, tr.cur = kCurIdle;
             if ((cur.flags & kCtxRays) == 0u) {// the job is complete: on to the other context's, if it waits with one
                 cur.flags |= kCtxDone;
                 if ((oth.flags & kCtxRays) != 0u) { ctx_swap(cur, oth); }
@@ -218,27 +215,15 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
             if ((cur.flags & kCtxRays) != 0u) {
                 ctx_start(cur, tr);
                 inv = safe_inverse(tr.d);
+                spb = tl.lds_base;
             }
         }
-#ifdef LR_TRACE_PROBE
-        if (COUNT && (threadIdx.x & 63u) == 0u) {
-            const auto probe_t3 = __builtin_readcyclecounter();
-            stats.nodes_empty += static_cast<uint32_t>(probe_t1 - probe_t0);
-            stats.steps_starved += static_cast<uint32_t>(probe_t3 - probe_t2);
-        }
-#endif
-        if (ALPHA && __any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
-        // (what the shading block has to do only changes when a lane runs out of rays: the test is skipped otherwise -- +1.9 % on C2.
-        // LR_POOL_EXIT_TEST 1 looks whenever a ray ends, also where its lane went straight on to its other context's job)
-#if !defined(LR_POOL_EXIT_TEST) || LR_POOL_EXIT_TEST == 2
-        if (!__any(live && tr.phase == kPhaseIdle)) { continue; }
-#elif LR_POOL_EXIT_TEST == 1
-        if (!__any(ended)) { continue; }
-#endif
-        if (__ballot(tr.phase != kPhaseIdle) == 0ull) { break; }
+        // (what the shading block has to do only changes when a lane runs out of rays: the tests are skipped otherwise -- round 4: +1.9 % on C2)
+        if (!lr_any(ended && tr.cur == kCurIdle)) { continue; }
+        if (lr_ballot(tr.cur != kCurIdle) == 0ull) { break; }
         if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
-    trav_unpostpone(stack, tr, leaf);
+    tr.sp = tl.sp_of(spb);
 }
 
 template<uint32_t F>
@@ -401,17 +386,27 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             const auto ro = oth.no, rd = oth.nd;// the path segment the job traced
             const auto hit_tri = oth.tri;
             const auto hit_u = oth.u, hit_v = oth.v;
+            // (LR_POOL_STATE_LEAN, Independent sampler: quad 3 -- pixel, work item -- never changes along a path; it is written when the path
+            // starts and read where the path ends or is parked, not at every vertex)
+            constexpr bool LEAN_STATE = LR_POOL_STATE_LEAN != 0 && !PCG;
+            const auto load_ids = [&]() {
+                const auto q3 = state_load(side, 3u);
+                pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
+            };
             if (path_open) {
-                const auto q0 = state_load(side, 0u), q1 = state_load(side, 1u), q2 = state_load(side, 2u), q3 = state_load(side, 3u);
+                const auto q0 = state_load(side, 0u), q1 = state_load(side, 1u), q2 = state_load(side, 2u);
                 nee = mk3(q0.x, q0.y, q0.z), pdf_bsdf = q0.w;
                 beta = mk3(q1.x, q1.y, q1.z);
                 const auto packed = __float_as_uint(q1.w);
                 dp = packed & 0x3fffffu;
                 Li = mk3(q2.x, q2.y, q2.z);
-                pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
-                uint32_t words[kWfSamplerWordsMax];
-                words[0] = __float_as_uint(q2.w), words[1] = __float_as_uint(q3.z), words[2] = __float_as_uint(q3.w);
-                words[3] = PCG ? __float_as_uint(state_load(side, QUADS - 1u).x) : 0u;
+                uint32_t words[kWfSamplerWordsMax] = {__float_as_uint(q2.w), 0u, 0u, 0u};
+                if (!LEAN_STATE) {
+                    const auto q3 = state_load(side, 3u);
+                    pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
+                    words[1] = __float_as_uint(q3.z), words[2] = __float_as_uint(q3.w);
+                    words[3] = PCG ? __float_as_uint(state_load(side, QUADS - 1u).x) : 0u;
+                }
                 sampler.restore(scene, words);
             }
             auto want_shadow = false, want_closest = false;
@@ -455,13 +450,14 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     }
                     if (WF) {// ---- park (at once: the hit and the direction die here instead of living through the closure code below -- 25 -> 15
                         // spilled VGPRs in the camera pass): one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
-                        if (__any(park_kind != kInvalid)) {
+                        if (lr_any(park_kind != kInvalid)) {
 #pragma unroll
                             for (auto k = 0u; k < kWfKinds; k++) {
-                                const auto mask = __ballot(park_kind == k);
+                                const auto mask = lr_ballot(park_kind == k);
                                 if (mask == 0ull) { continue; }
                                 const auto out = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
                                 if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
+                                    if (LEAN_STATE) { load_ids(); }
                                     const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
                                     q.put3(out, 0u, rd);
                                     q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
@@ -534,6 +530,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 if (park_kind != kInvalid) { path_open = false; }// (it goes on elsewhere: nothing to accumulate here)
             }
             if (path_open && !want_shadow && !want_closest) {// path complete: film.accumulate (integrator.cpp:74)
+                if (LEAN_STATE) { load_ids(); }
                 const auto rgb = Li * scene.shutter_weight;
                 if (CONT || path_item != item) {// (its wave has left the path's work item: the frame's sums directly)
                     wf_film_accumulate(scene, args.film, pixel_index, rgb, scene.film_clamp);
@@ -562,7 +559,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             auto got = false;
             auto new_k = 0u, new_item = kInvalid, new_px = 0u, new_py = 0u, new_s = 0u;
             for (;;) {
-                const auto mask = __ballot(need);
+                const auto mask = lr_ballot(need);
                 if (mask == 0ull) { break; }
                 if (q_next >= q_total) {// the item's queue is dry: on to the next item, the old one's paths finish beside the new one's
                     if (!items_left) { break; }
@@ -626,7 +623,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 state_store(side, 0u, make_float4(nee.x, nee.y, nee.z, pdf_bsdf));
                 state_store(side, 1u, make_float4(beta.x, beta.y, beta.z, __uint_as_float(dp)));
                 state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
-                state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2])));
+                if (!LEAN_STATE || got) { state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2]))); }
                 if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
                 if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
             }
@@ -681,14 +678,14 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 local.shade_calls++;
             }
         }
-        if (!__any(tr.phase != kPhaseIdle)) { break; }// nothing in flight and nothing to shade: every context of the wave is out of samples
+        if (!lr_any(tr.phase != kPhaseIdle)) { break; }// nothing in flight and nothing to shade: every context of the wave is out of samples
         // ==== (B) traverse: lanes switch to their other context's job inside the loop
         TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
             pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, items_left || q_next < q_total, ts);
             if (!ALPHA) { break; }
-            if (!__any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+            if (!lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
             resolve_pending_alpha(scene, stack, tr);
         }
         if (COUNT) {

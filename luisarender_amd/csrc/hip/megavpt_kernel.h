@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void megavpt_kernel(DScenePtr sce
                         }
                     }
                 }
-                if (!__any(tr.phase != kPhaseIdle)) { break; }
+                if (!lr_any(tr.phase != kPhaseIdle)) { break; }
                 // ==== trace every pending ray of the wave to completion
                 TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
                 trace_until_refill<COUNT, true>(scene, stack, tr, false, ray, 65, ts);

@@ -22,7 +22,17 @@ static float dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static V cross(V a, V b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static V norm(V a) { return a * (1.f / std::sqrt(dot(a, a))); }
 
-struct Stats { uint64_t rays{0}, nodes{0}, tris{0}, empty{0}, max_stack{0}; };
+struct Stats {
+    uint64_t rays{0}, nodes{0}, tris{0}, empty{0}, max_stack{0};
+    // round 5: what culling at pop time would save -- an entry is STALE when the entry distance it was pushed with no longer passes the slab
+    // test's own criterion against the ray's current t_max (BVH_SIM_CULL=1 skips such entries; 0 only counts them)
+    uint64_t pops{0}, stale_inner{0}, stale_leaf{0}, stale_chain[8]{};// stale_chain[k]: pops that skipped k stale entries in a row (k capped at 7)
+    uint64_t depth_hist[64]{};// per ray: deepest stack
+    uint64_t hits_hist[5]{};  // node visits by the number of children hit
+};
+static bool g_cull = false;
+static int g_partial_sort = 0;
+static int g_t_bits = 32;// the entry distance is kept with this many of its top bits (truncation rounds DOWN: conservative)
 
 struct Hit { float t; uint32_t tri; float u, v; };
 
@@ -51,11 +61,26 @@ static void quantise(const lr_accel &acc) {
 static bool trace(const lr_accel &acc, V o, V d, float t_min, float t_max, bool any, Hit &hit, Stats &st) {
     V inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
     uint32_t stack[256];
-    uint32_t sp = 0, cur = 0;
+    float stack_t[256];
+    uint32_t sp = 0, cur = 0, deepest = 0;
+    // pop with the stale test: returns the next entry worth visiting (or ~0u)
+    auto pop = [&]() -> uint32_t {
+        st.pops++;
+        int chain = 0;
+        while (sp) {
+            --sp;
+            if (stack_t[sp] <= t_max * 1.0000004f) { st.stale_chain[std::min(chain, 7)]++; return stack[sp]; }
+            ((stack[sp] & 0x80000000u) ? st.stale_leaf : st.stale_inner)++;
+            if (!g_cull) { st.stale_chain[std::min(chain, 7)]++; return stack[sp]; }
+            chain++;
+        }
+        st.stale_chain[std::min(chain, 7)]++;
+        return ~0u;
+    };
     hit.tri = ~0u;
     st.rays++;
     for (;;) {
-        if (cur == ~0u) { break; }
+        if (cur == ~0u) { st.depth_hist[std::min(deepest, 63u)]++; break; }
         if (cur & 0x80000000u) {
             auto &t = acc.triangles[cur & ((1u << 27u) - 1u)];
             st.tris++;
@@ -70,9 +95,9 @@ static bool trace(const lr_accel &acc, V o, V d, float t_min, float t_max, bool 
             auto tt = dot(e2, qvec) * inv_det;
             if (det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && tt > t_min && tt < t_max && (t.flags & 1u)) {
                 t_max = tt, hit.t = tt, hit.tri = cur & ((1u << 27u) - 1u), hit.u = u, hit.v = v;
-                if (any) { return true; }
+                if (any) { st.depth_hist[std::min(deepest, 63u)]++; return true; }
             }
-            cur = sp ? stack[--sp] : ~0u;
+            cur = pop();
             continue;
         }
         auto &n = g_quantised ? g_qnodes[cur] : acc.nodes[cur];
@@ -89,14 +114,30 @@ static bool trace(const lr_accel &acc, V o, V d, float t_min, float t_max, bool 
             std::memcpy(&bits, &tn, 4);
             key[i] = h ? ((bits & ~3u) | static_cast<uint32_t>(i)) : ~0u;
         }
-        std::sort(key, key + 4);
+        if (g_partial_sort) {// (round 5 candidate: three comparators put the nearest child first and leave the rest as they fall)
+            auto cs = [&](int a, int b) { if (key[a] > key[b]) { std::swap(key[a], key[b]); } };
+            cs(0, 1), cs(2, 3), cs(0, 2);
+            if (g_partial_sort >= 2) { cs(1, 3); }
+        } else {
+            std::sort(key, key + 4);
+        }
+        {
+            int h = 0;
+            for (int i = 0; i < 4; i++) { h += key[i] != ~0u; }
+            st.hits_hist[h]++;
+        }
         if (key[0] == ~0u) { st.empty++; }
         for (int i = 3; i >= 1; i--) {
-            if (key[i] != ~0u) { stack[sp++] = n.child[key[i] & 3u]; }
+            if (key[i] != ~0u) {
+                auto tb = (key[i] & ~3u) & (g_t_bits >= 32 ? ~0u : ~0u << (32 - g_t_bits));
+                std::memcpy(&stack_t[sp], &tb, 4);
+                stack[sp++] = n.child[key[i] & 3u];
+            }
         }
         st.max_stack = std::max<uint64_t>(st.max_stack, sp);
+        deepest = std::max(deepest, sp);
         if (key[0] != ~0u) { cur = n.child[key[0] & 3u]; }
-        else { cur = sp ? stack[--sp] : ~0u; }
+        else { cur = pop(); }
     }
     return hit.tri != ~0u;
 }
@@ -128,6 +169,9 @@ int main(int argc, char **argv) {
         for (uint32_t i = 0; i < acc.triangle_count; i++) { if (is_light[acc.triangles[i].inst]) { light_tris.push_back(i); } }
     }
     if (auto e = std::getenv("BVH_SIM_QUANTISED"); e != nullptr && std::atoi(e) != 0) { g_quantised = true, quantise(acc); }
+    if (auto e = std::getenv("BVH_SIM_CULL"); e != nullptr) { g_cull = std::atoi(e) != 0; }
+    if (auto e = std::getenv("BVH_SIM_T_BITS"); e != nullptr) { g_t_bits = std::atoi(e); }
+    if (auto e = std::getenv("BVH_SIM_PARTIAL_SORT"); e != nullptr) { g_partial_sort = std::atoi(e); }
     Stats closest, shadow;
     auto &cam = s.camera;
     auto m = cam.camera_to_world;
@@ -172,6 +216,20 @@ int main(int argc, char **argv) {
                 build_ms, acc.node_count, acc.triangle_count, (unsigned long long)closest.rays, per(closest.nodes, closest.rays), per(closest.tris, closest.rays),
                 100. * per(closest.empty, closest.nodes), (unsigned long long)shadow.rays, per(shadow.nodes, shadow.rays), per(shadow.tris, shadow.rays),
                 per(closest.nodes + shadow.nodes, closest.rays + shadow.rays), (unsigned long long)std::max(closest.max_stack, shadow.max_stack));
+    std::printf("closest pops %llu (%.2f / ray): stale inner %.1f%% of node visits, stale leaf %.1f%% of triangle tests (cull %d, t bits %d); entries skipped per pop 0..7+:",
+                (unsigned long long)closest.pops, per(closest.pops, closest.rays), 100. * per(closest.stale_inner, closest.nodes), 100. * per(closest.stale_leaf, closest.tris), g_cull ? 1 : 0, g_t_bits);
+    for (auto c : closest.stale_chain) { std::printf(" %.3f", per(c, closest.pops)); }
+    std::printf("\nchildren hit per node visit 0..4 (closest | shadow):");
+    for (int i = 0; i < 5; i++) { std::printf(" %.3f|%.3f", per(closest.hits_hist[i], closest.nodes), per(shadow.hits_hist[i], shadow.nodes)); }
+    std::printf("\ndeepest stack per ray (closest | shadow), cumulative share of rays:");
+    {
+        uint64_t cc = 0, cs = 0;
+        for (int i = 0; i < 40; i++) {
+            cc += closest.depth_hist[i], cs += shadow.depth_hist[i];
+            if (i >= 4 && i % 2 == 0) { std::printf(" %d: %.4f|%.4f", i, per(cc, closest.rays), per(cs, shadow.rays)); }
+        }
+    }
+    std::printf("\n");
     lrhost_scene_destroy(scene);
     return 0;
 }
