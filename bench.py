@@ -236,6 +236,8 @@ def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, sp
     from luisarender_amd.render import MegaPathRenderer
     scene, desc, res, spp = build_scene(workload, tmp, spp_override, sampler)
     renderer = MegaPathRenderer(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
+    if getattr(args, "scheduler", "auto") != "auto":  # A/B and profiling runs only; the line says so (config.scheduler_override)
+        renderer.set_scheduler(args.scheduler == "pool")
     renderer.upload(scene)
     film = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     renderer.bind_film(film.data_ptr())
@@ -351,6 +353,8 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override the workload's spp (invalidates the headline number)")
     ap.add_argument("--sampler", default="Independent", choices=["Independent", "PaddedSobol", "Sobol"],
                     help="sampler of the timed frame (anything but Independent invalidates the headline number)")
+    ap.add_argument("--scheduler", default=os.environ.get("LRHIP_SCHEDULER", "auto"), choices=["auto", "legacy", "pool"],
+                    help="force one kernel family (lrhip_set_scheduler) for A/B and profiling runs; anything but auto is recorded in config.scheduler_override")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic from profiles/ or null)")
@@ -388,6 +392,8 @@ def main():
                            "collective": getattr(run_workload, "collective", None),
                            "scheduler": "path pool, two contexts per lane (megapool_kernel.h)" if variant & 4096 else "one path per lane (megapath_kernel.h)"},
             }
+            if args.scheduler != "auto":
+                out["config"]["scheduler_override"] = args.scheduler
             if args.spp is not None or args.sampler != "Independent":
                 out["config"]["note"] = "spp / sampler overridden: not the headline configuration"
             elif args.workload in BENCH_SPP_CAP:

@@ -218,7 +218,7 @@ struct RenderArgs {
     // keep the drain at the end of an item (its last paths finish with most lanes idle) rare, small ones at the end keep the tail
     // of the launch (waves out of items while the last ones finish) short.  Uniform chunks: chunk_big_count = chunk_count.
     uint32_t chunk_big_count, chunk_big, chunk_small;
-    float4 *pool;          // pool kernels (megapool_kernel.h): path slots [wave][slot][quad], L2 / Infinity-Cache resident
+    float4 *pool;          // pool kernels (megapool_kernel.h): path state of every thread's two contexts, [context][quad][thread], Infinity-Cache resident
 };
 
 // item number -> (tile of the range, chunk, sample range) under the chunking above

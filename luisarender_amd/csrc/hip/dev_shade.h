@@ -625,7 +625,7 @@ LR_D void reconstruct(const DScene &scene, uint32_t inst_id, uint32_t prim, f3 b
 // object-space form in the last bits only.
 LR_D void reconstruct_baked(const DScene &scene, uint32_t tri, float u, float v, SurfacePoint &sp) {
     auto q = reinterpret_cast<const float4 *>(scene.shade_tris + tri);
-    // (non-temporal loads of this one-touch record, so that it does not push BVH levels out of the L1: C2 854 -> 823 Msamples/s, round 4)
+    // (plain loads.  MEASURED, NOT KEPT: non-temporal loads of this one-touch record, so that it does not push BVH levels out of the L1 -- C2 854 -> 823 Msamples/s, round 4)
     auto q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
     auto w = 1.f - u - v;
     f3 p0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);

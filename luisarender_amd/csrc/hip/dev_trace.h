@@ -31,6 +31,7 @@
 //     leaving the loop.
 #pragma once
 #include "dev_scene.h"
+#include <type_traits>
 
 namespace lrd {
 
@@ -41,6 +42,7 @@ constexpr uint32_t kWavesPerBlock = kBlockThreads / 64u;
 #endif
 constexpr uint32_t kStackLds = LR_STACK_LDS; // entries per lane kept in LDS
 constexpr uint32_t kSpillEntries = 88u;      // HBM overflow entries per lane
+constexpr uint32_t kPoolParkedWords = 5u;    // what a pool kernel's lane keeps of its ray in flight on top of its stack across the shading block (megapool_kernel.h)
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kInvalid = 0xffffffffu;
 
@@ -176,7 +178,7 @@ constexpr uint32_t kCurIdle = 0xfffffffeu;
 constexpr uint32_t kStackStride = kBlockThreads * 4u;// bytes between two entries of a lane's LDS stack
 struct TravLane {
     const float4 *tris;
-    const char *node_bytes;
+    const char *node_base[4];  // the packet table's base for load j of the cooperative fetch: 1040 j bytes BELOW the table (trav_node_fetch)
     uint32_t quarter;          // byte offset of this lane's quarter of a packet (cooperative fetch below)
     const float4 *mine;        // where this lane finds its own packet in the wave's staging area
     uint32_t lds_base;         // LDS byte address of entry 0 of this lane's stack
@@ -188,7 +190,11 @@ struct TravLane {
         const auto base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((TraversalStack::lds_u32 *)stack.lds));
         const auto first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base - lane * 4u)));// (whatever lane is first: the wave's row origin)
         static_assert(kStackLds >= 3u, "the wave-level overflow test assumes at least three LDS entries");
-        return TravLane{reinterpret_cast<const float4 *>(scene.bvh_tris), reinterpret_cast<const char *>(scene.nodes), (lane & 3u) << 4u,
+        const auto nodes = reinterpret_cast<const char *>(scene.nodes);
+        constexpr auto region = static_cast<ptrdiff_t>(kStageRegion * 16u);
+        auto b1 = nodes - region, b2 = nodes - 2 * region, b3 = nodes - 3 * region;
+        asm("" : "+s"(b1)); asm("" : "+s"(b2)); asm("" : "+s"(b3));// (four scalar bases: left to itself the compiler re-derives them from one with 64-bit vector adds, per load)
+        return TravLane{reinterpret_cast<const float4 *>(scene.bvh_tris), {nodes, b1, b2, b3}, (lane & 3u) << 4u,
                         stack.stage + (lane & 3u) * kStageRegion + (lane >> 2u) * 4u, base,
                         first + 252u, first + (kStackLds - 3u) * kStackStride + 252u};
     }
@@ -223,7 +229,8 @@ LR_D void trav_node_fetch(const TraversalStack &stack, const TravLane &tl, const
     const auto want = (is_inner ? tr.cur : 0u) << 6u;
 #define LR_FETCH(j) { \
         const auto w = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(want), (j) * 0x55, 0xf, 0xf, true)) | tl.quarter; /* quad_perm:[j,j,j,j] */ \
-        __builtin_amdgcn_global_load_lds((global_void *)(tl.node_bytes + w), (lds_void *)(stack.stage + (j) * kStageRegion), 16, 0, 0); }
+        /* the instruction's immediate offset moves BOTH addresses: the four regions of the staging area are named by it (one M0 for all four loads), and the table base of load j is that much lower */ \
+        __builtin_amdgcn_global_load_lds((global_void *)(tl.node_base[j] + w), (lds_void *)stack.stage, 16, (j) * (kStageRegion * 16u), 0); }
     LR_FETCH(0) LR_FETCH(1) LR_FETCH(2) LR_FETCH(3)
 #undef LR_FETCH
 }
@@ -233,82 +240,93 @@ LR_D void trav_fetch_wait() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template<bool COUNT, bool FETCHED = false>
-LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    if (!FETCHED) {
-        trav_node_fetch(stack, tl, tr, is_inner);
-        trav_fetch_wait();
-    }
-    const auto mine = tl.mine;
+// The slab tests of one staged packet and the near -> far order of its children: key[i] = (float_bits(t_near) & ~3) | slot, ascending, a
+// missed child's key is kInvalid (negative as an int; a valid key is a non-negative float's bits).
+LR_D void trav_slab_sort(const float4 *mine, const TravState &tr, f3 inv, uint32_t (&key)[4]) {
     auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
-    const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(mine + 3));// q3 = child[4] stays in LDS
-    if (is_inner) {
-        if (COUNT) { stats.nodes++; }
 #ifdef LR_PROBE_NODE
-        {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
-            float dummy = tr.t_min;
+    {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
+        float dummy = tr.t_min;
 #pragma unroll
-            for (auto i = 0; i < LR_PROBE_NODE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
-            asm volatile("" ::"v"(dummy));
-        }
+        for (auto i = 0; i < LR_PROBE_NODE; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+        asm volatile("" ::"v"(dummy));
+    }
 #endif
-        // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
-        //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
-        // An EMPTY slot has inverted planes (lo 255, hi 0) and names the scene's sentinel leaf (a triangle nothing hits,
-        // lrhip.hip: quantise_node), so it needs no test of its own: it fails the slab test wherever the node has an extent
-        // and costs one wasted triangle test where it has none.
-        auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
-        auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
-        auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
-        auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-        uint32_t key[4];
-        // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis.  (Bit selects on
-        // a per-ray sign mask, six v_bfi_b32 instead of three v_cmp + six v_cndmask, were measured in round 3 -- the issue-cost
-        // table has the second v_cndmask behind one v_cmp at ~14 cycles -- and changed nothing: 836.3 / 836.7 vs 834.8 / 836.3.)
-        auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
-        auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
-        auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
-        // (round 4, two more forms of these selects, after profiles/r04h_cndmask_forms.json priced a v_cndmask_b32_e32 right behind another
-        // one at 19 cycles: one v_swap_b32 under EXEC per axis -- compare, s_and_saveexec, branch, swap, restore -- lost 2.7 % (965 -> 939);
-        // per-ray sign masks in SGPRs, remade at every turnover, and six v_cndmask_b32_e64 on them, no compare: 961 vs 961, the
-        // one-path-per-lane kernel 841 vs 848.  Here each pair sits right behind its own v_cmp, which is the cheap case)
+    // packet: q0 = (origin.xyz, scale.x)  q1 = (lo_x4, lo_y4, lo_z4, hi_x4) bytes
+    //         q2 = (hi_y4, hi_z4, scale.y, scale.z)  q3 = child[4]
+    // An EMPTY slot has inverted planes (lo 255, hi 0) and names the scene's sentinel leaf (a triangle nothing hits,
+    // lrhip.hip: quantise_node), so it needs no test of its own: it fails the slab test wherever the node has an extent
+    // and costs one wasted triangle test where it has none.
+    auto ax = q0.w * inv.x, ay = q2.z * inv.y, az = q2.w * inv.z;
+    auto bx = (q0.x - tr.o.x) * inv.x, by = (q0.y - tr.o.y) * inv.y, bz = (q0.z - tr.o.z) * inv.z;
+    auto lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+    auto hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    // near / far plane words by the sign of the ray direction (scale >= 0): no per-child min/max per axis.  (Bit selects on
+    // a per-ray sign mask, six v_bfi_b32 instead of three v_cmp + six v_cndmask, were measured in round 3 -- the issue-cost
+    // table has the second v_cndmask behind one v_cmp at ~14 cycles -- and changed nothing: 836.3 / 836.7 vs 834.8 / 836.3.)
+    auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
+    auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
+    auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
+    // (round 4, two more forms of these selects, after profiles/r04h_cndmask_forms.json priced a v_cndmask_b32_e32 right behind another
+    // one at 19 cycles: one v_swap_b32 under EXEC per axis -- compare, s_and_saveexec, branch, swap, restore -- lost 2.7 % (965 -> 939);
+    // per-ray sign masks in SGPRs, remade at every turnover, and six v_cndmask_b32_e64 on them, no compare: 961 vs 961, the
+    // one-path-per-lane kernel 841 vs 848.  Here each pair sits right behind its own v_cmp, which is the cheap case)
 #pragma unroll
-        for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
-            auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),
-                            vmax2(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
-            auto tf = vmin3(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by),
-                            vmin2(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
-            auto h = tn <= tf * 1.0000004f;
-            key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
-        }
-        // (the slot kept in the key as a byte offset, slot * 4 in four key bits, saves the shift: measured, no change)
-        auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
-        // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
-        cswap(key[0], key[1]);
-        cswap(key[2], key[3]);
-        cswap(key[0], key[2]);
-#if !defined(LR_SORT_COMPARATORS) || LR_SORT_COMPARATORS >= 4// (experiment: 3 = the nearest child first, the others as they fall; tools/bvh_sim.cpp BVH_SIM_PARTIAL_SORT: +1.05 % steps per ray on C2)
-        cswap(key[1], key[3]);
+    for (auto i = 0; i < 4; i++) {// 24 v_cvt_f32_ubyteN + 24 v_fma_f32 (a v_pk_fma_f32 issues no faster than two of them)
+        auto tn = vmax3(fmaf(ubyte_to_float(nx, i), ax, bx), fmaf(ubyte_to_float(ny, i), ay, by),
+                        vmax2(fmaf(ubyte_to_float(nz, i), az, bz), tr.t_min));
+        auto tf = vmin3(fmaf(ubyte_to_float(fx, i), ax, bx), fmaf(ubyte_to_float(fy, i), ay, by),
+                        vmin2(fmaf(ubyte_to_float(fz, i), az, bz), tr.t_max));
+        auto h = tn <= tf * 1.0000004f;
+        key[i] = h ? ((__float_as_uint(tn) & 0xfffffffcu) | static_cast<uint32_t>(i)) : kInvalid;
+    }
+    // (the slot kept in the key as a byte offset, slot * 4 in four key bits, saves the shift: measured, no change)
+    // near -> far: 5-comparator network on (float_bits(t) & ~3) | slot keys (t >= 0)
+    cswap(key[0], key[1]);
+    cswap(key[2], key[3]);
+    cswap(key[0], key[2]);
+#if !defined(LR_SORT_COMPARATORS) || LR_SORT_COMPARATORS >= 4// (experiment: 3 = the nearest child first, the others as they fall; tools/bvh_sim.cpp BVH_SIM_PARTIAL_SORT: +1.05 % steps per ray on C2; measured 966 against 989 Msamples/s)
+    cswap(key[1], key[3]);
 #endif
 #if !defined(LR_SORT_COMPARATORS) || LR_SORT_COMPARATORS >= 5
-        cswap(key[1], key[2]);
+    cswap(key[1], key[2]);
 #endif
-        // push far -> near so that the nearest is popped first; keep the nearest in `cur` (a valid key is a non-negative float's bits)
-        if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, ref_of(key[3]), deep); }
-        if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, ref_of(key[2]), deep); }
-        if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, ref_of(key[1]), deep); }
-#ifndef LR_TRACE_PROBE
-        if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
-#endif
-        if (static_cast<int>(key[0]) >= 0) { tr.cur = ref_of(key[0]); }
-        else { tr.cur = trav_pop(stack, tl, spb, deep); }
-    }
-    // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
+}
+// the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
+LR_D void trav_packets_done() {
     __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+template<bool COUNT>
+LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    trav_node_fetch(stack, tl, tr, is_inner);
+    trav_fetch_wait();
+    const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(tl.mine + 3));// q3 = child[4] stays in LDS
+    if (is_inner) {
+        if (COUNT) { stats.nodes++; }
+        uint32_t key[4];
+        trav_slab_sort(tl.mine, tr, inv, key);
+        auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
+        // push far -> near so that the nearest is popped first; keep the nearest in `cur`.  (ONE wave-level branch on `deep` around the
+        // lot, not one per access: a wave's scalar and branch instructions cost it issue slots like its vector ones)
+        auto tail = [&](auto deep_c) {
+            constexpr bool D = decltype(deep_c)::value;
+            if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, ref_of(key[3]), D); }
+            if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, ref_of(key[2]), D); }
+            if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, ref_of(key[1]), D); }
+            if (static_cast<int>(key[0]) >= 0) { tr.cur = ref_of(key[0]); }
+            else { tr.cur = trav_pop(stack, tl, spb, D); }
+        };
+        if (deep) { tail(std::true_type{}); }
+        else { tail(std::false_type{}); }
+#ifndef LR_TRACE_PROBE
+        if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
+#endif
+    }
+    trav_packets_done();
 }
 
 // ---- leaf step of a lane standing at a leaf: Moeller-Trumbore on ONE pre-transformed triangle (3 x dwordx4).  The host builds
@@ -325,72 +343,79 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // are fewer than the votes, extra pops and longer live ranges they add to EVERY iteration.
 struct LeafTriangle { float4 a, b, c; };
 LR_D LeafTriangle trav_leaf_fetch(const TravLane &tl, uint32_t ref) {
-    auto tb = tl.tris + static_cast<size_t>(ref & ((1u << 27u) - 1u)) * 3u;
+    // (a 32-bit byte offset from the scalar table base: 48 B x 2^27 triangles does not fit 32 bits, 48 B x the 89 M a 4 GB table holds does -- lrhip_upload_scene refuses more)
+    auto tb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tl.tris) + (ref & ((1u << 27u) - 1u)) * 48u);
     // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
     return LeafTriangle{tb[0], tb[1], tb[2]};
 }
+// the triangle test of a lane at leaf `ref`; returns true if the ray has found an occluder (a shadow ray's hit: the rest of its stack is dropped)
 template<bool COUNT, bool ALPHA>
-LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats, const LeafTriangle *fetched = nullptr) {
+LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, TraceStats &stats) {
     auto found = false;
-    const auto ref = tr.cur;
-    {
-        const auto tri = fetched != nullptr ? *fetched : trav_leaf_fetch(tl, ref);
-        auto a = tri.a, b = tri.b, c = tri.c;
-        if (COUNT) { stats.tris++; }
+    auto a = tri.a, b = tri.b, c = tri.c;
+    if (COUNT) { stats.tris++; }
 #ifdef LR_PROBE_LEAF
-        {
-            float dummy = tr.t_min;
+    {
+        float dummy = tr.t_min;
 #pragma unroll
-            for (auto i = 0; i < LR_PROBE_LEAF; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
-            asm volatile("" ::"v"(dummy));
-        }
+        for (auto i = 0; i < LR_PROBE_LEAF; i++) { asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dummy)); }
+        asm volatile("" ::"v"(dummy));
+    }
 #endif
-        auto flags = __float_as_uint(c.w);
-        f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-        auto pvec = cross(tr.d, e2);
-        auto det = dot(e1, pvec);
+    auto flags = __float_as_uint(c.w);
+    f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+    auto pvec = cross(tr.d, e2);
+    auto det = dot(e1, pvec);
 #ifdef LR_EXACT_LEAF
-        auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
+    auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
 #else
-        auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
+    auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
 #endif
-        auto tvec = tr.o - p0;
-        auto u = dot(tvec, pvec) * inv_det;
-        auto qvec = cross(tvec, e1);
-        auto v = dot(tr.d, qvec) * inv_det;
-        auto t = dot(e2, qvec) * inv_det;
-        auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
-        if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
-            tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
-            tr.phase |= kPhasePendingAlpha;
-            ok = false;
-        }
-        if (ok) {
-            tr.t_max = t;
-            found = true;
-            if (tr.phase == kPhaseClosest) {
-                tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
-                tr.hit.u = u, tr.hit.v = v;
-                tr.hit.tri = ref & ((1u << 27u) - 1u);
-            }
+    auto tvec = tr.o - p0;
+    auto u = dot(tvec, pvec) * inv_det;
+    auto qvec = cross(tvec, e1);
+    auto v = dot(tr.d, qvec) * inv_det;
+    auto t = dot(e2, qvec) * inv_det;
+    auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
+    if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
+        tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
+        tr.phase |= kPhasePendingAlpha;
+        ok = false;
+    }
+    if (ok) {
+        tr.t_max = t;
+        found = true;
+        if (tr.phase == kPhaseClosest) {
+            tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
+            tr.hit.u = u, tr.hit.v = v;
+            tr.hit.tri = ref & ((1u << 27u) - 1u);
         }
     }
     if (tr.phase == kPhaseShadow && found) {
         tr.occluded = true;
-        spb = tl.lds_base;// any-hit: drop the rest of the stack
+        return true;
     }
+    return false;
+}
+template<bool COUNT, bool ALPHA>
+LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats) {
+    const auto tri = trav_leaf_fetch(tl, tr.cur);
+    if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }// any-hit: drop the rest of the stack
     if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
         tr.cur = trav_pop(stack, tl, spb, deep);
     }
 }
 
-// ONE ITERATION's walk for the wave: the lanes at inner nodes test their packets, the lanes at leaves their triangles.
-// LR_FUSED_FETCH (experiment, round 4: +-1 %; kept measurable in round 5, where the loop's instruction count is a fifth lower): both
-// gathers of an iteration -- node packets and leaf triangles -- are requested up front and waited for ONCE; a lane that arrives at a leaf
-// in the node step tests it in the NEXT iteration.
-#ifndef LR_FUSED_FETCH
-#define LR_FUSED_FETCH 0
-#endif
+// ONE ITERATION's walk for the wave: the lanes at inner nodes test their packets, the lanes at leaves (the ones that were, and the ones the
+// node step has just sent there) their triangles.
+//
+// MEASURED IN ROUND 5 AND NOT KEPT (profiles/r05d_pipelined_iteration.txt): a PIPELINED iteration -- the four child references and the pop of a
+// lane that hit nothing read from the LDS together and waited for once, the triangle loads of every lane at a leaf issued BEFORE the
+// pushes, what a leaf lane goes on with read while its triangle is on its way.  Five LDS round trips shorter per iteration, films
+// bit-identical, and SLOWER: the pool kernel 959 against 1005 Msamples/s (C2, 256 spp), the one-path kernel 837 against 898, the Cornell box
+// 3662 against 4029.  It executes more instructions (five exec regions per iteration instead of two, unconditional address arithmetic),
+// and a wave issues at most one instruction of ANY kind every ~4.5 cycles: what an iteration costs a wave is its instruction count --
+// scalar and branch instructions included -- as much as the round trips it waits for.
 template<bool COUNT, bool ALPHA>
 LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, TraceStats &stats) {
     const auto is_inner = static_cast<int>(tr.cur) >= 0;
@@ -398,21 +423,10 @@ LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravSt
     // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
     // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
     const auto deep = lr_any(spb > tl.s_deep);
-#if LR_FUSED_FETCH
-    const auto is_leaf = static_cast<int>(tr.cur) < static_cast<int>(kCurIdle);
-    const auto any_inner = lr_any(is_inner);
-    if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
-    LeafTriangle tri;
-    if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
-    trav_fetch_wait();
-    if (is_leaf) { trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats, &tri); }
-    if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
-#else
     if (lr_any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
     if (static_cast<int>(tr.cur) < static_cast<int>(kCurIdle)) {// at a leaf (ALPHA: a lane that parks a candidate stays at it, and the wave leaves the loop)
         trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats);
     }
-#endif
 }
 
 // Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`

@@ -515,11 +515,16 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     if (ctx->bvh_depth == 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_upload_scene: the BVH must have one-triangle leaves (lrhost_scene_build_accel builds them)"); }
     ctx->features = s->any_non_opaque != 0u ? lrd::kFeatAlpha : 0u;
     ctx->env_tree = false;
-    // a leaf names its triangle in 27 bits (the sentinel of the empty slots is one more) and the fetch addresses packets by 32-bit byte offsets
-    if (s->accel.triangle_count >= (1u << 27u) - 1u || s->accel.node_count >= (1u << 26u)) {
-        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 2^27 - 2 BVH triangles or 2^26 - 1 BVH packets");
+    // a leaf names its triangle in 27 bits (the sentinel of the empty slots is one more); the traversal loop addresses packets and leaf
+    // triangles by 32-bit byte offsets from their table bases (64 B x 2^26 packets, 48 B x 89 478 484 triangles = 4 GiB)
+    constexpr uint32_t kMaxBvhTriangles = static_cast<uint32_t>((1ull << 32u) / sizeof(lr_bvh_triangle)) - 2u;
+    static_assert(sizeof(lr_bvh_triangle) == 48u && kMaxBvhTriangles < (1u << 27u) - 1u, "dev_trace.h: trav_leaf_fetch multiplies the leaf's triangle index by 48 in 32 bits");
+    if (s->accel.triangle_count >= kMaxBvhTriangles || s->accel.node_count >= (1u << 26u)) {
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 89 478 482 BVH triangles or 2^26 - 1 BVH packets");
     }
-    if (ctx->bvh_depth * 3u > 11u + lrd::kSpillEntries) {// (11: the pool kernels' 16 LDS entries less the five words a lane parks on top of its stack across the shading block)
+    // a walk pushes at most three entries per level; a pool kernel parks five more words on top of a lane's stack across the shading block
+    // (megapool_kernel.h).  From the constants of THIS build: the `make shallow` library keeps 4 entries in LDS, not 16
+    if (ctx->bvh_depth * 3u + lrd::kPoolParkedWords > lrd::kStackLds + lrd::kSpillEntries) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: BVH depth " + std::to_string(ctx->bvh_depth) +
                                                  " exceeds the traversal stack capacity");
     }
@@ -935,7 +940,7 @@ constexpr uint32_t kPoolAutoTriangles = 65536u;
 bool wants_pool(const lrhip_ctx *ctx) {
     return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= kPoolAutoTriangles);
 }
-// slot records of the pool kernels: kPoolSlots x (8 | 9) float4 per resident wave (megapool_kernel.h)
+// path state of the pool kernels: two contexts per thread, 4 (Independent sampler) | 5 float4 each, [context][quad][thread] (megapool_kernel.h); sized for 5
 int ensure_pool(lrhip_ctx *ctx, uint32_t resident_blocks) {
     return ensure(ctx->pool, static_cast<size_t>(resident_blocks) * lrd::kWavesPerBlock * lrd::kPoolSlots * lrd::pool_quads<true>() * sizeof(float4));
 }
@@ -1191,8 +1196,10 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
         if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
         ctx->scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr);
         ctx->scene.wf.accum_scale = static_cast<float>(std::ldexp(1.0, fixed_bits));
-        ctx->scene.wf.count_at_flush = 1u;
     }
+    // how this launch's kernel counts its samples, set on EVERY path (the field lives in ctx->scene and used to keep whatever the
+    // last pool / wavefront call left in it): a pool kernel counts an item's samples when its wave leaves the item, the others where they finish
+    ctx->scene.wf.count_at_flush = pool ? 1u : 0u;
     // the scene record of THIS launch (shutter weight, film clamp, ...) in stream order; ctx->scene is pageable host memory, so
     // the copy has left it when the call returns
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }

@@ -75,7 +75,7 @@ namespace lrd {
 #define LR_POOL_PARK_ON_STACK 1// the five parked words of the ray in flight go on top of the lane's traversal stack (0: an LDS area of their own, LR_STACK_LDS <= 11)
 #endif
 #ifndef LR_POOL_STATE_LEAN
-#define LR_POOL_STATE_LEAN 0
+#define LR_POOL_STATE_LEAN 1
 #endif
 #ifndef LR_POOL_RAY_INIT
 #define LR_POOL_RAY_INIT if (!mine)
@@ -129,7 +129,7 @@ LR_D void ctx_start(PathCtx &c, TravState &tr) {
 }
 
 // The lane's two contexts are `cur` -- the one whose ray the lane traces (or traced last) -- and `oth`, the one that waits.  A lane
-// that goes on to its other context's job EXCHANGES the two: seventeen v_swap_b32, no copy through a third register, no per-field
+// that goes on to its other context's job EXCHANGES the two: nineteen v_swap_b32, no copy through a third register, no per-field
 // select on a "which one" bit in the loop (the first form of this kernel: 60 instructions per turnover where this one has 20).
 LR_D void swap_words(float &x, float &y) { asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
 LR_D void swap_words(uint32_t &x, uint32_t &y) { asm volatile("v_swap_b32 %0, %1" : "+v"(x), "+v"(y)); }
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     constexpr bool COUNT = (F & kFeatCount) != 0u, PCG = (F & kFeatGeneric) != 0u, ENV = (F & kFeatEnv) != 0u,
                    ALPHA = (F & kFeatAlpha) != 0u, DISNEY = (F & kFeatDisney) != 0u, WF = (F & kFeatWf) != 0u, CONT = (F & kFeatCont) != 0u;
     static_assert((F & kFeatPool) != 0u, "a pool variant");
+    static_assert(kPoolParkedWords == 5u, "the shading block parks five words on top of a lane's stack (below): lrhip_upload_scene bounds the BVH depth with this constant");
     static_assert((F & (kFeatMix | kFeatLayered | kFeatAux | kFeatVpt | kFeatNest)) == 0u, "the pool scheduler exists for the lean kernels (closures inline)");
     static_assert(!WF || !DISNEY, "a wavefront variant is a lean kernel: the heavy closures live in heavy_kernel.h");
     static_assert(!CONT || WF, "the continuation pass exists in wavefront mode only");

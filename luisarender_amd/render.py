@@ -29,8 +29,6 @@ class MegaPathRenderer:
         self._check(self._lib.lrhip_create(device, C.byref(self._ctx)))
         self._scene = None
         self.width = self.height = 0
-        if os.environ.get("LRHIP_SCHEDULER") in ("legacy", "pool"):  # tools / A-B runs only, like LRHIP_LIB
-            self.set_scheduler(os.environ["LRHIP_SCHEDULER"] == "pool")
 
     def _check(self, rc: int) -> None:
         if rc != 0:

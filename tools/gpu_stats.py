@@ -1,5 +1,5 @@
 """SIMD-occupancy diagnostics of the megakernel on the bench workload (GPU box).  LRHIP_SCHEDULER=legacy: the round 1-3 kernels."""
-import sys, tempfile
+import os, sys, tempfile
 sys.path.insert(0, '.')
 from luisarender_amd import Scene
 from luisarender_amd.render import MegaPathRenderer
@@ -18,6 +18,8 @@ with tempfile.TemporaryDirectory() as tmp:
     else:
         sc = Scene.load(gen())
     r = MegaPathRenderer(0)
+    if os.environ.get('LRHIP_SCHEDULER') in ('legacy', 'pool'):  # (the override lives HERE, not in the renderer: ADVICE r04)
+        r.set_scheduler(os.environ['LRHIP_SCHEDULER'] == 'pool')
     r.upload(sc)
     r.render(0, spp, counters=True, sync=True)
     c = r.counters()
