@@ -387,13 +387,34 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             const auto ro = oth.no, rd = oth.nd;// the path segment the job traced
             const auto hit_tri = oth.tri;
             const auto hit_u = oth.u, hit_v = oth.v;
-            // (LR_POOL_STATE_LEAN, Independent sampler: quad 3 -- pixel, work item -- never changes along a path; it is written when the path
-            // starts and read where the path ends or is parked, not at every vertex)
-            constexpr bool LEAN_STATE = LR_POOL_STATE_LEAN != 0 && !PCG;
+            // What the block reads of the record, and when (round 5).  Quads 0-2 -- NEE term, pdf, throughput, depth, radiance, sampler word 0
+            // -- where the context's path is taken up.  Quad 3's pixel and work item never change along a path: written when the path starts,
+            // read where it ends or is parked (LR_POOL_STATE_LEAN: +1.7 % on C2; 0 restores the read at every vertex).  The GENERIC sampler's
+            // other three words (quads 3 and 4) are read where the vertex's random numbers are drawn and written back right there: outside
+            // that stretch the sampler holds no register (sampler_take / sampler_leave below).
+            constexpr bool LEAN_STATE = LR_POOL_STATE_LEAN != 0;
+            auto word0 = 0u;// the sampler's first state word (Independent: its only one)
             const auto load_ids = [&]() {
                 const auto q3 = state_load(side, 3u);
                 pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
             };
+            // generic sampler: the stream position comes into the registers ...
+            const auto sampler_take = [&]() {
+                const auto q3 = state_load(side, 3u);
+                uint32_t words[kWfSamplerWordsMax] = {word0, __float_as_uint(q3.z), __float_as_uint(q3.w), __float_as_uint(state_load(side, QUADS - 1u).x)};
+                sampler.restore(scene, words);
+            };
+            // ... and leaves them again (`Li` is final where a vertex's numbers are drawn: quad 2 is complete)
+            const auto sampler_leave = [&]() {
+                uint32_t words[kWfSamplerWordsMax] = {0u, 0u, 0u, 0u};
+                sampler.save(words);
+                word0 = words[0];
+                state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
+                const auto q3 = state_load(side, 3u);
+                state_store(side, 3u, make_float4(q3.x, q3.y, __uint_as_float(words[1]), __uint_as_float(words[2])));
+                state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f));
+            };
+            auto sampler_left = false;// (PCG: quads 2-4 of this context are up to date already)
             if (path_open) {
                 const auto q0 = state_load(side, 0u), q1 = state_load(side, 1u), q2 = state_load(side, 2u);
                 nee = mk3(q0.x, q0.y, q0.z), pdf_bsdf = q0.w;
@@ -401,14 +422,12 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 const auto packed = __float_as_uint(q1.w);
                 dp = packed & 0x3fffffu;
                 Li = mk3(q2.x, q2.y, q2.z);
-                uint32_t words[kWfSamplerWordsMax] = {__float_as_uint(q2.w), 0u, 0u, 0u};
-                if (!LEAN_STATE) {
-                    const auto q3 = state_load(side, 3u);
-                    pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
-                    words[1] = __float_as_uint(q3.z), words[2] = __float_as_uint(q3.w);
-                    words[3] = PCG ? __float_as_uint(state_load(side, QUADS - 1u).x) : 0u;
+                word0 = __float_as_uint(q2.w);
+                if (!LEAN_STATE) { load_ids(); }
+                if (!PCG) {
+                    uint32_t words[kWfSamplerWordsMax] = {word0, 0u, 0u, 0u};
+                    sampler.restore(scene, words);
                 }
-                sampler.restore(scene, words);
             }
             auto want_shadow = false, want_closest = false;
             unsigned long long t_closure_sum = 0ull;// (COUNT: wave cycles inside the closure section of this batch; lanes agree)
@@ -421,6 +440,17 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     if (COUNT) { local.shade_busy++; }
                     const auto wo = -rd;
                     const auto hit_valid = hit_tri != kInvalid;
+                    // GENERIC SAMPLER (PCG32 / Sobol / PaddedSobol, dev_shade.h): every draw is a three-way dispatch around hashes, a permutation
+                    // and table walks, and the sampler's four state words were alive through the whole block: <4098> wanted 158 VGPRs and
+                    // spilled 33 on its hot path in round 4.  Now the sampler is in the registers for two short stretches only -- the light's
+                    // three numbers, then the closure's three or four behind the evaluation (sampler_take / sampler_leave): 154 wanted, 17
+                    // spilled, PaddedSobol C2 820 -> 875+ Msamples/s at 256 spp, films bit-identical (profiles/r05f).  MEASURED, NOT KEPT: all of
+                    // a vertex's numbers drawn in one stretch where the first is used (20 spilled), or before the hit is even reconstructed,
+                    // where next to nothing else is alive (162 wanted, 24 spilled: seven floats alive through the block cost more than the
+                    // draws' temporaries at its peak).
+                    auto u_light_selection = 0.f, u_lobe = 0.f, u_rr = 0.f;
+                    f2 u_light_surface{0.f, 0.f}, u_bsdf{0.f, 0.f};
+                    const auto rr = (dp & 0xffffu) + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
                     if (!hit_valid && scene.env_kind != kEnvNone) {// miss, mega_path.cpp:70-76 -> evaluate_miss, uniform.cpp:67-76
                         f3 L = mk3(scene.env_L[0], scene.env_L[1], scene.env_L[2]);
                         auto pdf = kInvPi * 0.25f;
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                                 const auto out = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
                                 if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
                                     if (LEAN_STATE) { load_ids(); }
+                                    if (PCG) { sampler_take(); }
                                     const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
                                     q.put3(out, 0u, rd);
                                     q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
@@ -476,8 +507,12 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
                         // light selection, light surface (2), lobe, bsdf (2), [rr]
-                        const auto u_light_selection = sampler.next_1d();
-                        const auto u_light_surface = sampler.next_2d();
+                        {
+                            if (PCG) { sampler_take(); }
+                            u_light_selection = sampler.next_1d();
+                            u_light_surface = sampler.next_2d();
+                            if (PCG) { sampler_leave(), sampler_left = true; }
+                        }
                         // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63 (dev_shade.h: sample_one_light)
                         const auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
                         shadow = pick.shadow;
@@ -494,8 +529,15 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
                             want_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
                         }
-                        const auto u_lobe = sampler.next_1d();
-                        const auto u_bsdf = sampler.next_2d();
+                        {
+                            if (PCG) { sampler_take(); }
+                            u_lobe = sampler.next_1d();
+                            u_bsdf = sampler.next_2d();
+                            if (PCG) {
+                                if (rr) { u_rr = sampler.next_1d(); }
+                                sampler_leave();
+                            }
+                        }
                         const auto bs = closure_sample<DISNEY>(closure, sh, it.ng, wo, u_lobe, u_bsdf);
                         auto eta = 1.f;
                         const auto has_eta = closure_eta(closure, eta);
@@ -511,9 +553,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         }
                         if (any_nan(beta)) { beta = mk3(0.f); }// zero_if_any_nan
                         auto alive = !(beta.x <= 0.f && beta.y <= 0.f && beta.z <= 0.f);
-                        const auto rr = (dp & 0xffffu) + 1u >= scene.rr_depth;// Russian roulette, mega_path.cpp:148-153
-                        auto u_rr = 0.f;
-                        if (rr) { u_rr = sampler.next_1d(); }// (drawn before the closure in the reference: same stream position)
+                        if (!PCG && rr) { u_rr = sampler.next_1d(); }// (drawn before the closure in the reference: same stream position)
                         if (alive) {
                             const auto q = fmaxf(max_component(beta) * eta_scale, .05f);
                             if (rr) {
@@ -581,6 +621,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 q_next += min(static_cast<uint32_t>(__popcll(mask)), avail);
             }
             if (got) {
+                sampler_left = false;// (the context takes another path: every quad of its record is written below)
                 if (CONT) {// a path comes back from the heavy kernel: as if this context's vertex had just been shaded
                     const auto rec = new_item * item_records + new_k;
                     const auto &q = cont_queue;
@@ -619,13 +660,19 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             const auto t_launch = COUNT ? __builtin_readcyclecounter() : 0ull;
             const auto go = path_open && (want_shadow || want_closest);
             if (go) {
-                uint32_t words[kWfSamplerWordsMax] = {0u, 0u, 0u, 0u};
-                sampler.save(words);
                 state_store(side, 0u, make_float4(nee.x, nee.y, nee.z, pdf_bsdf));
                 state_store(side, 1u, make_float4(beta.x, beta.y, beta.z, __uint_as_float(dp)));
-                state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
-                if (!LEAN_STATE || got) { state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2]))); }
-                if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
+                if (!PCG || !sampler_left) {// (generic sampler: a vertex's draws have left quads 2-4 up to date; a path that starts writes them here)
+                    uint32_t words[kWfSamplerWordsMax] = {word0, 0u, 0u, 0u};
+                    if (!PCG || got) { sampler.save(words); }
+                    state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
+                    if (got) {
+                        state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2])));
+                        if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
+                    } else if (!LEAN_STATE && !PCG) {
+                        state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), 0.f, 0.f));
+                    }
+                }
                 if (COUNT) { local.closest_rays += want_closest ? 1u : 0u, local.shadow_rays += want_shadow ? 1u : 0u; }
             }
             // ---- the contexts come back: the current one from the LDS, and with it origin and direction of the ray in flight; the other
