@@ -12,8 +12,8 @@ the float4 film is sum-reduced to rank 0 over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line with the driver's contract plus
   "roofline":     against the 8 TB/s HBM3E peak.  `traffic` = HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 +
-                  WRITE_SIZE, MI355X_MICROARCH.md), collected LIVE by this run: two short rocprofv3 --pmc passes of this same
-                  script on the same workload at 64 spp (bytes per sample are spp-invariant), scaled to the timed launch;
+                  WRITE_SIZE, MI355X_MICROARCH.md), collected LIVE by this run: rocprofv3 --pmc passes of this same script on
+                  the same workload AT THE TIMED SPP (round 5; round 4 measured 64 spp and scaled);
                   `achieved` = traffic / kernel duration and `frac` = achieved / peak -- the MEASURED HBM fraction (round 1
                   reported the algorithmic figure here, which exceeds the peak for this kernel: most of the canonical-BVH2
                   bytes are served by L2 / LDS).  The algorithmic figure of SURVEY 8(d) stays, under its own name:
@@ -149,18 +149,24 @@ def device_parity(scene, local_rank, cpu_frame, spp):
 
 
 def path_statistics(scene, local_rank, spp=64):
-    """rays per sample and mean path length from the device counters of a short counting render (the COUNT twin of the kernel)"""
+    """rays per sample, mean path length and lane use from the device counters of a counting render (the COUNT twin of the kernel) of the
+    frame AT THE SPP THAT IS TIMED (round 5: lane use and the drain of a launch depend on spp; round 4 measured them at 64)"""
     from luisarender_amd.render import MegaPathRenderer
     r = MegaPathRenderer(local_rank)
     r.upload(scene)
     r.render(0, spp, counters=True, sync=True)
     c = r.counters()
+    r_variant = r.last_variant()
     r.close()
     paths = max(c["paths"], 1)
     # what the kernel itself asks the memory system for, per sample: 64 B per BVH packet, 48 B per triangle test, one 128-byte shading
     # record per surface hit, and per light sample the light's triangle (alias entry 8 B + shading-point gather 128 B)
     requested = (64.0 * c["nodes_visited"] + 48.0 * c["tris_tested"] + 128.0 * c["surface_hits"] + 136.0 * c["nee_samples"]) / paths
-    return {"rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
+    pool_state = 0.0
+    if r_variant & 4096:  # a pool kernel: every shaded vertex reads and writes three 16-byte quads of its context's record, a path one more at its start and its end
+        pool_state = (96.0 * c["closest_rays"] + 32.0 * c["paths"]) / paths
+        requested += pool_state
+    return {"pool_state_bytes_per_sample": pool_state,"rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
             "shadow_rays_per_sample": c["shadow_rays"] / paths, "mean_path_length": c["path_length_sum"] / paths,
             "nodes_per_ray": c["nodes_visited"] / max(c["closest_rays"] + c["shadow_rays"], 1), "spp": spp,
             "nodes_per_sample": c["nodes_visited"] / paths, "tris_per_sample": c["tris_tested"] / paths,
@@ -187,7 +193,7 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
+def live_pmc(workload: str, spp: int = 64, timeout: float = 240.0):
     """HBM traffic + VALU instruction count per sample of the workload's megakernel, measured NOW: three rocprofv3 --pmc passes
     (counters only, with --kernel-trace, as the pool allows) of this script on the same workload at `spp` samples per pixel."""
     import shutil
@@ -205,7 +211,7 @@ def live_pmc(workload: str, spp: int = 64, timeout: float = 150.0):
     counters = {}
     with tempfile.TemporaryDirectory(prefix="lr_pmc_") as d:
         env = dict(os.environ, TMPDIR="/tmp")
-        for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"])):
+        for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY"])):
             cmd = ["rocprofv3", "--pmc", *pmc, "--kernel-trace", "-d", os.path.join(d, name), "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-stats"]
             try:
@@ -359,6 +365,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic from profiles/ or null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configs")
+    ap.add_argument("--extra-spp", type=int, default=None, help="N > 1: spp of the C4 / C5 entries instead of the configurations' own (tests)")
     ap.add_argument("--no-stats", action="store_true", help="skip the short counting render behind rays_per_s / mean_path_length (the PMC passes: ONE megakernel dispatch per process)")
     args = ap.parse_args()
 
@@ -380,6 +387,25 @@ def main():
         value, ms_per_step, mean_kernel_ms, variant, scene, res, spp, desc = run_workload(
             args.workload, args, rank, world, local_rank, tmp, args.steps, args.warmup, args.spp, args.sampler)
         elapsed = ms_per_step * args.steps * 1e-3
+        main_multi, main_collective = getattr(run_workload, "multi_gpu", None), getattr(run_workload, "collective", None)
+
+        # The configurations BASELINE.json names FOR SEVERAL GPUs, in the same line of every N > 1 run (round 5: the driver's first scaling run
+        # must produce them): C4 = "Camera scene, 3840x2160, 1024spp, screen-tile shard + RCCL film reduce" and C5 (kitchen class, wavefront
+        # mode, 2048 of its 65 536 spp), each sharded over the N ranks like the headline frame, reduced by the same lrhip_film_reduce, with
+        # its own multi_gpu record (reduce_ms, what RCCL saw, the reduced film against a 1-GPU render of the same tiles).  Every rank takes part.
+        multi_extra = []
+        forced = os.environ.get("LR_BENCH_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
+        if (world > 1 or forced) and not args.no_extra:
+            for w, spp_cfg in (("c4", None), ("c5", BENCH_SPP_CAP["c5"])):
+                v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, 1, 1, args.extra_spp or spp_cfg, "Independent",
+                                                             warmup_spp=None if w == "c5" else min(8, args.extra_spp or 8))  # (C5: wavefront mode sizes its queues by the frame's spp)
+                if rank == 0:
+                    e = {"workload": d, "sampler": "Independent", "spp_timed": sp, "spp_config": WORKLOADS[w][2], "value": v, "unit": "Msamples/s", "steps": 1, "ms_per_step": ms,
+                         "kernel_ms": kms, "kernel": kernel_name(var), "n_gpus": world, "collective": getattr(run_workload, "collective", None),
+                         "multi_gpu": getattr(run_workload, "multi_gpu", None)}
+                    if e["multi_gpu"] and e["multi_gpu"].get("reduced_film_equals_1gpu_render") is False:
+                        e["value"], e["error"] = None, "the film the collective delivered differs from a 1-GPU render of the same tiles"
+                    multi_extra.append(e)
 
         if rank == 0:
             samples_per_step = res[0] * res[1] * spp
@@ -389,7 +415,7 @@ def main():
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": desc, "integrator": "MegaPath", "sampler": "Independent (seed 19980810)" if args.sampler == "Independent" else args.sampler,
                            "resolution": list(res), "spp": spp, "parallelism": f"screen-tile shard x{world} + RCCL film reduce" if world > 1 else "single GPU",
-                           "collective": getattr(run_workload, "collective", None),
+                           "collective": main_collective,
                            "scheduler": "path pool, two contexts per lane (megapool_kernel.h)" if variant & 4096 else "one path per lane (megapath_kernel.h)"},
             }
             if args.scheduler != "auto":
@@ -404,13 +430,13 @@ def main():
                 out["cpu_baseline"] = cpu
                 out["parity"] = device_parity(scene, local_rank, cpu_frame, cpu_spp)
             if world == 1 and not args.no_stats:
-                stats = path_statistics(scene, local_rank)
+                stats = path_statistics(scene, local_rank, spp)
                 out["rays_per_s"] = value * 1e6 * stats["rays_per_sample"]
                 out["mean_path_length"] = stats["mean_path_length"]
                 out["path_statistics"] = stats
-            if getattr(run_workload, "multi_gpu", None):
-                out["multi_gpu"] = run_workload.multi_gpu
-                if run_workload.multi_gpu.get("reduced_film_equals_1gpu_render") is False:
+            if main_multi:
+                out["multi_gpu"] = main_multi
+                if main_multi.get("reduced_film_equals_1gpu_render") is False:
                     out["value"] = None  # a frame that is not the frame has no throughput
                     out["error"] = "the film the collective delivered differs from a 1-GPU render of the same tiles"
             # one launch renders this rank's shard: samples_per_step / world samples
@@ -418,7 +444,7 @@ def main():
             algorithmic_gbps = bytes_per_sample * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
             pmc, pmc_source = None, None
             if world == 1 and not args.no_pmc:
-                pmc, pmc_source = live_pmc(args.workload), "live: rocprofv3 --pmc passes of this run, same workload at 64 spp, scaled per sample"
+                pmc, pmc_source = live_pmc(args.workload, spp), f"live: rocprofv3 --pmc passes of this run, the same workload at the timed {spp} spp"
             if pmc is None or "hbm_bytes_per_sample" not in pmc:
                 prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
                 if os.path.exists(prof):
@@ -454,18 +480,30 @@ def main():
                 import torch
                 simds = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
                 simd_cycles = simds * mean_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
+                counters = pmc.get("counters") or {}
                 out["roofline"]["valu"] = {
                     "issue_frac": instr * VALU_CYCLES_PER_WAVE_INSTR_MIX / simd_cycles,
                     "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"], "wave_instr_per_launch": instr,
                     "cycles_per_wave_instr": VALU_CYCLES_PER_WAVE_INSTR_MIX, "simds": simds, "shader_clock_hz": SHADER_CLOCK_HZ, "simd_cycles_per_launch": simd_cycles,
-                    "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the kernel's own "
-                                   "opcode mix priced with the issue costs measured on the box (profiles/r03_valu_peak.json, tools/valu_peak2.hip, 64 opcodes: 2.4 cycles "
-                                   "per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every min / max / cvt / cmp / cndmask / shift / packed op, 8.2 per "
-                                   "transcendental): 807 cycles for the 247 VALU instructions of the traversal loop (profiles/r03_isa_census.txt, tools/isa_census.py)",
+                    "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the opcode mix of the kernel that ran "
+                                   "(the pool kernel's traversal loop, profiles/r05_isa_census_pool.txt, tools/isa_census.py) priced with the issue costs measured on the box "
+                                   "(profiles/r04h_cndmask_forms.json, tools/valu_peak2.hip: 2.4 cycles per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every min / max / "
+                                   "cvt / cmp / cndmask / shift / packed op, 8.2 per transcendental)",
+                    # what a change of the instruction count buys, MEASURED (round 5, profiles/r05b_sensitivity_probes.txt, r05c_pmc_*.json): 9.3 % more VALU instructions
+                    # (32 dependent v_fma per node step) cost 4.3 % time, 6.3 % fewer gained 2.4 %, three waves per SIMD instead of four cost 16 %
+                    "time_elasticity_to_valu_instructions": 0.42,
+                    "elasticity_source": "profiles/r05b_sensitivity_probes.txt (pn32: +9.3 % instructions, +4.3 % time), profiles/r05c_pmc_{r04,base}.json (-6.3 %, -2.4 %)",
                 }
-                counters = pmc.get("counters") or {}
+                if counters.get("SQ_ACTIVE_INST_VALU"):
+                    # SQ_ACTIVE_INST_VALU counts, in units of four cycles and summed over the waves, the cycles a wave has a VALU instruction in flight
+                    # (~4.2 per instruction whatever its class): against the launch's SIMD-cycles it says how full the pipes are IF the waves' instructions
+                    # never overlap -- an upper bound on their occupancy (it exceeds 1 in builds with more instructions in flight), not a proof of saturation
+                    out["roofline"]["valu"]["pmc_busy"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+                    out["roofline"]["valu"]["pmc_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel cycles); per-wave in-flight cycles summed over four waves per SIMD: an upper bound"
                 if counters.get("SQ_ACTIVE_INST_VALU") and counters.get("SQ_WAVE_CYCLES"):
                     out["roofline"]["valu"]["pmc_active_inst_valu_over_wave_cycles"] = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
+                if counters.get("SQ_WAIT_ANY") and counters.get("SQ_WAVE_CYCLES"):
+                    out["roofline"]["valu"]["pmc_wait_any_over_wave_cycles"] = counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"]
             if stats:
                 out["roofline"]["lanes"] = stats["lanes"]
                 req_gbps = stats["requested_bytes_per_sample"] * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
@@ -487,14 +525,14 @@ def main():
                 # (workload, timed steps, spp (None = the configuration's), seconds of oracle, whole configuration on the CPU, sampler)
                 for w, steps, spp_o, cpu_s, whole, sampler in (("c1", 3, None, 30.0, True, "Independent"), ("c3", 1, None, 8.0, False, "Independent"),
                                                                ("c4", 1, None, 10.0, False, "Independent"), ("c5", 1, BENCH_SPP_CAP["c5"], 8.0, False, "Independent"),
-                                                               ("c2", 1, None, 0.0, False, "PaddedSobol")):
+                                                               ("c2", 1, None, 8.0, False, "PaddedSobol")):  # (round 5: the low-discrepancy line has its own oracle leg and parity)
                     v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler, warmup_spp=None if w in ("c1", "c5") else 8)  # (C5: wavefront mode sizes its queues by the frame's spp -- a warm-up on fewer samples leaves a 76-89 GB allocation inside the timed step)
                     e = {"workload": d, "sampler": sampler, "spp_timed": sp, "spp_config": WORKLOADS[w][2], "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
                          "kernel_ms": kms, "kernel": kernel_name(var), "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
                     if cpu_s > 0.0:
                         e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _, (cpu_frame, cpu_spp) = cpu_baseline(sc, r, cpu_s, full_spp=sp if whole else None)
                         e["parity"] = device_parity(sc, local_rank, cpu_frame, cpu_spp)
-                    else:  # (the same frame and estimator as the headline line, another sampler: its parity is the twin tests', tests/test_gpu_parity.py)
+                    else:
                         e["parity"] = None
                     if whole:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration --
                         # and the REFERENCE'S OWN code beside it (oracle/_ref, one thread, a bounded sample of the same frame); absent
@@ -512,6 +550,8 @@ def main():
                             e["cpu_reference"] = ref
                     extra.append(e)
                 out["extra_configs"] = extra
+            if multi_extra:
+                out["extra_configs"] = out.get("extra_configs", []) + multi_extra
             out["source_hash"] = source_hash()  # the kernel + BVH-builder sources this line was measured on (profiles/*.json carry the same)
             print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -109,10 +109,20 @@ def test_bench_multi_gpu_path_runs_as_the_driver_launches_it(tmp_path):
     env = dict(os.environ, LR_BENCH_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29517",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "c1", "--spp", "8",
-           "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-stats"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+           "--no-cpu-baseline", "--no-pmc", "--no-stats", "--extra-spp", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "lrhip_film_reduce" in line["config"]["collective"], line["config"]
     m = line["multi_gpu"]
     assert m["reduced_film_equals_1gpu_render"] is True and m["reduce_ms"] >= 0.0 and m["reduce_bytes"] == 512 * 512 * 16, m
+    # round 5: a multi-GPU run also carries the configurations BASELINE.json names for 8 GPUs -- C4 (3840 x 2160) and C5
+    # (wavefront mode) -- each sharded, reduced and checked like the headline frame
+    extra = {e["workload"].split("-class")[0]: e for e in line["extra_configs"]}
+    assert set(extra) == {"Camera", "Kitchen"}, list(extra)
+    for name, res in (("Camera", (3840, 2160)), ("Kitchen", (1280, 720))):
+        e = extra[name]
+        assert e["value"] > 0 and e["spp_timed"] == 4 and "lrhip_film_reduce" in e["collective"], e
+        assert e["multi_gpu"]["reduced_film_equals_1gpu_render"] is True and e["multi_gpu"]["checked_sample_counts_ok"] is True, e["multi_gpu"]
+        assert e["multi_gpu"]["reduce_bytes"] == res[0] * res[1] * 16 and e["multi_gpu"]["rccl_saw_all_ranks"] is True, e["multi_gpu"]
+    assert extra["Kitchen"]["kernel"].startswith("lrd::megapool_kernel<5")  # the wavefront camera pass of the pool family

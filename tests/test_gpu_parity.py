@@ -356,15 +356,55 @@ def test_kitchen_class_scene(renderer, tmp_path):
     """BASELINE C5 stand-in at reduced size: every closure of SURVEY row a14 + NormalMap / alpha wrappers — the
     all-features variant.  Layered and alpha-tested surfaces are statistical by construction (their internal streams are
     seeded from hit-point bits), so the image is compared on 8x8 block means.  Measured: per-pixel rel-L1 4.8e-2,
-    block rel-L1 2.1e-2, mean 2e-5, closest rays 1 810 464 vs 1 810 586."""
+    block rel-L1 2.1e-2, mean 2e-5, closest rays 1 810 464 vs 1 810 586.  Bars (round 5): twice the measured distance; the mean at twice what
+    16 spp of this estimator leave of it (test_kitchen_class_scene_converges_on_the_oracle: +-1.4e-3 at 16 and 64 spp, 3e-4 at 256)."""
     sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16))
     gpu, gc, cpu, cc = _render_both(renderer, sc, 16)
     assert _variant(renderer) == WF | 8 | 16 | 32 | 64 | 1  # wavefront mode: lean alpha kernel + Disney / Mix / Layered in the heavy kernel + COUNT
     assert np.array_equal(gpu[..., 3], cpu[..., 3])
     assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 2e-3 * cc["closest_rays"]
     g, c = _blocks(gpu), _blocks(cpu)
-    assert np.abs(g - c).sum() / np.abs(c).sum() < 6e-2
-    assert abs(g.mean() - c.mean()) / c.mean() < 5e-3
+    err, bias = np.abs(g - c).sum() / np.abs(c).sum(), abs(g.mean() - c.mean()) / c.mean()
+    print(f"c5 at 256 x 144, 16 spp: block rel-L1 {err:.3e}, mean {bias:.2e}")
+    assert err < 4.2e-2 and bias < 3e-3
+
+
+def test_kitchen_class_scene_converges_on_the_oracle(renderer, tmp_path):
+    """"statistical by construction" as a MEASUREMENT.  C5 is the one configuration where the device sits above the
+    scene's own noise floor at a few spp: its Layered walks and alpha tests are seeded from hit-point BITS (layered.cpp:270,
+    geometry.cpp:165-192), so a last-bit difference of a hit point -- fp contraction, baked vs object-space triangles -- gives such a
+    vertex another random stream: another, equally valid, estimate of the same integral.  If that is all there is, the block-mean
+    distance between device and oracle is Monte-Carlo noise: it falls like 1 / sqrt(spp), its mean vanishes, and the device is no
+    further from the oracle on its own baked triangles than the oracle is from ITSELF across the two geometry modes.  A bias would
+    show as a distance that stops falling.  Same frame, samples [0, 16), [0, 64), [0, 256) accumulated on all three sides."""
+    sc = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(192, 112), spp=256))
+    plain, baked = Oracle(sc), Oracle(sc, bake_instances=True)
+    cpu = cpu_baked = None
+    renderer.upload(sc)
+    rows, begin = {}, 0
+    for spp in (16, 64, 256):
+        renderer.render(begin, spp, counters=False, sync=True)  # (progressive: the film carries on)
+        gpu = renderer.download(converted=False)
+        cpu, _ = plain.render(begin, spp, film=cpu)
+        cpu_baked, _ = baked.render(begin, spp, film=cpu_baked)
+        begin = spp
+        assert _variant(renderer) == WF | 8 | 16 | 32 | 64 and np.array_equal(gpu[..., 3], cpu[..., 3]) and (gpu[..., 3] == spp).mean() > 0.999
+        g, c, b = _blocks(gpu), _blocks(cpu), _blocks(cpu_baked)
+        d = lambda x, y: float(np.abs(x - y).sum() / np.abs(y).sum())  # noqa: E731
+        rows[spp] = {"device_vs_oracle": d(g, c), "device_vs_baked_oracle": d(g, b), "oracle_vs_oracle": d(b, c),
+                     "bias": float((g.mean() - c.mean()) / c.mean()), "bias_baked": float((g.mean() - b.mean()) / b.mean())}
+        print(f"c5 192 x 112 at {spp} spp: block rel-L1 device vs oracle {rows[spp]['device_vs_oracle']:.3e}, vs oracle on baked triangles {rows[spp]['device_vs_baked_oracle']:.3e}, "
+              f"oracle vs oracle {rows[spp]['oracle_vs_oracle']:.3e}; mean bias {rows[spp]['bias']:+.2e} (baked {rows[spp]['bias_baked']:+.2e})")
+    # (a) the distance falls with the samples -- as fast as the scene's own floor does.  Pure 1 / sqrt(spp) would be a factor 2 per 4 x spp; the
+    # ORACLE AGAINST ITSELF across its two geometry modes falls by 1.53 and 1.57 on this frame (measured, round 5: block means of a clamped,
+    # firefly-prone estimator), the device against either oracle by 1.63 ... 1.81: asserted at 1.5, and at no slower than 0.95 x the floor's own rate
+    for lo, hi in ((16, 64), (64, 256)):
+        floor_rate = rows[lo]["oracle_vs_oracle"] / rows[hi]["oracle_vs_oracle"]
+        for k in ("device_vs_oracle", "device_vs_baked_oracle"):
+            assert rows[hi][k] < rows[lo][k] / 1.5 and rows[lo][k] / rows[hi][k] > 0.95 * floor_rate, (k, lo, hi, floor_rate, rows)
+    assert abs(rows[256]["bias"]) < 1e-3 and abs(rows[256]["bias_baked"]) < 1e-3, rows  # (b) the mean vanishes
+    for spp in rows:  # (c) no further from the oracle than the oracle's two geometry modes are from each other
+        assert rows[spp]["device_vs_baked_oracle"] < 1.5 * rows[spp]["oracle_vs_oracle"], (spp, rows)
 
 
 def test_kernel_variant_selection(renderer):
@@ -543,7 +583,7 @@ def test_full_size_c3_c4_c5_properties(renderer, tmp_path, config):
         g, c = _blocks(a), _blocks(b)
         err = np.abs(g - c).sum() / np.abs(c).sum()
         print(f"{config}: block rel-L1 {err:.3e}, mean {abs(g.mean() - c.mean()) / c.mean():.2e}")
-        assert err < 8e-2 and abs(g.mean() - c.mean()) / c.mean() < 1e-2
+        assert err < 5.4e-2 and abs(g.mean() - c.mean()) / c.mean() < 4.5e-3  # (twice the measured 2.67e-2 / 2.2e-3 of 2 spp, profiles/r04_parity_bars.txt; the distance is the scene's own noise: test_kitchen_class_scene_converges_on_the_oracle)
     else:
         same = _same_geometry(sc, spp, film, rect=rect, cpu=sub)
         print(f"{config}: rel-L1 {_rel_l1(a, b):.3e}, mean {abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean():.2e}; same baked geometry: rel-L1 {same[0]:.3e}, mean {same[1]:.2e}; "
@@ -736,7 +776,7 @@ def test_edge_cases(renderer):
     for res, spp in (((1, 1), 1), ((3, 5), 2), ((9, 8), 1), ((17, 1), 3)):
         sc = Scene.from_string(cornell_box(resolution=res, spp=spp))
         gpu, gc, cpu, cc = _render_both(renderer, sc, spp)
-        assert gpu.shape == (res[1], res[0], 4) and np.array_equal(gpu[..., 3], cpu[..., 3]) and (gpu[..., 3] == spp).all()
+        assert gpu.shape == (res[1], res[0], 4) and np.array_equal(gpu[..., 3], cpu[..., 3]) and (gpu[..., 3] == spp).mean() > 0.999
         assert gc["closest_rays"] == cc["closest_rays"] and _rel_l1(gpu, cpu) < 1e-4, res
     one = Scene.from_string("""
 Shape tri : InlineMesh { positions { -1,-1,0, 1,-1,0, 0,1,0 } indices { 0,1,2 } light : Diffuse { emission : Constant { v { 2, 3, 4 } } two_sided { true } } }

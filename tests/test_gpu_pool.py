@@ -90,6 +90,62 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
     assert np.allclose(pool[..., :3], lane[..., :3], rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["lean", "padded_sobol", "pcg", "environment", "env_disney", "wf_mix_alpha", "wf_layered_sobol"])
+def test_shipped_pool_kernels_equal_their_counting_twins(renderer, tmp_path, case):
+    """the tests above drive the COUNT twins of the pool kernels (they need the counters); bench.py and the CLI launch
+    the binaries WITHOUT counters -- <4096> (C2), <4098> (C2 with a low-discrepancy sampler), <4100> (C3), <4116> (C4), <5128> / <7176>
+    (C5's camera and continuation passes).  A shipped binary and its twin are the same template with `if (COUNT)` blocks but different
+    BINARIES (round 1 saw one that kept its ray counts and emitted NaNs), so each shipped pool binary is held to its twin here: the same
+    paths (equal sample counts), the same film -- the pool kernels sum in fixed point, so whatever differs is a path's VALUE (a
+    differently contracted fp32 expression on a specular chain), not the order of the adds -- and the shipped binary deterministic."""
+    from helpers import MATERIALS
+    from test_environment import sky_image
+    from luisarender_amd.scene import save_image
+
+    def mat(*names):
+        return "".join(MATERIALS[k].replace("Surface m ", f"Surface {k} ") + "\n" for k in names)
+    sky = str(tmp_path / "sky.exr")
+    save_image(sky, sky_image())
+    env = f'render {{\n  environment : Spherical {{ emission : Image {{ file {{ "{sky}" }} }} }}'
+    text, variant = {
+        "lean": (cornell_box(resolution=64, spp=8, short_box_surface="glass", tall_box_surface="metal", extra_surfaces=mat("glass", "metal")), POOL),
+        "padded_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PaddedSobol"), POOL | 2),
+        "pcg": (cornell_box(resolution=64, spp=8, sampler="PCG32"), POOL | 2),
+        "environment": (cornell_box(resolution=64, spp=8).replace("render {", env), POOL | 4),
+        "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), POOL | 4 | 16),
+        # wavefront mode: the lean camera pass <5128> + the continuation pass <7176> around the heavy-closure kernel
+        "wf_mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + ALPHA), POOL | WF | 8 | 32),
+        "wf_layered_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="cutout", extra_surfaces=mat("layered") + ALPHA, sampler="PaddedSobol"),
+                             POOL | WF | 8 | 16 | 64 | 2),
+    }[case]
+    sc = Scene.from_string(text)
+    films = []
+    try:
+        renderer.set_scheduler(True)
+        for count in (True, False, False):
+            renderer.upload(sc)
+            renderer.render(0, 8, counters=count, sync=True)
+            assert renderer.last_variant() == (variant | (1 if count else 0)), (case, renderer.last_variant())
+            films.append(renderer.download(converted=False))
+    finally:
+        renderer.set_scheduler(None)
+    twin, shipped, again = films
+    assert twin[..., :3].sum() > 0 and np.isfinite(shipped).all() and np.array_equal(twin[..., 3], shipped[..., 3]), case
+    assert np.array_equal(shipped, again), case  # the shipped binary twice: bit for bit
+    if case.startswith("wf_layered"):  # (Layered seeds its walk from position bits: block means, as tests/test_gpu_parity.py does)
+        def blocks(f):
+            h, w = f.shape[0] // 8, f.shape[1] // 8
+            return f[:h * 8, :w * 8, :3].reshape(h, 8, w, 8, 3).mean(axis=(1, 3))
+        g, c = blocks(shipped), blocks(twin)
+        err, bias = float(np.abs(g - c).sum() / np.abs(c).sum()), float(abs(g.mean() - c.mean()) / c.mean())
+        print(f"{case}: shipped vs counting twin block rel-L1 {err:.3e}, mean {bias:.2e}")
+        assert err < 0.15 and bias < 3e-2
+    else:
+        err, bias = _rel_l1(shipped, twin), float(abs(shipped[..., :3].mean() - twin[..., :3].mean()) / twin[..., :3].mean())
+        print(f"{case}: shipped vs counting twin rel-L1 {err:.3e}, mean {bias:.2e}, bit-identical {bool(np.array_equal(shipped, twin))}")
+        assert err < 3e-3 and bias < 1e-3, (case, err, bias)
+
+
 def test_pool_kernels_against_the_oracle(renderer):
     scene = Scene.from_string(cornell_box(resolution=128, spp=16))
     try:
