@@ -19,7 +19,7 @@
 namespace lrd {
 
 #ifndef LR_HEAVY_WAVES
-#define LR_HEAVY_WAVES 2// waves per SIMD the register allocator may assume (2: 256 VGPRs)
+#define LR_HEAVY_WAVES 3// waves per SIMD the register allocator may assume (3: 168 VGPRs.  C5 at 1024 spp, round 5: 555.5 / 555.7 / 567.3 / 562.6 Msamples/s at 1 / 2 / 3 / 4, profiles/r05j_c5_heavy_waves.txt)
 #endif
 
 // One instantiation per closure KIND (0 Disney, 1 Mix, 2 Layered): the Disney kernel holds the Disney closure inline and nothing

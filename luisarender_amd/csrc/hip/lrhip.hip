@@ -936,9 +936,22 @@ int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
 // spp) ... 1.12 (256 spp); C3 1.18; C4 1.06; C5 (wavefront mode) 1.10.
 // A room scene swept over its triangle count (profiles/r04i_scheduler_crossover.txt): 0.88 at 2-5 thousand triangles, 0.93 at 12, 0.96 at
 // 30, 1.06 at 100, 1.20 at 400 thousand.
-constexpr uint32_t kPoolAutoTriangles = 65536u;
+// Round 5 (tools/sched_sweep.py, profiles/r05j_scheduler_sweep.txt: the room scene over its triangle count x path depth x spp, the Cornell
+// box over depth x spp): what the pool buys grows with the LENGTH of the walks (triangles) and of the paths (depth) and with the share of
+// a launch that is drain (few samples per pixel); the break-even moves from ~30 thousand triangles (depth 16, 16 spp) to ~100 thousand
+// (depth 16, 256 spp), ~130 (depth 4, 16 spp) and ~180 (depth 4, 256 spp).  The rule follows it with the SCENE's own numbers -- its BVH
+// triangles, its integrator's depth, the spp its description asks for (not the spp of this call: every call of a frame must take the
+// same kernel family, whose film sums differ in their last bits) -- and is never more than 1.4 % off the better kernel in that sweep
+// (the triangle count alone: 3.8 %).
+constexpr uint32_t kPoolAutoTriangles = 98304u;
+uint32_t pool_auto_triangles(uint32_t max_depth, uint32_t scene_spp) {
+    auto t = kPoolAutoTriangles;
+    if (max_depth <= 6u) { t *= 2u; }
+    if (scene_spp != 0u && scene_spp < 64u) { t /= 2u; }
+    return t;
+}
 bool wants_pool(const lrhip_ctx *ctx) {
-    return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= kPoolAutoTriangles);
+    return ctx->scheduler == 2u || (ctx->scheduler == 0u && ctx->update_counts[1] >= pool_auto_triangles(ctx->scene.max_depth, ctx->scene.sampler_spp));
 }
 // path state of the pool kernels: two contexts per thread, 4 (Independent sampler) | 5 float4 each, [context][quad][thread] (megapool_kernel.h); sized for 5
 int ensure_pool(lrhip_ctx *ctx, uint32_t resident_blocks) {

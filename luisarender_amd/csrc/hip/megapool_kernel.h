@@ -24,7 +24,7 @@
 //     (profiles/r04c_*, r04g_*).
 // Measured (profiles/r04_final_schedulers.txt, kernel time of the one-path-per-lane kernel / this one, same build, same box): C2 1.08
 // at 1024 spp, C3 1.18, C4 1.06, C5 (wavefront mode) 1.10 at 64 spp; a Cornell box 0.88 -- lrhip.hip: wants_pool picks this kernel
-// from 65536 triangles up (the two break even at 50-60 thousand: profiles/r04i_scheduler_crossover.txt).
+// from ~100 thousand triangles up, earlier for deep paths at few samples per pixel, later for shallow ones (lrhip.hip: pool_auto_triangles; profiles/r05j_scheduler_sweep.txt).
 //
 // MEASURED AND NOT KEPT (profiles/r04a_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
 // shade queues of slot numbers in LDS, lanes fetching their next job from the ray queue inside the loop.  It filled the lanes (0.93 /
