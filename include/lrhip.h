@@ -190,10 +190,16 @@ int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
  * partition.  Measured on MI355X (profiles/r04_final_*): lane utilisation of the traversal loop 0.56 -> 0.91, of the shading block
  * 0.47 -> 0.63, films equal to the one-path-per-lane kernels' to 8e-8, and 5 .. 18 % faster on every scene but the smallest ones
  * (a Cornell box: 13 % slower -- a ray is a handful of steps there and the pool's costlier shading block is not paid back).  They
- * serve every scene the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes); a frame whose sums do
- * not fit fixed point (film clamp x spp beyond 2^37, a non-finite clamp), paths deeper than 65535, and the variants with
- * out-of-line closures / sibling integrators / media always run on the one-path-per-lane kernels.
- *   mode  0 = automatic: the pool kernels on scenes of 65536 BVH triangles or more (they break even at 50-60 thousand), one path per lane below;
+ * serve every scene the lean kernels serve (basic closures and Disney inline, the wavefront-mode passes).
+ * The fixed-point film -- the pool kernels' and wavefront mode's alike -- holds film clamp x spp up to 2^37 per call: a call beyond that
+ * (a clamp of 1e7 at 65536 spp) is rendered in sample sub-ranges that fit, one after the other (round 5; the film is the same film: a
+ * sub-range is what a progressive caller would have passed).  Only a clamp that cannot hold ONE sample (clamping switched off: 1e20,
+ * inf) takes the float-accumulating kernels of rounds 1-3 instead -- one path per lane, Mix / Layered scenes on the all-in-one
+ * variants (about half the speed of wavefront mode on the kitchen class) -- as do paths deeper than 65535 and the variants with
+ * out-of-line closures / sibling integrators / media.  lrhip_last_variant tells which family rendered (LRHIP_FEAT_POOL, LRHIP_FEAT_WAVEFRONT).
+ *   mode  0 = automatic: the pool kernels where they are the faster ones -- from 98304 BVH triangles up, from twice that for paths of
+ *             depth <= 6, from half of it for scenes of fewer than 64 spp (tools/sched_sweep.py: triangles x depth x spp; the choice is
+ *             never more than 1.4 % off the better kernel there) -- one path per lane below;
  *         1 = one path per lane; 2 = the pool kernels wherever one exists for the scene
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u

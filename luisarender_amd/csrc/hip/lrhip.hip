@@ -118,6 +118,7 @@ struct lrhip_ctx {
     bool own_stream{true};
     hipEvent_t ev_begin{nullptr}, ev_end{nullptr};
     bool timed{false};
+    bool in_split{false};        // lrhip_render is rendering a call in sample sub-ranges (below): the first sub-range's begin event stands for the call
     std::vector<DeviceBuffer> scene_buffers;
     lrd::DScene scene{};
     bool scene_ready{false};
@@ -1068,7 +1069,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     const auto shard_tiles = static_cast<double>(tile_count) / std::max(p->balance_shards, 1u);
     auto item_scale = 1.25;
     if (ctx->diag_item_scale != 0.) { item_scale *= std::max(0.01, std::fabs(ctx->diag_item_scale)); }
-    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    if (!ctx->in_split) { LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream)); }
     for (auto g0 = 0u; g0 < tiles_in_range; g0 += group_tiles) {// tile groups: what fits the queues at a time (see above)
     const auto group_count = std::min(group_tiles, tiles_in_range - g0);
     args.tile_begin = p->tile_begin + g0 * p->tile_stride;
@@ -1138,7 +1139,26 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // out-of-line closures: Mix / Layered surfaces, and Disney together with an alpha test (no lean <Alpha | Disney> variant is
     // precompiled; such a scene ran at 433 Msamples/s on <60> where its Mix-holding sibling ran at 480 in wavefront mode).
     // (both need the film's fixed-point sums: a frame they cannot hold -- fixed_point_bits -- takes the float-accumulating kernels)
-    const auto fixed_bits = fixed_point_bits(ctx->scene.film_clamp, (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f, spp);
+    const auto weight = (p->flags & LRHIP_RENDER_SHUTTER_WEIGHT) != 0u ? p->shutter_weight : 1.f;
+    const auto fixed_bits = fixed_point_bits(ctx->scene.film_clamp, weight, spp);
+    // A call whose sums do not fit the fixed-point film as a whole (clamp x spp beyond 2^37: a clamp of 1e7 at 65536 spp) is rendered in sample
+    // sub-ranges that do, one resolve into the float film per range, instead of silently leaving wavefront mode and the pool kernels for the
+    // all-in-one variants (the kitchen class runs at ~300 instead of ~560 Msamples/s there).  Only a clamp that does not even
+    // hold ONE sample (switched off: 1e20, inf) still takes the float-accumulating kernels -- lrhip.h says so.
+    if (fixed_bits < 0 && !ctx->in_split && fixed_point_bits(ctx->scene.film_clamp, weight, 1u) >= 0) {
+        auto n = spp;
+        while (n > 1u && fixed_point_bits(ctx->scene.film_clamp, weight, n) < 0) { n = (n + 1u) / 2u; }
+        ctx->in_split = true;
+        LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+        auto rc = LRHIP_OK;
+        for (auto s0 = p->spp_begin; s0 < p->spp_end && rc == LRHIP_OK; s0 += n) {
+            auto sub = *p;
+            sub.spp_begin = s0, sub.spp_end = std::min(p->spp_end, s0 + n);
+            rc = lrhip_render(ctx, &sub);
+        }
+        ctx->in_split = false;
+        return rc;
+    }
     if (fixed_bits >= 0 && ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
         const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
         const auto plain = pick_variant(ctx->features, false, generic_sampler);
@@ -1217,7 +1237,7 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // the copy has left it when the call returns
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
     LR_HIP_CHECK(hipMemcpyAsync(ctx->scene_record.ptr, &ctx->scene, sizeof(lrd::DScene), hipMemcpyHostToDevice, ctx->stream));
-    LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
+    if (!ctx->in_split) { LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream)); }
     LR_HIP_CHECK(kVariants[vi].launch(blocks, ctx->stream, static_cast<const lrd::DScene *>(ctx->scene_record.ptr), &args));
     ctx->last_variant = kVariants[vi].mask;
     LR_HIP_CHECK(hipGetLastError());

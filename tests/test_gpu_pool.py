@@ -251,6 +251,30 @@ def test_frames_that_do_not_fit_fixed_point_take_the_float_kernels(renderer, tmp
     assert float(np.abs(f[..., :3] - np.round(f[..., :3])).max()) > 1e-3  # not whole numbers
 
 
+def test_a_call_beyond_the_fixed_point_range_is_rendered_in_sample_sub_ranges(renderer):
+    """film clamp x spp beyond 2^37 (a clamp of 1e9 at 1024 spp here) used to send the whole call to the float-accumulating
+    kernels -- a Mix / Layered scene silently out of wavefront mode.  lrhip_render now renders such a call in sample sub-ranges that fit
+    (128 spp each here), one resolve per range: same kernel family, same samples, the same film as the caller's own progressive calls."""
+    from helpers import MATERIALS
+    surf = MATERIALS["mix_nested"].replace("Surface m ", "Surface mix_nested ") + "\n"
+    text = cornell_box(resolution=32, spp=1024, short_box_surface="mix_nested", extra_surfaces=surf).replace("film : Color {", "film : Color { clamp { 1e9 }")
+    scene = Scene.from_string(text)
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(scene)
+        renderer.render(0, 1024, sync=True)
+        whole = renderer.download(False)
+        assert (renderer.last_variant() & (POOL | WF)) == (POOL | WF), renderer.last_variant()
+        assert np.isfinite(whole).all() and (whole[..., 3] == 1024).all() and renderer.last_render_ms() > 0
+        renderer.upload(scene)
+        for s in range(0, 1024, 128):  # the sub-ranges by hand
+            renderer.render(s, s + 128, sync=True)
+        parts = renderer.download(False)
+        assert np.array_equal(whole, parts)
+    finally:
+        renderer.set_scheduler(None)
+
+
 def test_scheduler_argument_is_checked(renderer):
     import ctypes as C
     assert renderer._lib.lrhip_set_scheduler(renderer._ctx, 3) != 0 and b"lrhip_set_scheduler" in renderer._lib.lrhip_last_error()
