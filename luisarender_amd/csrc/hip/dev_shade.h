@@ -722,6 +722,8 @@ LR_D void trace_until_refill(const DScene &scene, const TraversalStack &stack, T
     for (;;) {
         trace_steps<COUNT, ALPHA>(scene, stack, tr, has_next, next_closest, refill, stats, idle_at_entry);
         if (!ALPHA) { break; }
+        // (candidates wait in batches, dev_trace.h: LR_ALPHA_BATCH; the wave may also have left for the shading block with some still waiting:
+        // they are resolved either way, and trace_steps returns at once when its reason to leave still stands)
         if (!lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
         resolve_pending_alpha(scene, stack, tr);
     }

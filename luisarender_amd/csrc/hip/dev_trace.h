@@ -175,6 +175,19 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
 //     instruction each) instead of four v_mov_b32 dpp + four v_lshl_or_b32.
 // Same walk, same order of every lane's operations: films and counters are bit-identical to round 4's (tests/test_gpu_pool.py twins).
 constexpr uint32_t kCurIdle = 0xfffffffeu;
+// ALPHA kernels: a lane whose candidate hit waits for its alpha test keeps its leaf, marked with bit 30 (a leaf names its triangle in 27
+// bits): such a `cur` is neither an inner node (negative) nor a leaf to test (>= kCurParked as an int) -- the lane sits out until the wave
+// has LR_ALPHA_BATCH of them (or nothing else to do) and leaves the loop for the tests.  Round 5: the wave used to leave for EVERY candidate.
+constexpr uint32_t kCurParked = 0xc0000000u;
+#ifndef LR_ALPHA_BATCH
+#define LR_ALPHA_BATCH 8
+#endif
+// whether the wave should leave a traversal loop for the alpha tests of its parked candidates
+LR_D bool alpha_tests_due(const uint32_t phase, const uint32_t cur) {
+    const auto parked = lr_ballot((phase & 4u) != 0u);// kPhasePendingAlpha
+    if (parked == 0ull) { return false; }
+    return static_cast<uint32_t>(__popcll(parked)) >= static_cast<uint32_t>(LR_ALPHA_BATCH) || !lr_any(cur < kCurParked);
+}
 constexpr uint32_t kStackStride = kBlockThreads * 4u;// bytes between two entries of a lane's LDS stack
 struct TravLane {
     const float4 *tris;
@@ -401,9 +414,8 @@ template<bool COUNT, bool ALPHA>
 LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats) {
     const auto tri = trav_leaf_fetch(tl, tr.cur);
     if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }// any-hit: drop the rest of the stack
-    if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) {// (a parked lane stays at its leaf)
-        tr.cur = trav_pop(stack, tl, spb, deep);
-    }
+    if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = trav_pop(stack, tl, spb, deep); }
+    else { tr.cur |= 0x40000000u; }// (a parked lane keeps its leaf, marked: kCurParked)
 }
 
 // ONE ITERATION's walk for the wave: the lanes at inner nodes test their packets, the lanes at leaves (the ones that were, and the ones the
@@ -424,7 +436,7 @@ LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravSt
     // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
     const auto deep = lr_any(spb > tl.s_deep);
     if (lr_any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
-    if (static_cast<int>(tr.cur) < static_cast<int>(kCurIdle)) {// at a leaf (ALPHA: a lane that parks a candidate stays at it, and the wave leaves the loop)
+    if (static_cast<int>(tr.cur) < static_cast<int>(kCurParked)) {// at a leaf (ALPHA: not one that waits for its alpha test)
         trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats);
     }
 }
@@ -469,7 +481,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
             stats.steps_starved += static_cast<uint32_t>(__builtin_readcyclecounter() - probe_t2);
         }
 #endif
-        if (ALPHA && lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        if (ALPHA && alpha_tests_due(tr.phase, tr.cur)) { break; }
         // ---- ray finished: switch from the shadow ray to the closest-hit ray, or go idle.  (Nothing the tests below look at changes
         // in an iteration in which no ray ended.)
         const auto ended = tr.cur == kInvalid;

@@ -165,14 +165,15 @@ LR_D bool pool_shade_due(uint32_t phase, uint32_t cur_flags, uint32_t oth_flags,
 }
 
 // The traversal loop of the pool kernel: dev_trace.h's node and leaf steps; a lane whose job ends switches to its other context's
-// rays without leaving the loop.  Returns when the shading block is due or nothing is in flight (ALPHA: also when a lane holds a
-// candidate hit for the alpha test, dev_shade.h: resolve_pending_alpha).  Must be called by all 64 lanes.
+// rays without leaving the loop.  Returns false when the shading block is due or nothing is in flight; ALPHA: true when LR_ALPHA_BATCH lanes
+// hold a candidate hit for the alpha test (dev_shade.h: resolve_pending_alpha) and the wave is to come straight back.  Must be called by all 64 lanes.
 template<bool COUNT, bool ALPHA>
-LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &cur, PathCtx &oth, bool samples_left, TraceStats &stats) {
+LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState &tr, PathCtx &cur, PathCtx &oth, bool samples_left, TraceStats &stats) {
     const auto tl = TravLane::make(scene, stack);
     auto inv = safe_inverse(tr.d);
     auto spb = tl.spb_of(tr.sp);
     if (tr.phase == kPhaseIdle) { tr.cur = kCurIdle; }// (inside the loop a lane's state is read off `cur`: dev_trace.h, TravLane)
+    auto for_alpha = false;// (ALPHA: the wave leaves for the alpha tests of its parked candidates and comes straight back)
     for (;;) {
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
@@ -188,7 +189,7 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         const auto probe_t1 = __builtin_readcyclecounter();
         const auto probe_t2 = probe_t1;
 #endif
-        if (ALPHA && lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
+        if (ALPHA && alpha_tests_due(tr.phase, tr.cur)) { for_alpha = true; break; }
         // ---- rays that ended: the job's next ray, the other context's job, or idle -- once LR_POOL_TURNOVER_LANES lanes wait with one, or no
         // lane has anything left to traverse.  (Nothing below changes in an iteration without a turnover: the exit tests run behind one.)
         const auto ended = tr.cur == kInvalid;
@@ -200,7 +201,7 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         }
 #endif
         if (n_ended == 0u) { continue; }
-        if (n_ended < static_cast<uint32_t>(LR_POOL_TURNOVER_LANES) && lr_any(tr.cur < kCurIdle)) { continue; }
+        if (n_ended < static_cast<uint32_t>(LR_POOL_TURNOVER_LANES) && lr_any(tr.cur < kCurParked)) { continue; }
         if (ended) {
             if (tr.phase == kPhaseShadow) {
                 if (tr.occluded) { cur.flags |= kCtxOccluded; }
@@ -224,6 +225,7 @@ LR_D void pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
     tr.sp = tl.sp_of(spb);
+    return for_alpha;
 }
 
 template<uint32_t F>
@@ -731,10 +733,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
         TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
-            pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, items_left || q_next < q_total, ts);
+            const auto for_alpha = pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, items_left || q_next < q_total, ts);
             if (!ALPHA) { break; }
-            if (!lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { break; }
-            resolve_pending_alpha(scene, stack, tr);
+            // (candidates may wait when the wave leaves for the shading block, too: no lane takes one into it)
+            if (lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { resolve_pending_alpha(scene, stack, tr); }
+            if (!for_alpha) { break; }
         }
         if (COUNT) {
             if (lane == 0u) { local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
