@@ -15,7 +15,7 @@ ORACLE_FLAGS ?= -std=c++17 -O3 -march=x86-64-v3 -ffp-contract=off -fPIC -Wall -W
 # -fno-slp-vectorize (round 2): the SLP vectorizer pairs scalar fp32 operations into v_pk_* instructions.  On gfx950 a wave64
 # v_pk_fma_f32 issues in ~4.2 cycles against ~2.4 for a v_fma_f32 (tools/valu_peak.hip), so a pair gains little, and the packing
 # costs v_mov shuffles into consecutive registers plus register pressure.  Off: C2 689 -> 774 Msamples/s (+12 %), C3 651 -> 758,
-# C4 683 -> 747, C5 255 -> 276 at the A/B sizes (profiles/r02f_ab_compiler_flags.txt).  The slab test's hand-written v2f FMAs stay.
+# C4 683 -> 747, C5 255 -> 276 at the A/B sizes (profiles/archive/r02f_ab_compiler_flags.txt).  The slab test's hand-written v2f FMAs stay.
 # Same arithmetic per lane.  -fno-vectorize (loop vectorizer), -O2, -fno-unroll-loops, relaxed-occupancy scheduling: no change.
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -fno-hip-fp32-correctly-rounded-divide-sqrt -fapprox-func -fno-slp-vectorize
 
@@ -77,7 +77,7 @@ VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=o
 # broken again without the SLP vectorizer, <124> (not <125>) non-deterministic at 4 waves after one more change -- each time
 # bit-identical to the good builds with this flag.  Some scenes pass on a broken binary (the kitchen parity test did), so tests cannot
 # establish that a fast build is sound; the flag removes the mechanism.  Cost: kitchen stand-in 275 -> 256 Msamples/s, <60> 350 -> 298
-# (profiles/r02f_ab_compiler_flags.txt).  Round 4: the LEAN variants too -- since round 3 they make a real call of their own
+# (profiles/archive/r02f_ab_compiler_flags.txt).  Round 4: the LEAN variants too -- since round 3 they make a real call of their own
 # (the texture callback of load_lobe, dev_math.h: LR_TEX_LAMBDA, is out of line) and spill SGPRs, i.e. they hold exactly the
 # ingredients; no binary of theirs was ever caught wrong (profiles/r03s_sgpr_spill_repro.txt: bit-identical with and without the
 # flag), but the same was true of <124> for two rounds.  Cost, same box: C2 782.3 -> 777.0, C3 809.6 -> 803.4, C4 875.6 -> 876.2

@@ -56,14 +56,15 @@ BENCH_SPP_CAP = {"c5": 2048}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Algorithmic bytes per sample (SURVEY §8d formula on the oracle's canonical-BVH2 counters).  Measured live by
 # the cpu_baseline leg at N = 1 (and reported from that measurement); at N > 1 no oracle runs, so the N = 1
-# value of the same seeded workload is used (profiles/r01_bench_c2_1gpu.json).
-# (all five measured by the cpu_baseline leg of profiles/r01d_bench_c*_1gpu.json)
+# value of the same seeded workload is used (profiles/archive/r01_bench_c2_1gpu.json).
+# (all five measured by the cpu_baseline leg of profiles/archive/r01d_bench_c*_1gpu.json)
 ALGORITHMIC_BYTES_PER_SAMPLE = {"c2": 15104.1, "c1": 3909.0, "c3": 11125.0, "c4": 8323.0, "c5": 13974.0}
-# VALU issue rates calibrated on the box (tools/valu_peak.hip -> profiles/r02_valu_peak.json): cycles a SIMD needs per wave64
+# VALU issue rates calibrated on the box (tools/valu_peak.hip -> profiles/archive/r02_valu_peak.json): cycles a SIMD needs per wave64
 # instruction with >= 2 waves resident: v_fma_f32 / v_add_u32 2.3-2.6, v_max_f32 / v_cvt_f32_ubyte / v_pk_fma_f32 4.1-4.3
 VALU_CYCLES_PER_WAVE_INSTR = (2.4, 4.2)
-# ... and the kernel's own mix priced with that table: tools/isa_census.py on the lean kernel's traversal loop (where two thirds of the
-# instructions are issued) gives 807 issue cycles for 247 VALU instructions (profiles/r03_isa_census.txt) = 3.27 cycles per instruction
+# ... and the kernel's own mix priced with that table: tools/isa_census.py on the traversal loop OF THE KERNEL THAT RUNS (round 5: the pool
+# kernel <4096>; where two thirds of the instructions are issued) gives 828 issue cycles for 253 VALU instructions
+# (profiles/r05_isa_census_pool.txt) = 3.27 cycles per instruction -- the figure round 3's census of the one-path kernel gave, too (807 / 247)
 VALU_CYCLES_PER_WAVE_INSTR_MIX = 3.27
 SHADER_CLOCK_HZ = 2.4e9
 L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth, MI355X_MICROARCH.md (4 MiB per XCD, 32 MiB aggregate, ~34.5 TB/s)

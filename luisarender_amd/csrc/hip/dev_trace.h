@@ -7,7 +7,7 @@
 //
 // What bounds this loop on CDNA4 is not HBM bytes but the per-CU vector L1 (TCP): a gather where
 // every lane touches its own cache line costs one tag lookup per lane per instruction (measured:
-// ~1 lane-request/clk/CU, profiles/r01).  So the node fetch is organised around cache lines, not
+// ~1 lane-request/clk/CU, profiles/archive/r01).  So the node fetch is organised around cache lines, not
 // lanes:
 //   * nodes are 64-byte quantised BVH4 packets (DNodeQ: box origin + per-axis scale + 8-bit child
 //     planes + 4 child references) — half the bytes of fp32 child boxes, conservative by

@@ -107,7 +107,7 @@ LR_D uint32_t wf_reserve(uint32_t *counter, unsigned long long mask, uint32_t la
 
 // Work distribution: ONE atomic counter over the item space (tiles x sample-chunks, tile-major).  The 4096 resident waves then work
 // on a moving front of ~300 neighbouring tiles, so every XCD's L2 already holds the front's BVH lines; per-XCD item ranges were
-// measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/r02b_ab_xcd_waves.txt).
+// measured in round 2 and lost 1 % (eight fronts = eight tails; profiles/archive/r02b_ab_xcd_waves.txt).
 LR_D uint32_t next_item(uint32_t *counter, uint32_t item_count, uint32_t lane) {
     uint32_t item = 0u;
     if (lane == 0u) { item = atomicAdd(counter, 1u); }

@@ -103,7 +103,7 @@ constexpr uint32_t kSceneVariantCount = sizeof(kSceneVariants) / sizeof(kSceneVa
 #ifndef LR_WAVES_LAYERED
 #define LR_WAVES_LAYERED 4
 #endif
-// MEASURED AND NOT KEPT (round 2, profiles/r02d_heavy_parking.txt): (1) the traversal as a real call in these variants, so that it
+// MEASURED AND NOT KEPT (round 2, profiles/archive/r02d_heavy_parking.txt): (1) the traversal as a real call in these variants, so that it
 // gets a register allocation of its own (its loops then hold no spills): kitchen stand-in 202 -> 129 Msamples/s at 2 waves, 165 at
 // 4 -- the state crosses the call through scratch and the loop loses its software pipelining across calls; (2) <60> at 3 waves per
 // SIMD: +9 % without parking, nothing with it; (3) texture / environment code inlined in the heavy variants: basic hits 335 -> 391

@@ -24,7 +24,7 @@ def test_metric_is_the_baseline_metric():
 
 
 def test_committed_headline_line_follows_the_contract():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02j_bench_c2_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "archive", "r02j_bench_c2_1gpu.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(line[key], typ), key
@@ -55,7 +55,7 @@ def test_committed_headline_line_follows_the_contract():
 def test_committed_line_times_the_reference_code_beside_the_kernel():
     """BASELINE configs[0] (Cornell 512x512, 64 spp) rides in extra_configs with BOTH CPU legs: the oracle on all cores ("port") and
     the reference's own MegaPath code through oracle/_ref on one thread ("reference")."""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02j_bench_c2_1gpu.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "archive", "r02j_bench_c2_1gpu.json")))
     c1 = line["extra_configs"][0]
     assert "Cornell" in c1["workload"] and c1["cpu_baseline"]["kind"] == "port" and c1["cpu_baseline"]["cores"] >= 1
     ref = c1["cpu_reference"]

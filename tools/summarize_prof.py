@@ -2,7 +2,7 @@
 """Summarise a tools/profile_c2.sh output directory (rocprofv3 rocpd sqlite files) into a small JSON
 that is committed under profiles/.
 
-    python tools/summarize_prof.py gpurun_out/prof_r01c profiles/r01_c2_1024spp.json [samples_per_launch]
+    python tools/summarize_prof.py gpurun_out/prof_r01c profiles/archive/r01_c2_1024spp.json [samples_per_launch]
 """
 import json
 import os
