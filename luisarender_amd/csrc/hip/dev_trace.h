@@ -322,6 +322,8 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         if (COUNT) { stats.nodes++; }
         uint32_t key[4];
         trav_slab_sort(tl.mine, tr, inv, key);
+        // (MEASURED, NOT KEPT, round 5: the four references through the registers -- a fourth ds_read_b128, two compares and three selects per
+        // reference instead of a dependent LDS round trip: 533 against 1012 Msamples/s, profiles/r05n_refs_in_vgprs.txt; runs of v_cndmask on one VCC again)
         auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
         // push far -> near so that the nearest is popped first; keep the nearest in `cur`.  (ONE wave-level branch on `deep` around the
         // lot, not one per access: a wave's scalar and branch instructions cost it issue slots like its vector ones)
