@@ -511,8 +511,9 @@ def main():
                 out["roofline"]["l2"] = {
                     "frac": req_gbps / L2_PEAK_GBPS, "requested_gbps": req_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s",
                     "requested_bytes_per_sample": stats["requested_bytes_per_sample"],
+                    "pool_state_bytes_per_sample": stats.get("pool_state_bytes_per_sample"),
                     "note": "the kernel's own requests per sample from its counters (path_statistics: 64 B x nodes + 48 B x triangle tests + 128 B x surface hits "
-                            "+ 136 B x light samples) x samples / kernel time, against the aggregate L2 bandwidth (MI355X_MICROARCH.md); the vector L1 serves "
+                            "+ 136 B x light samples + the pool kernels' path state: 96 B per shaded vertex, 32 B per path) x samples / kernel time, against the aggregate L2 bandwidth (MI355X_MICROARCH.md); the vector L1 serves "
                             "part of them (the BVH's top levels), so this is an upper bound on L2 traffic",
                 }
             if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None:

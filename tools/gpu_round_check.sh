@@ -33,7 +33,7 @@ python tools/wf_trace.py $O/trace_c5 | head -16 | tee $O/wf_trace_c5.txt
 timeout 600 python tools/shard_probe.py 1024 2>&1 | grep -v amdgpu.ids | tee $O/shard_probe.txt
 timeout 600 python tools/ab_sched.py 1024 c2 2>&1 | grep "^c2" | tee $O/ab_sched_c2_1024spp.txt
 timeout 600 python tools/ab_sched.py 64 c1 c3 c4 c5 2>&1 | grep "^c[0-9]" | tee $O/ab_sched_others_64spp.txt
-LRHIP_SCHEDULER=legacy timeout 300 python tools/gpu_stats.py 64 c2 2>&1 | grep -v amdgpu | tail -8 > $O/stats_lane_c2.txt; LRHIP_SCHEDULER=pool timeout 300 python tools/gpu_stats.py 64 c2 2>&1 | grep -v amdgpu | tail -8 > $O/stats_pool_c2.txt
+LRHIP_SCHEDULER=legacy timeout 300 python tools/gpu_stats.py 1024 c2 2>&1 | grep -v amdgpu | tail -8 > $O/stats_lane_c2.txt; LRHIP_SCHEDULER=pool timeout 300 python tools/gpu_stats.py 1024 c2 2>&1 | grep -v amdgpu | tail -8 > $O/stats_pool_c2.txt
 grep -h "utilisation" $O/stats_lane_c2.txt $O/stats_pool_c2.txt
 LR_BENCH_FORCE_COLLECTIVE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats > $O/bench_forced_collective.json 2> $O/bench_forced_collective.err
 python -c "
