@@ -96,6 +96,28 @@ def test_round3_line_carries_parity_path_statistics_and_every_baseline_config():
     assert c1["parity"]["rel_l1"] < 1e-4 and c1["cpu_reference"]["kind"] == "reference"  # full C1 against the CPU leg's frame
 
 
+def test_round5_line_measures_its_roofline_block_at_the_timed_configuration():
+    """the line of the round-5 state (profiles/r05_final_bench_c2_1gpu.json, the driver's default command) -- the
+    roofline block measured at the timed 1024 spp and reproducible from its own fields, the low-discrepancy line with a parity of its own."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench_c2_1gpu.json")))
+    assert line["n_gpus"] == 1 and line["value"] > 1000 and line["config"]["spp"] == 1024 and "scheduler_override" not in line["config"]
+    r = line["roofline"]
+    assert r["kernel"] == "lrd::megapool_kernel<4096u>" and "1024 spp" in r["traffic_source"] and 0.2 < r["frac"] < 0.4
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    v = r["valu"]
+    assert abs(v["issue_frac"] - v["wave_instr_per_launch"] * v["cycles_per_wave_instr"] / v["simd_cycles_per_launch"]) < 1e-9
+    assert abs(v["simd_cycles_per_launch"] - v["simds"] * r["kernel_ms"] * 1e-3 * v["shader_clock_hz"]) < 1e-3 * v["simd_cycles_per_launch"]
+    assert 0.9 < v["pmc_busy"] < 1.1 and v["time_elasticity_to_valu_instructions"] == 0.42 and 0.3 < v["pmc_wait_any_over_wave_cycles"] < 0.7
+    assert "1024 spp" in r["lanes"]["note"] and r["lanes"]["trace"] > 0.9 and r["lanes"]["trace_starved"] < 0.01
+    assert line["path_statistics"]["spp"] == 1024 and line["path_statistics"]["pool_state_bytes_per_sample"] > 200
+    extra = {(e["workload"].split(",")[0].split(" (")[0], e["sampler"]): e for e in line["extra_configs"]}
+    sobol = extra["Contemporary Bathroom-class", "PaddedSobol"]
+    assert sobol["spp_timed"] == 1024 and sobol["value"] > 880 and sobol["kernel"] == "lrd::megapool_kernel<4098u>"
+    assert sobol["parity"]["rel_l1"] < 1e-2 and sobol["parity"]["finite"] and sobol["cpu_baseline"]["kind"] == "port"
+    for key, floor in ((("Cornell Box", "Independent"), 3800), (("Bedroom-class", "Independent"), 1000), (("Camera-class", "Independent"), 1000), (("Kitchen-class", "Independent"), 550)):
+        assert extra[key]["value"] > floor and extra[key]["parity"]["finite"], key
+
+
 import pytest  # noqa: E402
 
 
