@@ -204,6 +204,9 @@ int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u
 int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);
+/* The automatic rule's threshold (no device needed): the number of BVH triangles from which a scene whose integrator allows paths of
+ * `max_depth` vertices and whose description asks for `scene_spp` samples per pixel (0 = unknown) renders on the pool kernels.       */
+uint32_t lrhip_pool_auto_triangles(uint32_t max_depth, uint32_t scene_spp);
 
 const char *lrhip_last_error(void);
 

@@ -1255,6 +1255,8 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     return LRHIP_OK;
 }
 
+uint32_t lrhip_pool_auto_triangles(uint32_t max_depth, uint32_t scene_spp) { return pool_auto_triangles(max_depth, scene_spp); }
+
 int lrhip_set_diagnostics(lrhip_ctx *ctx, uint32_t force_features, double item_scale) {
     if (ctx == nullptr) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_diagnostics: ctx is NULL"); }
     ctx->diag_force_features = force_features, ctx->diag_item_scale = item_scale;

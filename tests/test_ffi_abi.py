@@ -78,3 +78,21 @@ def test_work_items_partition_the_sample_range():
                 tapered += big_count < count
     assert tapered > 100  # the taper is what is normally used
     assert lib.lrhip_work_items(0, 16, 1, 1, C.byref(out)) != 0
+
+
+def test_scheduler_rule_is_a_function_of_the_scene():
+    """lrhip_pool_auto_triangles (no device needed): from how many BVH triangles on the automatic scheduler takes the pool kernels -- the
+    rule of tools/sched_sweep.py's sweep (profiles/r05j_scheduler_sweep.txt): ~100 thousand triangles, twice that for shallow paths, half of
+    it for scenes of few samples per pixel; a function of the SCENE (depth, its own spp), never of a call's sample range."""
+    lib = C.CDLL(os.path.join(_ffi.LIB_DIR, "liblrhip.so"))
+    lib.lrhip_pool_auto_triangles.argtypes = [C.c_uint32, C.c_uint32]
+    lib.lrhip_pool_auto_triangles.restype = C.c_uint32
+    base = lib.lrhip_pool_auto_triangles(16, 1024)
+    assert base == 98304
+    assert lib.lrhip_pool_auto_triangles(4, 1024) == 2 * base and lib.lrhip_pool_auto_triangles(6, 1024) == 2 * base and lib.lrhip_pool_auto_triangles(7, 1024) == base
+    assert lib.lrhip_pool_auto_triangles(16, 16) == base // 2 and lib.lrhip_pool_auto_triangles(16, 64) == base and lib.lrhip_pool_auto_triangles(16, 0) == base
+    assert lib.lrhip_pool_auto_triangles(4, 16) == base
+    # the sweep's break-even points lie on the right side of it: (triangles, depth, spp) -> pool is the faster family
+    for tris, depth, spp, pool_faster in ((30_000, 16, 256, False), (60_000, 16, 16, True), (60_000, 16, 256, False), (100_000, 16, 256, True),
+                                          (100_000, 4, 256, False), (400_000, 4, 256, True), (400_000, 16, 16, True), (5_000, 4, 16, False)):
+        assert (tris >= lib.lrhip_pool_auto_triangles(depth, spp)) == pool_faster, (tris, depth, spp)
