@@ -311,12 +311,14 @@ LR_D void trav_packets_done() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template<bool COUNT>
+template<bool COUNT, bool FETCHED = false>
 LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    trav_node_fetch(stack, tl, tr, is_inner);
-    trav_fetch_wait();
+    if (!FETCHED) {
+        trav_node_fetch(stack, tl, tr, is_inner);
+        trav_fetch_wait();
+    }
     const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(tl.mine + 3));// q3 = child[4] stays in LDS
     if (is_inner) {
         if (COUNT) { stats.nodes++; }
@@ -430,13 +432,28 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // 3662 against 4029.  It executes more instructions (five exec regions per iteration instead of two, unconditional address arithmetic),
 // and a wave issues at most one instruction of ANY kind every ~4.5 cycles: what an iteration costs a wave is its instruction count --
 // scalar and branch instructions included -- as much as the round trips it waits for.
-template<bool COUNT, bool ALPHA>
+template<bool COUNT, bool ALPHA, bool FUSED = false>
 LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, TraceStats &stats) {
     const auto is_inner = static_cast<int>(tr.cur) >= 0;
     // one WAVE-LEVEL test per iteration decides whether any lane could touch the HBM overflow area of the stack in this iteration
     // (a lane at an inner node pushes at most three entries); if none can -- nearly always -- every push and pop of the
     // iteration is a bare LDS access instead of a compare + branch + access per entry (round 3: +1 %)
     const auto deep = lr_any(spb > tl.s_deep);
+    if (FUSED) {// (experiment LR_POOL_FUSED_FETCH: both gathers of the iteration requested up front, one wait; a lane the node step sends to a leaf tests it in the NEXT iteration)
+        const auto is_leaf = static_cast<int>(tr.cur) < static_cast<int>(kCurParked);
+        const auto any_inner = lr_any(is_inner);
+        if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
+        LeafTriangle tri{};
+        if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
+        trav_fetch_wait();
+        if (is_leaf) {
+            if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }
+            if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = trav_pop(stack, tl, spb, deep); }
+            else { tr.cur |= 0x40000000u; }
+        }
+        if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
+        return;
+    }
     if (lr_any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
     if (static_cast<int>(tr.cur) < static_cast<int>(kCurParked)) {// at a leaf (ALPHA: not one that waits for its alpha test)
         trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats);

@@ -74,6 +74,17 @@ namespace lrd {
 #ifndef LR_POOL_PARK_ON_STACK
 #define LR_POOL_PARK_ON_STACK 1// the five parked words of the ray in flight go on top of the lane's traversal stack (0: an LDS area of their own, LR_STACK_LDS <= 11)
 #endif
+#ifndef LR_POOL_FUSED_FETCH
+// The pool kernels request BOTH gathers of an iteration -- the packets of the lanes at inner nodes, the triangles of the lanes at leaves -- up
+// front and wait once (dev_trace.h: trav_iteration<.., FUSED>); a lane the node step sends to a leaf tests it in the next iteration (5 %
+// more iterations, each with one round trip instead of two in a row).  Round 4 measured this at +-1 % and left it off; with the loop a
+// fifth lighter the round trips weigh more: C2 1022.5 -> 1043.2 at 1024 spp, C3 1024.6 -> 1033.3, C4 1015.4 -> 1031.4,
+// films BIT-IDENTICAL (both flows share trav_leaf_test; profiles/r05o_pool_fused_fetch.txt).  The one-path-per-lane kernels keep the serial
+// flow: their scenes' walks are a handful of steps out of the L1, and the extra iterations cost the Cornell box 7 %.  So do the ALPHA pool
+// kernels (alpha-tested traversal): fused, the alpha-only stand-in runs at 750 instead of 859 Msamples/s and C5 at 504 instead of 567
+// (profiles/r05q_fused_fetch_alpha_kernels.txt); the wavefront passes WITHOUT alpha gain 0.7 %.
+#define LR_POOL_FUSED_FETCH 1
+#endif
 #ifndef LR_POOL_STATE_LEAN
 #define LR_POOL_STATE_LEAN 1
 #endif
@@ -184,7 +195,7 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
 #ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: the iteration's walk -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         const auto probe_t0 = __builtin_readcyclecounter();
 #endif
-        trav_iteration<COUNT, ALPHA>(stack, tl, tr, spb, inv, stats);
+        trav_iteration<COUNT, ALPHA, LR_POOL_FUSED_FETCH != 0 && !ALPHA>(stack, tl, tr, spb, inv, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
         const auto probe_t2 = probe_t1;
