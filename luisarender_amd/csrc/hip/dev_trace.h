@@ -329,13 +329,19 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
         // push far -> near so that the nearest is popped first; keep the nearest in `cur`.  (ONE wave-level branch on `deep` around the
         // lot, not one per access: a wave's scalar and branch instructions cost it issue slots like its vector ones)
+        // the four references are requested together -- one LDS round trip instead of up to four in a row (a missed child's key reads slot 3:
+        // harmless); round 5, with the loop lighter: +0.5 % on both kernel families, profiles/r05r_refs_batched_turnover.txt
+        const auto r0 = ref_of(key[0]), r1 = ref_of(key[1]), r2 = ref_of(key[2]), r3 = ref_of(key[3]);
         auto tail = [&](auto deep_c) {
             constexpr bool D = decltype(deep_c)::value;
-            if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, ref_of(key[3]), D); }
-            if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, ref_of(key[2]), D); }
-            if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, ref_of(key[1]), D); }
-            if (static_cast<int>(key[0]) >= 0) { tr.cur = ref_of(key[0]); }
-            else { tr.cur = trav_pop(stack, tl, spb, D); }
+            // (a lane that hit nothing pushes nothing: its pop goes out with the reference reads, not behind the pushes -- round 5: +0.8 % on the
+            // one-path kernel, +1.2 % on the Cornell box)
+            auto popped = kInvalid;
+            if (static_cast<int>(key[0]) < 0) { popped = trav_pop(stack, tl, spb, D); }
+            if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, r3, D); }
+            if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, r2, D); }
+            if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, r1, D); }
+            tr.cur = static_cast<int>(key[0]) >= 0 ? r0 : popped;
         };
         if (deep) { tail(std::true_type{}); }
         else { tail(std::false_type{}); }
@@ -417,8 +423,14 @@ LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, T
 template<bool COUNT, bool ALPHA>
 LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats) {
     const auto tri = trav_leaf_fetch(tl, tr.cur);
-    if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }// any-hit: drop the rest of the stack
-    if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = trav_pop(stack, tl, spb, deep); }
+    // what the lane goes on with is read from its stack while the triangle is on its way (a lane that finds an occluder, or parks a candidate
+    // for its alpha test, does not take it): one LDS round trip off the iteration's critical path -- round 5: the one-path kernel +1.5 % on
+    // C2, +3.5 % on the Cornell box (profiles/r05s_early_pops.txt).  The pool kernels' fused flow (trav_iteration) pops behind the test:
+    // there the same move LOST 7.5 %.
+    auto spb_next = spb;
+    const auto next = trav_pop(stack, tl, spb_next, deep);
+    if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base, tr.cur = kInvalid; }// any-hit: drop the rest of the stack
+    else if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = next, spb = spb_next; }
     else { tr.cur |= 0x40000000u; }// (a parked lane keeps its leaf, marked: kCurParked)
 }
 

@@ -68,8 +68,9 @@ namespace lrd {
 // A ray that ended waits until this many lanes have one (or no lane has anything left to traverse): the turnover code of the loop --
 // results into the context, exchange of the contexts, the next ray into the traversal state, 1 / d -- then runs once for all of them,
 // every seventh iteration or so instead of in seven of ten.  C2, 256 spp: 918 Msamples/s at 1 (no waiting), 924 at 5 (on the build
-// before), 955 at 8, 954 at 12, 945 at 16, 916 at 24 (profiles/r04f_turnover_and_stack.txt).
-#define LR_POOL_TURNOVER_LANES 8
+// before), 955 at 8, 954 at 12, 945 at 16, 916 at 24 (profiles/r04f_turnover_and_stack.txt).  Round 5, the loop lighter: 12 is 0.3-0.6 % ahead of
+// 8 in four A/Bs (r05a, r05d, r05l, r05r), 6 and 4 behind.
+#define LR_POOL_TURNOVER_LANES 12
 #endif
 #ifndef LR_POOL_PARK_ON_STACK
 #define LR_POOL_PARK_ON_STACK 1// the five parked words of the ray in flight go on top of the lane's traversal stack (0: an LDS area of their own, LR_STACK_LDS <= 11)

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=gpurun_out/r05r; mkdir -p $O
+SCHED=both timeout 900 python tools/ab_libs.py 256 c2 base rb t12f t6f s60f 2>&1 | grep -v amdgpu.ids | tee $O/ab_c2_256.txt
