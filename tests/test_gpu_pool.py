@@ -79,8 +79,8 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
     # the same paths: every counter of the path topology is EQUAL (not close: same kernel code per vertex, same random numbers)
     for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nee_samples", "path_length_sum"):
         assert c_pool[k] == c_lane[k], (k, c_pool[k], c_lane[k])
-    # ... and the traversal work agrees to the few boxes a postponed leaf lets through (dev_trace.h: LEAF BATCHING -- which boxes a ray
-    # visits between a leaf and its test depends on when the WAVE runs its leaf step, i.e. on the other lanes)
+    # ... and the traversal work agrees (a lane's walk is the same sequence of steps under either scheduler; the 5 % are headroom from
+    # round 4's leaf-batching experiment, whose postponed leaves let a few more boxes through -- that code is gone since round 5)
     for k in ("nodes_visited", "tris_tested"):
         assert abs(c_pool[k] - c_lane[k]) <= 0.05 * c_lane[k], (k, c_pool[k], c_lane[k])
     err = _rel_l1(pool, lane)
