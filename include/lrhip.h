@@ -204,6 +204,16 @@ int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
  * lrhip_last_variant reports LRHIP_FEAT_POOL when the pool kernels rendered.                                                         */
 #define LRHIP_FEAT_POOL 4096u
 int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);
+/* Texel storage of the NEXT lrhip_upload_scene (round 5).  The host hands every image over as float RGBA texels (lr_scene.texels: what the
+ * reference's textures hold).  An image whose every texel is an 8-bit code's float -- decoded from a PNG / JPEG / BMP / TGA file -- can stay
+ * 8 bits per channel on the device: a quarter of the footprint in HBM and in the caches, decoded per lookup to exactly the floats the host
+ * made (both of the host readers' conversions, b * (1 / 255.f) and b / 255.f, bit for bit: tests/test_gpu_parity.py).
+ *   mode  1 = automatic (default): where the scene's image texels exceed 192 MB as floats (below that the caches hold them and the
+ *             decode's few instructions per texel are not paid back: kitchen class -1.5 %, camera class +4 %);
+ *         0 = never; 2 = every image that qualifies (A/B, tests)                                                                      */
+int lrhip_set_texture_storage(lrhip_ctx *ctx, uint32_t mode);
+uint64_t lrhip_packed_texels(lrhip_ctx *ctx); /* texels of the uploaded scene held as 8-bit codes (4 bytes each instead of 16) */
+
 /* The automatic rule's threshold (no device needed): the number of BVH triangles from which a scene whose integrator allows paths of
  * `max_depth` vertices and whose description asks for `scene_spp` samples per pixel (0 = unknown) renders on the pool kernels.       */
 uint32_t lrhip_pool_auto_triangles(uint32_t max_depth, uint32_t scene_spp);

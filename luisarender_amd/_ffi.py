@@ -223,5 +223,8 @@ def hip_lib(path: str | None = None) -> C.CDLL:
         lib.lrhip_set_diagnostics.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
         lib.lrhip_set_wavefront.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         lib.lrhip_set_scheduler.argtypes = [C.c_void_p, C.c_uint32]
+        lib.lrhip_set_texture_storage.argtypes = [C.c_void_p, C.c_uint32]
+        lib.lrhip_packed_texels.restype = C.c_uint64
+        lib.lrhip_packed_texels.argtypes = [C.c_void_p]
         lib._lr_ready = True
     return lib

@@ -373,8 +373,36 @@ LR_D float pow_nonpositive(float c, float g) {
     const auto odd = fabsf(gi) < 16777216.f && (static_cast<int>(gi) & 1) != 0;
     return odd ? -magnitude : magnitude;
 }
+// EIGHT-BIT TEXELS STAY EIGHT BITS ON THE DEVICE (round 5).  The host decodes every image to float RGBA (what the reference's textures hold
+// and what the oracle reads); an image whose every texel is an 8-bit code's float -- a PNG / JPEG / BMP / TGA albedo or roughness map --
+// is uploaded as one 32-bit word per texel instead of sixteen bytes (lrhip.hip: pack_byte_textures), behind the float texels in the same
+// buffer, and decoded here to EXACTLY the floats the host made: `pad` bits 0-1 say how the host converted (1: b * (1 / 255.f), the PNG
+// reader; 2: b / 255.f, the other readers -- byte_over_255 below, checked against the division for all 256 codes at upload), bits 4-7
+// mark channels that hold ONE value over the whole image (a padded alpha of 1: lr_texture::v carries it).  A quarter of the
+// footprint: the camera-class stand-in's eight 2k x 2k maps are 128 MB instead of 512 MB, and the frame runs 3.5-4 % faster
+// (profiles/r05zd_byte_textures.txt; profiles/r05zb_c4_texture_size.txt: the same frame with smaller images).  Which scenes get it:
+// lrhip_set_texture_storage (lrhip.h).
+LR_HD float byte_over_255(float b) {// correctly rounded b / 255.f for b = 0 .. 255: one Newton step on the reciprocal product
+    const auto q = b * (1.f / 255.f);
+    const auto r = fmaf(-q, 255.f, b);
+    return fmaf(r, 1.f / 255.f, q);
+}
 LR_D float4 texel_at(const float *texels, const lr_texture &t, int xx, int yy) {
-    return reinterpret_cast<const float4 *>(texels)[t.texel_offset + static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx)];
+    const auto index = static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx);
+    if (t.pad == 0u) { return reinterpret_cast<const float4 *>(texels)[t.texel_offset + index]; }
+    const auto p = reinterpret_cast<const uint32_t *>(texels)[t.texel_offset + index];
+    // b * (1 / 255.f) is byte_over_255 without its correction step: one expression for both forms, the correction's weight 0 under form 1.
+    // (Measured on the camera-class frame, films bit-identical: this against a select between the two forms +0.5 %, the texels in tiles of
+    // 8 x 4 -- one 128-byte line per tile -- instead of rows +0.4 %, both +1.0 %, a repeat of the base +0.4 %: the tiles were not kept,
+    // profiles/r05ze_texel_layout_ab.txt.)
+    const auto k = (t.pad & 3u) == 1u ? 0.f : 1.f / 255.f;
+    auto code = [&](uint32_t b, uint32_t c) {
+        const auto f = static_cast<float>(b);
+        const auto q = f * (1.f / 255.f);
+        const auto v = fmaf(fmaf(-q, 255.f, f), k, q);
+        return (t.pad & (16u << c)) != 0u ? t.v[c] : v;
+    };
+    return make_float4(code(p & 255u, 0u), code((p >> 8u) & 255u, 1u), code((p >> 16u) & 255u, 2u), code(p >> 24u, 3u));
 }
 LR_D float4 texel_fetch(const float *texels, const lr_texture &t, int x, int y) {
     auto zero = false;

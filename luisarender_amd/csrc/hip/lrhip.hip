@@ -118,6 +118,8 @@ struct lrhip_ctx {
     bool own_stream{true};
     hipEvent_t ev_begin{nullptr}, ev_end{nullptr};
     bool timed{false};
+    uint32_t byte_textures{1u};  // 8-bit images as 8-bit texels on the device (lrhip_upload_scene): lrhip_set_texture_storage: 0 never, 1 = where the scene's float texels exceed kByteTextureFloatBytes, 2 always
+    uint64_t packed_texel_words{0u};// texels of the uploaded scene held as 8-bit codes (lrhip_packed_texels)
     bool in_split{false};        // lrhip_render is rendering a call in sample sub-ranges (below): the first sub-range's begin event stands for the call
     std::vector<DeviceBuffer> scene_buffers;
     lrd::DScene scene{};
@@ -442,6 +444,62 @@ int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
     return LRHIP_OK;
 }
 
+// Images whose every texel is an 8-bit code's float are kept as 8-bit texels on the device (dev_shade.h: texel_at): one 32-bit word per
+// texel, appended behind the float texels of the scene (offsets in 32-bit words from the same base pointer).  A channel qualifies if all
+// its texels are b * (1 / 255.f) (form 1), all are b / 255.f (form 2), or all hold one value (a padded alpha); an image qualifies if
+// all four channels do and the coded ones agree on the form.  The device's decode reproduces the host's floats bit for bit: form 1 is
+// the same multiplication, form 2 is checked against the division for all 256 codes first.  Returns the packed words; `textures` (the
+// copy that goes to the device) gets the new offsets, the form and the constant channels.
+constexpr uint64_t kByteTextureFloatBytes = 192ull << 20u;
+static std::vector<uint32_t> pack_byte_textures(const lr_scene *s, std::vector<lr_texture> &textures) {
+    std::vector<uint32_t> packed;
+    auto division_ok = true;
+    for (auto b = 0u; b < 256u; b++) { division_ok = division_ok && lrd::byte_over_255(static_cast<float>(b)) == static_cast<float>(b) / 255.f; }
+    const auto base = static_cast<uint64_t>(s->texel_count) * 4u;// the float texels, in 32-bit words
+    for (auto &t : textures) {
+        t.pad = 0u;
+        const auto count = static_cast<uint64_t>(t.width) * t.height;
+        if (t.kind != LR_TEX_IMAGE || count == 0u || t.texel_offset + count > s->texel_count) { continue; }
+        const auto px = s->texels + t.texel_offset * 4u;
+        bool same[4], product[4], quotient[4];
+        for (auto c = 0u; c < 4u; c++) {
+            same[c] = true, product[c] = true, quotient[c] = division_ok;
+            for (uint64_t i = 0u; i < count && (same[c] || product[c] || quotient[c]); i++) {
+                const auto v = px[i * 4u + c];
+                same[c] = same[c] && v == px[c];
+                const auto code = v >= 0.f && v <= 1.f ? std::floor(v * 255.f + .5f) : -1.f;
+                product[c] = product[c] && code >= 0.f && code * (1.f / 255.f) == v;
+                quotient[c] = quotient[c] && code >= 0.f && code / 255.f == v;
+            }
+        }
+        auto use = 0u, constant = 0u;
+        for (auto f = 1u; f <= 2u && use == 0u; f++) {// the form under which every channel is either coded or one value
+            auto all = true;
+            auto mask = 0u;
+            for (auto c = 0u; c < 4u; c++) {
+                const auto coded = f == 1u ? product[c] : quotient[c];
+                if (!coded && same[c]) { mask |= 1u << c; }
+                all = all && (coded || same[c]);
+            }
+            if (all && mask != 15u) { use = f, constant = mask; }
+        }
+        if (use == 0u) { continue; }
+        t.pad = use | (constant << 4u);
+        for (auto c = 0u; c < 4u; c++) { if ((constant >> c) & 1u) { t.v[c] = px[c]; } }
+        t.texel_offset = base + packed.size();
+        for (uint64_t i = 0u; i < count; i++) {
+            auto word = 0u;
+            for (auto c = 0u; c < 4u; c++) {
+                const auto v = px[i * 4u + c];
+                const auto code = (constant >> c) & 1u ? 0u : static_cast<uint32_t>(std::floor(v * 255.f + .5f));
+                word |= (code & 255u) << (8u * c);
+            }
+            packed.push_back(word);
+        }
+    }
+    return packed;
+}
+
 // Every index one table holds into another, checked once: the caller may be a third party, and nothing may read out of bounds
 // on either side of the boundary (lrhip.h: "nothing throws or aborts across the boundary").
 static std::string validate_indices(const lr_scene *s) {
@@ -553,8 +611,27 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_UP(upload(ctx, s->tri_pdf, s->triangle_count, &d.tri_pdf));
     LR_UP(upload(ctx, s->light_instances, s->light_instance_count, &d.light_instances));
     LR_UP(upload(ctx, s->surfaces, s->surface_count, &d.surfaces));
-    LR_UP(upload(ctx, s->textures, s->texture_count, &d.textures));
-    LR_UP(upload(ctx, s->texels, s->texel_count * 4u, &d.texels));
+    {// textures: 8-bit images are uploaded as 8-bit texels (pack_byte_textures above; dev_shade.h: texel_at), behind the float texels
+        std::vector<lr_texture> textures(s->textures, s->textures + s->texture_count);
+        // ... where the float texels are more than the caches hold: the decode costs a few instructions per texel, which a scene whose
+        // images sit in the L2 / Infinity Cache anyway does not get back (kitchen class, 36 MB of float texels: -1.5 % packed; camera
+        // class, 512 MB: +4 %; the same frame at 128 MB of float texels: +-0 -- profiles/r05zd_byte_textures.txt, r05zc_byte_textures_always.txt, r05zb_c4_texture_size.txt)
+        auto image_texels = static_cast<uint64_t>(0u);
+        for (auto &t : textures) { if (t.kind == LR_TEX_IMAGE) { image_texels += static_cast<uint64_t>(t.width) * t.height; } }
+        const auto pack = ctx->byte_textures == 2u || (ctx->byte_textures == 1u && image_texels * 16u > kByteTextureFloatBytes);
+        for (auto &t : textures) { t.pad = 0u; }
+        const auto packed = pack ? pack_byte_textures(s, textures) : std::vector<uint32_t>{};
+        LR_UP(upload(ctx, textures.data(), textures.size(), &d.textures));
+        DeviceBuffer b;
+        const auto float_bytes = static_cast<size_t>(s->texel_count) * 4u * sizeof(float);
+        b.bytes = std::max<size_t>(float_bytes + packed.size() * sizeof(uint32_t), 16u);
+        LR_HIP_CHECK(hipMalloc(&b.ptr, b.bytes));
+        ctx->scene_buffers.emplace_back(b);
+        if (float_bytes != 0u) { LR_HIP_CHECK(hipMemcpy(b.ptr, s->texels, float_bytes, hipMemcpyHostToDevice)); }
+        if (!packed.empty()) { LR_HIP_CHECK(hipMemcpy(static_cast<char *>(b.ptr) + float_bytes, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
+        d.texels = static_cast<const float *>(b.ptr);
+        ctx->packed_texel_words = packed.size();
+    }
     LR_UP(upload(ctx, &s->filter, 1u, &d.filter));
     auto instances = build_instances(s);
     LR_UP(upload(ctx, instances.data(), instances.size(), &d.instances));
@@ -1252,6 +1329,14 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
                            args.partial, pixel_count, chunk_count, ctx->width, tiles_x, p->tile_begin, p->tile_end, p->tile_stride);
         LR_HIP_CHECK(hipGetLastError());
     }
+    return LRHIP_OK;
+}
+
+uint64_t lrhip_packed_texels(lrhip_ctx *ctx) { return ctx != nullptr ? ctx->packed_texel_words : 0u; }
+
+int lrhip_set_texture_storage(lrhip_ctx *ctx, uint32_t mode) {
+    if (ctx == nullptr || mode > 2u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_texture_storage: invalid argument"); }
+    ctx->byte_textures = mode;
     return LRHIP_OK;
 }
 

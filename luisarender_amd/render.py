@@ -139,6 +139,15 @@ class MegaPathRenderer:
         sends eight tiles through the queues at a time (tests: what a GPU short of memory does)"""
         self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
 
+    def set_texture_storage(self, mode: int = 1) -> None:
+        """lrhip_set_texture_storage: 8-bit images as 8-bit texels on the device from the next upload on (0 never, 1 automatic: scenes
+        whose images exceed 192 MB as floats, 2 every image that qualifies)"""
+        self._check(self._lib.lrhip_set_texture_storage(self._ctx, mode))
+
+    def packed_texels(self) -> int:
+        """lrhip_packed_texels: how many texels of the uploaded scene the device holds as 8-bit codes"""
+        return int(self._lib.lrhip_packed_texels(self._ctx))
+
     def set_scheduler(self, pool: bool | None = None) -> None:
         """lrhip_set_scheduler: None = automatic (the path-pool kernels of round 4 -- two path contexts per lane, fixed-point film sums,
         overlapping work items -- where they are the faster family (from ~100 thousand BVH triangles; lrhip.h), the one-path-per-lane kernels below), False = one path per

@@ -1155,3 +1155,48 @@ def test_two_contexts_driven_from_two_host_threads_render_one_frame(tmp_path):
         total = films[0] + films[1]
         assert np.isfinite(total).all() and (total[..., 3] == 8).all(), name
         assert np.array_equal(total, full), name
+
+
+def test_byte_texels_decode_to_the_floats_the_host_made(tmp_path):
+    """lrhip_set_texture_storage (round 5): an image whose texels are 8-bit codes' floats stays 8 bits per channel on the device
+    (lrhip.hip: pack_byte_textures; dev_shade.h: texel_at).  The decode must give back exactly the floats the host readers made --
+    b * (1 / 255.f) from the PNG reader, b / 255.f from the JPEG / BMP / TGA readers and from a PFM that holds byte / 255 -- so the
+    film of storage mode 2 is the film of mode 0, bit for bit; a float picture that is no 8-bit code stays float."""
+    from luisarender_amd.render import MegaPathRenderer
+    from luisarender_amd.scenes.configs import write_pfm, write_png
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:37, 0:53]
+    rgb = np.stack([(x * 5 + y) % 256, (y * 7 + 3 * x) % 256, rng.integers(0, 256, x.shape)], axis=-1).astype(np.uint8)
+    write_png(tmp_path / "rgb.png", rgb)                                                      # b * (1 / 255.f), sRGB by default
+    write_png(tmp_path / "grey.png", ((x * 9 + y * 4) % 256).astype(np.uint8))                # one channel, replicated by the reader
+    codes = np.stack([rng.integers(0, 256, (16, 16)) for _ in range(3)], axis=-1).reshape(16, 16, 3)
+    codes[:4] = np.arange(256 * 3).reshape(-1)[:4 * 16 * 3].reshape(4, 16, 3) % 256           # every code at least once over the picture
+    write_pfm(tmp_path / "quot.pfm", codes.astype(np.float32) / np.float32(255.0))            # b / 255.f
+    write_pfm(tmp_path / "free.pfm", rng.random((9, 11, 3)).astype(np.float32))               # no 8-bit picture: stays float
+    text = """
+Shape floor : InlineMesh { positions { -4,0,-4, 4,0,-4, 4,0,4, -4,0,4 } indices { 0,2,1, 0,3,2 } uvs { 0,0, 1,0, 1,1, 0,1 }
+  surface : Matte { Kd : Image { file { "rgb.png" } uv_scale { 2.5, -3 } filter { "bilinear" } } } }
+Shape back : InlineMesh { positions { -4,0,-4, 4,0,-4, 4,5,-4, -4,5,-4 } indices { 0,1,2, 0,2,3 } uvs { 0,0, 1,0, 1,1, 0,1 }
+  surface : Plastic { Kd : Image { file { "quot.pfm" } encoding { "linear" } filter { "point" } } roughness : Image { file { "grey.png" } encoding { "linear" } } eta : Constant { v { 1.5 } } } }
+Shape side : InlineMesh { positions { -4,0,4, -4,0,-4, -4,5,-4, -4,5,4 } indices { 0,1,2, 0,2,3 } uvs { 0,0, 1,0, 1,1, 0,1 }
+  surface : Matte { Kd : Image { file { "free.pfm" } encoding { "linear" } filter { "bilinear" } } } }
+Shape lamp : InlineMesh { positions { -1,4.9,-1, 1,4.9,-1, 1,4.9,1, -1,4.9,1 } indices { 0,1,2, 0,2,3 } light : Diffuse { emission : Constant { v { 12, 11, 10 } } } }
+Camera cam : Pinhole { fov { 55 } spp { 8 } film : Color { resolution { 96, 64 } } position { 2, 2.5, 7 } look_at { -0.5, 1.5, 0 } }
+render { cameras { @cam } shapes { @floor, @back, @side, @lamp } integrator : MegaPath { depth { 5 } } }
+"""
+    (tmp_path / "scene.luisa").write_text(text)
+    sc = Scene.load(str(tmp_path / "scene.luisa"))
+    films, packed = {}, {}
+    for mode in (0, 1, 2):
+        r = MegaPathRenderer(0)
+        r.set_texture_storage(mode)
+        r.upload(sc)
+        r.render(0, 8, sync=True)
+        films[mode], packed[mode] = r.download(converted=False), r.packed_texels()
+        r.close()
+    assert packed[0] == 0 and packed[1] == 0                         # automatic: a few kB of texels stay float
+    assert packed[2] == 37 * 53 * 2 + 16 * 16, packed                 # the two PNGs and the byte / 255 PFM, not the free-valued one
+    assert np.isfinite(films[0]).all() and films[0][..., :3].mean() > 0.01
+    assert np.array_equal(films[0], films[2]) and np.array_equal(films[0], films[1])
+    with pytest.raises(Exception):
+        MegaPathRenderer(0).set_texture_storage(3)

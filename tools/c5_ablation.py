@@ -34,6 +34,7 @@ with tempfile.TemporaryDirectory() as tmp:
     if len(sys.argv) > 2:
         cases = {k: v for k, v in cases.items() if k in sys.argv[2:]}
     r = MegaPathRenderer(0)
+    r.set_texture_storage(int(os.environ.get('TEXTURE_STORAGE', '1')))  # 0 float texels, 1 automatic, 2 8-bit texels wherever an image qualifies
     r.set_diagnostics(force_features=int(os.environ.get("FORCE_FEATURES", "0")))
     r.set_wavefront(os.environ.get("WAVEFRONT", "1") != "0", int(os.environ.get("WF_SLICE_PATHS", "0")))  # WAVEFRONT=0: the all-in-one megakernel variants
     for name, text in cases.items():
