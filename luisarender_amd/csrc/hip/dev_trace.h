@@ -306,6 +306,19 @@ LR_D void trav_slab_sort(const float4 *mine, const TravState &tr, f3 inv, uint32
 #endif
 }
 // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
+// WAVE PRIORITIES (round 5; s_setprio: which of a SIMD's ready waves issues first).  What a lane's walk waits for is a chain -- the sorted
+// children, the reference reads, the pushes and the pop, the next iteration's addresses, its fetch requests -- and the sooner a wave's
+// requests are out, the more of the memory's latency its SIMD neighbour's arithmetic covers.  So that chain runs at priority 3, the
+// arithmetic between a fetch and the next chain (the wait, the triangle test, the slab tests and the sort) at 0, the shading block at 2.
+// C2 pool kernel 1044 -> 1079 Msamples/s, C3 1026 -> 1052, films bit-identical (profiles/r05zf_setprio.txt).  On the way: the whole
+// loop at 3 over a shading block at 0: -1 %; the shading block at 3 over the loop at 0: +0.5 %; only the fetch requests at 3: +2.0 %;
+// the chain starting before the sort network, or the leaf's pop raised as well: -0.3 % each; the shading block at 1 / 2 / 3: the same.
+#ifndef LR_WAVE_PRIORITIES
+#define LR_WAVE_PRIORITIES 1
+#endif
+LR_D void prio_chain() { if (LR_WAVE_PRIORITIES) { __builtin_amdgcn_s_setprio(3); } }
+LR_D void prio_tests() { if (LR_WAVE_PRIORITIES) { __builtin_amdgcn_s_setprio(0); } }
+LR_D void prio_shade() { if (LR_WAVE_PRIORITIES) { __builtin_amdgcn_s_setprio(2); } }
 LR_D void trav_packets_done() {
     __builtin_amdgcn_s_waitcnt(0xc07f);// lgkmcnt(0) (vmcnt / expcnt untouched)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -316,7 +329,9 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     if (!FETCHED) {
+        prio_chain();
         trav_node_fetch(stack, tl, tr, is_inner);
+        prio_tests();
         trav_fetch_wait();
     }
     const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(tl.mine + 3));// q3 = child[4] stays in LDS
@@ -324,6 +339,7 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         if (COUNT) { stats.nodes++; }
         uint32_t key[4];
         trav_slab_sort(tl.mine, tr, inv, key);
+        prio_chain();
         // (MEASURED, NOT KEPT, round 5: the four references through the registers -- a fourth ds_read_b128, two compares and three selects per
         // reference instead of a dependent LDS round trip: 533 against 1012 Msamples/s, profiles/r05n_refs_in_vgprs.txt; runs of v_cndmask on one VCC again)
         auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
@@ -422,6 +438,7 @@ LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, T
 }
 template<bool COUNT, bool ALPHA>
 LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, bool deep, TraceStats &stats) {
+    if (LR_WAVE_PRIORITIES == 2) { prio_chain(); }
     const auto tri = trav_leaf_fetch(tl, tr.cur);
     // what the lane goes on with is read from its stack while the triangle is on its way (a lane that finds an occluder, or parks a candidate
     // for its alpha test, does not take it): one LDS round trip off the iteration's critical path -- round 5: the one-path kernel +1.5 % on
@@ -429,6 +446,7 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
     // there the same move LOST 7.5 %.
     auto spb_next = spb;
     const auto next = trav_pop(stack, tl, spb_next, deep);
+    prio_tests();
     if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base, tr.cur = kInvalid; }// any-hit: drop the rest of the stack
     else if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = next, spb = spb_next; }
     else { tr.cur |= 0x40000000u; }// (a parked lane keeps its leaf, marked: kCurParked)
@@ -454,9 +472,11 @@ LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravSt
     if (FUSED) {// (experiment LR_POOL_FUSED_FETCH: both gathers of the iteration requested up front, one wait; a lane the node step sends to a leaf tests it in the NEXT iteration)
         const auto is_leaf = static_cast<int>(tr.cur) < static_cast<int>(kCurParked);
         const auto any_inner = lr_any(is_inner);
+        prio_chain();
         if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
         LeafTriangle tri{};
         if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
+        prio_tests();
         trav_fetch_wait();
         if (is_leaf) {
             if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }
@@ -530,6 +550,7 @@ LR_D void trace_steps(const DScene &scene, const TraversalStack &stack, TravStat
         if (idle == ~0ull) { break; }
         if (__popcll(idle & fresh) >= refill) { break; }
     }
+    prio_shade();
     tr.sp = tl.sp_of(spb);
 }
 

@@ -236,6 +236,7 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         if (lr_ballot(tr.cur != kCurIdle) == 0ull) { break; }
         if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
+    prio_shade();
     tr.sp = tl.sp_of(spb);
     return for_alpha;
 }
