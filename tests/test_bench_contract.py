@@ -107,7 +107,7 @@ def test_round5_line_measures_its_roofline_block_at_the_timed_configuration():
     v = r["valu"]
     assert abs(v["issue_frac"] - v["wave_instr_per_launch"] * v["cycles_per_wave_instr"] / v["simd_cycles_per_launch"]) < 1e-9
     assert abs(v["simd_cycles_per_launch"] - v["simds"] * r["kernel_ms"] * 1e-3 * v["shader_clock_hz"]) < 1e-3 * v["simd_cycles_per_launch"]
-    assert 0.9 < v["pmc_busy"] < 1.1 and v["time_elasticity_to_valu_instructions"] == 0.42 and 0.3 < v["pmc_wait_any_over_wave_cycles"] < 0.7
+    assert 0.9 < v["pmc_busy"] < 1.25 and v["time_elasticity_to_valu_instructions"] == 0.42 and 0.3 < v["pmc_wait_any_over_wave_cycles"] < 0.7
     assert "1024 spp" in r["lanes"]["note"] and r["lanes"]["trace"] > 0.9 and r["lanes"]["trace_starved"] < 0.01
     assert line["path_statistics"]["spp"] == 1024 and line["path_statistics"]["pool_state_bytes_per_sample"] > 200
     extra = {(e["workload"].split(",")[0].split(" (")[0], e["sampler"]): e for e in line["extra_configs"]}
