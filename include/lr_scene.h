@@ -79,7 +79,9 @@ typedef struct lr_texture {
     /* checkerboard: on/off child texture ids and uv scale                      */
     int32_t child[2];
     float checker_scale;
-    uint32_t pad;
+    uint32_t pad;          /* ignored on input.  (The DEVICE copy of an image's record uses it for the texel storage: 0 = float texels;
+                              else bits 0-1 the host's 8-bit conversion, bits 4-7 channels that hold one value, kept in `v`, and
+                              texel_offset counts 32-bit words -- lrhip_set_texture_storage, lrhip.hip: pack_byte_textures)        */
 } lr_texture;
 
 /* ---- surfaces: one record per registered Surface node (pipeline surface tag) */
