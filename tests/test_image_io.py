@@ -404,3 +404,37 @@ def test_exr_piz_corrupt_chunks_fail_with_an_error(tmp_path):
     (tmp_path / "bad.exr").write_bytes(bytes(raw[:len(raw) - 20]))
     with pytest.raises(HostError):
         load_image(str(tmp_path / "bad.exr"))
+
+
+def test_the_device_decodes_an_8_bit_code_to_the_float_the_host_readers_make():
+    """dev_shade.h: texel_at keeps 8-bit images as 8-bit texels (lrhip_set_texture_storage) and must hand the shading code the very floats
+    the host readers made: b * (1 / 255.f) (the PNG reader) is its first product; b / 255.f (JPEG / BMP / TGA, image_codecs.cpp) is that
+    product plus ONE Newton step, fma(fma(-q, 255, b), 1 / 255.f, q).  Restated here in exact rational arithmetic with one rounding per
+    operation (what fp32 multiply / fma do), for all 256 codes, against numpy's correctly rounded fp32 division.  (lrhip_upload_scene runs
+    the same check on the device's own function before it packs anything; the GPU side is
+    tests/test_gpu_parity.py::test_byte_texels_decode_to_the_floats_the_host_made.)"""
+    from fractions import Fraction
+
+    def f32(x: Fraction) -> Fraction:  # round to nearest even at 24 bits (normal range: every value here is in [2^-30, 256])
+        if x == 0:
+            return x
+        sign, x = (-1, -x) if x < 0 else (1, x)
+        e = x.numerator.bit_length() - x.denominator.bit_length()
+        if Fraction(2) ** e > x:
+            e -= 1
+        ulp = Fraction(2) ** (e - 23)
+        n, rest = divmod(x, ulp)
+        if rest * 2 > ulp or (rest * 2 == ulp and n % 2 == 1):
+            n += 1
+        return sign * n * ulp
+
+    k = f32(Fraction(1, 255))
+    assert float(k) == float(np.float32(1.0) / np.float32(255.0))
+    for b in range(256):
+        q = f32(b * k)
+        assert float(q) == float(np.float32(b) * np.float32(float(k)))           # form 1: the PNG reader's product
+        r = f32(b - q * 255)                                                     # fma(-q, 255, b): one rounding
+        v = f32(r * k + q)                                                       # fma(r, 1 / 255.f, q)
+        assert float(v) == float(np.float32(b) / np.float32(255.0)), b           # form 2: the division, correctly rounded
+        assert float(f32(r * 0 + q)) == float(q)                                 # the same expression with the correction's weight 0 is form 1
+    assert sum(1 for b in range(256) if f32(b * k) != f32(Fraction(b, 255))) > 20  # (the two forms do differ: the step is needed)
