@@ -81,6 +81,9 @@ typedef struct lrhip_counters {
     /* wave cycles of three sections of the shading block: hit reconstruction + emission + light sample, closure evaluate + sample +
      * Russian roulette, path regeneration (camera rays); the remainder of shade_cycles is queue bookkeeping and ray launch */
     uint64_t shade_light_cycles, shade_closure_cycles, shade_regen_cycles;
+    /* round 6: section cycles of the traversal loop and the shading block from the stall-probe build of the counting kernels
+     * (make hip-variant DEFS=-DLR_STALL_PROBE, tools/stall_probe.py; slot names there); zero in the shipped library */
+    uint64_t probe[16];
 } lrhip_counters;
 
 int lrhip_create(int device_ordinal, lrhip_ctx **out);

@@ -138,10 +138,10 @@ class HipCounters(C.Structure):
     _fields_ = [(n, u64) for n in ("paths", "closest_rays", "shadow_rays", "nodes_visited", "tris_tested",
                                    "surface_hits", "nee_samples", "path_length_sum", "trace_steps", "trace_steps_busy",
                                    "shade_calls", "shade_busy", "trace_steps_starved", "shade_cycles", "trace_cycles", "wave_cycles", "nodes_empty",
-                                   "shade_light_cycles", "shade_closure_cycles", "shade_regen_cycles")]
+                                   "shade_light_cycles", "shade_closure_cycles", "shade_regen_cycles")] + [("probe", u64 * 16)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: (int(getattr(self, n)) if n != "probe" else [int(x) for x in self.probe]) for n, _ in self._fields_}
 
 
 class RenderParams(C.Structure):

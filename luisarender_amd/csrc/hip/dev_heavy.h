@@ -17,11 +17,20 @@ namespace lrd {
 
 // closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
 // per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
+#ifndef LR_LOBE_IMAGE_PASSES
+#define LR_LOBE_IMAGE_PASSES 4// looked-up slots of a surface kept in registers (more than these: looked up where the closure's code asks)
+#endif
+#ifndef LR_LOBE_FORM
+#define LR_LOBE_FORM 1
+#endif
+// closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
+// per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
 LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
     c = tb.closures[t];
     fr = base;
     if (c.dynamic || eta_i != 1.f) {// (eta_i != 1: the bottom of a Layered surface under a refractive top)
-        auto &raw = tb.surfaces[t];
+        auto &rec = tb.surfaces[t];
+        auto &raw = rec.raw;
         if (raw.normal_tex >= 0) {
             auto v = texture_eval_tables(tb.textures, tb.texels, raw.normal_tex, uv);
             auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
@@ -30,9 +39,18 @@ LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const
             fr = frame_from_normal_tangent(clamp_shading_normal(normal, ng, wo), base.s);
         }
         auto dyn = c.dynamic;
+        // the lookup of a slot whose texture is NOT constant: the out-of-line lambda of round 3 (dev_math.h: LR_TEX_LAMBDA), now asked for
+        // those slots only -- a constant slot is a plain load from the surface's own record (dev_scene.h: DSurface), independent of the
+        // other slots' and issued with them, where it used to be a call and a dependent round trip through the texture table each
+        const auto lookup = [&](int32_t id) LR_TEX_LAMBDA { return texture_eval_tables(tb.textures, tb.texels, id, uv); };
+        const auto mask = rec.dynamic_mask;
         c = resolve_closure(
-            raw, [&](int32_t id) LR_TEX_LAMBDA { return texture_eval_tables(tb.textures, tb.texels, id, uv); },
-            [&](int32_t id) { return tb.textures[id].channels; }, eta_i);
+            raw,
+            [&](int slot) {
+                if ((mask >> slot) & 1u) { return lookup(raw.tex[slot]); }
+                return *reinterpret_cast<const float4 *>(rec.value[slot]);
+            },
+            [&](int slot) { return (rec.channels[slot >> 3] >> ((slot & 7) * 4)) & 15u; }, eta_i);
         c.dynamic = dyn;
     }
 }

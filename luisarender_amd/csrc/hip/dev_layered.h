@@ -44,7 +44,7 @@ static_assert(LR_LAYER_LEVELS >= 1 && LR_LAYER_LEVELS <= 2, "dev_heavy.h: layer_
 
 struct LobeTables {// the scene tables closure loading reads (dev_heavy.h: load_lobe)
     const DClosure *closures;
-    const lr_surface *surfaces;
+    const DSurface *surfaces;
     const lr_texture *textures;
     const float *texels;
 };

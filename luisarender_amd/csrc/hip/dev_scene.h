@@ -51,6 +51,23 @@ enum : uint32_t {// DClosure::e slots of a Disney closure (DisneyContext, disney
     kDisneySheen, kDisneySheenTint, kDisneyClearcoat, kDisneyClearcoatGloss, kDisneySpecularTrans, kDisneyFlatness
 };// diffuse_trans lives in s1; x[0] = lobe mask, x[1] = transmissive, x[2] = thin
 
+// One surface as the device reads it for a DYNAMIC closure (some parameter an image / checkerboard texture, or a normal map): the host's
+// record and, beside it, what every texture SLOT of the record evaluates to where its texture is constant (round 6).  Per-hit closure
+// resolution used to ask the texture table about every slot through one out-of-line lookup each -- a Disney surface with two image maps
+// made thirteen dependent round trips of ~2.3 k cycles for its eleven constants, one surface kind after the other (the stall probe:
+// 92 k of the camera class's 185 k cycles per shading batch, profiles/r06_stalls_c4.txt).  Now the constants are plain loads from this
+// record -- independent of each other, issued together -- and only the slots in `dynamic_mask` are looked up (dev_heavy.h: load_lobe).
+constexpr uint32_t kSurfaceSlots = 13u;// texture slots a surface kind uses (lr_scene.h: Disney's 0 .. 12)
+struct alignas(16) DSurface {
+    float value[kSurfaceSlots][4]; // Texture::evaluate of the slot's texture where it is constant (lr_texture::v); 16-byte aligned: read as float4
+    uint32_t dynamic_mask;         // slots whose texture is not constant: evaluated per hit
+    uint32_t channels[2];          // lr_texture::channels of the slot's texture, 4 bits per slot
+    uint32_t pad;
+    lr_surface raw;                // the host's record (136 B)
+    uint32_t pad2[6];
+};
+static_assert(sizeof(lr_surface) == 136 && sizeof(DSurface) == 384, "DSurface: 13 slot values + masks + the host's record");
+
 struct alignas(16) DLight {
     float L[3];          // emission * scale for constant emission
     int32_t emission_tex;// >= 0 and dynamic: evaluate per hit
@@ -155,7 +172,7 @@ struct DScene {
     const lr_light_handle *light_instances;
     // shading tables
     const DClosure *closures;
-    const lr_surface *surfaces;// raw records for dynamic closures
+    const DSurface *surfaces;// the host's records + their constant texture slots (dynamic closures, alpha / opacity wrappers)
     const DLight *lights;
     const lr_texture *textures;
     const float *texels;
@@ -199,6 +216,7 @@ struct DCounters {
     unsigned long long paths, closest_rays, shadow_rays, nodes_visited, tris_tested, surface_hits, nee_samples,
         path_length_sum, trace_steps, trace_steps_busy, shade_calls, shade_busy, trace_steps_starved, shade_cycles, trace_cycles, wave_cycles, nodes_empty,
         shade_light_cycles, shade_closure_cycles, shade_regen_cycles;// sections of the shading block (round 3)
+    unsigned long long probe[16];// -DLR_STALL_PROBE builds only (dev_trace.h: THE STALL PROBE): section cycles summed over waves; zero otherwise
 };
 
 struct RenderArgs {

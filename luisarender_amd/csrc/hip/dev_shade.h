@@ -480,16 +480,16 @@ template<typename TexFn, typename ChannelsFn>
 LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&channels, float eta_i) {
     DClosure c{};
     c.kind = s.kind;
-    auto albedo = [&](int32_t id, float dv, f3 &value, float &strength) {// evaluate_albedo_spectrum + srgb decode
-        if (id < 0) { value = mk3(dv), strength = dv; return; }
-        value = saturate(extend_rgb(tex(id), channels(id)));
+    auto albedo = [&](int slot, float dv, f3 &value, float &strength) {// evaluate_albedo_spectrum + srgb decode
+        if (s.tex[slot] < 0) { value = mk3(dv), strength = dv; return; }
+        value = saturate(extend_rgb(tex(slot), channels(slot)));
         strength = cie_y(value);
     };
-    auto alpha = [&](int32_t id, float dv) {// e.g. mirror.cpp:145-154
-        if (id < 0) { c.alpha_x = c.alpha_y = dv; return; }
-        auto r = tex(id);
+    auto alpha = [&](int slot, float dv) {// e.g. mirror.cpp:145-154
+        if (s.tex[slot] < 0) { c.alpha_x = c.alpha_y = dv; return; }
+        auto r = tex(slot);
         auto remap = (s.flags & LR_SURFACE_FLAG_REMAP_ROUGHNESS) != 0u;
-        if (channels(id) == 1u) { c.alpha_x = c.alpha_y = remap ? roughness_to_alpha(r.x) : r.x; }
+        if (channels(slot) == 1u) { c.alpha_x = c.alpha_y = remap ? roughness_to_alpha(r.x) : r.x; }
         else { c.alpha_x = remap ? roughness_to_alpha(r.x) : r.x, c.alpha_y = remap ? roughness_to_alpha(r.y) : r.y; }
     };
     auto store = [](float *dst, f3 v) { dst[0] = v.x, dst[1] = v.y, dst[2] = v.z; };
@@ -497,38 +497,38 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
     float strength;
     switch (s.kind) {
         case LR_SURFACE_MATTE: {// matte.cpp:119-134
-            albedo(s.tex[0], 1.f, v, strength);
+            albedo(0, 1.f, v, strength);
             store(c.c0, v);
             // the host drops a black sigma texture (`_sigma && !_sigma->node()->is_black()`, matte.cpp:125)
-            c.s0 = s.tex[1] >= 0 ? saturate(tex(s.tex[1]).x) * 90.f : 0.f;
+            c.s0 = s.tex[1] >= 0 ? saturate(tex(1).x) * 90.f : 0.f;
             break;
         }
         case LR_SURFACE_MIRROR: {// mirror.cpp:141-163
-            alpha(s.tex[1], 0.f);
-            albedo(s.tex[0], 1.f, v, strength);
+            alpha(1, 0.f);
+            albedo(0, 1.f, v, strength);
             store(c.c0, v);
             break;
         }
         case LR_SURFACE_GLASS: {// glass.cpp:232-285 (fixed spectrum: eta = first channel)
-            alpha(s.tex[2], 0.f);
+            alpha(2, 0.f);
             float kr_lum, kt_lum;
-            albedo(s.tex[0], 1.f, v, kr_lum);
+            albedo(0, 1.f, v, kr_lum);
             store(c.c0, v);
-            albedo(s.tex[1], 1.f, v, kt_lum);
+            albedo(1, 1.f, v, kt_lum);
             store(c.c1, v);
             c.s2 = kr_lum == 0.f ? 0.f : kr_lum / (kr_lum + kt_lum);
             c.s0 = eta_i;
-            c.s1 = s.tex[3] >= 0 ? tex(s.tex[3]).x : 1.5f;
+            c.s1 = s.tex[3] >= 0 ? tex(3).x : 1.5f;
             break;
         }
         case LR_SURFACE_PLASTIC: {// plastic.cpp:256-291
-            alpha(s.tex[1], 0.f);
-            auto eta = (s.tex[3] >= 0 ? tex(s.tex[3]).x : 1.5f) / eta_i;
+            alpha(1, 0.f);
+            auto eta = (s.tex[3] >= 0 ? tex(3).x : 1.5f) / eta_i;
             f3 kd, sigma_a;
             float kd_lum, sigma_lum;
-            albedo(s.tex[0], 1.f, kd, kd_lum);
-            albedo(s.tex[2], 0.f, sigma_a, sigma_lum);
-            auto thickness = s.tex[4] >= 0 ? tex(s.tex[4]).x : 1.f;
+            albedo(0, 1.f, kd, kd_lum);
+            albedo(2, 0.f, sigma_a, sigma_lum);
+            auto thickness = s.tex[4] >= 0 ? tex(4).x : 1.f;
             auto average_transmittance = expf(-2.f * sigma_lum * thickness);
             auto diffuse_fresnel = fresnel_dielectric_integral(eta);
             store(c.c0, kd / (mk3(1.f) - kd * diffuse_fresnel));
@@ -538,19 +538,19 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
             break;
         }
         case LR_SURFACE_METAL: {// metal.cpp:273-308
-            alpha(s.tex[1], .5f);
+            alpha(1, .5f);
             store(c.c0, mk3(s.f[0], s.f[1], s.f[2]));
             store(c.c1, mk3(s.f[3], s.f[4], s.f[5]));
-            if (s.tex[0] >= 0) { albedo(s.tex[0], 1.f, v, strength); } else { v = mk3(1.f); }
+            if (s.tex[0] >= 0) { albedo(0, 1.f, v, strength); } else { v = mk3(1.f); }
             store(c.c2, v);
             c.s0 = eta_i;
             break;
         }
         case LR_SURFACE_DISNEY: {// disney.cpp:932-1003
-            albedo(s.tex[0], 1.f, v, strength);
+            albedo(0, 1.f, v, strength);
             store(c.c0, v);
             c.s0 = strength;
-            auto scalar = [&](int slot, float dv) { return s.tex[slot] >= 0 ? tex(s.tex[slot]).x : dv; };
+            auto scalar = [&](int slot, float dv) { return s.tex[slot] >= 0 ? tex(slot).x : dv; };
             c.e[kDisneyMetallic] = scalar(1, 0.f);
             c.e[kDisneyEtaI] = eta_i, c.e[kDisneyEtaT] = scalar(2, 1.5f);
             auto roughness = scalar(3, .5f);
@@ -565,15 +565,15 @@ LR_HD DClosure resolve_closure(const lr_surface &s, TexFn &&tex, ChannelsFn &&ch
             break;
         }
         case LR_SURFACE_LAYERED: {// layered.cpp:478-500
-            c.s0 = s.tex[0] >= 0 ? fmaxf(tex(s.tex[0]).x, 1.17549435e-38f) : 1e-2f;
-            c.s1 = s.tex[1] >= 0 ? tex(s.tex[1]).x : 0.f;
-            albedo(s.tex[2], 1.f, v, strength);
+            c.s0 = s.tex[0] >= 0 ? fmaxf(tex(0).x, 1.17549435e-38f) : 1e-2f;
+            c.s1 = s.tex[1] >= 0 ? tex(1).x : 0.f;
+            albedo(2, 1.f, v, strength);
             store(c.c0, v);
             c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = s.u[2], c.x[3] = s.u[3];
             break;
         }
         case LR_SURFACE_MIX: {// mix.cpp:198-212
-            c.s0 = s.tex[0] >= 0 ? clampf(tex(s.tex[0]).x, 0.f, 1.f) : 0.5f;
+            c.s0 = s.tex[0] >= 0 ? clampf(tex(0).x, 0.f, 1.f) : 0.5f;
             c.x[0] = s.u[0], c.x[1] = s.u[1], c.x[2] = s.u[2];// children, nesting depth below this node
             break;
         }
@@ -683,10 +683,10 @@ LR_D void reconstruct_baked(const DScene &scene, uint32_t tri, float u, float v,
 // Surface::Instance::evaluate_opacity: OpacitySurfaceWrapper (surface.h:183-189) and MixSurfaceInstance (mix.cpp:63-70)
 LR_D float surface_opacity(const DScene &scene, uint32_t tag, f2 uv) {
     auto one = [&](uint32_t t) {
-        auto alpha_tex = scene.surfaces[t].alpha_tex;
+        auto alpha_tex = scene.surfaces[t].raw.alpha_tex;
         return alpha_tex >= 0 ? texture_eval(scene, alpha_tex, uv).x : 1.f;
     };
-    if (scene.surfaces[tag].kind != LR_SURFACE_MIX) { return one(tag); }
+    if (scene.surfaces[tag].raw.kind != LR_SURFACE_MIX) { return one(tag); }
     // a Mix tree (children may be Mix surfaces, at most 3 levels below the root): the product over its leaves, multiplied in
     // the order the recursion a.opacity * b.opacity visits them
     uint32_t stack[8];
@@ -694,9 +694,10 @@ LR_D float surface_opacity(const DScene &scene, uint32_t tag, f2 uv) {
     stack[sp++] = tag;
     auto opacity = 1.f;
     while (sp > 0u) {
-        auto &s = scene.surfaces[stack[--sp]];
+        const auto tag_here = stack[--sp];
+        auto &s = scene.surfaces[tag_here].raw;
         if (s.kind == LR_SURFACE_MIX && sp + 2u <= 8u) { stack[sp++] = s.u[1], stack[sp++] = s.u[0]; }
-        else { opacity *= one(static_cast<uint32_t>(&s - scene.surfaces)); }
+        else { opacity *= one(tag_here); }
     }
     return opacity;
 }
@@ -724,7 +725,7 @@ LR_D bool alpha_skip(const DScene &scene, uint32_t inst_id, uint32_t prim, float
 LR_D void resolve_pending_alpha(const DScene &scene, const TraversalStack &stack, TravState &tr) {
     if ((tr.phase & kPhasePendingAlpha) != 0u) {
         const auto phase = tr.phase & ~kPhasePendingAlpha;
-        const auto tri_index = tr.cur & ((1u << 27u) - 1u);
+        const auto tri_index = tr.cur & kLeafIndexMask;
         const auto tb = reinterpret_cast<const float4 *>(scene.bvh_tris) + static_cast<size_t>(tri_index) * 3u;
         const auto inst = __float_as_uint(tb[0].w), prim = __float_as_uint(tb[1].w);
         if (!alpha_skip(scene, inst, prim, tr.pend_u, tr.pend_v)) {

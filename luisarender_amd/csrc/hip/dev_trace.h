@@ -31,6 +31,7 @@
 //     leaving the loop.
 #pragma once
 #include "dev_scene.h"
+#include <initializer_list>
 #include <type_traits>
 
 namespace lrd {
@@ -64,7 +65,78 @@ struct TraceStats {
     uint32_t steps, steps_busy;// loop iterations of the wave / iterations in which this lane did work
     uint32_t steps_starved;    // iterations this lane sat out because its pixel had no samples left to start
     uint32_t nodes_empty;      // node visits without a hit child
+#ifdef LR_STALL_PROBE
+    uint32_t probe_lds;// LDS byte address of this wave's probe words (eight section sums + the last timestamp), 0 = not a sampled wave: THE STALL PROBE below
+#endif
 };
+
+// THE STALL PROBE (round 6; -DLR_STALL_PROBE, counting kernels only; tools/stall_probe.py).  The box offers no PC sampling and no thread trace
+// (profiles/r06a_pc_sampling_unavailable.txt), so the iteration is cut at its waits by hand: an s_memtime at every section boundary, each
+// followed by s_waitcnt lgkmcnt(0) (the timestamp itself returns through that counter -- so every LDS access of a section has landed when
+// the section's time is taken), the values that cross the boundary pinned on both sides of it.  All marks stand at WAVE-UNIFORM points
+// (the divergent regions of the node / leaf step are split around them in the probed flow below); the sums and the last timestamp live in
+// nine LDS words per wave, updated by lane 0 (the first form kept them in SGPRs: the loop has none to spare, they were spilled to SCRATCH
+// with -amdgpu-spill-sgpr-to-vgpr=0, and every reload's s_waitcnt vmcnt(0) waited for the iteration's gathers as well -- the probed wave
+// ran ten times slower and the time piled up wherever the reloads stood: profiles/r06b_stall_probe_first_attempt.txt); lane 0 adds them to
+// lrhip_counters::probe after every traversal call.  ONE WAVE IN 36 takes the timestamps (TraceStats::probe_lds != 0).
+// Sections (cycles of a wave, whatever it waited for inside them):
+//   issue     address arithmetic + the fetch requests of the iteration (packets, and -- fused flow -- the leaf triangles)
+//   vm_wait   s_waitcnt vmcnt(0) of trav_fetch_wait: the iteration's gather(s) on their way
+//   leaf      the triangle test, its pop
+//   packet    the lane's three ds_read_b128 of its staged packet, until they have returned
+//   slab      24 cvt + 24 fma + min / max + the sort network: arithmetic only -- what it takes beyond its priced issue cycles is the wave
+//             waiting for an issue slot (the SIMD's other waves)
+//   chain     the four reference reads, pushes / pop, lgkmcnt(0) of trav_packets_done
+//   tail      end of the iteration: votes, turnover of ended rays, exit tests
+//   leaf_wait serial flow only (ALPHA pool kernels, one-path kernels): the leaf step's own wait for its triangle
+enum : uint32_t { kProbeIssue, kProbeVmWait, kProbeLeaf, kProbePacket, kProbeSlab, kProbeChain, kProbeTail, kProbeLeafWait, kProbeSlots };
+#ifdef LR_STALL_PROBE
+LR_D uint32_t probe_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return static_cast<uint32_t>(t);
+}
+typedef __attribute__((address_space(3))) uint32_t probe_lds_u32;
+constexpr uint32_t kProbeWords = 16u;// LDS words per wave: [0..7] section sums, [8] the last timestamp
+LR_D void probe_start(TraceStats &s) {
+    if (s.probe_lds != 0u) {
+        const auto t = probe_now();
+        if ((threadIdx.x & 63u) == 0u) { reinterpret_cast<probe_lds_u32 *>(static_cast<uintptr_t>(s.probe_lds))[8] = t; }
+    }
+}
+LR_D void probe_mark(TraceStats &s, uint32_t slot) {
+    if (s.probe_lds != 0u) {
+        const auto t = probe_now();
+        if ((threadIdx.x & 63u) == 0u) {
+            const auto words = reinterpret_cast<probe_lds_u32 *>(static_cast<uintptr_t>(s.probe_lds));
+            const auto last = words[8];
+            words[8] = t;
+            words[slot] += t - last;
+        }
+    }
+}
+template<typename T>
+LR_D int probe_pin_one(T &x) { asm volatile("" : "+v"(x)); return 0; }
+template<typename... T>
+LR_D void probe_pin(T &...x) { (void)std::initializer_list<int>{0, probe_pin_one(x)...}; }
+// LR_STALL_PROBE = 1: the SHIPPED flow with four marks (requests out / gathers landed / walk done / iteration done): what the wait for the
+// iteration's gathers is of an iteration, undisturbed.  = 2: the split flow with every section (its own cost: it serialises the two gathers
+// and runs ~4x slower per iteration -- its arithmetic sections are what it is read for, not its waits).
+#define LR_MARK(slot, ...) do { if (COUNT) { probe_pin(__VA_ARGS__); probe_mark(stats, slot); probe_pin(__VA_ARGS__); } } while (0)
+#define LR_PIN(...) do { if (COUNT) { probe_pin(__VA_ARGS__); } } while (0)// (values that must not be touched before this point: loads whose wait belongs to the NEXT section)
+#if LR_STALL_PROBE >= 2
+#define LR_MARK2(slot, ...) LR_MARK(slot, __VA_ARGS__)
+#define LR_PIN2(...) LR_PIN(__VA_ARGS__)
+#else
+#define LR_MARK2(slot, ...) do { } while (0)
+#define LR_PIN2(...) do { } while (0)
+#endif
+#else
+#define LR_MARK(slot, ...) do { } while (0)
+#define LR_PIN(...) do { } while (0)
+#define LR_MARK2(slot, ...) do { } while (0)
+#define LR_PIN2(...) do { } while (0)
+#endif
 
 struct TraversalStack {
     uint32_t *lds;      // &stack[0][tid]; stride kBlockThreads
@@ -179,12 +251,16 @@ constexpr uint32_t kCurIdle = 0xfffffffeu;
 // bits): such a `cur` is neither an inner node (negative) nor a leaf to test (>= kCurParked as an int) -- the lane sits out until the wave
 // has LR_ALPHA_BATCH of them (or nothing else to do) and leaves the loop for the tests.  Round 5: the wave used to leave for EVERY candidate.
 constexpr uint32_t kCurParked = 0xc0000000u;
+constexpr uint32_t kCurParkBit = 0x40000000u;// what a lane ORs into the leaf it stands at when its candidate waits
+constexpr uint32_t kLeafIndexBits = 27u;     // a leaf names its triangle in the low 27 bits (lrhip_upload_scene bounds the table)
+constexpr uint32_t kLeafIndexMask = (1u << kLeafIndexBits) - 1u;
+static_assert(kCurParkBit > kLeafIndexMask && (kLeafFlag | kCurParkBit) == kCurParked, "the park bit lies above a leaf's triangle index and below the leaf flag");
 #ifndef LR_ALPHA_BATCH
 #define LR_ALPHA_BATCH 8
 #endif
 // whether the wave should leave a traversal loop for the alpha tests of its parked candidates
 LR_D bool alpha_tests_due(const uint32_t phase, const uint32_t cur) {
-    const auto parked = lr_ballot((phase & 4u) != 0u);// kPhasePendingAlpha
+    const auto parked = lr_ballot((phase & kPhasePendingAlpha) != 0u);
     if (parked == 0ull) { return false; }
     return static_cast<uint32_t>(__popcll(parked)) >= static_cast<uint32_t>(LR_ALPHA_BATCH) || !lr_any(cur < kCurParked);
 }
@@ -255,8 +331,7 @@ LR_D void trav_fetch_wait() {
 }
 // The slab tests of one staged packet and the near -> far order of its children: key[i] = (float_bits(t_near) & ~3) | slot, ascending, a
 // missed child's key is kInvalid (negative as an int; a valid key is a non-negative float's bits).
-LR_D void trav_slab_sort(const float4 *mine, const TravState &tr, f3 inv, uint32_t (&key)[4]) {
-    auto q0 = mine[0], q1 = mine[1], q2 = mine[2];
+LR_D void trav_slab_sort_q(float4 q0, float4 q1, float4 q2, const TravState &tr, f3 inv, uint32_t (&key)[4]) {
 #ifdef LR_PROBE_NODE
     {// sensitivity probe: LR_PROBE_NODE extra dependent VALU ops per node step
         float dummy = tr.t_min;
@@ -305,6 +380,7 @@ LR_D void trav_slab_sort(const float4 *mine, const TravState &tr, f3 inv, uint32
     cswap(key[1], key[2]);
 #endif
 }
+LR_D void trav_slab_sort(const float4 *mine, const TravState &tr, f3 inv, uint32_t (&key)[4]) { trav_slab_sort_q(mine[0], mine[1], mine[2], tr, inv, key); }
 // the staged packets are read until here: no lane's next fetch may land before every lane's reads have returned
 // WAVE PRIORITIES (round 5; s_setprio: which of a SIMD's ready waves issues first).  What a lane's walk waits for is a chain -- the sorted
 // children, the reference reads, the pushes and the pop, the next iteration's addresses, its fetch requests -- and the sooner a wave's
@@ -324,6 +400,18 @@ LR_D void trav_packets_done() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// the pushes / pop of a node step: far -> near so that the nearest is popped first; the nearest stays in `cur`
+template<bool D>
+LR_D void trav_node_tail(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, const uint32_t (&key)[4], uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+    // (a lane that hit nothing pushes nothing: its pop goes out with the reference reads, not behind the pushes -- round 5: +0.8 % on the
+    // one-path kernel, +1.2 % on the Cornell box)
+    auto popped = kInvalid;
+    if (static_cast<int>(key[0]) < 0) { popped = trav_pop(stack, tl, spb, D); }
+    if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, r3, D); }
+    if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, r2, D); }
+    if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, r1, D); }
+    tr.cur = static_cast<int>(key[0]) >= 0 ? r0 : popped;
+}
 template<bool COUNT, bool FETCHED = false>
 LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravState &tr, uint32_t &spb, f3 inv, bool is_inner, bool deep, TraceStats &stats) {
     typedef __attribute__((address_space(3))) void lds_void;
@@ -331,10 +419,35 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
     if (!FETCHED) {
         prio_chain();
         trav_node_fetch(stack, tl, tr, is_inner);
+        LR_MARK(kProbeIssue);
         prio_tests();
         trav_fetch_wait();
+        LR_MARK(kProbeVmWait);
     }
     const auto child_words = reinterpret_cast<lds_cu32 *>((lds_void *)(tl.mine + 3));// q3 = child[4] stays in LDS
+    auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
+#if defined(LR_STALL_PROBE) && LR_STALL_PROBE >= 2
+    if (COUNT) {// the probed flow: the same operations, the divergent region split at the section boundaries (marks stand at wave-uniform points)
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (is_inner) { q0 = tl.mine[0], q1 = tl.mine[1], q2 = tl.mine[2]; }
+        LR_MARK(kProbePacket, q0.x, q1.x, q2.x);
+        uint32_t key[4] = {kInvalid, kInvalid, kInvalid, kInvalid};
+        if (is_inner) {
+            stats.nodes++;
+            trav_slab_sort_q(q0, q1, q2, tr, inv, key);
+        }
+        LR_MARK(kProbeSlab, key[0], key[1], key[2], key[3]);
+        if (is_inner) {
+            prio_chain();
+            const auto r0 = ref_of(key[0]), r1 = ref_of(key[1]), r2 = ref_of(key[2]), r3 = ref_of(key[3]);
+            if (deep) { trav_node_tail<true>(stack, tl, tr, spb, key, r0, r1, r2, r3); }
+            else { trav_node_tail<false>(stack, tl, tr, spb, key, r0, r1, r2, r3); }
+        }
+        trav_packets_done();
+        LR_MARK(kProbeChain, tr.cur, spb);
+        return;
+    }
+#endif
     if (is_inner) {
         if (COUNT) { stats.nodes++; }
         uint32_t key[4];
@@ -342,25 +455,13 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
         prio_chain();
         // (MEASURED, NOT KEPT, round 5: the four references through the registers -- a fourth ds_read_b128, two compares and three selects per
         // reference instead of a dependent LDS round trip: 533 against 1012 Msamples/s, profiles/r05n_refs_in_vgprs.txt; runs of v_cndmask on one VCC again)
-        auto ref_of = [&](uint32_t k) { return child_words[k & 3u]; };// ds_read_b32 from the staged packet
         // push far -> near so that the nearest is popped first; keep the nearest in `cur`.  (ONE wave-level branch on `deep` around the
         // lot, not one per access: a wave's scalar and branch instructions cost it issue slots like its vector ones)
         // the four references are requested together -- one LDS round trip instead of up to four in a row (a missed child's key reads slot 3:
         // harmless); round 5, with the loop lighter: +0.5 % on both kernel families, profiles/r05r_refs_batched_turnover.txt
         const auto r0 = ref_of(key[0]), r1 = ref_of(key[1]), r2 = ref_of(key[2]), r3 = ref_of(key[3]);
-        auto tail = [&](auto deep_c) {
-            constexpr bool D = decltype(deep_c)::value;
-            // (a lane that hit nothing pushes nothing: its pop goes out with the reference reads, not behind the pushes -- round 5: +0.8 % on the
-            // one-path kernel, +1.2 % on the Cornell box)
-            auto popped = kInvalid;
-            if (static_cast<int>(key[0]) < 0) { popped = trav_pop(stack, tl, spb, D); }
-            if (static_cast<int>(key[3]) >= 0) { trav_push(stack, tl, spb, r3, D); }
-            if (static_cast<int>(key[2]) >= 0) { trav_push(stack, tl, spb, r2, D); }
-            if (static_cast<int>(key[1]) >= 0) { trav_push(stack, tl, spb, r1, D); }
-            tr.cur = static_cast<int>(key[0]) >= 0 ? r0 : popped;
-        };
-        if (deep) { tail(std::true_type{}); }
-        else { tail(std::false_type{}); }
+        if (deep) { trav_node_tail<true>(stack, tl, tr, spb, key, r0, r1, r2, r3); }
+        else { trav_node_tail<false>(stack, tl, tr, spb, key, r0, r1, r2, r3); }
 #ifndef LR_TRACE_PROBE
         if (COUNT && key[0] == kInvalid) { stats.nodes_empty++; }
 #endif
@@ -383,7 +484,7 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 struct LeafTriangle { float4 a, b, c; };
 LR_D LeafTriangle trav_leaf_fetch(const TravLane &tl, uint32_t ref) {
     // (a 32-bit byte offset from the scalar table base: 48 B x 2^27 triangles does not fit 32 bits, 48 B x the 89 M a 4 GB table holds does -- lrhip_upload_scene refuses more)
-    auto tb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tl.tris) + (ref & ((1u << 27u) - 1u)) * 48u);
+    auto tb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tl.tris) + (ref & kLeafIndexMask) * 48u);
     // (non-temporal loads here -- a leaf's triangle is touched once -- were measured in round 4: C2 854 -> 761 Msamples/s)
     return LeafTriangle{tb[0], tb[1], tb[2]};
 }
@@ -427,7 +528,7 @@ LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, T
         if (tr.phase == kPhaseClosest) {
             tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
             tr.hit.u = u, tr.hit.v = v;
-            tr.hit.tri = ref & ((1u << 27u) - 1u);
+            tr.hit.tri = ref & kLeafIndexMask;
         }
     }
     if (tr.phase == kPhaseShadow && found) {
@@ -449,7 +550,7 @@ LR_D void trav_leaf_step(const TraversalStack &stack, const TravLane &tl, TravSt
     prio_tests();
     if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base, tr.cur = kInvalid; }// any-hit: drop the rest of the stack
     else if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = next, spb = spb_next; }
-    else { tr.cur |= 0x40000000u; }// (a parked lane keeps its leaf, marked: kCurParked)
+    else { tr.cur |= kCurParkBit; }// (a parked lane keeps its leaf, marked: kCurParked)
 }
 
 // ONE ITERATION's walk for the wave: the lanes at inner nodes test their packets, the lanes at leaves (the ones that were, and the ones the
@@ -476,20 +577,54 @@ LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravSt
         if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
         LeafTriangle tri{};
         if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
+        LR_MARK(kProbeIssue);
         prio_tests();
         trav_fetch_wait();
+        LR_MARK(kProbeVmWait);
+        LR_PIN2(tri.a.x, tri.b.x, tri.c.x, tri.c.w);
         if (is_leaf) {
             if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base; }
             if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = trav_pop(stack, tl, spb, deep); }
-            else { tr.cur |= 0x40000000u; }
+            else { tr.cur |= kCurParkBit; }
         }
+        LR_MARK2(kProbeLeaf, tr.cur, spb);
         if (any_inner) { trav_node_step<COUNT, true>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
+#if defined(LR_STALL_PROBE) && LR_STALL_PROBE < 2
+        LR_MARK(kProbeChain, tr.cur, spb);// (level 1: everything of the walk behind the wait -- triangle test, slab tests, sort, pushes / pops)
+#endif
         return;
     }
     if (lr_any(is_inner)) { trav_node_step<COUNT>(stack, tl, tr, spb, inv, is_inner, deep, stats); }
+#if defined(LR_STALL_PROBE) && LR_STALL_PROBE >= 2
+    if (COUNT) {// the serial flow's leaf step, split at its wait (trav_leaf_step below is what ships)
+        const auto at_leaf = static_cast<int>(tr.cur) < static_cast<int>(kCurParked);
+        LeafTriangle tri{};
+        auto spb_next = spb;
+        auto next = kInvalid;
+        if (at_leaf) {
+            tri = trav_leaf_fetch(tl, tr.cur);
+            next = trav_pop(stack, tl, spb_next, deep);
+        }
+        LR_MARK(kProbeIssue);
+        prio_tests();
+        __builtin_amdgcn_s_waitcnt(0);
+        LR_MARK(kProbeLeafWait);
+        LR_PIN(tri.a.x, tri.b.x, tri.c.x, tri.c.w, next);
+        if (at_leaf) {
+            if (trav_leaf_test<COUNT, ALPHA>(tr, tr.cur, tri, stats)) { spb = tl.lds_base, tr.cur = kInvalid; }
+            else if (!ALPHA || !(tr.phase & kPhasePendingAlpha)) { tr.cur = next, spb = spb_next; }
+            else { tr.cur |= kCurParkBit; }
+        }
+        LR_MARK(kProbeLeaf, tr.cur, spb);
+        return;
+    }
+#endif
     if (static_cast<int>(tr.cur) < static_cast<int>(kCurParked)) {// at a leaf (ALPHA: not one that waits for its alpha test)
         trav_leaf_step<COUNT, ALPHA>(stack, tl, tr, spb, deep, stats);
     }
+#if defined(LR_STALL_PROBE) && LR_STALL_PROBE < 2
+    LR_MARK(kProbeChain, tr.cur, spb);// (level 1, serial flow: slab tests, sort, pushes / pops AND the leaf step with its own wait for the triangle)
+#endif
 }
 
 // Runs traversal steps for the whole wave until no lane has a ray in flight or at least `refill`

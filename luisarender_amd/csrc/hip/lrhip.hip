@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
@@ -120,6 +121,7 @@ struct lrhip_ctx {
     bool timed{false};
     uint32_t byte_textures{1u};  // 8-bit images as 8-bit texels on the device (lrhip_upload_scene): lrhip_set_texture_storage: 0 never, 1 = where the scene's float texels exceed kByteTextureFloatBytes, 2 always
     uint64_t packed_texel_words{0u};// texels of the uploaded scene held as 8-bit codes (lrhip_packed_texels)
+    uint64_t texel_bytes{0u};       // bytes of the texel table on the device (float texels of the images that stay float + the packed words)
     bool in_split{false};        // lrhip_render is rendering a call in sample sub-ranges (below): the first sub-range's begin event stands for the call
     std::vector<DeviceBuffer> scene_buffers;
     lrd::DScene scene{};
@@ -450,12 +452,12 @@ int lrhip_update_scene(lrhip_ctx *ctx, const lr_scene *s) {
 // all four channels do and the coded ones agree on the form.  The device's decode reproduces the host's floats bit for bit: form 1 is
 // the same multiplication, form 2 is checked against the division for all 256 codes first.  Returns the packed words; `textures` (the
 // copy that goes to the device) gets the new offsets, the form and the constant channels.
+// Offsets of packed images come out relative to the packed area.
 constexpr uint64_t kByteTextureFloatBytes = 192ull << 20u;
 static std::vector<uint32_t> pack_byte_textures(const lr_scene *s, std::vector<lr_texture> &textures) {
     std::vector<uint32_t> packed;
     auto division_ok = true;
     for (auto b = 0u; b < 256u; b++) { division_ok = division_ok && lrd::byte_over_255(static_cast<float>(b)) == static_cast<float>(b) / 255.f; }
-    const auto base = static_cast<uint64_t>(s->texel_count) * 4u;// the float texels, in 32-bit words
     for (auto &t : textures) {
         t.pad = 0u;
         const auto count = static_cast<uint64_t>(t.width) * t.height;
@@ -486,7 +488,7 @@ static std::vector<uint32_t> pack_byte_textures(const lr_scene *s, std::vector<l
         if (use == 0u) { continue; }
         t.pad = use | (constant << 4u);
         for (auto c = 0u; c < 4u; c++) { if ((constant >> c) & 1u) { t.v[c] = px[c]; } }
-        t.texel_offset = base + packed.size();
+        t.texel_offset = packed.size();// (relative to the packed area: lrhip_upload_scene adds its base)
         for (uint64_t i = 0u; i < count; i++) {
             auto word = 0u;
             for (auto c = 0u; c < 4u; c++) {
@@ -577,7 +579,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     // a leaf names its triangle in 27 bits (the sentinel of the empty slots is one more); the traversal loop addresses packets and leaf
     // triangles by 32-bit byte offsets from their table bases (64 B x 2^26 packets, 48 B x 89 478 484 triangles = 4 GiB)
     constexpr uint32_t kMaxBvhTriangles = static_cast<uint32_t>((1ull << 32u) / sizeof(lr_bvh_triangle)) - 2u;
-    static_assert(sizeof(lr_bvh_triangle) == 48u && kMaxBvhTriangles < (1u << 27u) - 1u, "dev_trace.h: trav_leaf_fetch multiplies the leaf's triangle index by 48 in 32 bits");
+    static_assert(sizeof(lr_bvh_triangle) == 48u && kMaxBvhTriangles < lrd::kLeafIndexMask, "dev_trace.h: trav_leaf_fetch multiplies the leaf's triangle index by 48 in 32 bits");
     if (s->accel.triangle_count >= kMaxBvhTriangles || s->accel.node_count >= (1u << 26u)) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: more than 89 478 482 BVH triangles or 2^26 - 1 BVH packets");
     }
@@ -610,7 +612,6 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     LR_UP(upload(ctx, s->tri_alias, s->triangle_count, &d.tri_alias));
     LR_UP(upload(ctx, s->tri_pdf, s->triangle_count, &d.tri_pdf));
     LR_UP(upload(ctx, s->light_instances, s->light_instance_count, &d.light_instances));
-    LR_UP(upload(ctx, s->surfaces, s->surface_count, &d.surfaces));
     {// textures: 8-bit images are uploaded as 8-bit texels (pack_byte_textures above; dev_shade.h: texel_at), behind the float texels
         std::vector<lr_texture> textures(s->textures, s->textures + s->texture_count);
         // ... where the float texels are more than the caches hold: the decode costs a few instructions per texel, which a scene whose
@@ -621,16 +622,45 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         const auto pack = ctx->byte_textures == 2u || (ctx->byte_textures == 1u && image_texels * 16u > kByteTextureFloatBytes);
         for (auto &t : textures) { t.pad = 0u; }
         const auto packed = pack ? pack_byte_textures(s, textures) : std::vector<uint32_t>{};
+        // The float texels of an image that is held packed do NOT go to the device as well (the camera class kept 512 MB of dead
+        // floats beside its 128 MB of codes): what is uploaded is the union of the texel ranges the float-kept images name, closed up, with
+        // their offsets rebased (ranges that overlap -- two records over one image -- stay one range).
+        std::vector<std::pair<uint64_t, uint64_t>> ranges;// [begin, end) in texels, of the images that stay float
+        for (auto &t : textures) {
+            const auto count = static_cast<uint64_t>(t.width) * t.height;
+            if (t.kind == LR_TEX_IMAGE && t.pad == 0u && count != 0u && t.texel_offset + count <= s->texel_count) { ranges.emplace_back(t.texel_offset, t.texel_offset + count); }
+        }
+        std::sort(ranges.begin(), ranges.end());
+        std::vector<std::array<uint64_t, 3>> kept;// merged ranges: begin, end, where it starts on the device
+        uint64_t kept_texels = 0u;
+        for (auto &r : ranges) {
+            if (!kept.empty() && r.first <= kept.back()[1]) {
+                if (r.second > kept.back()[1]) { kept_texels += r.second - kept.back()[1], kept.back()[1] = r.second; }
+            } else {
+                kept.push_back({r.first, r.second, kept_texels}), kept_texels += r.second - r.first;
+            }
+        }
+        if (packed.empty()) { kept.assign(1u, {0u, s->texel_count, 0u}), kept_texels = s->texel_count; }// (nothing packed: the table as the host made it)
+        for (auto &t : textures) {
+            if (t.kind != LR_TEX_IMAGE) { continue; }
+            if (t.pad != 0u) { t.texel_offset += kept_texels * 4u; continue; }// packed: 32-bit words from the same base, behind the floats
+            for (auto &k : kept) {
+                if (t.texel_offset >= k[0] && t.texel_offset < k[1]) { t.texel_offset = t.texel_offset - k[0] + k[2]; break; }
+            }
+        }
         LR_UP(upload(ctx, textures.data(), textures.size(), &d.textures));
         DeviceBuffer b;
-        const auto float_bytes = static_cast<size_t>(s->texel_count) * 4u * sizeof(float);
+        const auto float_bytes = static_cast<size_t>(kept_texels) * 4u * sizeof(float);
         b.bytes = std::max<size_t>(float_bytes + packed.size() * sizeof(uint32_t), 16u);
         LR_HIP_CHECK(hipMalloc(&b.ptr, b.bytes));
         ctx->scene_buffers.emplace_back(b);
-        if (float_bytes != 0u) { LR_HIP_CHECK(hipMemcpy(b.ptr, s->texels, float_bytes, hipMemcpyHostToDevice)); }
+        for (auto &k : kept) {
+            if (k[1] > k[0]) { LR_HIP_CHECK(hipMemcpy(static_cast<char *>(b.ptr) + k[2] * 16u, s->texels + k[0] * 4u, (k[1] - k[0]) * 16u, hipMemcpyHostToDevice)); }
+        }
         if (!packed.empty()) { LR_HIP_CHECK(hipMemcpy(static_cast<char *>(b.ptr) + float_bytes, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
         d.texels = static_cast<const float *>(b.ptr);
         ctx->packed_texel_words = packed.size();
+        ctx->texel_bytes = b.bytes;
     }
     LR_UP(upload(ctx, &s->filter, 1u, &d.filter));
     auto instances = build_instances(s);
@@ -644,6 +674,23 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     // closures: fold constant textures on the host (same arithmetic as the per-hit device path)
     auto is_constant = [&](int32_t id) { return id < 0 || s->textures[id].kind == LR_TEX_CONSTANT; };
     std::vector<lrd::DClosure> closures(s->surface_count);
+    // the surfaces as the device reads them for dynamic closures: the host's record + every texture slot's value where its texture is
+    // constant + which slots need a lookup per hit (dev_scene.h: DSurface)
+    std::vector<lrd::DSurface> surfaces(s->surface_count);
+    for (uint32_t i = 0; i < s->surface_count; i++) {
+        auto &rec = surfaces[i];
+        std::memset(&rec, 0, sizeof(rec));
+        rec.raw = s->surfaces[i];
+        for (auto slot = 0u; slot < lrd::kSurfaceSlots; slot++) {
+            const auto id = rec.raw.tex[slot];
+            if (id < 0) { continue; }
+            auto &t = s->textures[id];
+            if (t.kind == LR_TEX_CONSTANT) { std::memcpy(rec.value[slot], t.v, sizeof(t.v)); }
+            else { rec.dynamic_mask |= 1u << slot; }
+            rec.channels[slot >> 3u] |= (t.channels & 15u) << ((slot & 7u) * 4u);
+        }
+    }
+    LR_UP(upload(ctx, surfaces.data(), surfaces.size(), &d.surfaces));
     for (uint32_t i = 0; i < s->surface_count; i++) {
         auto &surf = s->surfaces[i];
         if (surf.kind == LR_SURFACE_DISNEY) { ctx->features |= lrd::kFeatDisney; }
@@ -703,11 +750,11 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         if (!dynamic) {
             c = lrd::resolve_closure(
                 surf,
-                [&](int32_t id) {
-                    auto &t = s->textures[id];
+                [&](int slot) {
+                    auto &t = s->textures[surf.tex[slot]];
                     return make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
                 },
-                [&](int32_t id) { return s->textures[id].channels; }, 1.f);
+                [&](int slot) { return s->textures[surf.tex[slot]].channels; }, 1.f);
         } else {
             c.kind = surf.kind;
             c.x[0] = surf.u[0], c.x[1] = surf.u[1], c.x[2] = surf.u[2], c.x[3] = surf.u[3];// children / masks are needed before resolution
@@ -1197,6 +1244,24 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     return LRHIP_OK;
 }
 
+// Which of the kernels that sum the film in 64-bit fixed point a call of this scene takes, PROVIDED the sums fit (fixed_point_bits):
+// 1 wavefront mode (render_wavefront), 2 a pool kernel, 0 neither (the float-accumulating kernels of rounds 1-3).  One place for the
+// conditions: lrhip_render decides with it whether a call beyond the fixed-point range is worth rendering in sample sub-ranges.
+static int fixed_point_film_kind(const lrhip_ctx *ctx, bool count, bool generic) {
+    if (ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        const auto plain = pick_variant(ctx->features, false, generic);
+        if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) { return 1; }
+    }
+    auto features = ctx->features | (ctx->diag_force_features & lrd::kFeatSceneMask);
+    if (ctx->env_tree && (features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) { features |= lrd::kFeatMix; }
+    const auto vi = pick_variant(features, count, generic);
+    if (wants_pool(ctx) && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
+        const auto vp = pick_variant(features, count, generic, true);
+        if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { return 2; }
+    }
+    return 0;
+}
+
 int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (ctx == nullptr || p == nullptr || !ctx->scene_ready) { return fail(LRHIP_ERROR_INVALID, "lrhip_render: no scene uploaded"); }
     auto tiles_x = (ctx->width + 7u) / 8u, tiles_y = (ctx->height + 7u) / 8u;
@@ -1222,26 +1287,29 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // sub-ranges that do, one resolve into the float film per range, instead of silently leaving wavefront mode and the pool kernels for the
     // all-in-one variants (the kitchen class runs at ~300 instead of ~560 Msamples/s there).  Only a clamp that does not even
     // hold ONE sample (switched off: 1e20, inf) still takes the float-accumulating kernels -- lrhip.h says so.
-    if (fixed_bits < 0 && !ctx->in_split && fixed_point_bits(ctx->scene.film_clamp, weight, 1u) >= 0) {
+    // (Only where the frame WOULD be summed in fixed point -- wavefront mode or a pool kernel, the conditions of the two branches below:
+    // the float-accumulating kernels render such a call in one launch as before, in their usual order of adds.  ADVICE r05.)
+    const auto count_flag = (p->flags & LRHIP_RENDER_COUNTERS) != 0u;
+    const auto generic_flag = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
+    if (fixed_bits < 0 && !ctx->in_split && fixed_point_bits(ctx->scene.film_clamp, weight, 1u) >= 0 && fixed_point_film_kind(ctx, count_flag, generic_flag) != 0) {
         auto n = spp;
         while (n > 1u && fixed_point_bits(ctx->scene.film_clamp, weight, n) < 0) { n = (n + 1u) / 2u; }
+        LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));// (before the flag: a failure here must not leave it set)
+        struct SplitGuard {
+            lrhip_ctx *c;
+            ~SplitGuard() { c->in_split = false; }
+        } guard{ctx};
         ctx->in_split = true;
-        LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream));
         auto rc = LRHIP_OK;
         for (auto s0 = p->spp_begin; s0 < p->spp_end && rc == LRHIP_OK; s0 += n) {
             auto sub = *p;
             sub.spp_begin = s0, sub.spp_end = std::min(p->spp_end, s0 + n);
             rc = lrhip_render(ctx, &sub);
         }
-        ctx->in_split = false;
         return rc;
     }
-    if (fixed_bits >= 0 && ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        const auto generic_sampler = ctx->scene.sampler_kind != LR_SAMPLER_INDEPENDENT;
-        const auto plain = pick_variant(ctx->features, false, generic_sampler);
-        if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) {
-            return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, (p->flags & LRHIP_RENDER_COUNTERS) != 0u, generic_sampler);
-        }
+    if (fixed_bits >= 0 && fixed_point_film_kind(ctx, count_flag, generic_flag) == 1) {
+        return render_wavefront(ctx, p, tiles_x, tiles_y, tiles_in_range, tile_count, count_flag, generic_flag);
     }
     // Chunking (chunking_of above: tapered items) is a function of the frame only (tile_count, spp, balance_shards), never of the device or the tile
     // range of this call: tile_count is that of ONE shard of the frame as the caller declares it (balance_shards), so that every shard

@@ -186,7 +186,11 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
     auto spb = tl.spb_of(tr.sp);
     if (tr.phase == kPhaseIdle) { tr.cur = kCurIdle; }// (inside the loop a lane's state is read off `cur`: dev_trace.h, TravLane)
     auto for_alpha = false;// (ALPHA: the wave leaves for the alpha tests of its parked candidates and comes straight back)
+#ifdef LR_STALL_PROBE
+    if (COUNT) { probe_start(stats); }
+#endif
     for (;;) {
+        LR_MARK(kProbeTail, tr.cur);// (dev_trace.h, THE STALL PROBE: what the end of the previous iteration took)
         if (COUNT) {
             stats.steps++, stats.steps_busy += tr.phase != kPhaseIdle ? 1u : 0u;
 #ifndef LR_TRACE_PROBE
@@ -236,6 +240,7 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
         if (lr_ballot(tr.cur != kCurIdle) == 0ull) { break; }
         if (pool_shade_due(tr.phase, cur.flags, oth.flags, samples_left)) { break; }
     }
+    LR_MARK(kProbeTail, tr.cur);
     prio_shade();
     tr.sp = tl.sp_of(spb);
     return for_alpha;
@@ -261,6 +266,15 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     static_assert(kStackLds + 5u <= 16u, "the parking area is carved out of the round 1-3 stack: compile such pool variants with LR_STACK_LDS <= 11");
 #endif
     __shared__ unsigned long long s_film[CONT ? 1u : kWavesPerBlock * 192u];// per-wave tile accumulators, fixed point [pixel][rgb]
+#ifdef LR_STALL_PROBE
+    __shared__ uint32_t s_probe[kWavesPerBlock * kProbeWords];
+    if ((threadIdx.x & 63u) < kProbeWords) { s_probe[(threadIdx.x >> 6u) * kProbeWords + (threadIdx.x & 63u)] = 0u; }// (every wave its own words)
+    // one wave in 36 takes the timestamps and reports (dev_trace.h: THE STALL PROBE): wave (block / 9) % 4 of every ninth block -- spread over the
+    // XCDs (blocks go round the eight of them) and over the SIMDs.  (With EVERY wave adding its shading sections to the four global counters after
+    // every batch -- 80 million atomics on one cache line per frame -- one L2 channel was the bottleneck of the whole kernel: every gather that
+    // crossed it queued behind them, and the probed kernel ran 3.5 times slower in all its waves.)
+    const auto probe_wave = (F & kFeatCount) != 0u && (blockIdx.x % 9u) == 0u && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6u) == ((blockIdx.x / 9u) & 3u);
+#endif
     const auto tid = threadIdx.x;
     const auto lane = tid & 63u;
     const auto gtid = blockIdx.x * kBlockThreads + tid;
@@ -446,6 +460,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             }
             auto want_shadow = false, want_closest = false;
             unsigned long long t_closure_sum = 0ull;// (COUNT: wave cycles inside the closure section of this batch; lanes agree)
+#ifdef LR_STALL_PROBE
+            uint32_t t_lobe = 0u, t_eval = 0u, t_sample = 0u, t_hit = 0u, t_light = 0u;// (sections of the block, lrhip_counters::probe[8..11] + [7] is the traversal's)
+            const auto probe_clock = []() { return static_cast<uint32_t>(__builtin_readcyclecounter()); };
+            const auto t_block = probe_clock();
+#endif
             auto park_kind = kInvalid;// WF: closure kind (0 Disney, 1 Mix, 2 Layered) of the heavy surface this path just reached
             if (path_open) {
                 if (traced_shadow) {// direct lighting of the bounce that spawned the shadow ray, mega_path.cpp:124-130
@@ -474,6 +493,9 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     }
                     SurfacePoint it;
                     auto has_surface = false;
+#ifdef LR_STALL_PROBE
+                    const auto t_h0 = probe_clock();
+#endif
                     if (hit_valid) {
                         reconstruct_baked(scene, hit_tri, hit_u, hit_v, it);
                         it.back_facing = dot(wo, it.ng) < 0.0f;
@@ -518,6 +540,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             }
                         }
                     }
+#ifdef LR_STALL_PROBE
+                    asm volatile("" : "+v"(it.p.x), "+v"(it.ng.x), "+v"(Li.x));
+                    const auto t_h1 = probe_clock();
+                    t_hit = t_h1 - t_h0;
+#endif
                     if (has_surface) {
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
@@ -531,12 +558,23 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63 (dev_shade.h: sample_one_light)
                         const auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
                         shadow = pick.shadow;
+#ifdef LR_STALL_PROBE
+                        asm volatile("" : "+v"(shadow.o.x), "+v"(shadow.d.x));
+#endif
                         const auto t_closure = COUNT ? __builtin_readcyclecounter() : 0ull;
+#ifdef LR_STALL_PROBE
+                        t_light = static_cast<uint32_t>(t_closure) - t_h1;
+#endif
                         // ---- material, mega_path.cpp:111-143: the five basic closures (and Disney in a <Disney> variant) inline
                         const LobeTables tables{scene.closures, scene.surfaces, scene.textures, scene.texels};
                         DClosure closure;
                         Frame sh;
                         load_lobe(tables, it.uv, it.ng, wo, (it.tags >> 12u) & 4095u, it.shading, closure, sh);
+#ifdef LR_STALL_PROBE
+                        asm volatile("" : "+v"(closure.c0[0]), "+v"(closure.s0), "+v"(sh.n.x));
+                        const auto t_l1 = probe_clock();
+                        t_lobe = t_l1 - static_cast<uint32_t>(t_closure);
+#endif
                         if (pick.pdf > 0.0f) {
                             const auto eval = closure_evaluate<DISNEY>(closure, sh, it.ng, wo, shadow.d);
                             const auto w = balance(pick.pdf, eval.pdf) / pick.pdf;
@@ -544,6 +582,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             // the reference traces the shadow ray unconditionally; a zero contribution cannot change Li
                             want_shadow = nee.x != 0.f || nee.y != 0.f || nee.z != 0.f;
                         }
+#ifdef LR_STALL_PROBE
+                        asm volatile("" : "+v"(nee.x), "+v"(nee.y), "+v"(nee.z));
+                        const auto t_e1 = probe_clock();
+                        t_eval = t_e1 - t_l1;
+#endif
                         {
                             if (PCG) { sampler_take(); }
                             u_lobe = sampler.next_1d();
@@ -579,6 +622,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         dp++;// (depth < 65536: lrhip_render sends deeper paths to the round 1-3 kernels)
                         want_closest = alive && (dp & 0xffffu) < scene.max_depth;
                         if (COUNT) { t_closure_sum += __builtin_readcyclecounter() - t_closure; }
+#ifdef LR_STALL_PROBE
+                        asm volatile("" : "+v"(beta.x), "+v"(ray.d.x));
+                        t_sample = probe_clock() - t_e1;
+#endif
                     }
                 }
             }
@@ -731,6 +778,23 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 ctx_swap(cur, oth);
                 ctx_start(cur, tr);
             }
+#ifdef LR_STALL_PROBE
+            if (COUNT) {// the block's sections as the slowest lane saw them (lanes that ran a section agree to within its divergence)
+                const auto wave_max = [](uint32_t v) {
+                    for (auto off = 32; off > 0; off >>= 1) { v = max(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), off))); }
+                    return v;
+                };
+                const auto m_hit = wave_max(t_hit), m_light = wave_max(t_light), m_lobe = wave_max(t_lobe), m_eval = wave_max(t_eval), m_sample = wave_max(t_sample);
+                if (probe_wave && lane == 0u) {
+                    atomicAdd(&args.counters->probe[14], 1ull);// (batches of the reporting waves)
+                    atomicAdd(&args.counters->probe[15], static_cast<unsigned long long>(probe_clock() - t_block));// (... and their cycles in the block)
+                    atomicAdd(&args.counters->probe[8], static_cast<unsigned long long>(m_hit + m_light));
+                    atomicAdd(&args.counters->probe[9], static_cast<unsigned long long>(m_lobe));
+                    atomicAdd(&args.counters->probe[10], static_cast<unsigned long long>(m_eval));
+                    atomicAdd(&args.counters->probe[11], static_cast<unsigned long long>(m_sample));
+                }
+            }
+#endif
             if (COUNT) {
                 if (lane == 0u) {
                     const auto t_end = __builtin_readcyclecounter();
@@ -743,7 +807,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
         }
         if (!lr_any(tr.phase != kPhaseIdle)) { break; }// nothing in flight and nothing to shade: every context of the wave is out of samples
         // ==== (B) traverse: lanes switch to their other context's job inside the loop
-        TraceStats ts{0u, 0u, 0u, 0u, 0u, 0u};
+        TraceStats ts{};
+#ifdef LR_STALL_PROBE
+        ts.probe_lds = probe_wave ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>((TraversalStack::lds_u32 *)(s_probe + wave_in_block * kProbeWords))) : 0u;
+#endif
         const auto t_trace = COUNT ? __builtin_readcyclecounter() : 0ull;
         for (;;) {
             const auto for_alpha = pool_trace<COUNT, ALPHA>(scene, stack, tr, cur, oth, items_left || q_next < q_total, ts);
@@ -752,6 +819,15 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
             if (lr_any((tr.phase & kPhasePendingAlpha) != 0u)) { resolve_pending_alpha(scene, stack, tr); }
             if (!for_alpha) { break; }
         }
+#ifdef LR_STALL_PROBE
+        if (COUNT && ts.probe_lds != 0u && lane == 0u) {// section cycles of this traversal call (the wave's LDS words) -> lrhip_counters::probe
+            const auto words = s_probe + wave_in_block * kProbeWords;
+#pragma unroll
+            for (auto i = 0u; i < kProbeSlots; i++) { atomicAdd(&args.counters->probe[i], static_cast<unsigned long long>(words[i])), words[i] = 0u; }
+            atomicAdd(&args.counters->probe[12], static_cast<unsigned long long>(ts.steps));// the sampled waves' iterations ...
+            atomicAdd(&args.counters->probe[13], static_cast<unsigned long long>(__builtin_readcyclecounter() - t_trace));// ... and their cycles in the loop
+        }
+#endif
         if (COUNT) {
             if (lane == 0u) { local.trace_cycles += __builtin_readcyclecounter() - t_trace; }
             local.nodes_visited += ts.nodes, local.tris_tested += ts.tris, local.nodes_empty += ts.nodes_empty;
