@@ -151,6 +151,7 @@ double lrhip_last_render_ms(lrhip_ctx *ctx);
 #define LRHIP_FEAT_ENVIRONMENT 4u
 #define LRHIP_FEAT_ALPHA 8u
 #define LRHIP_FEAT_DISNEY 16u
+#define LRHIP_FEAT_BYTE_TEXELS 8192u /* a lean kernel that decodes 8-bit texels (lrhip_set_texture_storage) */
 #define LRHIP_FEAT_MIX 32u
 #define LRHIP_FEAT_LAYERED 64u
 #define LRHIP_FEAT_AUX_INTEGRATORS 128u
@@ -213,7 +214,11 @@ int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode);
  * made (both of the host readers' conversions, b * (1 / 255.f) and b / 255.f, bit for bit: tests/test_gpu_parity.py).
  *   mode  1 = automatic (default): where the scene's image texels exceed 192 MB as floats (below that the caches hold them and the
  *             decode's few instructions per texel are not paid back: kitchen class -1.5 %, camera class +4 %);
- *         0 = never; 2 = every image that qualifies (A/B, tests)                                                                      */
+ *         0 = never; 2 = every image that qualifies (A/B, tests).
+ * Round 6: the decode is compiled into the kernels that need it only (lean kernels of the LRHIP_FEAT_BYTE_TEXELS bit -- the Disney feature
+ * sets of both schedulers -- and every variant that makes real calls); a MegaPath scene with alpha-tested, Mix or Layered surfaces or
+ * nested Combined environments renders on kernels without it and keeps float texels under mode 1; mode 2 on such a scene is
+ * LRHIP_ERROR_UNSUPPORTED at upload.  The float texels of a packed image are not uploaded as well.                                    */
 int lrhip_set_texture_storage(lrhip_ctx *ctx, uint32_t mode);
 uint64_t lrhip_packed_texels(lrhip_ctx *ctx); /* texels of the uploaded scene held as 8-bit codes (4 bytes each instead of 16) */
 

@@ -20,8 +20,20 @@ namespace lrd {
 #ifndef LR_LOBE_IMAGE_PASSES
 #define LR_LOBE_IMAGE_PASSES 4// looked-up slots of a surface kept in registers (more than these: looked up where the closure's code asks)
 #endif
+// LR_LOBE_FORM 2: the first two looked-up slots of every lane in two WAVE-LEVEL passes ahead of the kinds' own code -- a batch whose lanes
+// stand on Disney, Plastic and Matte surfaces with two image maps each makes two lookups, not five one kind after the other.  Camera class
+// (<4116>) 1075 -> 1125 Msamples/s at 64 spp, films bit-identical; but the six registers the results wait in cost the kernels whose scenes
+// hold no image at all their allocation: C2 <4096> 1075 -> 1032, the kitchen class' wavefront passes 585 -> 577 (profiles/r06i_lobe_forms.txt).
+// So: in the lean kernels WITH the Disney closure (the variants textured scenes of the camera class' kind take), form 1 elsewhere.
+// Measured with it and not kept: the closure resolution as one out-of-line function with the passes inside (its 41 words of result through
+// memory, 340 scratch instructions of callee saves per call: every configuration 5 - 12 % slower, r06g), and touching the texels ahead of
+// the lookups instead of keeping results (-7 %, r06i).
 #ifndef LR_LOBE_FORM
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 16) && !((LR_VARIANT) & (96 | 256))
+#define LR_LOBE_FORM 2
+#else
 #define LR_LOBE_FORM 1
+#endif
 #endif
 // closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
 // per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
@@ -44,10 +56,40 @@ LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const
         // other slots' and issued with them, where it used to be a call and a dependent round trip through the texture table each
         const auto lookup = [&](int32_t id) LR_TEX_LAMBDA { return texture_eval_tables(tb.textures, tb.texels, id, uv); };
         const auto mask = rec.dynamic_mask;
+#if LR_LOBE_FORM == 2
+        f3 looked0 = mk3(0.f), looked1 = mk3(0.f);
+        {
+            auto left = mask;
+            if (lr_any(left != 0u)) {
+                if (left != 0u) {
+                    const auto slot = static_cast<uint32_t>(__builtin_ctz(left));
+                    left &= left - 1u;
+                    const auto v = lookup(raw.tex[slot]);
+                    looked0 = mk3(v.x, v.y, v.z);
+                }
+                if (lr_any(left != 0u)) {
+                    if (left != 0u) {
+                        const auto slot = static_cast<uint32_t>(__builtin_ctz(left));
+                        const auto v = lookup(raw.tex[slot]);
+                        looked1 = mk3(v.x, v.y, v.z);
+                    }
+                }
+            }
+        }
+#endif
         c = resolve_closure(
             raw,
             [&](int slot) {
+#if LR_LOBE_FORM == 2
+                if ((mask >> slot) & 1u) {
+                    const auto rank = __builtin_popcount(mask & ((1u << slot) - 1u));
+                    if (rank >= 2) { return lookup(raw.tex[slot]); }
+                    const auto v = rank == 0 ? looked0 : looked1;
+                    return make_float4(v.x, v.y, v.z, 0.f);
+                }
+#else
                 if ((mask >> slot) & 1u) { return lookup(raw.tex[slot]); }
+#endif
                 return *reinterpret_cast<const float4 *>(rec.value[slot]);
             },
             [&](int slot) { return (rec.channels[slot >> 3] >> ((slot & 7) * 4)) & 15u; }, eta_i);

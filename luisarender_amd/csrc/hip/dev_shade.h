@@ -382,6 +382,14 @@ LR_D float pow_nonpositive(float c, float g) {
 // footprint: the camera-class stand-in's eight 2k x 2k maps are 128 MB instead of 512 MB, and the frame runs 3.5-4 % faster
 // (profiles/r05zd_byte_textures.txt; profiles/r05zb_c4_texture_size.txt: the same frame with smaller images).  Which scenes get it:
 // lrhip_set_texture_storage (lrhip.h).
+// (compiled into the variants that make real calls, the heavy kernels and the lean kernels of the kFeatByteTex bit: dev_wavefront.h)
+#ifndef LR_BYTE_TEXELS
+#if defined(LR_VARIANT) && !((LR_VARIANT) & (96 | 256 | 8192))
+#define LR_BYTE_TEXELS 0
+#else
+#define LR_BYTE_TEXELS 1
+#endif
+#endif
 LR_HD float byte_over_255(float b) {// correctly rounded b / 255.f for b = 0 .. 255: one Newton step on the reciprocal product
     const auto q = b * (1.f / 255.f);
     const auto r = fmaf(-q, 255.f, b);
@@ -389,7 +397,7 @@ LR_HD float byte_over_255(float b) {// correctly rounded b / 255.f for b = 0 .. 
 }
 LR_D float4 texel_at(const float *texels, const lr_texture &t, int xx, int yy) {
     const auto index = static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx);
-    if (t.pad == 0u) { return reinterpret_cast<const float4 *>(texels)[t.texel_offset + index]; }
+    if (!LR_BYTE_TEXELS || t.pad == 0u) { return reinterpret_cast<const float4 *>(texels)[t.texel_offset + index]; }
     const auto p = reinterpret_cast<const uint32_t *>(texels)[t.texel_offset + index];
     // b * (1 / 255.f) is byte_over_255 without its correction step: one expression for both forms, the correction's weight 0 under form 1.
     // (Measured on the camera-class frame, films bit-identical: this against a select between the two forms +0.5 %, the texels in tiles of
@@ -402,7 +410,9 @@ LR_D float4 texel_at(const float *texels, const lr_texture &t, int xx, int yy) {
         const auto v = fmaf(fmaf(-q, 255.f, f), k, q);
         return (t.pad & (16u << c)) != 0u ? t.v[c] : v;
     };
-    return make_float4(code(p & 255u, 0u), code((p >> 8u) & 255u, 1u), code((p >> 16u) & 255u, 2u), code(p >> 24u, 3u));
+    // (x, y, z only: no consumer on the device reads a texture's fourth channel -- closure parameters, emission, normal maps take xyz, opacity
+    // and scalars x -- and behind the out-of-line lookup the compiler cannot know that; round 6)
+    return make_float4(code(p & 255u, 0u), code((p >> 8u) & 255u, 1u), code((p >> 16u) & 255u, 2u), 0.f);
 }
 LR_D float4 texel_fetch(const float *texels, const lr_texture &t, int x, int y) {
     auto zero = false;
@@ -447,8 +457,7 @@ LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texe
         auto mix = [&](float a, float b, float c, float d) {
             return (a * (1.f - tx) + b * tx) * (1.f - ty) + (c * (1.f - tx) + d * tx) * ty;
         };
-        v = make_float4(mix(c00.x, c10.x, c01.x, c11.x), mix(c00.y, c10.y, c01.y, c11.y),
-                        mix(c00.z, c10.z, c01.z, c11.z), mix(c00.w, c10.w, c01.w, c11.w));
+        v = make_float4(mix(c00.x, c10.x, c01.x, c11.x), mix(c00.y, c10.y, c01.y, c11.y), mix(c00.z, c10.z, c01.z, c11.z), 0.f);
     }
     auto decode = [&](float c, int ch) {// image.cpp:138-153
         // x^y through the hardware's log2 / exp2 (v_log_f32 / v_exp_f32, ~1 ulp each) instead of powf (158 instructions with the
@@ -462,7 +471,7 @@ LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texe
         }
         return ti.scale[ch] * c;
     };
-    return make_float4(decode(v.x, 0), decode(v.y, 1), decode(v.z, 2), decode(v.w, 3));
+    return make_float4(decode(v.x, 0), decode(v.y, 1), decode(v.z, 2), 0.f);// (the fourth channel of an image: never read on the device, see texel_at)
 }
 LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) { return texture_eval_tables(scene.textures, scene.texels, id, uv_it); }
 

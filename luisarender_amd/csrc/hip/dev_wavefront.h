@@ -18,6 +18,11 @@ enum : uint32_t {
     kFeatWf = 1024u, kFeatCont = 2048u,
     // round 4: the path-pool scheduler (megapool_kernel.h) instead of one path per lane; exists for the lean masks and the wavefront passes
     kFeatPool = 4096u,
+    // round 6: the lean kernel decodes 8-bit texels (dev_shade.h: texel_at, LR_BYTE_TEXELS).  The decode's branch in the texture lookup cost
+    // every lean kernel its allocation -- C2, whose scene holds no image, 2.8 %, C3 1.7 %, C5 1.3 % (profiles/r06k_byte_texel_bit.txt) -- so it
+    // is compiled into the lean kernels of this bit only, which lrhip_render takes when the uploaded scene holds packed texels; the variants
+    // that make real calls (Mix / Layered / auxiliary / volumetric) and the heavy kernels keep it in their one out-of-line lookup
+    kFeatByteTex = 8192u,
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 

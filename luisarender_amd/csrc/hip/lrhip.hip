@@ -64,9 +64,13 @@ int find_variant(const VariantEntry *table, size_t n, uint32_t mask) {
 
 // smallest precompiled superset of the scene's feature bits (+ the count / generic-sampler bits, which are exact) among the
 // variants of one scheduler: `pool` = the path-pool kernels of round 4 (megapool_kernel.h), otherwise the one-path-per-lane kernels
-int pick_variant(uint32_t scene_features, bool count, bool generic, bool pool = false) {
+// `byte_texels`: the scene holds packed 8-bit texels -- only a kernel that decodes them will do (the lean ones of the kFeatByteTex bit, and every
+// variant that makes real calls: dev_wavefront.h); a scene without them never takes a kFeatByteTex kernel
+bool decodes_byte_texels(uint32_t mask) { return (mask & (lrd::kFeatByteTex | lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatVpt)) != 0u; }
+int pick_variant(uint32_t scene_features, bool count, bool generic, bool pool = false, bool byte_texels = false) {
     for (uint32_t i = 0u; i < lrd::kSceneVariantCount; i++) {
         if (((lrd::kSceneVariants[i] & lrd::kFeatPool) != 0u) != pool) { continue; }
+        if (byte_texels ? !decodes_byte_texels(lrd::kSceneVariants[i]) : (lrd::kSceneVariants[i] & lrd::kFeatByteTex) != 0u) { continue; }
         if ((lrd::kSceneVariants[i] & scene_features) == scene_features) {
             auto mask = lrd::kSceneVariants[i] | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
             for (uint32_t k = 0u; k < lrd::kSceneVariantCount * 4u; k++) {
@@ -619,7 +623,22 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
         // class, 512 MB: +4 %; the same frame at 128 MB of float texels: +-0 -- profiles/r05zd_byte_textures.txt, r05zc_byte_textures_always.txt, r05zb_c4_texture_size.txt)
         auto image_texels = static_cast<uint64_t>(0u);
         for (auto &t : textures) { if (t.kind == LR_TEX_IMAGE) { image_texels += static_cast<uint64_t>(t.width) * t.height; } }
-        const auto pack = ctx->byte_textures == 2u || (ctx->byte_textures == 1u && image_texels * 16u > kByteTextureFloatBytes);
+        // ... and where the kernels the scene renders on decode them (round 6: the decode is compiled into the lean kernels of the kFeatByteTex
+        // bit only, which exist for the Disney feature sets of both schedulers -- dev_wavefront.h): a scene with alpha-tested surfaces, Mix or
+        // Layered surfaces (wavefront mode: lean passes without the decode) or nested Combined environments keeps float texels.  The sibling
+        // integrators and the volumetric kernel run on variants that always decode.
+        auto lean_decodes = s->any_non_opaque == 0u;
+        for (uint32_t i = 0; i < s->surface_count && lean_decodes; i++) { lean_decodes = s->surfaces[i].kind != LR_SURFACE_MIX && s->surfaces[i].kind != LR_SURFACE_LAYERED; }
+        if (s->environment.kind == LR_ENV_COMBINED) {
+            for (uint32_t i = 0; i < s->environment_child_count; i++) { lean_decodes = lean_decodes && s->environment_children[i].kind != LR_ENV_COMBINED; }
+        }
+        const auto decodes = lean_decodes || s->integrator.kind != LR_INTEGRATOR_MEGAPATH;
+        if (ctx->byte_textures == 2u && !decodes) {
+            release_scene(ctx);
+            return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_upload_scene: texture storage mode 2 (always 8-bit texels) on a scene whose kernels do not decode them "
+                                                 "(alpha-tested, Mix or Layered surfaces, nested Combined environments under MegaPath)");
+        }
+        const auto pack = decodes && (ctx->byte_textures == 2u || (ctx->byte_textures == 1u && image_texels * 16u > kByteTextureFloatBytes));
         for (auto &t : textures) { t.pad = 0u; }
         const auto packed = pack ? pack_byte_textures(s, textures) : std::vector<uint32_t>{};
         // The float texels of an image that is held packed do NOT go to the device as well (the camera class kept 512 MB of dead
@@ -1091,6 +1110,9 @@ int ensure_pool(lrhip_ctx *ctx, uint32_t resident_blocks) {
 // persistent ones (an empty round costs a few microseconds), so a slice is one uninterrupted stretch of the stream.
 static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32_t tiles_x, uint32_t tiles_y, uint32_t tiles_in_range,
                             uint32_t tile_count, bool count, bool generic) {
+    if (ctx->packed_texel_words != 0u) {// (lrhip_upload_scene packs no scene that renders in wavefront mode: its lean passes hold no 8-bit texel decode)
+        return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: wavefront mode with 8-bit texels on the device (lrhip_set_texture_storage)");
+    }
     const auto spp = p->spp_end - p->spp_begin;
     const auto pixel_count = ctx->width * ctx->height;
     const auto sampler_words = generic ? lrd::kWfSamplerWordsMax : 1u;
@@ -1249,14 +1271,15 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
 // conditions: lrhip_render decides with it whether a call beyond the fixed-point range is worth rendering in sample sub-ranges.
 static int fixed_point_film_kind(const lrhip_ctx *ctx, bool count, bool generic) {
     if (ctx->wf_mode != 1u && ctx->diag_force_features == 0u && !ctx->env_tree && (ctx->features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        const auto plain = pick_variant(ctx->features, false, generic);
+        const auto plain = pick_variant(ctx->features, false, generic, false, ctx->packed_texel_words != 0u);
         if (plain >= 0 && (kVariants[plain].mask & (lrd::kFeatMix | lrd::kFeatLayered)) != 0u) { return 1; }
     }
     auto features = ctx->features | (ctx->diag_force_features & lrd::kFeatSceneMask);
     if (ctx->env_tree && (features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) { features |= lrd::kFeatMix; }
-    const auto vi = pick_variant(features, count, generic);
+    const auto byte_texels = ctx->packed_texel_words != 0u;
+    const auto vi = pick_variant(features, count, generic, false, byte_texels);
     if (wants_pool(ctx) && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        const auto vp = pick_variant(features, count, generic, true);
+        const auto vp = pick_variant(features, count, generic, true, byte_texels);
         if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { return 2; }
     }
     return 0;
@@ -1342,12 +1365,13 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     // nested Combined environments are walked by out-of-line code (dev_shade.h: LR_ENV_TREE), which the variants that make real calls
     // anyway hold -- the ones with the Mix interpreter (the auxiliary and volumetric kernels are such variants already)
     if (ctx->env_tree && (features & (lrd::kFeatAux | lrd::kFeatVpt)) == 0u) { features |= lrd::kFeatMix; }
-    auto vi = pick_variant(features, count, generic);
+    const auto byte_texels = ctx->packed_texel_words != 0u;// (only a kernel that decodes 8-bit texels will do: pick_variant)
+    auto vi = pick_variant(features, count, generic, false, byte_texels);
     // round 4: the path-pool scheduler (megapool_kernel.h) where a pool kernel is compiled for a scene the legacy search would have given
     // a lean kernel (no out-of-line closures, no sibling integrator), and the fixed-point film can hold the frame
     auto pool = false;
     if (wants_pool(ctx) && fixed_bits >= 0 && ctx->scene.max_depth < 65536u && vi >= 0 && (kVariants[vi].mask & (lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatAux | lrd::kFeatVpt)) == 0u) {
-        const auto vp = pick_variant(features, count, generic, true);
+        const auto vp = pick_variant(features, count, generic, true, byte_texels);
         if (vp >= 0 && kVariants[vp].launch != nullptr && kVariants[vp].occupancy != nullptr && (kVariants[vp].mask & lrd::kFeatWf) == 0u) { vi = vp, pool = true; }
     }
     if (vi < 0 || kVariants[vi].launch == nullptr || kVariants[vi].occupancy == nullptr) {

@@ -54,6 +54,11 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatEnv | kFeatAlpha,
     kFeatDisney,
     kFeatEnv | kFeatDisney,
+    // round 6: lean kernels that decode 8-bit texels (kFeatByteTex), both schedulers: the Disney sets, which serve every packed scene
+    // without alpha tests or Mix / Layered surfaces (lrhip_upload_scene packs no other scene's images).  AHEAD of the call-making
+    // variants, which decode too: the search takes the first superset
+    kFeatByteTex | kFeatDisney,
+    kFeatByteTex | kFeatEnv | kFeatDisney,
     kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix,
     kFeatSceneMask,
     kFeatSceneMask | kFeatNest,
@@ -76,6 +81,8 @@ constexpr uint32_t kSceneVariants[] = {
     kFeatPool | kFeatEnv | kFeatAlpha,
     kFeatPool | kFeatDisney,
     kFeatPool | kFeatEnv | kFeatDisney,
+    kFeatByteTex | kFeatPool | kFeatDisney,
+    kFeatByteTex | kFeatPool | kFeatEnv | kFeatDisney,
     kFeatPool | kFeatWf,
     kFeatPool | kFeatEnv | kFeatWf,
     kFeatPool | kFeatAlpha | kFeatWf,

@@ -86,6 +86,9 @@ namespace lrd {
 // (profiles/r05q_fused_fetch_alpha_kernels.txt); the wavefront passes WITHOUT alpha gain 0.7 %.
 #define LR_POOL_FUSED_FETCH 1
 #endif
+#ifndef LR_POOL_FUSED_ALPHA
+#define LR_POOL_FUSED_ALPHA 0// (the ALPHA pool kernels under the fused flow: see above)
+#endif
 #ifndef LR_POOL_STATE_LEAN
 #define LR_POOL_STATE_LEAN 1
 #endif
@@ -200,7 +203,7 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
 #ifdef LR_TRACE_PROBE// (section cycles of the loop in the counting build: the iteration's walk -> nodes_empty, end of iteration -> trace_steps_starved; lane 0 reports)
         const auto probe_t0 = __builtin_readcyclecounter();
 #endif
-        trav_iteration<COUNT, ALPHA, LR_POOL_FUSED_FETCH != 0 && !ALPHA>(stack, tl, tr, spb, inv, stats);
+        trav_iteration<COUNT, ALPHA, LR_POOL_FUSED_FETCH != 0 && (!ALPHA || LR_POOL_FUSED_ALPHA != 0)>(stack, tl, tr, spb, inv, stats);
 #ifdef LR_TRACE_PROBE
         const auto probe_t1 = __builtin_readcyclecounter();
         const auto probe_t2 = probe_t1;

@@ -28,4 +28,6 @@
     /* ... the wavefront camera pass ... */ \
     X(5120) X(5121) X(5122) X(5123) X(5124) X(5125) X(5126) X(5127) X(5128) X(5129) X(5130) X(5131) X(5132) X(5133) X(5134) X(5135) \
     /* ... and the continuation pass */ \
-    X(7168) X(7169) X(7170) X(7171) X(7172) X(7173) X(7174) X(7175) X(7176) X(7177) X(7178) X(7179) X(7180) X(7181) X(7182) X(7183)
+    X(7168) X(7169) X(7170) X(7171) X(7172) X(7173) X(7174) X(7175) X(7176) X(7177) X(7178) X(7179) X(7180) X(7181) X(7182) X(7183) \
+    /* round 6: lean kernels that decode 8-bit texels (kFeatByteTex = 8192): Disney, environment + Disney, one path per lane and pool */ \
+    X(8208) X(8209) X(8210) X(8211) X(8212) X(8213) X(8214) X(8215) X(12304) X(12305) X(12306) X(12307) X(12308) X(12309) X(12310) X(12311)
