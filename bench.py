@@ -66,24 +66,48 @@ VALU_CYCLES_PER_WAVE_INSTR = (2.4, 4.2)
 # kernel <4096>; where two thirds of the instructions are issued) gives 828 issue cycles for 253 VALU instructions
 # (profiles/r05_isa_census_pool.txt) = 3.27 cycles per instruction -- the figure round 3's census of the one-path kernel gave, too (807 / 247)
 VALU_CYCLES_PER_WAVE_INSTR_MIX = 3.27
+# Round 6: the mix is priced PER KERNEL from what ran: a third PMC pass counts the wave-level VALU instructions by class (SQ_INSTS_VALU_ADD_F32 /
+# MUL_F32 / FMA_F32 -> 2.4 cycles, TRANS_F32 -> 8.2, CVT -> 4.2); what the hardware does not classify further (integer, compare, select, min / max,
+# moves) is priced at the mean of those opcodes in the pool kernel's census: (53 full x 2.4 + 120 half x 4.2 + 10 v_cndmask_e32 x 2.0) / 183 = 3.55
+# (profiles/r06_isa_census_pool.txt).  The static 3.27 above stays as the fallback where the class counters are missing.
+VALU_CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.4, "SQ_INSTS_VALU_MUL_F32": 2.4, "SQ_INSTS_VALU_FMA_F32": 2.4, "SQ_INSTS_VALU_TRANS_F32": 8.2, "SQ_INSTS_VALU_CVT": 4.2}
+VALU_OTHER_CYCLES = 3.55
+# the PMC passes of one run (rocprofv3 --pmc, counters only + --kernel-trace): SQ holds 8 counters per pass, the TCC 4 (FETCH_SIZE takes 3, WRITE_SIZE 2:
+# MI355X_MICROARCH.md "rocprofv3 PMC slots"), so the two byte counters ride in different passes and the SQ counters fill the rest
+PMC_PASSES = (
+    ("fetch", ["FETCH_SIZE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES", "SQ_INSTS_SALU"]),
+    ("write", ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INST_LEVEL_VMEM", "SQ_INSTS_LDS", "SQ_INST_LEVEL_LDS", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU"]),
+    ("mix", ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"]),
+)
+# what a pass falls back to when the box refuses the combination (one block per pass, as round 5 ran them)
+PMC_FALLBACK = {"fetch": [["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES", "SQ_INSTS_SALU"]],
+                "write": [["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INST_LEVEL_VMEM", "SQ_INSTS_LDS", "SQ_INST_LEVEL_LDS", "SQ_INSTS_SMEM"]]}
+# spp of the extra configurations' counter passes (their frames are timed at the configurations' own spp; three more passes of those would
+# take minutes): per-sample counters of the same frame at fewer samples per pixel, stated in every block's traffic_source
+PMC_SPP = {"c1": 64, "c3": 512, "c4": 128, "c5": 512, "c2": 1024, "c2:PaddedSobol": 512}
 SHADER_CLOCK_HZ = 2.4e9
 L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth, MI355X_MICROARCH.md (4 MiB per XCD, 32 MiB aggregate, ~34.5 TB/s)
 METRIC = "Msamples/s (+ fraction of HBM roofline) at fixed SPP, 1/2/4/8 GPU"
 
 
-def build_scene(workload: str, tmpdir: str, spp_override: int | None, sampler: str = "Independent"):
+SCENE_FILES = {}  # (workload, sampler, spp) -> the generated scene description (the PMC child processes load it instead of generating it again)
+
+
+def build_scene(workload: str, tmpdir: str, spp_override: int | None, sampler: str = "Independent", scene_file: str | None = None):
     from luisarender_amd import Scene
     from luisarender_amd.scenes import cornell_box, generate_room_scene
     desc, res, spp, depth = WORKLOADS[workload]
     spp = spp_override or min(spp, BENCH_SPP_CAP.get(workload, spp))
-    if workload == "c1":
+    if scene_file:
+        scene = Scene.load(scene_file)
+    elif workload == "c1":
         scene = Scene.from_string(cornell_box(resolution=res[0], spp=spp, depth=depth, sampler=sampler))
-    elif workload == "c2":
-        scene = Scene.load(generate_room_scene(tmpdir, resolution=res, spp=spp, depth=depth, sampler=sampler))
     else:
         from luisarender_amd.scenes import generate_bedroom_scene, generate_camera_scene, generate_kitchen_scene
-        gen = {"c3": generate_bedroom_scene, "c4": generate_camera_scene, "c5": generate_kitchen_scene}[workload]
-        scene = Scene.load(gen(tmpdir, resolution=res, spp=spp, depth=depth, sampler=sampler))
+        gen = {"c2": generate_room_scene, "c3": generate_bedroom_scene, "c4": generate_camera_scene, "c5": generate_kitchen_scene}[workload]
+        sub = os.path.join(tmpdir, f"{workload}_{sampler}_{spp}")  # (one directory per description: the generators write fixed file names)
+        SCENE_FILES[(workload, sampler)] = gen(sub, resolution=res, spp=spp, depth=depth, sampler=sampler)
+        scene = Scene.load(SCENE_FILES[(workload, sampler)])
     return scene, desc, res, spp
 
 
@@ -107,13 +131,15 @@ def cpu_baseline(scene, res, budget_s: float, full_spp: int | None = None):
     }, algorithmic_bytes(counters) / counters["paths"], counters, (oracle.convert(film), spp)
 
 
-def device_parity(scene, local_rank, cpu_frame, spp):
+def device_parity(scene, local_rank, cpu_frame, spp, scheduler="auto"):
     """The frame the CPU leg just rendered against the SAME samples [0, spp) on the device, shipped kernel, outside any timed region
     (VERDICT r02 1c).  FLIP on the central 512 x 512 of larger frames (the numpy restatement takes seconds per megapixel)."""
     import numpy as np
     from luisarender_amd.render import MegaPathRenderer
     from oracle import image_metrics as M
     r = MegaPathRenderer(local_rank)
+    if scheduler != "auto":
+        r.set_scheduler(scheduler == "pool")
     r.upload(scene)
     r.render(0, spp, counters=False, sync=True)
     gpu = r.download(converted=True)
@@ -149,11 +175,13 @@ def device_parity(scene, local_rank, cpu_frame, spp):
     return out
 
 
-def path_statistics(scene, local_rank, spp=64):
+def path_statistics(scene, local_rank, spp=64, scheduler="auto"):
     """rays per sample, mean path length and lane use from the device counters of a counting render (the COUNT twin of the kernel) of the
     frame AT THE SPP THAT IS TIMED (round 5: lane use and the drain of a launch depend on spp; round 4 measured them at 64)"""
     from luisarender_amd.render import MegaPathRenderer
     r = MegaPathRenderer(local_rank)
+    if scheduler != "auto":
+        r.set_scheduler(scheduler == "pool")
     r.upload(scene)
     r.render(0, spp, counters=True, sync=True)
     c = r.counters()
@@ -167,7 +195,9 @@ def path_statistics(scene, local_rank, spp=64):
     if r_variant & 4096:  # a pool kernel: every shaded vertex reads and writes three 16-byte quads of its context's record, a path one more at its start and its end
         pool_state = (96.0 * c["closest_rays"] + 32.0 * c["paths"]) / paths
         requested += pool_state
-    return {"pool_state_bytes_per_sample": pool_state,"rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
+    wave_cycles = max(c["wave_cycles"], 1)
+    return {"pool_state_bytes_per_sample": pool_state, "wave_life": {"traversal_loop": c["trace_cycles"] / wave_cycles, "shading_block": c["shade_cycles"] / wave_cycles},
+            "rays_per_sample": (c["closest_rays"] + c["shadow_rays"]) / paths, "closest_rays_per_sample": c["closest_rays"] / paths,
             "shadow_rays_per_sample": c["shadow_rays"] / paths, "mean_path_length": c["path_length_sum"] / paths,
             "nodes_per_ray": c["nodes_visited"] / max(c["closest_rays"] + c["shadow_rays"], 1), "spp": spp,
             "nodes_per_sample": c["nodes_visited"] / paths, "tris_per_sample": c["tris_tested"] / paths,
@@ -194,44 +224,207 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def live_pmc(workload: str, spp: int = 64, timeout: float = 240.0):
-    """HBM traffic + VALU instruction count per sample of the workload's megakernel, measured NOW: three rocprofv3 --pmc passes
-    (counters only, with --kernel-trace, as the pool allows) of this script on the same workload at `spp` samples per pixel."""
+def reference_leg(workload, res, spp, sampler, budget_s):
+    """The REFERENCE'S OWN MegaPath::Li (oracle/_ref = /root/reference/src compiled in place on the scalar LuisaCompute stand-in) on the bench's
+    own description of `workload` -- C2 in its InlineMesh form: the same 600 k instanced triangles, transforms and materials, the form the
+    reference's parser loads without an OBJ importer -- a pixel grid of the frame for a bounded time, ONE PROCESS PER HOST THREAD (the shim's
+    dispatch is serial; libref.so brings its own operator new, hence child processes).  None where oracle/_ref was not built."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
+        return None
+    procs = max(1, min(os.cpu_count() or 1, 64))
+    if workload == "c1":
+        procs = 1  # (configs[0] keeps round 5's one-thread figure: comparable across rounds)
+        make = "from luisarender_amd.scenes import cornell_box; text = cornell_box(resolution=%d, spp=%d, depth=%d, sampler=%r)" % (res[0], spp, WORKLOADS[workload][3], sampler)
+    else:
+        make = ("import tempfile; from luisarender_amd.scenes import generate_room_scene; d = tempfile.mkdtemp(prefix='lr_ref_'); "
+                "text = open(generate_room_scene(d, resolution=(%d, %d), spp=%d, depth=%d, sampler=%r, inline_meshes=True)).read()" % (res[0], res[1], spp, WORKLOADS[workload][3], sampler))
+    code = ("import json, sys; sys.path.insert(0, %r); from oracle.check import reference_rate; %s; "
+            "print(json.dumps(reference_rate(text, %f, first_sample=int(sys.argv[1]))))" % (ROOT, make, budget_s))
+    children = [subprocess.Popen([sys.executable, "-c", code, str(i * 4096)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+    results = []
+    for c in children:
+        try:
+            text, _ = c.communicate(timeout=budget_s + 120.0)
+            results.append(json.loads(text.strip().splitlines()[-1]))
+        except Exception:  # noqa: BLE001
+            c.kill()
+    results = [r for r in results if r]
+    if not results:
+        return None
+    out = dict(results[0])
+    out["value"] = sum(r["value"] for r in results)
+    out["cores"] = len(results)
+    out["sample"] = results[0]["sample"].replace(", 1 thread", f", in each of {len(results)} processes (one per host thread, disjoint sample numbers); value = their sum")
+    return out
+
+
+def kernel_names_of(variant: int):
+    """substrings of the kernel symbols a configuration's frame launches: the megakernel of `variant` (lrhip_last_variant), and in wavefront
+    mode (the mask holds closure bits the lean kernel does not: lrhip.hip) camera pass + continuation pass + the heavy-closure kernels"""
+    if variant & 1024:  # kFeatWf
+        camera = variant & ~(16 | 32 | 64 | 512)
+        return [f"_kernel<{camera}u>", f"_kernel<{camera | 2048}u>", "heavy_kernel<"]
+    return [f"_kernel<{variant}u>"]
+
+
+def pmc_child(spec: str, local_rank: int):
+    """--pmc-child: renders every configuration of `spec` once (workload:spp:sampler:scheduler:scene file, comma separated) -- the process the
+    counter passes of live_pmc profile.  Nothing is timed or printed."""
+    from luisarender_amd.render import MegaPathRenderer
+    with tempfile.TemporaryDirectory(prefix="lr_pmc_child_") as tmp:
+        for item in spec.split(","):
+            workload, spp, sampler, scheduler, scene_file = item.split(":", 4)
+            scene, _, _, _ = build_scene(workload, tmp, None, sampler, scene_file or None)
+            r = MegaPathRenderer(local_rank)
+            if scheduler != "auto":
+                r.set_scheduler(scheduler == "pool")
+            r.upload(scene)
+            r.render(0, int(spp), sync=True)
+            r.close()
+
+
+def live_pmc(configs, timeout: float = 420.0):
+    """HBM traffic, VALU instructions by class, wait / issue cycles and memory-instruction levels per sample of every configuration's kernels,
+    measured NOW: rocprofv3 --pmc passes (counters only, with --kernel-trace, as the pool allows) of this script in --pmc-child mode, which
+    renders each configuration once at its counter spp.  configs: [{"key", "workload", "spp", "sampler", "variant", "scheduler"}].
+    Returns {key: {...}} (a key is missing where nothing of its kernels was seen)."""
     import shutil
     import sqlite3
     import subprocess
     if shutil.which("rocprofv3") is None:
-        return None
-    # already under a profiler (someone runs `rocprofv3 ... -- python bench.py`): no nested passes; the committed profile of the same
-    # source hash (profiles/pmc_<workload>.json) answers instead
+        return {}
+    # already under a profiler (someone runs `rocprofv3 ... -- python bench.py`): no nested passes
     if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None
-    desc, res, _, _ = WORKLOADS[workload]
-    samples = res[0] * res[1] * spp
-    out = {"spp": spp, "samples_per_launch": samples, "tool": "rocprofv3 --pmc (separate passes) --kernel-trace"}
-    counters = {}
+        return {}
+    spec = ",".join(f"{c['workload']}:{c['spp']}:{c['sampler']}:{c.get('scheduler', 'auto')}:{SCENE_FILES.get((c['workload'], c['sampler']), '')}" for c in configs)
+    totals = {}  # kernel name -> counter -> total over its dispatches
+    errors = []
     with tempfile.TemporaryDirectory(prefix="lr_pmc_") as d:
         env = dict(os.environ, TMPDIR="/tmp")
-        for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY"])):
-            cmd = ["rocprofv3", "--pmc", *pmc, "--kernel-trace", "-d", os.path.join(d, name), "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--workload", workload, "--spp", str(spp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc", "--no-extra", "--no-stats"]
+
+        def one_pass(name, pmc):
+            cmd = ["rocprofv3", "--pmc", *pmc, "--kernel-trace", "-d", os.path.join(d, name), "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", spec]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(d, name)) for f in fs if f.endswith(".db")]
+            db = sqlite3.connect(dbs[0])
+            launches = dict(db.execute("select name, count(*) from kernels group by name"))
+            for kname, ns in db.execute("select name, sum(end - start) from kernels group by name"):
+                totals.setdefault(kname, {})["kernel_ns:" + name.split("_")[0]] = float(ns)  # (this pass's own kernel time: what its cycle counters are read against)
+            seen = 0
+            # (one row per dispatch and counter, as round 5 read them: the mean over a kernel's dispatches x its launches = the frame's total)
+            for kname, cname, mean in db.execute("select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
+                totals.setdefault(kname, {})[cname] = mean * launches.get(kname, 1)
+                seen += 1
+            if seen == 0:
+                raise RuntimeError("no counter rows")
+
+        for name, pmc in PMC_PASSES:
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
-                dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(d, name)) for f in fs if f.endswith(".db")]
-                db = sqlite3.connect(dbs[0])
-                for cname, value in db.execute("select counter_name, avg(value) from counters_collection where kernel_name like '%mega%_kernel%' group by counter_name"):
-                    counters[cname] = value
-            except Exception as e:  # no profiler on this box / a refused counter: report what was measured
-                out.setdefault("errors", []).append(f"{name}: {type(e).__name__}")
-    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-        # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 (MI355X_MICROARCH.md, HBM section)
-        out["hbm_bytes_per_sample"] = (counters["FETCH_SIZE"] * 2048.0 + counters["WRITE_SIZE"] * 1024.0) / samples
-        out["hbm_read_bytes_per_sample"] = counters["FETCH_SIZE"] * 2048.0 / samples
-        out["hbm_write_bytes_per_sample"] = counters["WRITE_SIZE"] * 1024.0 / samples
-    if "SQ_INSTS_VALU" in counters:
-        out["valu_wave_instr_per_sample"] = counters["SQ_INSTS_VALU"] / samples
-    out["counters"] = counters
+                one_pass(name, pmc)
+            except Exception as e:  # a refused combination / no profiler on this box: the smaller passes of round 5, then report what was measured
+                errors.append(f"{name}: {type(e).__name__}")
+                for i, part in enumerate(PMC_FALLBACK.get(name, [])):
+                    try:
+                        one_pass(f"{name}_{i}", part)
+                    except Exception as e2:  # noqa: BLE001
+                        errors.append(f"{name}_{i}: {type(e2).__name__}")
+    out = {}
+    for c in configs:
+        desc, res, _, _ = WORKLOADS[c["workload"]]
+        samples = res[0] * res[1] * c["spp"]
+        names = kernel_names_of(c["variant"])
+        counters, per_kernel = {}, {}
+        for kname, cs in totals.items():
+            if any(n in kname for n in names):
+                short = kname.split("(")[0].replace("void ", "")
+                per_kernel[short] = cs
+                for k, v in cs.items():
+                    counters[k] = counters.get(k, 0.0) + v
+        if not counters:
+            continue
+        o = {"spp": c["spp"], "samples_per_launch": samples, "tool": "rocprofv3 --pmc (separate passes, one child process per pass renders every configuration once) --kernel-trace",
+             "counters": counters, "kernels": sorted(per_kernel)}
+        if errors:
+            o["errors"] = errors
+        if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies a 128-byte request as 64 (MI355X_MICROARCH.md, HBM section)
+            o["hbm_bytes_per_sample"] = (counters["FETCH_SIZE"] * 2048.0 + counters["WRITE_SIZE"] * 1024.0) / samples
+            o["hbm_read_bytes_per_sample"] = counters["FETCH_SIZE"] * 2048.0 / samples
+            o["hbm_write_bytes_per_sample"] = counters["WRITE_SIZE"] * 1024.0 / samples
+        if "SQ_INSTS_VALU" in counters:
+            o["valu_wave_instr_per_sample"] = counters["SQ_INSTS_VALU"] / samples
+            classes = {k: counters[k] for k in VALU_CLASS_CYCLES if k in counters}
+            if len(classes) == len(VALU_CLASS_CYCLES):
+                other = max(counters["SQ_INSTS_VALU"] - sum(classes.values()), 0.0)
+                o["cycles_per_wave_instr"] = (sum(VALU_CLASS_CYCLES[k] * v for k, v in classes.items()) + VALU_OTHER_CYCLES * other) / counters["SQ_INSTS_VALU"]
+                o["valu_mix"] = {**{k.replace("SQ_INSTS_VALU_", "").lower(): v / counters["SQ_INSTS_VALU"] for k, v in classes.items()}, "other": other / counters["SQ_INSTS_VALU"]}
+        out[c["key"]] = o
     return out
+
+
+def roofline_block(workload, variant, kernel_ms, launch_samples, bytes_per_sample, pmc, pmc_source, stats, simds):
+    """the `roofline` object of one configuration: measured memory traffic against the HBM peak (the contract's achieved / peak / frac / traffic),
+    and beside it what actually bounds these kernels -- VALU issue priced per kernel, the waves' wait / issue-stall / active split, the L2"""
+    seconds = kernel_ms * 1e-3
+    algorithmic_gbps = bytes_per_sample * launch_samples / seconds / 1e9
+    traffic = pmc["hbm_bytes_per_sample"] * launch_samples if pmc and pmc.get("hbm_bytes_per_sample") else None
+    achieved = traffic / seconds / 1e9 if traffic else None
+    r = {
+        # What bounds these kernels is neither roof of the contract's vocabulary: a wave issues one instruction of any kind every ~4.5 cycles and
+        # waits for two dependent gathers per traversal iteration; at four waves per SIMD (128 VGPRs, 39 KB of LDS per block) the SIMD is neither
+        # full nor starved (DESIGN.md section 0; the stall probe's tables: profiles/r06_stalls_*.txt).  The contract's HBM figures stay: `achieved` /
+        # `frac` / `traffic` are the MEASURED memory-side traffic over the kernel's duration (FETCH_SIZE counts Infinity-Cache hits too: an
+        # upper bound on HBM traffic); one number per roof follows in `valu`, `waves`, `lanes`, `l2`.
+        "bound": "issue + latency at 4 waves per SIMD", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic, "traffic_source": pmc_source,
+        "kernel": kernel_name(variant) if not variant & 1024 else " + ".join(kernel_names_of(variant)), "kernel_ms": kernel_ms,
+        "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_gbps": algorithmic_gbps,
+        "algorithmic_frac_of_hbm_peak": algorithmic_gbps / HBM_PEAK_GBPS,
+        "note": "achieved / frac = MEASURED memory traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) per sample x the timed launch's samples over "
+                "its HIP-event duration; algorithmic_* = the canonical-BVH2 byte count of SURVEY 8(d), most of which L1 / L2 / LDS serve on chip (it may exceed "
+                "the HBM peak and is not a traffic figure); valu.issue_frac = priced VALU issue cycles over the launch's SIMD cycles, waves = where a wave's cycles go, "
+                "lanes = how many of the issued lanes did useful work, l2 = the kernel's own requests against the L2's bandwidth",
+    }
+    counters = (pmc or {}).get("counters") or {}
+    if pmc and pmc.get("valu_wave_instr_per_sample"):
+        instr = pmc["valu_wave_instr_per_sample"] * launch_samples
+        simd_cycles = simds * seconds * SHADER_CLOCK_HZ
+        price = pmc.get("cycles_per_wave_instr") or VALU_CYCLES_PER_WAVE_INSTR_MIX
+        r["valu"] = {
+            "issue_frac": instr * price / simd_cycles, "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"], "wave_instr_per_launch": instr,
+            "cycles_per_wave_instr": price, "valu_mix": pmc.get("valu_mix"), "simds": simds, "shader_clock_hz": SHADER_CLOCK_HZ, "simd_cycles_per_launch": simd_cycles,
+            "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the DYNAMIC class mix of the kernel(s) that ran "
+                           "(PMC: SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 x 2.4, TRANS_F32 x 8.2, CVT x 4.2, everything else x 3.55 = the mean price of the unclassified opcodes in the pool "
+                           "kernel's census) with the issue costs measured on the box (profiles/r04h_cndmask_forms.json, tools/valu_peak2.hip)"
+                           if pmc.get("cycles_per_wave_instr") else "static mix of the pool kernel's traversal loop (profiles/r05_isa_census_pool.txt): the class counters were not collected",
+            # what a change of the instruction count buys, MEASURED (round 5, profiles/r05b_sensitivity_probes.txt, r05c_pmc_*.json): 9.3 % more VALU instructions
+            # (32 dependent v_fma per node step) cost 4.3 % time, 6.3 % fewer gained 2.4 %, three waves per SIMD instead of four cost 16 %
+            "time_elasticity_to_valu_instructions": 0.42,
+            "elasticity_source": "profiles/r05b_sensitivity_probes.txt (pn32: +9.3 % instructions, +4.3 % time), profiles/r05c_pmc_{r04,base}.json (-6.3 %, -2.4 %); measured on C2's pool kernel",
+        }
+    if counters.get("SQ_WAVE_CYCLES"):
+        wc = counters["SQ_WAVE_CYCLES"]
+        # MI355X_MICROARCH.md: WAIT_ANY (parked at s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint
+        r["waves"] = {k: counters[c] / wc for k, c in (("waiting_at_waitcnt", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"), ("instruction_in_flight", "SQ_ACTIVE_INST_ANY")) if c in counters}
+        if counters.get("SQ_BUSY_CYCLES") and counters.get("kernel_ns:fetch"):
+            r["waves"]["effective_clock_ghz"] = counters["SQ_BUSY_CYCLES"] / 32.0 / counters["kernel_ns:fetch"]  # (busy cycles of the 32 shader engines over the counter pass's own kernel time)
+        # (SQ_INST_LEVEL_VMEM / SQ_INST_LEVEL_LDS are collected and kept in `counters`, but their ratio to the instruction counts comes out at ~37 and ~3
+        # "cycles" -- not a gather's latency in any unit the guide documents -- so no latency is derived from them; the stall probe times the waits)
+    if counters.get("TCC_HIT_sum") is not None and counters.get("TCC_MISS_sum"):
+        r["l2_hit_rate"] = counters["TCC_HIT_sum"] / (counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"])
+    if stats:
+        r["lanes"] = stats["lanes"]
+        r["wave_life"] = stats.get("wave_life")
+        req_gbps = stats["requested_bytes_per_sample"] * launch_samples / seconds / 1e9
+        r["l2"] = {
+            "frac": req_gbps / L2_PEAK_GBPS, "requested_gbps": req_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s",
+            "requested_bytes_per_sample": stats["requested_bytes_per_sample"], "pool_state_bytes_per_sample": stats.get("pool_state_bytes_per_sample"),
+            "note": "the kernel's own requests per sample from its counters (path_statistics: 64 B x nodes + 48 B x triangle tests + 128 B x surface hits "
+                    "+ 136 B x light samples + the pool kernels' path state: 96 B per shaded vertex, 32 B per path) x samples / kernel time, against the aggregate L2 bandwidth "
+                    "(MI355X_MICROARCH.md); the vector L1 serves part of them (the BVH's top levels), so this is an upper bound on L2 traffic; texel fetches are not in it",
+        }
+    return r
 
 
 def run_workload(workload, args, rank, world, local_rank, tmp, steps, warmup, spp_override=None, sampler="Independent", warmup_spp=None):
@@ -360,7 +553,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="override the workload's spp (invalidates the headline number)")
     ap.add_argument("--sampler", default="Independent", choices=["Independent", "PaddedSobol", "Sobol"],
                     help="sampler of the timed frame (anything but Independent invalidates the headline number)")
-    ap.add_argument("--scheduler", default=os.environ.get("LRHIP_SCHEDULER", "auto"), choices=["auto", "legacy", "pool"],
+    ap.add_argument("--scheduler", default="auto", choices=["auto", "legacy", "pool"],
                     help="force one kernel family (lrhip_set_scheduler) for A/B and profiling runs; anything but auto is recorded in config.scheduler_override")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,7 +561,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other BASELINE configs")
     ap.add_argument("--extra-spp", type=int, default=None, help="N > 1: spp of the C4 / C5 entries instead of the configurations' own (tests)")
     ap.add_argument("--no-stats", action="store_true", help="skip the short counting render behind rays_per_s / mean_path_length (the PMC passes: ONE megakernel dispatch per process)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)  # (the process live_pmc profiles: renders the given configurations once)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.pmc_child, int(os.environ.get("LOCAL_RANK", "0")))
+        return
 
     import torch
     import torch.distributed as dist
@@ -429,9 +626,9 @@ def main():
             if world == 1 and not args.no_cpu_baseline:  # the CPU leg runs on rank 0 at N = 1 only
                 cpu, bytes_per_sample, _, (cpu_frame, cpu_spp) = cpu_baseline(scene, res, args.cpu_seconds)
                 out["cpu_baseline"] = cpu
-                out["parity"] = device_parity(scene, local_rank, cpu_frame, cpu_spp)
+                out["parity"] = device_parity(scene, local_rank, cpu_frame, cpu_spp, args.scheduler)
             if world == 1 and not args.no_stats:
-                stats = path_statistics(scene, local_rank, spp)
+                stats = path_statistics(scene, local_rank, spp, args.scheduler)
                 out["rays_per_s"] = value * 1e6 * stats["rays_per_sample"]
                 out["mean_path_length"] = stats["mean_path_length"]
                 out["path_statistics"] = stats
@@ -442,82 +639,13 @@ def main():
                     out["error"] = "the film the collective delivered differs from a 1-GPU render of the same tiles"
             # one launch renders this rank's shard: samples_per_step / world samples
             launch_samples = samples_per_step / world
-            algorithmic_gbps = bytes_per_sample * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
-            pmc, pmc_source = None, None
-            if world == 1 and not args.no_pmc:
-                pmc, pmc_source = live_pmc(args.workload, spp), f"live: rocprofv3 --pmc passes of this run, the same workload at the timed {spp} spp"
-            if pmc is None or "hbm_bytes_per_sample" not in pmc:
-                prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-                if os.path.exists(prof):
-                    try:
-                        p = json.load(open(prof))
-                        if p.get("source_hash") == source_hash() and p.get("hbm_bytes_per_sample"):  # a profile of another build is not evidence
-                            p.setdefault("valu_wave_instr_per_sample", p.get("valu_wave_instructions_per_sample"))
-                            pmc, pmc_source = p, f"profiles/pmc_{args.workload}.json (same source hash)"
-                    except Exception:
-                        pass
-            traffic = pmc["hbm_bytes_per_sample"] * launch_samples if pmc and pmc.get("hbm_bytes_per_sample") else None
-            achieved = traffic / (mean_kernel_ms * 1e-3) / 1e9 if traffic else None
-            stats = out.get("path_statistics")
-            out["roofline"] = {
-                # What bounds the megakernel (lrd::megapool_kernel on the large scenes since round 4, lrd::megapath_kernel on the small ones)
-                # is VALU issue, jointly with the latency of its dependent gathers (DESIGN.md sections 4.1c and 5: filling the lanes of
-                # the traversal loop from 0.56 to 0.9 paid only once the scheduler's own instructions -- spills, turnovers -- were off
-                # the loop's hot path).  The contract's HBM figures stay: `achieved` /
-                # `frac` / `traffic` are the MEASURED memory traffic over the kernel's duration (FETCH_SIZE counts Infinity-Cache hits too:
-                # an upper bound on HBM traffic); one number per roof follows in `valu`, `lanes`, `l2`.
-                "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic, "traffic_source": pmc_source,
-                "kernel": kernel_name(variant), "kernel_ms": mean_kernel_ms,
-                "algorithmic_bytes_per_sample": bytes_per_sample, "algorithmic_gbps": algorithmic_gbps,
-                "algorithmic_frac_of_hbm_peak": algorithmic_gbps / HBM_PEAK_GBPS,
-                "note": "achieved / frac = MEASURED memory traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache hits included) over the kernel's HIP-event "
-                        "duration; algorithmic_* = the canonical-BVH2 byte count of SURVEY 8(d), most of which L1 / L2 / LDS serve on chip (it may exceed "
-                        "the HBM peak and is not a traffic figure); valu.issue_frac = the VALU pipes' occupancy, lanes = how many of the issued lanes "
-                        "did useful work, l2 = the kernel's own requests against the L2's bandwidth",
-            }
-            if pmc and pmc.get("valu_wave_instr_per_sample"):
-                instr = pmc["valu_wave_instr_per_sample"] * launch_samples
-                import torch
-                simds = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
-                simd_cycles = simds * mean_kernel_ms * 1e-3 * SHADER_CLOCK_HZ
-                counters = pmc.get("counters") or {}
-                out["roofline"]["valu"] = {
-                    "issue_frac": instr * VALU_CYCLES_PER_WAVE_INSTR_MIX / simd_cycles,
-                    "wave_instr_per_sample": pmc["valu_wave_instr_per_sample"], "wave_instr_per_launch": instr,
-                    "cycles_per_wave_instr": VALU_CYCLES_PER_WAVE_INSTR_MIX, "simds": simds, "shader_clock_hz": SHADER_CLOCK_HZ, "simd_cycles_per_launch": simd_cycles,
-                    "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the opcode mix of the kernel that ran "
-                                   "(the pool kernel's traversal loop, profiles/r05_isa_census_pool.txt, tools/isa_census.py) priced with the issue costs measured on the box "
-                                   "(profiles/r04h_cndmask_forms.json, tools/valu_peak2.hip: 2.4 cycles per wave64 v_fma / v_mul / v_add / v_and / v_mov, 4.2 for every min / max / "
-                                   "cvt / cmp / cndmask / shift / packed op, 8.2 per transcendental)",
-                    # what a change of the instruction count buys, MEASURED (round 5, profiles/r05b_sensitivity_probes.txt, r05c_pmc_*.json): 9.3 % more VALU instructions
-                    # (32 dependent v_fma per node step) cost 4.3 % time, 6.3 % fewer gained 2.4 %, three waves per SIMD instead of four cost 16 %
-                    "time_elasticity_to_valu_instructions": 0.42,
-                    "elasticity_source": "profiles/r05b_sensitivity_probes.txt (pn32: +9.3 % instructions, +4.3 % time), profiles/r05c_pmc_{r04,base}.json (-6.3 %, -2.4 %)",
-                }
-                if counters.get("SQ_ACTIVE_INST_VALU"):
-                    # SQ_ACTIVE_INST_VALU counts, in units of four cycles and summed over the waves, the cycles a wave has a VALU instruction in flight
-                    # (~4.2 per instruction whatever its class): against the launch's SIMD-cycles it says how full the pipes are IF the waves' instructions
-                    # never overlap -- an upper bound on their occupancy (it exceeds 1 in builds with more instructions in flight), not a proof of saturation
-                    out["roofline"]["valu"]["pmc_busy"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
-                    out["roofline"]["valu"]["pmc_busy_note"] = "SQ_ACTIVE_INST_VALU x 4 / (SIMDs x kernel cycles); per-wave in-flight cycles summed over four waves per SIMD: an upper bound"
-                if counters.get("SQ_ACTIVE_INST_VALU") and counters.get("SQ_WAVE_CYCLES"):
-                    out["roofline"]["valu"]["pmc_active_inst_valu_over_wave_cycles"] = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
-                if counters.get("SQ_WAIT_ANY") and counters.get("SQ_WAVE_CYCLES"):
-                    out["roofline"]["valu"]["pmc_wait_any_over_wave_cycles"] = counters["SQ_WAIT_ANY"] / counters["SQ_WAVE_CYCLES"]
-            if stats:
-                out["roofline"]["lanes"] = stats["lanes"]
-                req_gbps = stats["requested_bytes_per_sample"] * launch_samples / (mean_kernel_ms * 1e-3) / 1e9
-                out["roofline"]["l2"] = {
-                    "frac": req_gbps / L2_PEAK_GBPS, "requested_gbps": req_gbps, "peak": L2_PEAK_GBPS, "unit": "GB/s",
-                    "requested_bytes_per_sample": stats["requested_bytes_per_sample"],
-                    "pool_state_bytes_per_sample": stats.get("pool_state_bytes_per_sample"),
-                    "note": "the kernel's own requests per sample from its counters (path_statistics: 64 B x nodes + 48 B x triangle tests + 128 B x surface hits "
-                            "+ 136 B x light samples + the pool kernels' path state: 96 B per shaded vertex, 32 B per path) x samples / kernel time, against the aggregate L2 bandwidth (MI355X_MICROARCH.md); the vector L1 serves "
-                            "part of them (the BVH's top levels), so this is an upper bound on L2 traffic",
-                }
-            if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None:
-                extra = []
+            import torch
+            simds = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
+            headline_key = args.workload if args.sampler == "Independent" else f"{args.workload}:{args.sampler}"
+            # every configuration whose kernels the counter passes see: the headline at the timed spp, the others at PMC_SPP
+            pmc_configs = [{"key": headline_key, "workload": args.workload, "spp": spp, "sampler": args.sampler, "variant": variant, "scheduler": args.scheduler}]
+            extra, extra_state = [], {}
+            if world == 1 and not args.no_extra and args.workload == "c2" and args.spp is None and args.sampler == "Independent":
                 # Every other BASELINE configuration AT ITS STATED SIZE on this GPU (round 4; round 3 timed them at reduced spp), each with
                 # its own oracle leg on a bounded sample and the parity of the device against it: C1 = configs[0] whole (+ the reference's
                 # own code beside it), C3 at 4096 spp, C4 = the 8-GPU configuration's 1-GPU number at 1024 spp, C5 at 2048 of its 65 536 spp
@@ -531,26 +659,61 @@ def main():
                     v, ms, kms, var, sc, r, sp, d = run_workload(w, args, rank, world, local_rank, tmp, steps, 1, spp_o, sampler, warmup_spp=None if w in ("c1", "c5") else 8)  # (C5: wavefront mode sizes its queues by the frame's spp -- a warm-up on fewer samples leaves a 76-89 GB allocation inside the timed step)
                     e = {"workload": d, "sampler": sampler, "spp_timed": sp, "spp_config": WORKLOADS[w][2], "value": v, "unit": "Msamples/s", "steps": steps, "ms_per_step": ms,
                          "kernel_ms": kms, "kernel": kernel_name(var), "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE[w]}
-                    if cpu_s > 0.0:
+                    if cpu_s > 0.0 and not args.no_cpu_baseline:
                         e["cpu_baseline"], e["algorithmic_bytes_per_sample"], _, (cpu_frame, cpu_spp) = cpu_baseline(sc, r, cpu_s, full_spp=sp if whole else None)
                         e["parity"] = device_parity(sc, local_rank, cpu_frame, cpu_spp)
                     else:
                         e["parity"] = None
-                    if whole:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration --
-                        # and the REFERENCE'S OWN code beside it (oracle/_ref, one thread, a bounded sample of the same frame); absent
-                        # where oracle/_ref was not built
-                        # (in a child process: libref.so brings its own operator new and the reference's symbols)
-                        import subprocess
-                        code = ("import json, sys; sys.path.insert(0, %r); from oracle.check import reference_rate; "
-                                "from luisarender_amd.scenes import cornell_box; "
-                                "print(json.dumps(reference_rate(cornell_box(resolution=%d, spp=%d, depth=%d), 10.0)))" % (ROOT, r[0], sp, WORKLOADS[w][3]))
-                        try:
-                            ref = json.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
-                        except Exception:  # noqa: BLE001
-                            ref = None
+                    if whole and not args.no_cpu_baseline:  # BASELINE configs[0]: Cornell Box 512x512, 64 spp, depth 8 on the CPU -- the whole configuration --
+                        # and the REFERENCE'S OWN code beside it (oracle/_ref, a bounded sample of the same frame); absent where oracle/_ref was not built
+                        ref = reference_leg("c1", r, sp, sampler, 10.0)
                         if ref is not None:
                             e["cpu_reference"] = ref
+                    key = w if sampler == "Independent" else f"{w}:{sampler}"
+                    pmc_spp = min(sp, PMC_SPP.get(key, sp))
+                    if not args.no_stats:
+                        extra_state[key] = path_statistics(sc, local_rank, pmc_spp)
+                    pmc_configs.append({"key": key, "workload": w, "spp": pmc_spp, "sampler": sampler, "variant": var, "scheduler": "auto"})
+                    e["_key"] = key
+                    e["_variant"] = var
+                    e["_samples"] = r[0] * r[1] * sp
                     extra.append(e)
+            # the reference's own code beside the HEADLINE number too (round 6): MegaPath::Li of oracle/_ref on the bench's own C2 description
+            # (InlineMesh form: the same instances, transforms and materials), one process per host thread, a bounded time
+            if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+                ref = reference_leg("c2", res, spp, args.sampler, 12.0)
+                if ref is not None:
+                    out["cpu_reference"] = ref
+            pmc_all = {}
+            if world == 1 and not args.no_pmc:
+                pmc_all = live_pmc(pmc_configs)
+
+            def pmc_of(key, timed_spp):
+                p = pmc_all.get(key)
+                if p is None or "hbm_bytes_per_sample" not in p:
+                    return None, None
+                src = (f"live: rocprofv3 --pmc passes of this run ({', '.join(n for n, _ in PMC_PASSES)}), the same frame at {p['spp']} spp"
+                       + ("" if p["spp"] == timed_spp else f" (per-sample counters x the timed launch's samples; the frame is timed at {timed_spp} spp)"))
+                return p, src
+
+            pmc, pmc_source = pmc_of(headline_key, spp)
+            if pmc is None:
+                prof = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+                if os.path.exists(prof):
+                    try:
+                        p = json.load(open(prof))
+                        if p.get("source_hash") == source_hash() and p.get("hbm_bytes_per_sample"):  # a profile of another build is not evidence
+                            p.setdefault("valu_wave_instr_per_sample", p.get("valu_wave_instructions_per_sample"))
+                            pmc, pmc_source = p, f"profiles/pmc_{args.workload}.json (same source hash)"
+                    except Exception:
+                        pass
+            # (a scheduler override reaches the counting and parity renders as well: ADVICE r05)
+            out["roofline"] = roofline_block(args.workload, variant, mean_kernel_ms, launch_samples, bytes_per_sample, pmc, pmc_source, out.get("path_statistics"), simds)
+            for e in extra:
+                key, var, n = e.pop("_key"), e.pop("_variant"), e.pop("_samples")
+                p, src = pmc_of(key, e["spp_timed"])
+                e["roofline"] = roofline_block(key.split(":")[0], var, e["kernel_ms"], n, e["algorithmic_bytes_per_sample"], p, src, extra_state.get(key), simds)
+            if extra:
                 out["extra_configs"] = extra
             if multi_extra:
                 out["extra_configs"] = out.get("extra_configs", []) + multi_extra

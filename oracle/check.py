@@ -143,7 +143,7 @@ def algorithmic_bytes(counters: dict) -> float:
             + 208.0 * counters["nee_samples"] + 32.0 * counters["paths"])
 
 
-def reference_rate(scene_text: str, budget_s: float = 10.0):
+def reference_rate(scene_text: str, budget_s: float = 10.0, first_sample: int = 0):
     """Throughput of the REFERENCE'S OWN MegaPath code on this scene, one host thread: oracle/_ref/libref.so = /root/reference/src
     compiled in place against the scalar LuisaCompute stand-in (oracle/Makefile.ref), driven sample by sample (its Li() through
     ref_li, the entry tests/test_oracle_vs_ref.py pins the oracle with).  None where libref.so is absent.  This is the reference's
@@ -175,7 +175,7 @@ def reference_rate(scene_text: str, budget_s: float = 10.0):
         # a regular grid of pixels over the whole frame, sample after sample, until the budget is spent
         step = max(1, min(width, height) // 32)
         pixels = [(x, y) for y in range(step // 2, height, step) for x in range(step // 2, width, step)]
-        done, sample, t0 = 0, 0, time.perf_counter()
+        done, sample, t0 = 0, first_sample, time.perf_counter()
         while time.perf_counter() - t0 < budget_s:
             for x, y in pixels:
                 lib.ref_li(handle, x, y, sample, 0.0, out)
@@ -185,4 +185,4 @@ def reference_rate(scene_text: str, budget_s: float = 10.0):
         lib.ref_scene_destroy(handle)
     return {"value": done / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
             "sample": f"the reference's own MegaPath::Li (oracle/_ref: /root/reference/src compiled in place on a scalar LuisaCompute stand-in, NOT its "
-                      f"LLVM backend), {len(pixels)} pixels on a regular grid of the {width}x{height} frame x {sample} samples = {done} paths in {dt:.1f} s, 1 thread"}
+                      f"LLVM backend), {len(pixels)} pixels on a regular grid of the {width}x{height} frame x {sample - first_sample} samples = {done} paths in {dt:.1f} s, 1 thread"}
