@@ -26,9 +26,11 @@ class OracleCounters(C.Structure):
 
 
 
-def oracle_lib() -> C.CDLL:
-    """The CPU checker.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg call this."""
-    lib = _ffi._load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle.so"))
+def oracle_lib(name: str = "liboracle.so") -> C.CDLL:
+    """The CPU checker.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg call this.
+    name: liboracle.so, or liboracle_fma.so = the same source built with -ffp-contract=fast (Makefile: what fused multiply-adds alone do to
+    the oracle's frames -- the oracle's OWN sensitivity, tests/test_gpu_parity.py::test_lamp_lit_fog_converges_on_the_oracle)"""
+    lib = _ffi._load(os.path.join(os.path.dirname(os.path.abspath(__file__)), name))
     if not getattr(lib, "_lr_ready", False):
         lib.oracle_create.restype = C.c_void_p
         lib.oracle_create.argtypes = [C.POINTER(_ffi.Scene)]
@@ -64,10 +66,10 @@ def oracle_lib() -> C.CDLL:
 
 
 class Oracle:
-    def __init__(self, scene: Scene, camera: int = 0, bake_instances: bool = False):
+    def __init__(self, scene: Scene, camera: int = 0, bake_instances: bool = False, lib: str = "liboracle.so"):
         """bake_instances: intersect the fp32 WORLD-space triangles the host bakes for the device (lr_scene.accel.triangles) instead of the
         reference's object-space triangles behind the instance transform -- isolates the kernel from that design choice (oracle_bvh.h)"""
-        self._lib = oracle_lib()
+        self._lib = oracle_lib(lib)
         self._scene = scene
         self._view = scene.view(camera)
         self._ctx = self._lib.oracle_create(C.byref(self._view))

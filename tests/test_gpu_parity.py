@@ -352,6 +352,39 @@ def test_camera_class_scene(renderer, tmp_path):
     assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
 
 
+def test_camera_class_scene_with_the_maps_the_bench_holds(tmp_path):
+    """VERDICT r05 "weak" 2: the camera class with 2048 x 2048 maps, the size BENCH times -- 512 MB of float texels, above the 192 MB of the
+    automatic rule (lrhip_set_texture_storage mode 1), so the eight PNG maps stay 8-bit texels on the device and the frame renders on a
+    kernel of the LRHIP_FEAT_BYTE_TEXELS bit (round 6: <12308> / <8212>, the only lean kernels that hold the decode).  A window of the frame
+    against the oracle -- which reads the host's floats -- at the C4 bars; the packed frame equals the float frame bit for bit."""
+    from luisarender_amd.render import MegaPathRenderer
+    sc = Scene.load(generate_camera_scene(str(tmp_path), resolution=(256, 144), spp=8, texture_size=2048))
+    films, variants = {}, {}
+    for mode in (1, 0):
+        r = MegaPathRenderer(0)
+        r.set_texture_storage(mode)
+        r.upload(sc)
+        packed = r.packed_texels()
+        r.render(0, 8, counters=True, sync=True)
+        films[mode], variants[mode] = r.download(converted=False), r.last_variant()
+        if mode == 1:
+            gc = r.counters()
+            assert packed == 8 * 2048 * 2048, packed                      # the automatic rule fired: every map is held as codes
+        else:
+            assert packed == 0
+        r.close()
+    assert variants[1] & 8192 and (variants[1] & ~(4096 | 8192)) == 4 | 16 | 1, variants      # <environment + Disney> with the decode
+    assert not variants[0] & 8192 and (variants[0] & ~4096) == 4 | 16 | 1, variants
+    assert np.array_equal(films[0], films[1])                             # the decode gives back the host's floats: the same film
+    cpu, cc = Oracle(sc).render(0, 8)
+    gpu = films[1]
+    assert np.array_equal(gpu[..., 3], cpu[..., 3])
+    assert abs(gc["closest_rays"] - cc["closest_rays"]) <= 1e-3 * cc["closest_rays"]
+    print(f"c4 with 2048^2 maps, packed: rel-L1 {_rel_l1(gpu, cpu):.3e}")
+    assert _rel_l1(gpu, cpu) < 5e-3
+    assert abs(gpu[..., :3].mean() - cpu[..., :3].mean()) / cpu[..., :3].mean() < 1e-3
+
+
 def test_kitchen_class_scene(renderer, tmp_path):
     """BASELINE C5 stand-in at reduced size: every closure of SURVEY row a14 + NormalMap / alpha wrappers — the
     all-features variant.  Layered and alpha-tested surfaces are statistical by construction (their internal streams are
@@ -720,20 +753,12 @@ Surface skin : Glass { Kr : Constant { v { 1 } } Kt : Constant { v { 1 } } rough
 """
 
 
-@pytest.mark.parametrize("case", ["vacuum", "fog_env", "fog_lamp_and_medium_box"])
-def test_volumetric_megakernel(renderer, case):
-    """SURVEY §8 f3: MegaVPTNaive (mega_vpt_naive.cpp:170-483) on the device against its oracle restatement.  The sampler and
-    the PCG32 majorant streams are shared, so the two trace the same paths: `vacuum` (no medium) and `fog_env` (an
-    environment medium lit by a constant environment) agree like the path tracer does.
-    `fog_lamp_and_medium_box` is statistical BY CONSTRUCTION OF THE REFERENCE: after a medium "hit surface" event the ray
-    origin is moved onto the surface (homogeneous.cpp:64) and the emitter is evaluated from there (mega_vpt_naive.cpp:331);
-    the direction from that origin to the hit point lies in the surface up to rounding, so diffuse.cpp:84
-    (|cos| < 1e-6 -> no emission) fires or not depending on the last bits — fused multiply-adds alone move the oracle's own
-    mean by 0.5 % (measured), the device's arithmetic by 2.5 %.  That case checks block means with a wide bar and that the
-    medium box is really entered (it differs from the same scene without media by much more)."""
+def _vpt_scene(case, resolution=64, spp=64):
+    """the Cornell box under MegaVPTNaive: `vacuum` (no medium), `fog_env` (an environment medium lit by a constant environment),
+    `fog_lamp_and_medium_box` (the lamp-lit fog with a glass-skinned medium box, the whole box tilted)"""
     extra = "" if case == "vacuum" else FOG
     boxed = case == "fog_lamp_and_medium_box"
-    text = cornell_box(resolution=64, spp=64, depth=8, extra_surfaces=extra, short_box_surface="skin" if boxed else "white")
+    text = cornell_box(resolution=resolution, spp=spp, depth=8, extra_surfaces=extra, short_box_surface="skin" if boxed else "white")
     text = text.replace("integrator : MegaPath {", "integrator : MegaVPTNaive {")
     if case != "vacuum":
         text = text.replace("render {", "render {\n  environment_medium { @fog }")
@@ -748,6 +773,25 @@ def test_volumetric_megakernel(renderer, case):
         shapes = re.search(r"shapes \{ (.*?) \}\n  integrator", text, re.S).group(1)
         text = text.replace(f"shapes {{ {shapes} }}", "shapes { @tilted }")
         text = text.replace("Camera cam", f"Shape tilted : Group {{ shapes {{ {shapes} }} transform : SRT {{ rotate {{ 0.2, 1, 0.1, 5 }} translate {{ -23, 0, 25 }} }} }}\nCamera cam")
+    return text
+
+
+@pytest.mark.parametrize("case", ["vacuum", "fog_env", "fog_lamp_and_medium_box"])
+def test_volumetric_megakernel(renderer, case):
+    """SURVEY §8 f3: MegaVPTNaive (mega_vpt_naive.cpp:170-483) on the device against its oracle restatement.  The sampler and
+    the PCG32 majorant streams are shared, so the two trace the same paths: `vacuum` (no medium) and `fog_env` (an
+    environment medium lit by a constant environment) agree like the path tracer does.
+    `fog_lamp_and_medium_box` is statistical BY CONSTRUCTION OF THE REFERENCE: after a medium "hit surface" event the ray
+    origin is moved onto the surface (homogeneous.cpp:64) and the emitter is evaluated from there (mega_vpt_naive.cpp:331);
+    the direction from that origin to the hit point lies in the surface up to rounding, so diffuse.cpp:84
+    (|cos| < 1e-6 -> no emission) fires or not depending on the last bits — fused multiply-adds alone move the oracle's own
+    mean by 0.5 % (measured), the device's arithmetic by 2.5 %.  Round 6 measured what that is (test_lamp_lit_fog_converges_on_the_oracle
+    below): the estimator's mean depends on the intersector's rounding -- the oracle on the device's own baked triangles is 4.3 % darker
+    than on the object-space ones, the device lies between the two.  The bars here are twice what the device shows at 64 spp (block
+    rel-L1 3.97e-2, mean -2.4e-2); the case also checks that the medium box is really entered (it differs from the same scene without
+    media by much more)."""
+    boxed = case == "fog_lamp_and_medium_box"
+    text = _vpt_scene(case)
     sc = Scene.from_string(text)
     assert sc.view().integrator.kind == 3 and sc.view().medium_count == {"vacuum": 0, "fog_env": 1, "fog_lamp_and_medium_box": 2}[case]
     gpu, gc, cpu, cc = _render_both(renderer, sc, 64)
@@ -763,12 +807,71 @@ def test_volumetric_megakernel(renderer, case):
     if not boxed:
         assert _rel_l1(gpu, cpu) < 5e-3 and bias < 1e-3
     else:
-        assert err < 0.12 and bias < 0.06
+        assert err < 0.08 and bias < 0.05  # (twice the 3.97e-2 / 2.43e-2 measured in round 6)
         plain = Scene.from_string(text.replace(" medium { @inner }", "").replace("\n  environment_medium { @fog }", ""))
         renderer.upload(plain)
         renderer.render(0, 64, sync=True)
         p = _blocks(renderer.download(converted=False))
         assert np.abs(p - c).sum() / np.abs(c).sum() > 0.25
+
+
+def test_lamp_lit_fog_converges_on_the_oracle(renderer):
+    """the lamp-lit fog case's "statistical by construction" as a MEASUREMENT, the way the kitchen class got one in round 5.
+    The reference moves the ray origin ONTO the surface it just reached -- origin + direction * t_hit, homogeneous.cpp:64 -- and evaluates the
+    emitter from there (mega_vpt_naive.cpp:331), so diffuse.cpp:84's |cos| < 1e-6 test is decided by how far off the surface's plane the
+    rounding of t_hit and of the reconstructed hit point leave that origin.  Four sides render the same samples [0, 64), [0, 256), [0, 1024):
+    the device (volumetric kernel: no contraction, exact division, 1 / det in the triangle test), the oracle, the oracle BUILT WITH
+    -ffp-contract=fast (oracle/liboracle_fma.so: what fused multiply-adds alone do to it), and the oracle intersecting the WORLD-space
+    triangles the host bakes for the device instead of the reference's object-space ones (bake_instances).
+    MEASURED (round 6, profiles/r06n_fog_convergence.txt): this is not a lottery with fixed odds.  The oracle on the baked triangles is
+    4.3 % DARKER than the oracle on the object-space ones, at 64 spp and at 1024 spp alike -- t_hit from a world-space triangle test lands
+    the origin closer to the plane, the test fires more often -- while contraction alone moves the oracle by 0.8 % -> 0.2 % (noise).  The
+    estimator's MEAN is a function of the intersector's rounding; the reference's own intersector is LuisaCompute's (absent; DESIGN.md
+    section 8: unpinnable), the object-space one of the oracle is the builder's stand-in for it.  The device intersects baked triangles (like
+    the darker oracle) and reconstructs the hit point in object space (like the brighter one): it sits BETWEEN the two, -2.2 % ... -1.5 %
+    against the object-space oracle and +3 % against the baked one, and what is left after that offset keeps falling with the samples, within
+    twice the distance of the oracle's two builds.  Asserted: the device is no further from the reference-mode oracle than the oracle's own
+    second geometry mode is, its mean lies between the two modes', and its distance with the mean offset taken out falls by > 1.25 per
+    4 x spp and stays below twice the oracle pair's."""
+    sc = Scene.from_string(_vpt_scene("fog_lamp_and_medium_box", resolution=64, spp=1024))
+    plain, fused, baked = Oracle(sc), Oracle(sc, lib="liboracle_fma.so"), Oracle(sc, bake_instances=True)
+    cpu = cpu_fused = cpu_baked = None
+    renderer.upload(sc)
+    rows, begin = {}, 0
+
+    def blocks(f):  # block means of the per-pixel ESTIMATES (the film rejects NaN samples on every side, not necessarily the same ones)
+        return _blocks(f[..., :3] / np.maximum(f[..., 3:4], 1.0))
+
+    d = lambda x, y: float(np.abs(x - y).sum() / np.abs(y).sum())  # noqa: E731
+    for spp in (64, 256, 1024):
+        renderer.render(begin, spp, counters=False, sync=True)  # (progressive: the film carries on)
+        gpu = renderer.download(converted=False)
+        cpu, _ = plain.render(begin, spp, film=cpu)
+        cpu_fused, _ = fused.render(begin, spp, film=cpu_fused)
+        cpu_baked, _ = baked.render(begin, spp, film=cpu_baked)
+        begin = spp
+        assert _variant(renderer) == 256 and np.isfinite(gpu).all() and np.abs(gpu[..., 3] - cpu[..., 3]).max() <= max(8, spp // 8)
+        g, c, f, b = blocks(gpu), blocks(cpu), blocks(cpu_fused), blocks(cpu_baked)
+        rows[spp] = {"device_vs_oracle": d(g, c), "fma_oracle_vs_oracle": d(f, c), "baked_oracle_vs_oracle": d(b, c), "device_vs_baked_oracle": d(g, b),
+                     "device_vs_oracle_without_offset": d(g * (c.mean() / g.mean()), c),
+                     "bias": float((g.mean() - c.mean()) / c.mean()), "bias_fma_oracle": float((f.mean() - c.mean()) / c.mean()),
+                     "bias_baked_oracle": float((b.mean() - c.mean()) / c.mean())}
+        r = rows[spp]
+        print(f"vpt lamp-lit fog 64 x 64 at {spp} spp: block rel-L1 to the oracle: device {r['device_vs_oracle']:.3e} (mean offset taken out {r['device_vs_oracle_without_offset']:.3e}), "
+              f"fma oracle {r['fma_oracle_vs_oracle']:.3e}, baked-triangle oracle {r['baked_oracle_vs_oracle']:.3e}; device vs baked-triangle oracle {r['device_vs_baked_oracle']:.3e}; "
+              f"mean bias device {r['bias']:+.2e}, fma oracle {r['bias_fma_oracle']:+.2e}, baked-triangle oracle {r['bias_baked_oracle']:+.2e}")
+    for spp, r in rows.items():
+        # (a) no further from the reference-mode oracle than the oracle's own second geometry mode
+        assert r["device_vs_oracle"] < r["baked_oracle_vs_oracle"], (spp, rows)
+        # (b) the device's mean lies between the two geometry modes' (1 % of slack either side: 64 spp of this estimator)
+        assert r["bias_baked_oracle"] - 1e-2 < r["bias"] < 1e-2, (spp, rows)
+    # (c) what is left of the distance once the mean offset is out keeps falling with the samples (measured 3.45e-2 / 2.15e-2 / 1.55e-2: the offset
+    # is not uniform over the frame -- only the blocks that see lamp-lit surfaces carry it -- so it falls slower than the oracle's two builds approach
+    # each other, 3.35e-2 / 1.57e-2 / 1.02e-2) and stays within twice the oracle pair's distance at every sample count
+    for lo, hi in ((64, 256), (256, 1024)):
+        assert rows[lo]["device_vs_oracle_without_offset"] / rows[hi]["device_vs_oracle_without_offset"] > 1.25, (lo, hi, rows)
+    for spp, r in rows.items():
+        assert r["device_vs_oracle_without_offset"] < 2.0 * r["fma_oracle_vs_oracle"], (spp, rows)
 
 
 def test_edge_cases(renderer):
