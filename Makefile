@@ -84,7 +84,7 @@ VPT_HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -ffp-contract=o
 # establish that a fast build is sound; the flag removes the mechanism.  Cost: kitchen stand-in 275 -> 256 Msamples/s, <60> 350 -> 298
 # (profiles/archive/r02f_ab_compiler_flags.txt).  Round 4: the LEAN variants too -- since round 3 they make a real call of their own
 # (the texture callback of load_lobe, dev_math.h: LR_TEX_LAMBDA, is out of line) and spill SGPRs, i.e. they hold exactly the
-# ingredients; no binary of theirs was ever caught wrong (profiles/r03s_sgpr_spill_repro.txt: bit-identical with and without the
+# ingredients; no binary of theirs was ever caught wrong (profiles/archive/r03s_sgpr_spill_repro.txt: bit-identical with and without the
 # flag), but the same was true of <124> for two rounds.  Cost, same box: C2 782.3 -> 777.0, C3 809.6 -> 803.4, C4 875.6 -> 876.2
 # Msamples/s at 64 spp, films bit-identical (profiles/r04_ab_call_safe_lean.txt).
 CALL_SAFE_FLAGS ?= -mllvm -amdgpu-spill-sgpr-to-vgpr=0

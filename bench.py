@@ -396,7 +396,7 @@ def roofline_block(workload, variant, kernel_ms, launch_samples, bytes_per_sampl
             "cycles_per_wave_instr": price, "valu_mix": pmc.get("valu_mix"), "simds": simds, "shader_clock_hz": SHADER_CLOCK_HZ, "simd_cycles_per_launch": simd_cycles,
             "calibration": "issue_frac = wave_instr_per_launch x cycles_per_wave_instr / simd_cycles_per_launch.  cycles_per_wave_instr = the DYNAMIC class mix of the kernel(s) that ran "
                            "(PMC: SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 x 2.4, TRANS_F32 x 8.2, CVT x 4.2, everything else x 3.55 = the mean price of the unclassified opcodes in the pool "
-                           "kernel's census) with the issue costs measured on the box (profiles/r04h_cndmask_forms.json, tools/valu_peak2.hip)"
+                           "kernel's census) with the issue costs measured on the box (profiles/archive/r04h_cndmask_forms.json, tools/valu_peak2.hip)"
                            if pmc.get("cycles_per_wave_instr") else "static mix of the pool kernel's traversal loop (profiles/r05_isa_census_pool.txt): the class counters were not collected",
             # what a change of the instruction count buys, MEASURED (round 5, profiles/r05b_sensitivity_probes.txt, r05c_pmc_*.json): 9.3 % more VALU instructions
             # (32 dependent v_fma per node step) cost 4.3 % time, 6.3 % fewer gained 2.4 %, three waves per SIMD instead of four cost 16 %

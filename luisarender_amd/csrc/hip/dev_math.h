@@ -32,7 +32,7 @@ __device__ __forceinline__ bool lr_any(bool p) { return __any(p) != 0; }
 // variants it is the one real call they make -- only hits on textured closures take it: <0> 73 -> 58 KB, <20> 220 -> 153 KB, and C2,
 // which never runs it, +1.5 % from what the rest of the kernel gets out of the smaller function (C3 / C4 unchanged; inlined at every
 // use: C4 -1.2 %; EVERY texture lookup through one out-of-line function instead: C2 the same, C3 -0.5 %, C4 -1 %;
-// profiles/r03ae_texture_lambda_ab.txt).  Rounds 1-2 had the same call by accident: the inliner left the lambda out
+// profiles/archive/r03ae_texture_lambda_ab.txt).  Rounds 1-2 had the same call by accident: the inliner left the lambda out
 // of line while the texture code still held powf.
 #ifndef LR_CALL
 #if defined(LR_VARIANT) && ((LR_VARIANT) & (96 | 256)) && !defined(LR_CALL_INLINE)

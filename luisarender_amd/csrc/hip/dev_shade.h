@@ -128,7 +128,7 @@ struct PathSampler<true> {
     }
     // sobol.cpp:52-60: the XOR of the matrix columns the index has bits in -- taken a BYTE of the index at a time from the table
     // lrhip_upload_scene builds out of the same matrices (the product is linear over GF(2)): 4-5 independent loads per draw instead
-    // of a 30-40 trip loop with a dependent load per set bit (C2 stand-in, Sobol sampler: 425 -> 703 Msamples/s, profiles/r03ac_*)
+    // of a 30-40 trip loop with a dependent load per set bit (C2 stand-in, Sobol sampler: 425 -> 703 Msamples/s, profiles/archive/r03ac_*)
     LR_D uint32_t sobol_bits(uint64_t idx, uint32_t dim) const {
         constexpr uint32_t kBytes = (static_cast<uint32_t>(LR_SOBOL_MATRIX_SIZE) + 7u) / 8u;
         auto t = scene->sobol_bytes + dim * (kBytes * 256u);

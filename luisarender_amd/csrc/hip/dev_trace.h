@@ -161,7 +161,7 @@ struct TraversalStack {
     }
 };
 
-// Round 3 (profiles/r03_valu_peak.json: on gfx950 only v_fma / v_mul / v_add / v_and / v_xor / v_mov issue every 2 cycles per
+// Round 3 (profiles/archive/r03_valu_peak.json: on gfx950 only v_fma / v_mul / v_add / v_and / v_xor / v_mov issue every 2 cycles per
 // wave64; every min / max / cvt / cndmask / cmp / shift / 64-bit add / DPP / packed op takes 4, LDS-crossing ds_bpermute 25):
 //   * the packet fetch is organised by QUADS: load j of lane l fetches quarter (l & 3) of the packet of lane (l & ~3) + j, whose node
 //     index comes over a DPP quad_perm broadcast (VALU) instead of a ds_bpermute (LDS); addresses are 32-bit offsets from the scalar
@@ -172,7 +172,7 @@ struct TraversalStack {
 //   * one wave-level test per iteration decides whether any lane could reach the HBM overflow area of the stack; if not, every push
 //     and pop of the iteration is a bare LDS access.
 // A/B of the three against the round-2 forms (ds_bpermute + XOR swizzle, v_cndmask selects, per-entry range checks), C2 at 256 spp:
-// 813 -> 828 (quad fetch) / 820 (child reads) / 835 (both) -> 844 (stack test) Msamples/s; profiles/r03b_ab_quad_fetch.txt.
+// 813 -> 828 (quad fetch) / 820 (child reads) / 835 (both) -> 844 (stack test) Msamples/s; profiles/archive/r03b_ab_quad_fetch.txt.
 constexpr uint32_t kStageRegion = 65u;     // float4 per load region of the wave's staging area (64 + one float4 of bank stagger)
 constexpr uint32_t kStageWave = 4u * kStageRegion;          // float4 per wave
 
@@ -355,7 +355,7 @@ LR_D void trav_slab_sort_q(float4 q0, float4 q1, float4 q2, const TravState &tr,
     auto nx = inv.x < 0.f ? hix : lox, fx = inv.x < 0.f ? lox : hix;
     auto ny = inv.y < 0.f ? hiy : loy, fy = inv.y < 0.f ? loy : hiy;
     auto nz = inv.z < 0.f ? hiz : loz, fz = inv.z < 0.f ? loz : hiz;
-    // (round 4, two more forms of these selects, after profiles/r04h_cndmask_forms.json priced a v_cndmask_b32_e32 right behind another
+    // (round 4, two more forms of these selects, after profiles/archive/r04h_cndmask_forms.json priced a v_cndmask_b32_e32 right behind another
     // one at 19 cycles: one v_swap_b32 under EXEC per axis -- compare, s_and_saveexec, branch, swap, restore -- lost 2.7 % (965 -> 939);
     // per-ray sign masks in SGPRs, remade at every turnover, and six v_cndmask_b32_e64 on them, no compare: 961 vs 961, the
     // one-path-per-lane kernel 841 vs 848.  Here each pair sits right behind its own v_cmp, which is the cheap case)
@@ -474,7 +474,7 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 // of the wave every step, and at 4 triangles per leaf that cost more than the extra level of boxes
 // (measured on C2: 422 -> 537 Msamples/s, tris/ray 12.3 -> 3.4, nodes/ray 19.2 -> 21.6).
 //
-// MEASURED IN ROUND 4 AND NOT KEPT (the code is gone in round 5; profiles/r04d_leaf_batching.txt, r04e_fused_fetch.txt):
+// MEASURED IN ROUND 4 AND NOT KEPT (the code is gone in round 5; profiles/archive/r04d_leaf_batching.txt, r04e_fused_fetch.txt):
 //   * leaf batching -- a lane that arrives at a leaf keeps it in a register, goes on with its stack, and the wave runs the leaf step when
 //     12 ... 40 lanes hold one: the pool kernel 898 -> 889 / 891 / 875 / 835 / 767 Msamples/s, the one-path kernel 850 -> 820 ... 497; lanes
 //     simply WAITING at their leaf until 12 of them do: +0.6 %;

@@ -5,7 +5,7 @@
 // wave, so the Layered random walk or the Mix interpreter runs for full waves instead of for the two or three lanes of a
 // megakernel wave that happened to hit such a surface -- and with a register allocation of its own, which is what the heavy
 // closures cost the megakernel variants that held them (round 2: <124> carried a 2.4 KB/lane spill frame and its TRAVERSAL loop ran
-// 2.2x slower per step than the lean kernel's, profiles/r03a stats).  Per vertex it does what the megakernel's shading block does
+// 2.2x slower per step than the lean kernel's, profiles/archive/r03a stats).  Per vertex it does what the megakernel's shading block does
 // for a basic closure -- one iteration of the reference's depth loop from the light sample on (src/integrators/mega_path.cpp:88-154):
 // light selection + light sample (uniform.cpp:78-137), closure evaluate (NEE, MIS), closure sample, throughput, Russian roulette --
 // with the random numbers drawn in the reference's order from the path's own stream, and writes a CONTINUATION record (shadow ray +

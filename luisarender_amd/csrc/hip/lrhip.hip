@@ -1014,7 +1014,7 @@ int lrhip_film_clear(lrhip_ctx *ctx) {
 // size, the rest in items a third of it, and all big items are handed out before the first small one: the bulk drains rarely, the
 // end of the launch is made of short items.  C2 at 1024 spp, full frame / 1-of-8 shard: uniform 1213.5 / 164.5 ms, tapered 1197.5 /
 // 158.0 ms (kernel-level strong-scaling efficiency at 8 shards 0.922 -> 0.947); big factor 2 / 2.5 / 3.5 / 4, small divisor 2 / 3 /
-// 4 / 5 and fractions 0.75 / 0.85 / 0.9 were swept (profiles/r03p_taper_sweep.txt).  The partition is a function of (spp, shard_tiles, scale) only -- never of the device
+// 4 / 5 and fractions 0.75 / 0.85 / 0.9 were swept (profiles/archive/r03p_taper_sweep.txt).  The partition is a function of (spp, shard_tiles, scale) only -- never of the device
 // or of the tile range of the call -- so films stay bit-identical under any sharding with the same balance_shards.
 #ifndef LR_TAPER_BIG
 #define LR_TAPER_BIG 2.5
@@ -1078,7 +1078,7 @@ int ensure_accum(lrhip_ctx *ctx, uint32_t pixel_count) {
 // current context through the LDS) is not paid back by fuller traversal steps.  Measured in round 4 at the bench's scenes (kernel
 // time, one path per lane / pool, profiles/r04_final_schedulers.txt): Cornell box, 32 triangles, 0.88; C2 1.5 M triangles 1.08 (1024
 // spp) ... 1.12 (256 spp); C3 1.18; C4 1.06; C5 (wavefront mode) 1.10.
-// A room scene swept over its triangle count (profiles/r04i_scheduler_crossover.txt): 0.88 at 2-5 thousand triangles, 0.93 at 12, 0.96 at
+// A room scene swept over its triangle count (profiles/archive/r04i_scheduler_crossover.txt): 0.88 at 2-5 thousand triangles, 0.93 at 12, 0.96 at
 // 30, 1.06 at 100, 1.20 at 400 thousand.
 // Round 5 (tools/sched_sweep.py, profiles/r05j_scheduler_sweep.txt: the room scene over its triangle count x path depth x spp, the Cornell
 // box over depth x spp): what the pool buys grows with the LENGTH of the walks (triangles) and of the paths (depth) and with the share of
@@ -1155,7 +1155,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     scene.wf.accum = static_cast<unsigned long long *>(ctx->wf_accum.ptr), scene.wf.accum_scale = static_cast<float>(accum_scale);
     // kernels: the lean camera pass + continuation pass with the scene's environment / alpha needs, the heavy kernel with its nesting
     // (the alpha-tested traversal only where a surface may be non-opaque: the kitchen stand-in with its lace made opaque runs at 530.6
-    // instead of 520.5 Msamples/s on the lean kernels without it, profiles/r03ar_wavefront_without_alpha_ab.txt)
+    // instead of 520.5 Msamples/s on the lean kernels without it, profiles/archive/r03ar_wavefront_without_alpha_ab.txt)
     auto lean = (ctx->features & (lrd::kFeatEnv | lrd::kFeatAlpha)) | lrd::kFeatWf | (count ? lrd::kFeatCount : 0u) | (generic ? lrd::kFeatGeneric : 0u);
     const auto n_variants = sizeof(kVariants) / sizeof(kVariants[0]);
     // round 4: both lean passes under the path-pool scheduler (megapool_kernel.h) where those kernels are in the library

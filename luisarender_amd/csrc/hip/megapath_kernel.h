@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                    LAYERED = (F & kFeatLayered) != 0u, AUX = (F & kFeatAux) != 0u, WF = (F & kFeatWf) != 0u, CONT = (F & kFeatCont) != 0u;
     static_assert(!LAYERED || DISNEY, "the Layered interpreter instantiates the Disney closure");
     // (Disney inline in the wavefront kernels, only Mix / Layered parked, was measured: C5 at 512 spp 442 -> 386 Msamples/s -- the lean
-    // kernel pays 109 spilled VGPRs for it, profiles/r03i_wavefront_ab.txt)
+    // kernel pays 109 spilled VGPRs for it, profiles/archive/r03i_wavefront_ab.txt)
     static_assert(!WF || !(DISNEY || MIX || LAYERED || AUX), "a wavefront variant is a lean kernel: the heavy closures live in heavy_kernel.h");
     static_assert(!CONT || WF, "the continuation pass exists in wavefront mode only");
     constexpr uint32_t SAMPLER_WORDS = PathSampler<PCG>::kSavedWords;

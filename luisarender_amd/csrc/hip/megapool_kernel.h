@@ -2,7 +2,7 @@
 //
 // megapath_kernel.h (rounds 1-3) binds one path to one lane: a lane whose ray has finished waits, idle, until enough of its
 // neighbours have finished too (the refill threshold), and the shading block then runs for the ~half of the wave that has
-// something to shade.  Measured on the C2 stand-in (profiles/r03am_*): 56 % of the traversal loop's lane-steps and 47 % of the
+// something to shade.  Measured on the C2 stand-in (profiles/archive/r03am_*): 56 % of the traversal loop's lane-steps and 47 % of the
 // shading block's lanes did useful work while the VALU pipes were ~full -- the machine was busy computing masked-off lanes.
 //
 // Here a wave holds 128 paths, two CONTEXTS per lane.  While one context's rays are traced the other one waits -- for the shading
@@ -21,12 +21,12 @@
 //     loop), what is left of the ray in flight (hit so far, t_max, node, phase / stack depth) on top of the lane's own traversal
 //     stack.  This is what makes the scheme pay: with those six words in registers the block spilled 37 VGPRs on its hot path, the
 //     scratch traffic evicted the BVH's top levels from the 32 KB vector L1, and a node step took 4200 cycles instead of 2100
-//     (profiles/r04c_*, r04g_*).
+//     (profiles/archive/r04c_*, r04g_*).
 // Measured (profiles/r04_final_schedulers.txt, kernel time of the one-path-per-lane kernel / this one, same build, same box): C2 1.08
 // at 1024 spp, C3 1.18, C4 1.06, C5 (wavefront mode) 1.10 at 64 spp; a Cornell box 0.88 -- lrhip.hip: wants_pool picks this kernel
 // from ~100 thousand triangles up, earlier for deep paths at few samples per pixel, later for shallow ones (lrhip.hip: pool_auto_triangles; profiles/r05j_scheduler_sweep.txt).
 //
-// MEASURED AND NOT KEPT (profiles/r04a_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
+// MEASURED AND NOT KEPT (profiles/archive/r04a_*): 128 path SLOTS per wave shared by all lanes -- records of 128 B in global memory, ray and
 // shade queues of slot numbers in LDS, lanes fetching their next job from the ray queue inside the loop.  It filled the lanes (0.93 /
 // 0.79, 23 % fewer VALU instructions per sample, films equal to 6e-8) and was no faster: C2 830 against 854 Msamples/s at 256 spp,
 // C1 2420 against 4820.  Every job turnover read and wrote slot records whose lines the 4 MiB L2 of an XCD had long dropped (8 MiB of
@@ -68,7 +68,7 @@ namespace lrd {
 // A ray that ended waits until this many lanes have one (or no lane has anything left to traverse): the turnover code of the loop --
 // results into the context, exchange of the contexts, the next ray into the traversal state, 1 / d -- then runs once for all of them,
 // every seventh iteration or so instead of in seven of ten.  C2, 256 spp: 918 Msamples/s at 1 (no waiting), 924 at 5 (on the build
-// before), 955 at 8, 954 at 12, 945 at 16, 916 at 24 (profiles/r04f_turnover_and_stack.txt).  Round 5, the loop lighter: 12 is 0.3-0.6 % ahead of
+// before), 955 at 8, 954 at 12, 945 at 16, 916 at 24 (profiles/archive/r04f_turnover_and_stack.txt).  Round 5, the loop lighter: 12 is 0.3-0.6 % ahead of
 // 8 in four A/Bs (r05a, r05d, r05l, r05r), 6 and 4 behind.
 #define LR_POOL_TURNOVER_LANES 12
 #endif
@@ -125,7 +125,7 @@ struct PathCtx {
 // the first ray of a context's job into the lane's traversal state
 LR_D void ctx_start(PathCtx &c, TravState &tr) {
     // (written so that the compiler moves under EXEC instead of selecting: eight v_cndmask_b32_e32 in a row on one VCC cost 19 cycles
-    // EACH on this chip -- tools/valu_peak2.hip, profiles/r04h_cndmask_forms.json: 18.7 back to back, 2.2 with other VALU work
+    // EACH on this chip -- tools/valu_peak2.hip, profiles/archive/r04h_cndmask_forms.json: 18.7 back to back, 2.2 with other VALU work
     // between them, 4.2 in the VOP3 form -- and a job turnover was mostly that: C2 956 -> 965 Msamples/s)
     tr.o = c.no, tr.d = c.nd, tr.t_min = c.n_tmin, tr.t_max = c.n_tmax;
     tr.phase = kPhaseClosest;

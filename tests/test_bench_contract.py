@@ -83,8 +83,8 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_round3_line_carries_parity_path_statistics_and_every_baseline_config():
-    """the line of the round-3 state (profiles/r03zb_bench_c2_1gpu.json, the driver's default command)"""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r03zb_bench_c2_1gpu.json")))
+    """the line of the round-3 state (profiles/archive/r03zb_bench_c2_1gpu.json, the driver's default command)"""
+    line = json.load(open(os.path.join(ROOT, "profiles", "archive", "r03zb_bench_c2_1gpu.json")))
     assert line["n_gpus"] == 1 and line["value"] > 850 and line["roofline"]["traffic_source"].startswith("live") and 0.05 < line["roofline"]["frac"] < 0.5
     p = line["parity"]
     assert p["finite"] and p["samples"] == 1024 * 1024 * p["spp"] and p["rel_l1"] < 2e-2 and p["rmse_over_mean"] < 0.5 and abs(p["mean_bias"]) < 1e-3 and p["flip"] < 0.1

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Per-loop instruction census of a disassembled megakernel variant, priced with the on-box issue-cost table
-(profiles/r03_valu_peak.json, tools/valu_peak2.hip): for the traversal loop (the innermost loop that holds the four
+(profiles/archive/r03_valu_peak.json, tools/valu_peak2.hip): for the traversal loop (the innermost loop that holds the four
 global_load_lds), its node step and its leaf step, and for the whole kernel: instructions per class and the VALU issue cycles
 one wave-level pass costs a SIMD.
 
     tools/kernel_resources.sh 0 && /opt/rocm/lib/llvm/bin/llvm-objdump -d /tmp/kres/v0.co > /tmp/kres/v0.s
-    python tools/isa_census.py /tmp/kres/v0.s [profiles/r03_valu_peak.json]
+    python tools/isa_census.py /tmp/kres/v0.s [profiles/archive/r03_valu_peak.json]
 
 Cost classes (cycles per wave64 instruction per SIMD with >= 2 waves resident, measured):
   full   v_fma/mul/add/sub/fmac_f32, v_and/or/xor_b32, v_add/sub_u32, v_mov_b32                                ~2.4

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs of consecutive v_cndmask_b32_e32 (implicit VCC) in a disassembled kernel: on gfx950 such an instruction issued right behind
-another one costs ~19 cycles instead of 2-4 (tools/valu_peak2.hip, profiles/r04h_cndmask_forms.json); other VALU work between them,
+another one costs ~19 cycles instead of 2-4 (tools/valu_peak2.hip, profiles/archive/r04h_cndmask_forms.json); other VALU work between them,
 or the VOP3 form, does not.    llvm-objdump -d x.co > x.s && python tools/isa_cndmask_runs.py x.s [context lines]"""
 import re
 import sys

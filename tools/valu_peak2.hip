@@ -3,7 +3,7 @@
 // opcodes and one of them, v_cndmask_b32, came out at 23 cycles -- VERDICT r02 asks whether that is real).
 // Every opcode runs as 8 independent chains x 32 in an unrolled loop, no memory traffic; the clock is s_memtime-independent:
 // cycles = wall time x the device's reported peak clock, so "2.4" means 2 cycles at the clock the chip really ran at.
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_peak2.hip -o gpurun_out/valu_peak2 && gpurun_out/valu_peak2 > profiles/r03_valu_peak.json
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_peak2.hip -o gpurun_out/valu_peak2 && gpurun_out/valu_peak2 > profiles/archive/r03_valu_peak.json
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
