@@ -28,9 +28,15 @@ namespace lrd {
 // Measured with it and not kept: the closure resolution as one out-of-line function with the passes inside (its 41 words of result through
 // memory, 340 scratch instructions of callee saves per call: every configuration 5 - 12 % slower, r06g), and touching the texels ahead of
 // the lookups instead of keeping results (-7 %, r06i).
+// LR_LOBE_FORM 3 (round 6): ONE lookup of every lane at one place ahead of everything else -- its normal map if it has one, else its first
+// looked-up slot (DSurface::first_lookup, asked for beside the closure record) -- three registers instead of form 2's six.  The lean passes of
+// wavefront mode: the kitchen class' floor / Oren-Nayar / plastic albedo and the bumpy plastic's normal map were four lookups one kind after
+// the other; 592 -> 607 Msamples/s at 512 spp, films bit-identical (profiles/r06q_lobe_form3.txt).
 #ifndef LR_LOBE_FORM
 #if defined(LR_VARIANT) && ((LR_VARIANT) & 16) && !((LR_VARIANT) & (96 | 256))
 #define LR_LOBE_FORM 2
+#elif defined(LR_VARIANT) && ((LR_VARIANT) & 1024) && !((LR_VARIANT) & (96 | 256))
+#define LR_LOBE_FORM 3
 #else
 #define LR_LOBE_FORM 1
 #endif
@@ -38,23 +44,51 @@ namespace lrd {
 // closure record + shading frame of surface `t` on top of frame `base`: NormalMapWrapper (surface.h:236-254) and
 // per-hit texture resolution for "dynamic" closures (the constant ones were folded at upload by the same resolve_closure)
 LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const Frame &base, DClosure &c, Frame &fr, float eta_i = 1.f) {
+#if LR_LOBE_FORM == 3
+    const auto first_id = tb.surfaces[t].first_lookup;// (asked for beside the closure record, not behind it)
+#endif
     c = tb.closures[t];
     fr = base;
     if (c.dynamic || eta_i != 1.f) {// (eta_i != 1: the bottom of a Layered surface under a refractive top)
         auto &rec = tb.surfaces[t];
         auto &raw = rec.raw;
+#if LR_LOBE_FORM == 3
+        // the lookup of a slot whose texture is NOT constant: the out-of-line lambda of round 3 (dev_math.h: LR_TEX_LAMBDA), now asked for
+        // those slots only -- a constant slot is a plain load from the surface's own record (dev_scene.h: DSurface), independent of the
+        // other slots' and issued with them, where it used to be a call and a dependent round trip through the texture table each
+#if LR_TEX_BY_VALUE
+        const auto lookup = [&](int32_t id) { return texture_eval_slot(tb.textures, tb.texels, id, uv.x, uv.y); };
+#else
+        const auto lookup = [&](int32_t id) LR_TEX_LAMBDA_ATTR { return texture_eval_tables(tb.textures, tb.texels, id, uv); };
+#endif
+        // ONE lookup of every lane at ONE place ahead of everything else: the lane's normal map if it has one, else its first looked-up slot.
+        // (The kitchen class' lean hits: floor and Oren-Nayar albedo, the plastic's albedo, the bumpy plastic's normal map -- four lookups one
+        // kind after the other become one, and the plastic's roughness.)
+        const auto first_is_normal = raw.normal_tex >= 0;
+        float4 looked_first = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first_id >= 0) { looked_first = lookup(first_id); }
+        if (first_is_normal) {
+            auto v = looked_first;
+#else
         if (raw.normal_tex >= 0) {
             auto v = texture_eval_tables(tb.textures, tb.texels, raw.normal_tex, uv);
+#endif
             auto n_local = mk3(2.f * v.x - 1.f, 2.f * v.y - 1.f, 2.f * v.z - 1.f);
             if (raw.normal_strength != 1.f) { n_local = n_local * mk3(raw.normal_strength, raw.normal_strength, 1.f); }
             auto normal = to_world(base, n_local);
             fr = frame_from_normal_tangent(clamp_shading_normal(normal, ng, wo), base.s);
         }
         auto dyn = c.dynamic;
+#if LR_LOBE_FORM != 3
         // the lookup of a slot whose texture is NOT constant: the out-of-line lambda of round 3 (dev_math.h: LR_TEX_LAMBDA), now asked for
         // those slots only -- a constant slot is a plain load from the surface's own record (dev_scene.h: DSurface), independent of the
         // other slots' and issued with them, where it used to be a call and a dependent round trip through the texture table each
-        const auto lookup = [&](int32_t id) LR_TEX_LAMBDA { return texture_eval_tables(tb.textures, tb.texels, id, uv); };
+#if LR_TEX_BY_VALUE
+        const auto lookup = [&](int32_t id) { return texture_eval_slot(tb.textures, tb.texels, id, uv.x, uv.y); };
+#else
+        const auto lookup = [&](int32_t id) LR_TEX_LAMBDA_ATTR { return texture_eval_tables(tb.textures, tb.texels, id, uv); };
+#endif
+#endif
         const auto mask = rec.dynamic_mask;
 #if LR_LOBE_FORM == 2
         f3 looked0 = mk3(0.f), looked1 = mk3(0.f);
@@ -86,6 +120,11 @@ LR_D void load_lobe(const LobeTables &tb, f2 uv, f3 ng, f3 wo, uint32_t t, const
                     if (rank >= 2) { return lookup(raw.tex[slot]); }
                     const auto v = rank == 0 ? looked0 : looked1;
                     return make_float4(v.x, v.y, v.z, 0.f);
+                }
+#elif LR_LOBE_FORM == 3
+                if ((mask >> slot) & 1u) {
+                    if (!first_is_normal && (mask & ((1u << slot) - 1u)) == 0u) { return looked_first; }
+                    return lookup(raw.tex[slot]);
                 }
 #else
                 if ((mask >> slot) & 1u) { return lookup(raw.tex[slot]); }

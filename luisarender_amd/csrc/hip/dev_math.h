@@ -28,7 +28,8 @@ __device__ __forceinline__ bool lr_any(bool p) { return __any(p) != 0; }
 // calls only in those same variants (one copy instead of one per use: -60 % code, fewer spills in the main loop);
 // in the lean ones the call overhead costs more than it saves (measured inline vs call: C2 +2 %, C3 +1.4 %, C4 +7 %).
 // Every variant is its own translation unit (megapath_variant.hip defines LR_VARIANT), so this is a preprocessor choice.
-// LR_TEX_LAMBDA: the texture callback resolve_closure gets from load_lobe (dev_heavy.h), its ~20 uses in ONE place.  In the lean
+// LR_TEX_LAMBDA: the texture lookup behind the callback resolve_closure gets from load_lobe (dev_heavy.h; dev_shade.h: texture_eval_slot -- a
+// capturing lambda until round 6), its ~20 uses in ONE place.  In the lean
 // variants it is the one real call they make -- only hits on textured closures take it: <0> 73 -> 58 KB, <20> 220 -> 153 KB, and C2,
 // which never runs it, +1.5 % from what the rest of the kernel gets out of the smaller function (C3 / C4 unchanged; inlined at every
 // use: C4 -1.2 %; EVERY texture lookup through one out-of-line function instead: C2 the same, C3 -0.5 %, C4 -1 %;
@@ -37,14 +38,22 @@ __device__ __forceinline__ bool lr_any(bool p) { return __any(p) != 0; }
 #ifndef LR_CALL
 #if defined(LR_VARIANT) && ((LR_VARIANT) & (96 | 256)) && !defined(LR_CALL_INLINE)
 #define LR_CALL __device__ __noinline__
-#define LR_TEX_LAMBDA
+#define LR_TEX_LAMBDA __device__ __forceinline__
 #else
 #define LR_CALL __device__ __forceinline__
-#define LR_TEX_LAMBDA __attribute__((noinline))
+#define LR_TEX_LAMBDA __device__ __noinline__
 #endif
 #endif
 #ifndef LR_TEX_LAMBDA
-#define LR_TEX_LAMBDA// (LR_CALL given by the translation unit, heavy_variant.hip: texture_eval_tables is a real call itself)
+#define LR_TEX_LAMBDA __device__ __forceinline__// (LR_CALL given by the translation unit, heavy_variant.hip: texture_eval_tables is a real call itself)
+#endif
+#ifndef LR_TEX_BY_VALUE
+#define LR_TEX_BY_VALUE 0
+#endif
+#if defined(LR_VARIANT) && !((LR_VARIANT) & (96 | 256)) && !defined(LR_CALL_INLINE)
+#define LR_TEX_LAMBDA_ATTR __attribute__((noinline))
+#else
+#define LR_TEX_LAMBDA_ATTR
 #endif
 #ifndef LR_HEAVY
 #define LR_HEAVY __device__ __noinline__

@@ -62,7 +62,7 @@ struct alignas(16) DSurface {
     float value[kSurfaceSlots][4]; // Texture::evaluate of the slot's texture where it is constant (lr_texture::v); 16-byte aligned: read as float4
     uint32_t dynamic_mask;         // slots whose texture is not constant: evaluated per hit
     uint32_t channels[2];          // lr_texture::channels of the slot's texture, 4 bits per slot
-    uint32_t pad;
+    int32_t first_lookup;          // the texture a hit on this surface looks up FIRST: its normal map, else its first slot in dynamic_mask; -1: none (load_lobe, LR_LOBE_FORM 3)
     lr_surface raw;                // the host's record (136 B)
     uint32_t pad2[6];
 };

@@ -395,10 +395,35 @@ LR_HD float byte_over_255(float b) {// correctly rounded b / 255.f for b = 0 .. 
     const auto r = fmaf(-q, 255.f, b);
     return fmaf(r, 1.f / 255.f, q);
 }
+// LR_TEX_WIDE_RECORD: the out-of-line lookup reads a texture's record in one round trip and everything through explicitly global loads (texture_record below).
+// Measured (profiles/r06u_texture_record_loads.txt, films bit-identical): camera class <12308> 1146 -> 1163 Msamples/s at 64 spp; the kitchen
+// class' lean wavefront passes LOSE 0.4 % (the looked-up record's 28 registers across the call: 32 -> 48 spilled VGPRs in <5128>) and keep the
+// field-by-field reads.  The lookup as a free function with its arguments by value instead of a capturing lambda (LR_TEX_BY_VALUE, dev_heavy.h):
+// camera class -2.7 %, kitchen class -1 %: not kept.
+#ifndef LR_TEX_WIDE_RECORD
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 16) && !((LR_VARIANT) & (96 | 256))
+#define LR_TEX_WIDE_RECORD 1// the lean kernels with the Disney closure: what textured scenes of the camera class' kind render on
+#else
+#define LR_TEX_WIDE_RECORD 0
+#endif
+#endif
+// sixteen bytes from GLOBAL memory, said so
+typedef float lr_v4f __attribute__((ext_vector_type(4)));
+LR_D float4 global_load_f4(const void *base, uint64_t index) {
+    const auto v = ((const __attribute__((address_space(1))) lr_v4f *)base)[index];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 LR_D float4 texel_at(const float *texels, const lr_texture &t, int xx, int yy) {
     const auto index = static_cast<uint64_t>(yy) * t.width + static_cast<uint64_t>(xx);
+    // (explicitly global: behind an out-of-line lookup the compiler knows nothing of the pointer's origin and would read through flat_load)
+#if LR_TEX_WIDE_RECORD
+    typedef const __attribute__((address_space(1))) uint32_t global_u32;
+    if (!LR_BYTE_TEXELS || t.pad == 0u) { return global_load_f4(texels, t.texel_offset + index); }
+    const auto p = ((global_u32 *)texels)[t.texel_offset + index];
+#else
     if (!LR_BYTE_TEXELS || t.pad == 0u) { return reinterpret_cast<const float4 *>(texels)[t.texel_offset + index]; }
     const auto p = reinterpret_cast<const uint32_t *>(texels)[t.texel_offset + index];
+#endif
     // b * (1 / 255.f) is byte_over_255 without its correction step: one expression for both forms, the correction's weight 0 under form 1.
     // (Measured on the camera-class frame, films bit-identical: this against a select between the two forms +0.5 %, the texels in tiles of
     // 8 x 4 -- one 128-byte line per tile -- instead of rows +0.4 %, both +1.0 %, a repeat of the base +0.4 %: the tiles were not kept,
@@ -424,7 +449,30 @@ LR_D float4 texel_fetch(const float *texels, const lr_texture &t, int x, int y) 
 // Texture::Instance::evaluate (texture.cpp:21-79; image.cpp:132-168; checkerboard.cpp).  A REAL call (LR_CALL): one
 // copy of the format / address-mode / decode switches per kernel instead of one per use (it was 17 KB of code inlined
 // at every site: the <environment> variant carried eight copies), and its registers are not the megakernel's.
+// A texture's whole record in ONE round trip: seven 16-byte global loads issued together (round 6).  Read field by field where each was
+// used -- kind, then size and uv transform, then filter, address mode, encoding -- the out-of-line lookup waited for six to eight DEPENDENT
+// loads in a row before its texels were even requested (and through flat_load: see texel_at).
+static_assert(sizeof(lr_texture) == 112 && alignof(lr_texture) == 8, "lr_texture: seven 16-byte words (the table's base is 256-byte aligned)");
+LR_D lr_texture texture_record(const lr_texture *textures, int32_t id) {
+    float4 w[7];
+#pragma unroll
+    for (auto i = 0; i < 7; i++) { w[i] = global_load_f4(textures + id, static_cast<uint64_t>(i)); }
+    lr_texture t;
+    __builtin_memcpy(&t, w, sizeof(t));
+    return t;
+}
 LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texels, int32_t id, f2 uv_it) {
+#if LR_TEX_WIDE_RECORD
+    auto ti = texture_record(textures, id);
+    if (ti.kind == LR_TEX_CONSTANT) { return make_float4(ti.v[0], ti.v[1], ti.v[2], ti.v[3]); }
+    if (ti.kind == LR_TEX_CHECKERBOARD) {
+        auto parity = (static_cast<int>(floorf(uv_it.x * ti.checker_scale)) + static_cast<int>(floorf(uv_it.y * ti.checker_scale))) & 1;
+        auto child = parity ? ti.child[1] : ti.child[0];
+        if (child < 0) { return parity ? make_float4(0.f, 0.f, 0.f, 1.f) : make_float4(1.f, 1.f, 1.f, 1.f); }
+        ti = texture_record(textures, child);// one level of nesting: children are constant or image
+        if (ti.kind == LR_TEX_CONSTANT) { return make_float4(ti.v[0], ti.v[1], ti.v[2], ti.v[3]); }
+    }
+#else
     auto &t = textures[id];
     if (t.kind == LR_TEX_CONSTANT) { return make_float4(t.v[0], t.v[1], t.v[2], t.v[3]); }
     if (t.kind == LR_TEX_CHECKERBOARD) {
@@ -436,6 +484,7 @@ LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texe
         id = child;
     }
     auto &ti = textures[id];
+#endif
     f2 uv{uv_it.x * ti.uv_scale[0] + ti.uv_offset[0], uv_it.y * ti.uv_scale[1] + ti.uv_offset[1]};
     float4 v;
     if (ti.filter == LR_TEX_FILTER_POINT) {
@@ -472,6 +521,11 @@ LR_CALL float4 texture_eval_tables(const lr_texture *textures, const float *texe
         return ti.scale[ch] * c;
     };
     return make_float4(decode(v.x, 0), decode(v.y, 1), decode(v.z, 2), 0.f);// (the fourth channel of an image: never read on the device, see texel_at)
+}
+// the lookup load_lobe makes per looked-up slot (dev_heavy.h): out of line in the lean variants too (dev_math.h: LR_TEX_LAMBDA), with its
+// arguments BY VALUE -- as a capturing lambda it read the tables' pointers and uv back from the closure object through flat loads
+LR_TEX_LAMBDA float4 texture_eval_slot(const lr_texture *textures, const float *texels, int32_t id, float u, float v) {
+    return texture_eval_tables(textures, texels, id, f2{u, v});
 }
 LR_D float4 texture_eval(const DScene &scene, int32_t id, f2 uv_it) { return texture_eval_tables(scene.textures, scene.texels, id, uv_it); }
 

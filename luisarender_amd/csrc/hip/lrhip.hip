@@ -329,6 +329,12 @@ std::vector<lrd::DShadeTri> build_shade_tris(const lr_scene *s, const std::vecto
         }
         r.uv0x = v[0]->u, r.uv0y = v[0]->v, r.uv1x = v[1]->u, r.uv1y = v[1]->v, r.uv2x = v[2]->u, r.uv2y = v[2]->v;
         r.flags = inst.handle.x & 1023u, r.tags = inst.handle.y, r.offset_bits = inst.handle.w;
+        // (round 6) bits 10-11: 1 + the heavy-closure kind of the triangle's surface (Disney 1, Mix 2, Layered 3; 0: a basic closure) -- what the
+        // lean passes of wavefront mode park a hit by, read with the record instead of through a dependent gather of the closure table
+        if ((r.flags & LR_SHAPE_HAS_SURFACE) != 0u) {
+            const auto tag = (inst.handle.y >> 12u) & 4095u;
+            if (tag < s->surface_count && s->surfaces[tag].kind >= LR_SURFACE_DISNEY) { r.flags |= (s->surfaces[tag].kind - LR_SURFACE_DISNEY + 1u) << 10u; }
+        }
         r.tri_pdf = s->tri_pdf[mesh.triangle_offset + bt.prim];
         r.inst = bt.inst, r.prim = bt.prim, r.tri_offset = mesh.triangle_offset;
     }
@@ -708,6 +714,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
             else { rec.dynamic_mask |= 1u << slot; }
             rec.channels[slot >> 3u] |= (t.channels & 15u) << ((slot & 7u) * 4u);
         }
+        rec.first_lookup = rec.raw.normal_tex >= 0 ? rec.raw.normal_tex : (rec.dynamic_mask != 0u ? rec.raw.tex[__builtin_ctz(rec.dynamic_mask)] : -1);
     }
     LR_UP(upload(ctx, surfaces.data(), surfaces.size(), &d.surfaces));
     for (uint32_t i = 0; i < s->surface_count; i++) {

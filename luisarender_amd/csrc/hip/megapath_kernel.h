@@ -295,8 +295,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_of(F)) void megapath_kerne
                     // radiance so far (the emission of this vertex included), sampler position -- goes into the queue of its
                     // closure kind; heavy_kernel.h shades the vertex and hands the path back as a continuation record.
                     if (WF && has_surface) {
+#if LR_BAKED_SHADING
+                        const auto heavy_kind = (it.flags >> 10u) & 3u;// (baked into the triangle's record: lrhip.hip, build_shade_tris)
+                        if (heavy_kind != 0u) { park_kind = heavy_kind - 1u, has_surface = false; }
+#else
                         const auto kind = scene.closures[(it.tags >> 12u) & 4095u].kind;
                         if (kind >= LR_SURFACE_DISNEY) { park_kind = kind - LR_SURFACE_DISNEY, has_surface = false; }
+#endif
                     }
                     if (has_surface) {
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }

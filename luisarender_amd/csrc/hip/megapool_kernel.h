@@ -516,17 +516,30 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     // wavefront mode: a Disney / Mix / Layered surface is not shaded here (megapath_kernel.h): the path goes into the
                     // queue of its closure kind; heavy_kernel.h shades the vertex and hands the path back as a continuation record
                     if (WF && has_surface) {
-                        const auto kind = scene.closures[(it.tags >> 12u) & 4095u].kind;
-                        if (kind >= LR_SURFACE_DISNEY) { park_kind = kind - LR_SURFACE_DISNEY, has_surface = false; }
+                        const auto heavy_kind = (it.flags >> 10u) & 3u;// (baked into the triangle's record: lrhip.hip, build_shade_tris)
+                        if (heavy_kind != 0u) { park_kind = heavy_kind - 1u, has_surface = false; }
                     }
                     if (WF) {// ---- park (at once: the hit and the direction die here instead of living through the closure code below -- 25 -> 15
                         // spilled VGPRs in the camera pass): one atomic per closure kind and wave, field-major stores (coalesced over the parking lanes)
                         if (lr_any(park_kind != kInvalid)) {
+                            // (round 6: the queues' slots behind ONE atomic instruction -- the first lane of every kind reserves its kind's -- and one
+                            // round trip, where a batch with hits of all three kinds made three in a row)
+                            unsigned long long kind_mask[kWfKinds];
+#pragma unroll
+                            for (auto k = 0u; k < kWfKinds; k++) { kind_mask[k] = lr_ballot(park_kind == k); }
+                            // (the first lane of each kind is its leader: lanes 0-2 need not be among the ones that got here)
+                            static_assert(kWfKinds == 3u, "three closure kinds");
+                            const auto my_mask = park_kind == 0u ? kind_mask[0] : (park_kind == 1u ? kind_mask[1] : (park_kind == 2u ? kind_mask[2] : 0ull));
+                            auto reserved = 0u;
+                            if (my_mask != 0ull && lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(my_mask))) - 1u) {
+                                reserved = atomicAdd(scene.wf.counts + kWfCountHeavy + park_kind, static_cast<uint32_t>(__popcll(my_mask)));
+                            }
 #pragma unroll
                             for (auto k = 0u; k < kWfKinds; k++) {
-                                const auto mask = lr_ballot(park_kind == k);
+                                const auto mask = kind_mask[k];
                                 if (mask == 0ull) { continue; }
-                                const auto out = wf_reserve(scene.wf.counts + kWfCountHeavy + k, mask, lane);
+                                const auto leader = __ffsll(static_cast<long long>(mask)) - 1;
+                                const auto out = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(reserved), leader)) + lane_rank(mask);
                                 if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
                                     if (LEAN_STATE) { load_ids(); }
                                     if (PCG) { sampler_take(); }
