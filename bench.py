@@ -373,7 +373,7 @@ def roofline_block(workload, variant, kernel_ms, launch_samples, bytes_per_sampl
     r = {
         # What bounds these kernels is neither roof of the contract's vocabulary: a wave issues one instruction of any kind every ~4.5 cycles and
         # waits for two dependent gathers per traversal iteration; at four waves per SIMD (128 VGPRs, 39 KB of LDS per block) the SIMD is neither
-        # full nor starved (the stall probe's tables: profiles/r06_stalls_*.txt).  The contract's HBM figures stay: `achieved` /
+        # full nor starved (the stall probe's tables: profiles/r06f_stalls*.txt).  The contract's HBM figures stay: `achieved` /
         # `frac` / `traffic` are the MEASURED memory-side traffic over the kernel's duration (FETCH_SIZE counts Infinity-Cache hits too: an
         # upper bound on HBM traffic); one number per roof follows in `valu`, `waves`, `lanes`, `l2`.
         "bound": "issue + latency at 4 waves per SIMD", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -387,6 +387,11 @@ def roofline_block(workload, variant, kernel_ms, launch_samples, bytes_per_sampl
                 "lanes = how many of the issued lanes did useful work, l2 = the kernel's own requests against the L2's bandwidth",
     }
     counters = (pmc or {}).get("counters") or {}
+    if counters:
+        # the raw counter totals the figures of this block are made of, for the counter passes' own frame (pmc.samples paths): with a calculator,
+        # traffic = (FETCH_SIZE x 2048 + WRITE_SIZE x 1024) / pmc.samples x the timed launch's samples; frac = traffic / kernel_ms / 8 TB/s
+        r["pmc"] = {"spp": pmc.get("spp"), "samples": pmc.get("samples_per_launch"), "timed_launch_samples": launch_samples, "kernels": pmc.get("kernels"),
+                    "counters": {k: v for k, v in sorted(counters.items())}}
     if pmc and pmc.get("valu_wave_instr_per_sample"):
         instr = pmc["valu_wave_instr_per_sample"] * launch_samples
         simd_cycles = simds * seconds * SHADER_CLOCK_HZ

@@ -152,6 +152,7 @@ double lrhip_last_render_ms(lrhip_ctx *ctx);
 #define LRHIP_FEAT_ALPHA 8u
 #define LRHIP_FEAT_DISNEY 16u
 #define LRHIP_FEAT_BYTE_TEXELS 8192u /* a lean kernel that decodes 8-bit texels (lrhip_set_texture_storage) */
+#define LRHIP_FEAT_PADDED_SOBOL 16384u /* (with LRHIP_FEAT_GENERIC_SAMPLER | LRHIP_FEAT_POOL) a pool kernel compiled for the PaddedSobol sampler */
 #define LRHIP_FEAT_MIX 32u
 #define LRHIP_FEAT_LAYERED 64u
 #define LRHIP_FEAT_AUX_INTEGRATORS 128u

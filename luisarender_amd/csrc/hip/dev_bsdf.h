@@ -483,7 +483,7 @@ LR_HD void disney_sample_local(const DisneyLobes &L, f3 wo, float u_lobe, f2 u, 
 // the reflection lobe of Glass and the coat of Plastic; ONE visible-normal sample serves all of them; and
 // Surface::Closure::sample is "pick wi per kind, then evaluate" on the SAME evaluation code as Surface::Closure::evaluate
 // (the reference evaluates the sampled direction with the same functions: BxDF::sample = sample_wi + evaluate + pdf,
-// scattering.cpp:247-254).  Static VALU of evaluate + sample: 3456 -> see DESIGN.md §4.1.
+// scattering.cpp:247-254).  Static VALU of evaluate + sample: 3456 -> see DESIGN.md §4.6.
 // Inputs of basic_eval_local are in the frame Plastic works in (flipped so that wo is in +z, plastic.cpp:141-145).
 LR_HD BsdfEval basic_eval_local(const DClosure &c, GGX g, f3 wo_l, f3 wi_l, bool importance) {
     BsdfEval e{mk3(0.f), 0.f};

@@ -55,7 +55,7 @@ enum : uint32_t {// DClosure::e slots of a Disney closure (DisneyContext, disney
 // record and, beside it, what every texture SLOT of the record evaluates to where its texture is constant (round 6).  Per-hit closure
 // resolution used to ask the texture table about every slot through one out-of-line lookup each -- a Disney surface with two image maps
 // made thirteen dependent round trips of ~2.3 k cycles for its eleven constants, one surface kind after the other (the stall probe:
-// 92 k of the camera class's 185 k cycles per shading batch, profiles/r06_stalls_c4.txt).  Now the constants are plain loads from this
+// 92 k of the camera class's 185 k cycles per shading batch, profiles/r06f_stalls1_c4.txt).  Now the constants are plain loads from this
 // record -- independent of each other, issued together -- and only the slots in `dynamic_mask` are looked up (dev_heavy.h: load_lobe).
 constexpr uint32_t kSurfaceSlots = 13u;// texture slots a surface kind uses (lr_scene.h: Disney's 0 .. 12)
 struct alignas(16) DSurface {

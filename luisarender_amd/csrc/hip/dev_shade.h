@@ -99,6 +99,12 @@ LR_HD uint32_t xxhash32_2(uint32_t x, uint32_t y) {// rng.cpp:25-36
 // Generic sampler (runtime kind): PCG32 streams, the global Owen-scrambled Sobol sampler
 // (src/samplers/sobol.cpp:40-169) and PaddedSobol (src/samplers/padded_sobol.cpp:23-150).  Lives in its own
 // kernel instantiation so the default Independent path keeps a 1-register sampler.
+// -DLR_ONLY_SAMPLER=<kind> (experiment): the generic sampler's run-time kind as a compile-time constant -- what a kernel variant per sampler would be
+#ifdef LR_ONLY_SAMPLER
+#define LR_SAMPLER_KIND_OF(s) static_cast<uint32_t>(LR_ONLY_SAMPLER)
+#else
+#define LR_SAMPLER_KIND_OF(s) ((s).sampler_kind)
+#endif
 template<>
 struct PathSampler<true> {
     // FOUR words of per-path state (eight until round 3: two 64-bit words and four more, and the kernel spilled 25 VGPRs around them):
@@ -191,7 +197,7 @@ struct PathSampler<true> {
         scene = &s;
         tile_shared_pixel(s, x, y, index);
         w3 = x | (y << 16u);// (frames are at most 65535 pixels wide / high: lr_camera, lrhip_upload_scene)
-        if (s.sampler_kind == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
+        if (LR_SAMPLER_KIND_OF(s) == LR_SAMPLER_SOBOL) {// sobol.cpp:131-136 + _sobol_interval_to_index :67-96
             w2 = 2u;
             auto m = 31u - static_cast<uint32_t>(__clz(static_cast<int>(s.sobol_scale)));
             if (m == 0u) {
@@ -206,7 +212,7 @@ struct PathSampler<true> {
                 for (auto t = s.vdc_inv_bytes; bb != 0u; bb >>= 8u, t += 256u) { idx ^= t[bb & 255u]; }
                 set_wide(idx);
             }
-        } else if (s.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
+        } else if (LR_SAMPLER_KIND_OF(s) == LR_SAMPLER_PADDED_SOBOL) {
             lo = index, hi = 0u, w2 = 0u;
         } else {// PCG32::set_sequence(xxhash32 seed), rng.cpp:150-156
             lo = 0u, hi = 0u;
@@ -218,7 +224,7 @@ struct PathSampler<true> {
         }
     }
     LR_D float next_1d() {
-        auto kind = scene->sampler_kind;
+        auto kind = LR_SAMPLER_KIND_OF(*scene);
         if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:147-153
             w2 = w2 >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : w2;
             auto u = static_cast<float>(owen(xxhash32_2(w2, scene->seed), sobol_bits(wide(), w2))) * 0x1p-32f;
@@ -234,7 +240,7 @@ struct PathSampler<true> {
         return uint_to_unit_float(pcg_next());
     }
     LR_D f2 next_2d() {
-        auto kind = scene->sampler_kind;
+        auto kind = LR_SAMPLER_KIND_OF(*scene);
         f2 u;
         if (kind == LR_SAMPLER_SOBOL) {// sobol.cpp:154-162
             w2 = w2 + 1u >= static_cast<uint32_t>(LR_SOBOL_DIMENSIONS) ? 2u : w2;
@@ -258,7 +264,7 @@ struct PathSampler<true> {
         return u;
     }
     LR_D f2 next_pixel_2d() {// generate_pixel_2d: sobol.cpp:163-169, default sampler.h:48
-        if (scene->sampler_kind == LR_SAMPLER_SOBOL) {
+        if (LR_SAMPLER_KIND_OF(*scene) == LR_SAMPLER_SOBOL) {
             auto s = static_cast<float>(scene->sobol_scale);
             return {clampf(static_cast<float>(sobol_bits(wide(), 0u)) * 0x1p-32f * s - static_cast<float>(w3 & 0xffffu), 0.f, kOneMinusEpsilon),
                     clampf(static_cast<float>(sobol_bits(wide(), 1u)) * 0x1p-32f * s - static_cast<float>(w3 >> 16u), 0.f, kOneMinusEpsilon)};

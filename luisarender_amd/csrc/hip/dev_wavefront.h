@@ -23,6 +23,13 @@ enum : uint32_t {
     // is compiled into the lean kernels of this bit only, which lrhip_render takes when the uploaded scene holds packed texels; the variants
     // that make real calls (Mix / Layered / auxiliary / volumetric) and the heavy kernels keep it in their one out-of-line lookup
     kFeatByteTex = 8192u,
+    // round 6: the generic sampler's kind is PaddedSobol AT COMPILE TIME (the translation unit defines LR_ONLY_SAMPLER to match, megapath_variant.hip):
+    // no three-way dispatch at the draws, and the pool kernel keeps nothing of the stream but (sample index, pixel) -- the dimension is a
+    // function of the depth (megapool_kernel.h: PADDED).  PaddedSobol is what the reference's scene converter writes for every README scene
+    // (tools/tungsten2luisa.py:373-412).  Compiled for the lean pool kernels (variants.h: LR_PADDED_LIST); lrhip_render takes one where it
+    // exists and the scene's sampler is PaddedSobol, the run-time generic kernel of the same mask otherwise.  C2: 953 -> 975 Msamples/s at
+    // 256 spp, films bit-identical (profiles/r06y_padded_sobol_kernels.txt)
+    kFeatPadded = 16384u,
     kFeatSceneMask = kFeatEnv | kFeatAlpha | kFeatDisney | kFeatMix | kFeatLayered
 };
 

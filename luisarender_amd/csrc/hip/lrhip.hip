@@ -30,6 +30,7 @@
     extern "C" __attribute__((weak)) hipError_t lrhip_variant_launch_##mask(unsigned, hipStream_t, const lrd::DScene *, const lrd::RenderArgs *); \
     extern "C" __attribute__((weak)) hipError_t lrhip_variant_occupancy_##mask(int *);
 LR_VARIANT_LIST(LR_DECLARE_VARIANT)
+LR_PADDED_LIST(LR_DECLARE_VARIANT)
 #undef LR_DECLARE_VARIANT
 // the heavy-closure kernels of wavefront mode, one translation unit each (heavy_variant.hip, -DLR_HVARIANT=<mask>)
 #define LR_HEAVY_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(516) X(517) X(518) X(519) X(520) X(521) X(522) X(523)
@@ -48,6 +49,9 @@ struct VariantEntry {
 };
 #define LR_VARIANT_ENTRY(mask) VariantEntry{mask##u, lrhip_variant_launch_##mask, lrhip_variant_occupancy_##mask},
 const VariantEntry kVariants[] = {LR_VARIANT_LIST(LR_VARIANT_ENTRY)};
+// the lean pool kernels compiled for the PaddedSobol sampler (kFeatPadded, variants.h), looked up by mask
+const VariantEntry kPaddedVariants[] = {LR_PADDED_LIST(LR_VARIANT_ENTRY)};
+constexpr size_t kPaddedVariantCount = sizeof(kPaddedVariants) / sizeof(kPaddedVariants[0]);
 #undef LR_VARIANT_ENTRY
 static_assert(sizeof(kVariants) / sizeof(kVariants[0]) == lrd::kSceneVariantCount * 4u, "variants.h and kSceneVariants disagree");
 
@@ -145,6 +149,7 @@ struct lrhip_ctx {
     uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
     bool env_tree{false};// Combined environments nested in each other: only the call-making variants walk them (dev_shade.h)
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
+    int padded_blocks[16];// ... and of the kFeatPadded kernels (kPaddedVariants)
     uint32_t diag_force_features{0u};// lrhip_set_diagnostics (tests / tools)
     double diag_item_scale{0.};
     // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
@@ -987,6 +992,7 @@ int lrhip_upload_scene(lrhip_ctx *ctx, const lr_scene *s) {
     // persistent grid: as many blocks as are resident, asked per variant at its first launch (lrhip_render); the
     // traversal-stack overflow area is sized for the densest variant
     for (auto &b : ctx->variant_blocks) { b = -1; }
+    for (auto &b : ctx->padded_blocks) { b = -1; }
     for (auto &b : ctx->heavy_blocks) { b = -1; }
     ctx->grid_blocks = ctx->cu_count * kMaxBlocksPerCu;
     auto total_threads = static_cast<size_t>(ctx->grid_blocks) * lrd::kBlockThreads;
@@ -1385,12 +1391,20 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: no megakernel variant for feature mask " + std::to_string(ctx->features) +
                                                  " was compiled into this library");
     }
-    if (ctx->variant_blocks[vi] < 0) {
-        int blocks_per_cu = 0;
-        LR_HIP_CHECK(kVariants[vi].occupancy(&blocks_per_cu));
-        ctx->variant_blocks[vi] = std::max(1, std::min(blocks_per_cu, static_cast<int>(kMaxBlocksPerCu)));
+    // round 6: a pool kernel compiled for the PaddedSobol sampler, where the scene's sampler is that and such a kernel exists for the mask
+    auto entry = &kVariants[vi];
+    auto entry_blocks = &ctx->variant_blocks[vi];
+    static_assert(kPaddedVariantCount <= sizeof(ctx->padded_blocks) / sizeof(ctx->padded_blocks[0]), "lrhip_ctx::padded_blocks");
+    if (pool && generic && ctx->scene.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
+        const auto pv = find_variant(kPaddedVariants, kPaddedVariantCount, kVariants[vi].mask | lrd::kFeatPadded);
+        if (pv >= 0 && kPaddedVariants[pv].launch != nullptr && kPaddedVariants[pv].occupancy != nullptr) { entry = &kPaddedVariants[pv], entry_blocks = &ctx->padded_blocks[pv]; }
     }
-    auto resident = ctx->cu_count * static_cast<uint32_t>(ctx->variant_blocks[vi]);
+    if (*entry_blocks < 0) {
+        int blocks_per_cu = 0;
+        LR_HIP_CHECK(entry->occupancy(&blocks_per_cu));
+        *entry_blocks = std::max(1, std::min(blocks_per_cu, static_cast<int>(kMaxBlocksPerCu)));
+    }
+    auto resident = ctx->cu_count * static_cast<uint32_t>(*entry_blocks);
     args.total_threads = resident * lrd::kBlockThreads;
     const auto pool_film = pool;
     if (chunk_count > 1u && !pool_film) {// (the pool kernels add every item to the frame's fixed-point sums: no partial planes)
@@ -1414,8 +1428,8 @@ int lrhip_render(lrhip_ctx *ctx, const lrhip_render_params *p) {
     if (auto r = ensure(ctx->scene_record, sizeof(lrd::DScene)); r != LRHIP_OK) { return r; }
     LR_HIP_CHECK(hipMemcpyAsync(ctx->scene_record.ptr, &ctx->scene, sizeof(lrd::DScene), hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->in_split) { LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream)); }
-    LR_HIP_CHECK(kVariants[vi].launch(blocks, ctx->stream, static_cast<const lrd::DScene *>(ctx->scene_record.ptr), &args));
-    ctx->last_variant = kVariants[vi].mask;
+    LR_HIP_CHECK(entry->launch(blocks, ctx->stream, static_cast<const lrd::DScene *>(ctx->scene_record.ptr), &args));
+    ctx->last_variant = entry->mask;
     LR_HIP_CHECK(hipGetLastError());
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;

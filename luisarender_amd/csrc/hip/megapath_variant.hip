@@ -6,6 +6,9 @@
 #ifndef LR_VARIANT
 #error "compile with -DLR_VARIANT=<feature mask>"
 #endif
+#if ((LR_VARIANT) & 16384) && !defined(LR_ONLY_SAMPLER)// kFeatPadded: the generic sampler is PaddedSobol, at compile time (dev_shade.h: LR_SAMPLER_KIND_OF)
+#define LR_ONLY_SAMPLER LR_SAMPLER_PADDED_SOBOL
+#endif
 #if (LR_VARIANT) & 256// kFeatVpt: the volumetric megakernel
 #include "megavpt_kernel.h"
 #define LR_KERNEL megavpt_kernel

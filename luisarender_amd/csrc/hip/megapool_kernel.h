@@ -21,7 +21,7 @@
 //     loop), what is left of the ray in flight (hit so far, t_max, node, phase / stack depth) on top of the lane's own traversal
 //     stack.  This is what makes the scheme pay: with those six words in registers the block spilled 37 VGPRs on its hot path, the
 //     scratch traffic evicted the BVH's top levels from the 32 KB vector L1, and a node step took 4200 cycles instead of 2100
-//     (profiles/archive/r04c_*, r04g_*).
+//     (HISTORY.md appendix, section 4.1c; profiles/archive/r04c_*, r04g_*).
 // Measured (profiles/r04_final_schedulers.txt, kernel time of the one-path-per-lane kernel / this one, same build, same box): C2 1.08
 // at 1024 spp, C3 1.18, C4 1.06, C5 (wavefront mode) 1.10 at 64 spp; a Cornell box 0.88 -- lrhip.hip: wants_pool picks this kernel
 // from ~100 thousand triangles up, earlier for deep paths at few samples per pixel, later for shallow ones (lrhip.hip: pool_auto_triangles; profiles/r05j_scheduler_sweep.txt).
@@ -260,7 +260,17 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     static_assert(!WF || !DISNEY, "a wavefront variant is a lean kernel: the heavy closures live in heavy_kernel.h");
     static_assert(!CONT || WF, "the continuation pass exists in wavefront mode only");
     constexpr uint32_t SAMPLER_WORDS = PathSampler<PCG>::kSavedWords;
-    constexpr uint32_t QUADS = pool_quads<PCG>();
+    // PADDED (round 6): the generic sampler's kind known at compile time to be PaddedSobol (LR_ONLY_SAMPLER).  Its stream position is (sample
+    // index, pixel, dimension): the first two never change along a path -- written with quad 3 when the path starts -- and the dimension is a
+    // function of the depth (two for the pixel, two for a thin lens, six per vertex, one more from the Russian-roulette depth on): nothing
+    // is written back where a vertex's numbers are drawn, and the record is four quads like the Independent sampler's.
+#ifdef LR_ONLY_SAMPLER
+    constexpr bool PADDED = PCG && !WF && (LR_ONLY_SAMPLER) == LR_SAMPLER_PADDED_SOBOL;
+#else
+    constexpr bool PADDED = false;
+#endif
+    static_assert(PADDED == ((F & kFeatPadded) != 0u) || (F & kFeatPadded) == 0u, "a kFeatPadded kernel: generic sampler, no wavefront role, LR_ONLY_SAMPLER = PaddedSobol");
+    constexpr uint32_t QUADS = PADDED ? 4u : pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave
 #if LR_POOL_PARK_ON_STACK == 0
@@ -431,13 +441,23 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 pixel_index = __float_as_uint(q3.x), path_item = __float_as_uint(q3.y);
             };
             // generic sampler: the stream position comes into the registers ...
-            const auto sampler_take = [&]() {
+            const auto sampler_take = [&](uint32_t stage) {// stage: 0 the light's three numbers, 1 the closure's three or four
+                if (PADDED) {
+                    const auto q3 = state_load(side, 3u);
+                    const auto depth = dp & 0xffffu;
+                    const auto first_rr = scene.rr_depth == 0u ? 0u : scene.rr_depth - 1u;// the first depth that draws a roulette number
+                    const auto dimension = (scene.camera.kind == LR_CAMERA_THIN_LENS ? 4u : 2u) + 6u * depth + (depth > first_rr ? depth - first_rr : 0u) + 3u * stage;
+                    uint32_t words[kWfSamplerWordsMax] = {__float_as_uint(q3.z), 0u, dimension, __float_as_uint(q3.w)};
+                    sampler.restore(scene, words);
+                    return;
+                }
                 const auto q3 = state_load(side, 3u);
                 uint32_t words[kWfSamplerWordsMax] = {word0, __float_as_uint(q3.z), __float_as_uint(q3.w), __float_as_uint(state_load(side, QUADS - 1u).x)};
                 sampler.restore(scene, words);
             };
             // ... and leaves them again (`Li` is final where a vertex's numbers are drawn: quad 2 is complete)
             const auto sampler_leave = [&]() {
+                if (PADDED) { return; }
                 uint32_t words[kWfSamplerWordsMax] = {0u, 0u, 0u, 0u};
                 sampler.save(words);
                 word0 = words[0];
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                                 const auto out = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(reserved), leader)) + lane_rank(mask);
                                 if (park_kind == k && out < scene.wf.capacity) {// (capacity >= the slice's paths: never full; a bound, not a policy)
                                     if (LEAN_STATE) { load_ids(); }
-                                    if (PCG) { sampler_take(); }
+                                    if (PCG) { sampler_take(0u); }
                                     const auto q = wf_heavy_queue<SAMPLER_WORDS>(scene, k);
                                     q.put3(out, 0u, rd);
                                     q.put(out, 3u, hit_tri), q.put(out, 4u, hit_u), q.put(out, 5u, hit_v);
@@ -566,10 +586,10 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
                         // light selection, light surface (2), lobe, bsdf (2), [rr]
                         {
-                            if (PCG) { sampler_take(); }
+                            if (PCG) { sampler_take(0u); }
                             u_light_selection = sampler.next_1d();
                             u_light_surface = sampler.next_2d();
-                            if (PCG) { sampler_leave(), sampler_left = true; }
+                            if (PCG) { sampler_leave(), sampler_left = !PADDED; }
                         }
                         // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63 (dev_shade.h: sample_one_light)
                         const auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         t_eval = t_e1 - t_l1;
 #endif
                         {
-                            if (PCG) { sampler_take(); }
+                            if (PCG) { sampler_take(1u); }
                             u_lobe = sampler.next_1d();
                             u_bsdf = sampler.next_2d();
                             if (PCG) {
@@ -744,7 +764,9 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                     uint32_t words[kWfSamplerWordsMax] = {word0, 0u, 0u, 0u};
                     if (!PCG || got) { sampler.save(words); }
                     state_store(side, 2u, make_float4(Li.x, Li.y, Li.z, __uint_as_float(words[0])));
-                    if (got) {
+                    if (got && PADDED) {// (sample index and pixel: all the record keeps of the stream)
+                        state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[0]), __uint_as_float(words[3])));
+                    } else if (got) {
                         state_store(side, 3u, make_float4(__uint_as_float(pixel_index), __uint_as_float(path_item), __uint_as_float(words[1]), __uint_as_float(words[2])));
                         if (PCG) { state_store(side, QUADS - 1u, make_float4(__uint_as_float(words[3]), 0.f, 0.f, 0.f)); }
                     } else if (!LEAN_STATE && !PCG) {

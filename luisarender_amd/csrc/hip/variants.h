@@ -31,3 +31,9 @@
     X(7168) X(7169) X(7170) X(7171) X(7172) X(7173) X(7174) X(7175) X(7176) X(7177) X(7178) X(7179) X(7180) X(7181) X(7182) X(7183) \
     /* round 6: lean kernels that decode 8-bit texels (kFeatByteTex = 8192): Disney, environment + Disney, one path per lane and pool */ \
     X(8208) X(8209) X(8210) X(8211) X(8212) X(8213) X(8214) X(8215) X(12304) X(12305) X(12306) X(12307) X(12308) X(12309) X(12310) X(12311)
+
+// round 6: the lean pool kernels once more with the generic sampler's kind fixed to PaddedSobol (kFeatPadded = 16384 | kFeatGeneric): plain,
+// Disney, environment + Disney, and the 8-bit-texel Disney sets, each with its counting twin (measured, profiles/r06y_padded_sobol_kernels.txt: C2 949 -> 973
+// Msamples/s, the camera class under PaddedSobol 1007 -> 1068; the plain environment set <20486> gained nothing on the bedroom class, 971 -> 966, and is not built).  Not part of the
+// kSceneVariants x {Count} x {Generic} grid: lrhip_render looks them up by mask (kPaddedVariants).
+#define LR_PADDED_LIST(X) X(20482) X(20483) X(20498) X(20499) X(20502) X(20503) X(28690) X(28691) X(28694) X(28695)

@@ -151,7 +151,7 @@ class MegaPathRenderer:
     def set_scheduler(self, pool: bool | None = None) -> None:
         """lrhip_set_scheduler: None = automatic (the path-pool kernels of round 4 -- two path contexts per lane, fixed-point film sums,
         overlapping work items -- where they are the faster family (from ~100 thousand BVH triangles; lrhip.h), the one-path-per-lane kernels below), False = one path per
-        lane everywhere, True = the pool kernels wherever one exists for the scene (DESIGN.md section 4.1c)"""
+        lane everywhere, True = the pool kernels wherever one exists for the scene (DESIGN.md section 4.2)"""
         self._check(self._lib.lrhip_set_scheduler(self._ctx, 0 if pool is None else (2 if pool else 1)))
 
     def close(self) -> None:

@@ -112,7 +112,7 @@ def test_round5_line_measures_its_roofline_block_at_the_timed_configuration():
     assert line["path_statistics"]["spp"] == 1024 and line["path_statistics"]["pool_state_bytes_per_sample"] > 200
     extra = {(e["workload"].split(",")[0].split(" (")[0], e["sampler"]): e for e in line["extra_configs"]}
     sobol = extra["Contemporary Bathroom-class", "PaddedSobol"]
-    assert sobol["spp_timed"] == 1024 and sobol["value"] > 880 and sobol["kernel"] == "lrd::megapool_kernel<4098u>"
+    assert sobol["spp_timed"] == 1024 and sobol["value"] > 880 and sobol["kernel"] == "lrd::megapool_kernel<20482u>"
     assert sobol["parity"]["rel_l1"] < 1e-2 and sobol["parity"]["finite"] and sobol["cpu_baseline"]["kind"] == "port"
     for key, floor in ((("Cornell Box", "Independent"), 3800), (("Bedroom-class", "Independent"), 1000), (("Camera-class", "Independent"), 1000), (("Kitchen-class", "Independent"), 550)):
         assert extra[key]["value"] > floor and extra[key]["parity"]["finite"], key

@@ -51,8 +51,14 @@ ALPHA = ('Texture holes : Checkerboard { on : Constant { v { 1 } } off : Constan
          'Surface cutout : Matte { Kd : Constant { v { 0.7, 0.6, 0.2 } } alpha { @holes } }\n')
 
 
-@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "pcg", "mitchell", "rr", "alpha", "environment"])
+PADDED = 16384  # LRHIP_FEAT_PADDED_SOBOL: a pool kernel compiled for the PaddedSobol sampler (round 6)
+
+
+@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "padded_sobol", "padded_sobol_lens_rr", "pcg", "mitchell", "rr", "alpha", "environment"])
 def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(renderer, case):
+    """(padded_sobol*: the pool side is a kernel compiled for that sampler, which keeps only (sample index, pixel) of the stream and derives the
+    dimension from the depth -- two for the pixel, two for a thin lens, six per vertex, one more from the roulette depth on -- against the
+    run-time generic sampler of the one-path-per-lane kernel, which counts its draws: same numbers, same paths, same film)"""
     kw = dict(resolution=96, spp=24)
     if case == "glass":
         kw.update(extra_surfaces=GLASS, short_box_surface="crystal")
@@ -60,6 +66,10 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
         kw.update(extra_surfaces=DISNEY, tall_box_surface="paint")
     elif case == "sobol":
         kw.update(sampler="Sobol")
+    elif case == "padded_sobol":
+        kw.update(sampler="PaddedSobol", extra_surfaces=GLASS, short_box_surface="crystal")
+    elif case == "padded_sobol_lens_rr":
+        kw.update(sampler="PaddedSobol", rr_depth=3, depth=12, extra_surfaces=GLASS, short_box_surface="crystal")
     elif case == "pcg":
         kw.update(sampler="PCG32")
     elif case == "mitchell":
@@ -71,10 +81,14 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
     text = cornell_box(**kw)
     if case == "environment":  # the <environment> variants: rays that leave through the open front are lit
         text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
+    if case == "padded_sobol_lens_rr":
+        text = text.replace("Camera cam : Pinhole {\n  fov { 39.3 }", "Camera cam : ThinLens {\n  fov { 39.3 } aperture { 2 } focal_length { 50 } focus_distance { 1000 }")
+        assert "ThinLens" in text
     scene = Scene.from_string(text)
     out = _both(renderer, scene, 24, counters=True)
     (lane, v_lane, c_lane), (pool, v_pool, c_pool) = out["lane"], out["pool"]
-    assert (v_pool & POOL) != 0 and (v_lane & POOL) == 0 and (v_pool & ~POOL) == v_lane, (v_lane, v_pool)
+    assert (v_pool & POOL) != 0 and (v_lane & POOL) == 0 and (v_pool & ~(POOL | PADDED)) == v_lane, (v_lane, v_pool)
+    assert ((v_pool & PADDED) != 0) == case.startswith("padded_sobol"), v_pool
     assert np.isfinite(pool).all() and np.array_equal(pool[..., 3], lane[..., 3])
     # the same paths: every counter of the path topology is EQUAL (not close: same kernel code per vertex, same random numbers)
     for k in ("paths", "closest_rays", "shadow_rays", "surface_hits", "nee_samples", "path_length_sum"):
@@ -109,7 +123,7 @@ def test_shipped_pool_kernels_equal_their_counting_twins(renderer, tmp_path, cas
     env = f'render {{\n  environment : Spherical {{ emission : Image {{ file {{ "{sky}" }} }} }}'
     text, variant = {
         "lean": (cornell_box(resolution=64, spp=8, short_box_surface="glass", tall_box_surface="metal", extra_surfaces=mat("glass", "metal")), POOL),
-        "padded_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PaddedSobol"), POOL | 2),
+        "padded_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="glass", extra_surfaces=mat("glass"), sampler="PaddedSobol"), POOL | 2 | PADDED),
         "pcg": (cornell_box(resolution=64, spp=8, sampler="PCG32"), POOL | 2),
         "environment": (cornell_box(resolution=64, spp=8).replace("render {", env), POOL | 4),
         "env_disney": (cornell_box(resolution=64, spp=8, short_box_surface="disney", extra_surfaces=mat("disney")).replace("render {", env), POOL | 4 | 16),

@@ -1,5 +1,5 @@
 """tools/ that the design decisions lean on must keep building: tools/bvh_sim.cpp is the CPU model of the kernel's BVH walk
-(DESIGN.md §4.4) that the host builder's choices were compared with."""
+(DESIGN.md §4.6) that the host builder's choices were compared with."""
 import os
 import re
 import shutil
@@ -32,7 +32,7 @@ def test_bvh_sim_builds_and_counts(tmp_path):
 
 
 def test_default_builder_beats_the_round1b_builder_on_a_room(tmp_path):
-    """regression guard for DESIGN.md §4.4: on a (small) bathroom-class room the default builder (exact sweep + reinsertion +
+    """regression guard for DESIGN.md §4.6: on a (small) bathroom-class room the default builder (exact sweep + reinsertion +
     optimal collapse) visits clearly fewer nodes per ray than 16-bin SAH + greedy collapse"""
     from luisarender_amd.scenes import generate_room_scene
     if shutil.which("g++") is None:

@@ -34,3 +34,27 @@ for i, g in enumerate(gaps):
         a[1] += g
 for k, (n, us) in sorted(by_prev.items(), key=lambda kv: -kv[1][1])[:8]:
     print(f"  {k:90s} x{n:5d} mean {us / n:8.1f} us")
+# per ROUND of a slice (the launches between two camera passes, in order): mean duration of the continuation pass and of the heavy kernels --
+# how much of the frame is the tail of near-empty rounds
+rounds = {}
+index = {}
+for name, s, e, _ in rows:
+    short = name.split("(")[0]
+    if "kernel<" not in short:
+        continue
+    is_cont = "megap" in short and any(f"<{m}u>" in short for m in range(2048, 4096)) or any(f"<{m}u>" in short for m in range(6144, 8192))
+    is_camera = ("megapool_kernel" in short or "megapath_kernel" in short) and not is_cont
+    if is_camera:
+        index = {}
+        continue
+    key = "continuation" if is_cont else short.split("lrd::")[-1]
+    i = index.get(key, 0)
+    index[key] = i + 1
+    a = rounds.setdefault((key, i), [0, 0.0])
+    a[0] += 1
+    a[1] += (e - s) / 1e6
+if rounds:
+    keys = sorted({k for k, _ in rounds})
+    print("per round of a slice, mean ms:  " + "  ".join(f"{k[-22:]:>22s}" for k in keys))
+    for i in range(max(i for _, i in rounds) + 1):
+        print(f"  round {i:2d}                      " + "  ".join(f"{rounds[k, i][1] / rounds[k, i][0]:22.3f}" if (k, i) in rounds else " " * 22 for k in keys))
