@@ -249,6 +249,28 @@ LR_D bool pool_trace(const DScene &scene, const TraversalStack &stack, TravState
     return for_alpha;
 }
 
+// PADDED kernels: a stretch of a vertex's draws -- one number, two numbers, and a fourth where `four` -- is ONE real call, so that the hashes' and the
+// permutation's temporaries are not the shading block's: <20482> 16 -> 7 spilled VGPRs, C2 under PaddedSobol 974 -> 1004 Msamples/s at 256 spp, the
+// camera class 1067 -> 1111, films bit-identical (profiles/r06za_padded_draws_out_of_line.txt; LR_PADDED_DRAWS_OUT_OF_LINE=0 restores the inline draws).
+// The same for the run-time generic sampler (state in; numbers and state out: eight return registers): Sobol 886 -> 880, PCG32 980 -> 968 -- not kept.
+#ifndef LR_PADDED_DRAWS_OUT_OF_LINE
+#define LR_PADDED_DRAWS_OUT_OF_LINE 1
+#endif
+struct PaddedDraws {
+    float a, b, c, d;
+};
+[[maybe_unused]] static __device__ __noinline__ PaddedDraws padded_draws(const DScene *scene, uint32_t sample_index, uint32_t pixel, uint32_t dimension, bool four) {
+    PathSampler<true> sampler{};
+    uint32_t words[kWfSamplerWordsMax] = {sample_index, 0u, dimension, pixel};
+    sampler.restore(*scene, words);
+    PaddedDraws r;
+    r.a = sampler.next_1d();
+    const auto u = sampler.next_2d();
+    r.b = u.x, r.c = u.y;
+    r.d = four ? sampler.next_1d() : 0.f;
+    return r;
+}
+
 template<uint32_t F>
 __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(DScenePtr scene_ptr, RenderArgs args) {
     const DScene &scene = *(const DScene *)scene_ptr;
@@ -585,7 +607,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         if (COUNT) { local.path_length_sum++, local.nee_samples++; }
                         // random numbers are drawn where they are used, in the reference's order (mega_path.cpp:90-97):
                         // light selection, light surface (2), lobe, bsdf (2), [rr]
-                        {
+                        if constexpr (PADDED && LR_PADDED_DRAWS_OUT_OF_LINE != 0) {
+                            sampler_take(0u);
+                            const auto r = padded_draws(&scene, sampler.lo, sampler.w3, sampler.w2, false);
+                            u_light_selection = r.a, u_light_surface = f2{r.b, r.c};
+                        } else {
                             if (PCG) { sampler_take(0u); }
                             u_light_selection = sampler.next_1d();
                             u_light_surface = sampler.next_2d();
@@ -623,7 +649,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                         const auto t_e1 = probe_clock();
                         t_eval = t_e1 - t_l1;
 #endif
-                        {
+                        if constexpr (PADDED && LR_PADDED_DRAWS_OUT_OF_LINE != 0) {
+                            sampler_take(1u);
+                            const auto r = padded_draws(&scene, sampler.lo, sampler.w3, sampler.w2, rr);
+                            u_lobe = r.a, u_bsdf = f2{r.b, r.c}, u_rr = r.d;
+                        } else {
                             if (PCG) { sampler_take(1u); }
                             u_lobe = sampler.next_1d();
                             u_bsdf = sampler.next_2d();

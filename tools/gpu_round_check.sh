@@ -11,7 +11,7 @@
 TAG=${1:-rXX}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=gpurun_out/$TAG
-timeout 900 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; grep -E "passed|failed|FAILED|^E  |Fatal" $O/gpu_tests.log | tail -6
+timeout 1500 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; grep -E "passed|failed|FAILED|^E  |Fatal" $O/gpu_tests.log | tail -6
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 ( time timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err ) 2>&1 | grep real
 timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extra --no-stats > $O/bench_c5.json 2> $O/bench_c5.err
@@ -28,8 +28,8 @@ PY
 tools/profile_c2.sh $TAG 1024 > $O/profile.log 2>&1
 python tools/summarize_prof.py gpurun_out/prof_$TAG $O/c2_1024spp.json 1073741824 > /dev/null 2>&1; python -c "
 import json; d = json.load(open('$O/c2_1024spp.json')); print({k: d[k] for k in d if k not in ('top_kernels', 'kernel_ms_all', 'counters_mean_per_launch')})"
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$O/trace_c5 -o trace -- python $R/tools/c5_ablation.py 512 full > $R/$O/trace_c5.log 2>&1 )
-python tools/wf_trace.py $O/trace_c5 | head -16 | tee $O/wf_trace_c5.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$O/trace_c5 -o trace -- python $R/tools/c5_ablation.py 2048 full > $R/$O/trace_c5.log 2>&1 )
+python tools/wf_trace.py $O/trace_c5 | head -40 | tee $O/wf_trace_c5.txt
 timeout 600 python tools/shard_probe.py 1024 2>&1 | grep -v amdgpu.ids | tee $O/shard_probe.txt
 timeout 600 python tools/ab_sched.py 1024 c2 2>&1 | grep "^c2" | tee $O/ab_sched_c2_1024spp.txt
 timeout 600 python tools/ab_sched.py 64 c1 c3 c4 c5 2>&1 | grep "^c[0-9]" | tee $O/ab_sched_others_64spp.txt
