@@ -182,6 +182,10 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
  * free; a call over more tiles than the queues can hold takes them group after group, which changes no bit.
  *   mode         0 = automatic (default), 1 = never: the all-in-one megakernel variants (A/B, tests),
  *                2 = automatic with queues of eight tiles (tests: the tile groups a GPU short of memory would use)
+ *                Round 6: a slice runs ONE round and HANDS the paths still parked OVER to the next slice's first round (they are
+ *                independent of their slice and add to the frame's order-independent fixed-point sums; the call's last slice runs all its
+ *                rounds) -- its remaining rounds moved a few thousand paths each at one batch's latency, 6 % of a kitchen-class frame.
+ *                mode | rounds << 8 overrides the one (tests, A/B); mode | 65535 << 8: never, every slice runs all its rounds.
  *   slice_paths  paths per slice (0 = default 2^28: 76 .. 89 GB of queues when a whole slice is in flight)
  * lrhip_last_variant reports LRHIP_FEAT_WAVEFRONT | the lean kernel's bits | the closure bits the heavy kernel served.          */
 #define LRHIP_FEAT_WAVEFRONT 1024u

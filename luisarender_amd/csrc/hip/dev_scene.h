@@ -148,7 +148,9 @@ constexpr uint32_t kWfSamplerWordsMax = 4u;
 constexpr uint32_t kWfItemRecords = LR_WF_ITEM;    // continuation records per work item of the continuation pass, at most (megapath_kernel.h)
 // device-side counters (uint32 each): [0..2] parked paths per kind, [3] continuation records, [4] work counter of the continuation
 // pass, [5..7] work counters of the heavy kernels (one per kind)
-enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkCont = 4u, kWfWorkHeavy = 5u, kWfCounterWords = 8u };
+enum : uint32_t { kWfCountHeavy = 0u, kWfCountCont = 3u, kWfWorkCont = 4u, kWfWorkHeavy = 5u, kWfCounterWords = 8u,
+                  // round 6: behind the round's counters, the parked paths a slice HANDS OVER to the next one (film_kernels.h: wf_carry_kernel)
+                  kWfCarry = 8u, kWfCounterBufferWords = 12u };
 struct WfArgs {
     uint32_t *heavy;             // [kWfKinds][kWfHeavyWords + sampler words][capacity]
     uint32_t *cont;              // [kWfContWords + sampler words][capacity]

@@ -39,6 +39,28 @@ __global__ void wf_resolve_kernel(float4 *film, unsigned long long *accum, uint3
     a[0] = 0ull, a[1] = 0ull, a[2] = 0ull;
 }
 
+// Wavefront mode, round 6: THE TAIL OF A SLICE IS HANDED OVER.  A slice's rounds { heavy kernels -> continuation pass } thin out fast -- on the kitchen
+// class the third round moves a twelfth of the first one's paths -- and from then on a round takes what ONE batch's latency takes, whatever it moves:
+// 13 of a slice's 16 rounds were 24 ms of its ~400 (profiles/r06_final_wf_trace_c5_2048spp.txt, the per-round table).  Paths are independent
+// of their slice (a parked record holds pixel, depth and stream position; finished paths add to the frame's fixed-point sums, which are
+// order-independent), so after `rounds` rounds the paths still parked simply wait in their queues for the NEXT slice's first round and ride along with
+// its thousand times more numerous ones.  No host round trip: mode 0 (after a round from the hand-over round on) moves the three queues' counts
+// aside if they are at most `margin` (the slots the queues hold beyond a slice's own paths) -- the rounds still launched find empty queues and
+// cost microseconds; mode 1 (ahead of the next slice's camera pass) puts them back, and the camera pass parks behind them.  The frame's LAST
+// slice runs all its rounds.  Films bit-identical with and without (tests/test_gpu_pool.py).
+__global__ void wf_carry_kernel(uint32_t *counts, uint32_t margin, uint32_t mode) {
+    if (threadIdx.x != 0u || blockIdx.x != 0u) { return; }
+    const auto carried = counts[kWfCarry] + counts[kWfCarry + 1u] + counts[kWfCarry + 2u];
+    if (mode == 0u) {
+        const auto parked = static_cast<unsigned long long>(counts[kWfCountHeavy]) + counts[kWfCountHeavy + 1u] + counts[kWfCountHeavy + 2u];
+        if (carried == 0u && parked != 0ull && parked <= margin) {
+            for (auto k = 0u; k < kWfKinds; k++) { counts[kWfCarry + k] = counts[kWfCountHeavy + k], counts[kWfCountHeavy + k] = 0u; }
+        }
+    } else if (carried != 0u) {
+        for (auto k = 0u; k < kWfKinds; k++) { counts[kWfCountHeavy + k] += counts[kWfCarry + k], counts[kWfCarry + k] = 0u; }
+    }
+}
+
 // convert kernel of the Color film, color.cpp:87-93
 __global__ void film_convert_kernel(const float4 *film, float4 *out, uint32_t pixel_count, float sx, float sy, float sz) {
     auto i = blockIdx.x * blockDim.x + threadIdx.x;

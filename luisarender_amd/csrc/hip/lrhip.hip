@@ -113,6 +113,7 @@ struct DeviceBuffer {
 // chunking (and therefore the fp32 summation order of the film) is identical on every GPU
 constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
 constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
+constexpr uint32_t kWfCarryRounds = 1u;// wavefront mode: rounds of a slice before its parked paths wait for the next slice (film_kernels.h: wf_carry_kernel)
 constexpr uint64_t kWfQueueBudget = 96ull << 30u;// bytes the queues of wavefront mode may take (of 288 GB)
 #ifndef LR_MAX_BLOCKS_PER_CU
 #define LR_MAX_BLOCKS_PER_CU 8
@@ -157,6 +158,7 @@ struct lrhip_ctx {
     int heavy_blocks[sizeof(kHeavyVariants) / sizeof(kHeavyVariants[0])];// resident blocks per CU of each heavy-kernel variant (-1: not asked yet)
     uint32_t wf_mode{0u};        // lrhip_set_wavefront: 0 = automatic (scenes with Mix / Layered surfaces), 1 = never, 2 = automatic with tiny tile groups (tests)
     uint32_t wf_slice_paths{0u}; // paths per slice (queue capacity); 0 = default
+    uint32_t diag_wf_carry_rounds{0u};// lrhip_set_diagnostics: rounds before a slice hands its parked paths over (0 = kWfCarryRounds; 65535 = never: every slice drains)
     // round 4: the path-pool scheduler (megapool_kernel.h): slot records of every resident wave; lrhip_set_scheduler
     DeviceBuffer pool;
     uint32_t scheduler{0u};      // lrhip_set_scheduler: 0 = automatic (wants_pool below), 1 = one path per lane, 2 = the pool kernels where one exists for the scene
@@ -1149,14 +1151,17 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     auto fit_paths = std::min<uint64_t>(1ull << 30u,// (dev_wavefront.h: a slot's byte offset inside a queue column is 32 bits)
                                          std::max<uint64_t>(1ull << 16u, std::min<uint64_t>(have / 2u, kWfQueueBudget) / per_path));
     if (ctx->wf_mode == 2u) { fit_paths = 8ull * 64u * slice_spp; }// (tests: eight tiles at a time)
-    const auto group_tiles = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(tiles_in_range, fit_paths / (64ull * slice_spp))));
-    const auto capacity = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, 1ull << 30u));
+    // (round 6: the queues hold an eighth more than a slice's own paths -- room for what the slice before handed over, film_kernels.h: wf_carry_kernel)
+    const auto group_tiles = static_cast<uint32_t>(std::max<uint64_t>(1u, std::min<uint64_t>(tiles_in_range, fit_paths * 8u / 9u / (64ull * slice_spp))));
+    const auto slice_paths = std::min<uint64_t>(static_cast<uint64_t>(group_tiles) * 64u * slice_spp, (1ull << 30u) * 8u / 9u);
+    const auto carry_margin = static_cast<uint32_t>(slice_paths / 8u);
+    const auto capacity = static_cast<uint32_t>(slice_paths + carry_margin);
     const auto heavy_words = static_cast<size_t>(lrd::kWfKinds) * (lrd::kWfHeavyWords + sampler_words) * capacity;
     const auto cont_words = static_cast<size_t>(lrd::kWfContWords + sampler_words) * capacity;
     if (auto r = ensure(ctx->wf_heavy, heavy_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     if (auto r = ensure(ctx->wf_cont, cont_words * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     if (ctx->wf_counts.ptr == nullptr) {
-        if (auto r = ensure(ctx->wf_counts, lrd::kWfCounterWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
+        if (auto r = ensure(ctx->wf_counts, lrd::kWfCounterBufferWords * sizeof(uint32_t)); r != LRHIP_OK) { return r; }
     }
     if (auto r = ensure_accum(ctx, pixel_count); r != LRHIP_OK) { return r; }
     auto &scene = ctx->scene;
@@ -1229,6 +1234,9 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     auto item_scale = 1.25;
     if (ctx->diag_item_scale != 0.) { item_scale *= std::max(0.01, std::fabs(ctx->diag_item_scale)); }
     if (!ctx->in_split) { LR_HIP_CHECK(hipEventRecord(ctx->ev_begin, ctx->stream)); }
+    LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterBufferWords * sizeof(uint32_t), ctx->stream));// (nothing handed over yet)
+    // rounds a slice runs before it hands what is still parked over to the next one (the last slice of the call runs them all)
+    const auto carry_rounds = ctx->diag_wf_carry_rounds != 0u ? ctx->diag_wf_carry_rounds : kWfCarryRounds;
     for (auto g0 = 0u; g0 < tiles_in_range; g0 += group_tiles) {// tile groups: what fits the queues at a time (see above)
     const auto group_count = std::min(group_tiles, tiles_in_range - g0);
     args.tile_begin = p->tile_begin + g0 * p->tile_stride;
@@ -1246,8 +1254,10 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
             if (auto r = ensure(ctx->partial, static_cast<size_t>(chunk_count) * pixel_count * sizeof(float4)); r != LRHIP_OK) { return r; }
             args.partial = static_cast<float4 *>(ctx->partial.ptr);
         }
+        const auto last_slice = g0 + group_tiles >= tiles_in_range && s0 + slice_spp >= p->spp_end;
         LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
         LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 1u);// (the paths the slice before handed over)
         LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
         if (chunk_count > 1u && !pool_film) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
@@ -1266,6 +1276,9 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
             args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_cont) * lrd::kBlockThreads;
             LR_HIP_CHECK(kVariants[vi_cont].launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, 2u * sizeof(uint32_t), ctx->stream));// (+ its work counter, next to it)
+            if (!last_slice && round + 1u >= carry_rounds && carry_rounds < 0xffffu) {
+                hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 0u);
+            }
         }
     }
     }
@@ -1476,8 +1489,9 @@ int lrhip_set_scheduler(lrhip_ctx *ctx, uint32_t mode) {
 }
 
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths) {
-    if (ctx == nullptr || mode > 2u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_wavefront: invalid argument"); }
-    ctx->wf_mode = mode, ctx->wf_slice_paths = slice_paths;
+    if (ctx == nullptr || (mode & 0xffu) > 2u || (mode >> 24u) != 0u) { return fail(LRHIP_ERROR_INVALID, "lrhip_set_wavefront: invalid argument"); }
+    ctx->wf_mode = mode & 0xffu, ctx->wf_slice_paths = slice_paths;
+    ctx->diag_wf_carry_rounds = mode >> 8u;// (bits 8-23: rounds before a slice hands its parked paths over; 0 = default, 65535 = never)
     return LRHIP_OK;
 }
 

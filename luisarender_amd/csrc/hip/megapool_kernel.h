@@ -271,6 +271,25 @@ struct PaddedDraws {
     return r;
 }
 
+// LR_LIGHT_OUT_OF_LINE: the light sample of a vertex -- selection, the chain light instance -> instance -> alias table -> triangle -> vertices,
+// emission, environment sampling, the shadow ray -- as ONE real call with its thirteen inputs by value, in the pool kernels that hold the Disney
+// closure: their shading block is the one that spills (<12308> 67 -> 44 VGPRs), and the call's temporaries are not its allocation's any more.
+// Camera class 1166 -> 1227 Msamples/s at 64 spp, films bit-identical; the kernels without Disney LOSE (bedroom class <4100> 1092 -> 1015, 12 -> 27
+// spilled; the kitchen class' wavefront passes 640 -> 627) and keep the inline form (profiles/r06zd_light_sample_out_of_line.txt).
+#ifndef LR_LIGHT_OUT_OF_LINE
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 16) && !((LR_VARIANT) & (96 | 256))
+#define LR_LIGHT_OUT_OF_LINE 1
+#else
+#define LR_LIGHT_OUT_OF_LINE 0
+#endif
+#endif
+template<bool ENV>
+[[maybe_unused]] static __device__ __noinline__ LightPick sample_one_light_call(const DScene *scene, f3 p, f3 ng, f3 ns, uint32_t offset_bits, float u0, float u1, float u2) {
+    SurfacePoint it{};
+    it.p = p, it.ng = ng, it.shading.n = ns, it.offset_bits = offset_bits;
+    return sample_one_light<ENV>(*scene, it, u0, f2{u1, u2});
+}
+
 template<uint32_t F>
 __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(DScenePtr scene_ptr, RenderArgs args) {
     const DScene &scene = *(const DScene *)scene_ptr;
@@ -618,7 +637,11 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                             if (PCG) { sampler_leave(), sampler_left = !PADDED; }
                         }
                         // ---- sample one light, uniform.cpp:78-137 + light_sampler.cpp:57-63 (dev_shade.h: sample_one_light)
+#if LR_LIGHT_OUT_OF_LINE
+                        const auto pick = sample_one_light_call<ENV>(&scene, it.p, it.ng, it.shading.n, it.offset_bits, u_light_selection, u_light_surface.x, u_light_surface.y);
+#else
                         const auto pick = sample_one_light<ENV>(scene, it, u_light_selection, u_light_surface);
+#endif
                         shadow = pick.shadow;
 #ifdef LR_STALL_PROBE
                         asm volatile("" : "+v"(shadow.o.x), "+v"(shadow.d.x));
@@ -771,6 +794,8 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
                 } else {// MegakernelPathTracingInstance::Li prologue, mega_path.cpp:52-62
                     pixel_index = new_py * scene.camera.width + new_px;
                     path_item = new_item;
+                    // (MEASURED, NOT KEPT, round 6: this start of a path -- seed, filter tables, camera ray -- as one real call like the light sample: camera class
+                    // 1219 against 1219, C2 -1.6 %, C3 -2.5 %, C5 -0.8 %, profiles/r06ze_camera_start_out_of_line.txt)
                     sampler.start(scene, new_px, new_py, new_s);
                     const auto u_filter = sampler.next_pixel_2d();
                     const auto u_lens = scene.camera.kind == LR_CAMERA_THIN_LENS ? sampler.next_2d() : f2{.5f, .5f};

@@ -133,11 +133,12 @@ class MegaPathRenderer:
         the work-item size; the library itself reads no environment variable"""
         self._check(self._lib.lrhip_set_diagnostics(self._ctx, force_features, item_scale))
 
-    def set_wavefront(self, enabled: bool = True, slice_paths: int = 0, tiny_tile_groups: bool = False) -> None:
+    def set_wavefront(self, enabled: bool = True, slice_paths: int = 0, tiny_tile_groups: bool = False, carry_rounds: int = 0) -> None:
         """lrhip_set_wavefront: scenes with Mix / Layered surfaces render in wavefront mode by default (lean megakernel + heavy-closure
         kernel + continuation pass); enabled=False keeps them on the all-in-one megakernel variants (A/B, tests); tiny_tile_groups
         sends eight tiles through the queues at a time (tests: what a GPU short of memory does)"""
-        self._check(self._lib.lrhip_set_wavefront(self._ctx, (2 if tiny_tile_groups else 0) if enabled else 1, slice_paths))
+        # carry_rounds: rounds before a slice hands its parked paths over to the next one (0 = the library's default, 65535 = never)
+        self._check(self._lib.lrhip_set_wavefront(self._ctx, ((2 if tiny_tile_groups else 0) if enabled else 1) | (carry_rounds << 8), slice_paths))
 
     def set_texture_storage(self, mode: int = 1) -> None:
         """lrhip_set_texture_storage: 8-bit images as 8-bit texels on the device from the next upload on (0 never, 1 automatic: scenes

@@ -112,9 +112,42 @@ def test_round5_line_measures_its_roofline_block_at_the_timed_configuration():
     assert line["path_statistics"]["spp"] == 1024 and line["path_statistics"]["pool_state_bytes_per_sample"] > 200
     extra = {(e["workload"].split(",")[0].split(" (")[0], e["sampler"]): e for e in line["extra_configs"]}
     sobol = extra["Contemporary Bathroom-class", "PaddedSobol"]
-    assert sobol["spp_timed"] == 1024 and sobol["value"] > 880 and sobol["kernel"] == "lrd::megapool_kernel<20482u>"
+    assert sobol["spp_timed"] == 1024 and sobol["value"] > 880 and sobol["kernel"] == "lrd::megapool_kernel<4098u>"
     assert sobol["parity"]["rel_l1"] < 1e-2 and sobol["parity"]["finite"] and sobol["cpu_baseline"]["kind"] == "port"
     for key, floor in ((("Cornell Box", "Independent"), 3800), (("Bedroom-class", "Independent"), 1000), (("Camera-class", "Independent"), 1000), (("Kitchen-class", "Independent"), 550)):
+        assert extra[key]["value"] > floor and extra[key]["parity"]["finite"], key
+
+
+def test_round6_line_carries_a_roofline_block_for_every_configuration():
+    """the line of the round-6 state (profiles/r06_final_bench_c2_1gpu.json, the driver's default command) -- one
+    `roofline` block per configuration, each recomputable with a calculator from the raw counter totals it carries (`pmc.counters`), priced per
+    kernel from the dynamic class mix; `bound` says what DESIGN.md section 5 says; the reference's own code beside the HEADLINE number; the
+    PaddedSobol line on a kernel compiled for that sampler."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_final_bench_c2_1gpu.json")))
+    assert line["n_gpus"] == 1 and line["value"] > 1050 and line["config"]["spp"] == 1024 and "scheduler_override" not in line["config"]
+    ref = line["cpu_reference"]
+    assert ref["kind"] == "reference" and ref["cores"] >= 1 and ref["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    blocks = [("headline", line["roofline"])] + [(e["workload"].split(",")[0], e["roofline"]) for e in line["extra_configs"]]
+    assert len(blocks) == 6
+    for name, r in blocks:
+        assert r["bound"] == "issue + latency at 4 waves per SIMD" and r["unit"] == "GB/s" and r["peak"] == 8000.0, name
+        assert "pmc_busy" not in r.get("valu", {}), name  # (an in-flight sum, not a fraction of a roof: out of the block since round 6)
+        c, p = r["pmc"]["counters"], r["pmc"]
+        traffic = (c["FETCH_SIZE"] * 2048.0 + c["WRITE_SIZE"] * 1024.0) / p["samples"] * p["timed_launch_samples"]
+        assert abs(traffic - r["traffic"]) < 1e-9 * traffic, name
+        assert abs(r["frac"] - traffic / (r["kernel_ms"] * 1e-3) / 8e12) < 1e-9, name
+        v = r["valu"]
+        assert abs(v["wave_instr_per_sample"] - c["SQ_INSTS_VALU"] / p["samples"]) < 1e-9 * v["wave_instr_per_sample"], name
+        assert 2.4 < v["cycles_per_wave_instr"] < 4.2 and abs(sum(v["valu_mix"].values()) - 1.0) < 1e-9, name
+        assert abs(v["issue_frac"] - v["wave_instr_per_launch"] * v["cycles_per_wave_instr"] / v["simd_cycles_per_launch"]) < 1e-9, name
+        w = r["waves"]
+        assert 0.9 < w["waiting_at_waitcnt"] + w["issue_stalled"] + w["instruction_in_flight"] < 1.1, name
+        assert 0.0 < r["frac"] < 0.6 and r["lanes"]["trace"] > 0.5, name
+    extra = {(e["workload"].split(",")[0].split(" (")[0], e["sampler"]): e for e in line["extra_configs"]}
+    sobol = extra["Contemporary Bathroom-class", "PaddedSobol"]
+    assert sobol["kernel"] == "lrd::megapool_kernel<20482u>" and sobol["value"] > 950 and sobol["parity"]["rel_l1"] < 1e-2 and sobol["parity"]["finite"]
+    assert extra["Camera-class", "Independent"]["kernel"] == "lrd::megapool_kernel<12308u>" and extra["Camera-class", "Independent"]["value"] > 1100
+    for key, floor in ((("Cornell Box", "Independent"), 3800), (("Bedroom-class", "Independent"), 1050), (("Kitchen-class", "Independent"), 590)):
         assert extra[key]["value"] > floor and extra[key]["parity"]["finite"], key
 
 

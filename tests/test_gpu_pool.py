@@ -235,6 +235,42 @@ def test_pool_kernels_in_wavefront_mode(renderer, tmp_path):
         renderer.set_scheduler(None)
 
 
+def test_a_slice_hands_its_parked_paths_over_to_the_next_one(renderer, tmp_path):
+    """Round 6: in wavefront mode a slice runs ONE round { heavy kernels -> continuation pass } and leaves the paths still parked in their queues
+    for the next slice's first round (film_kernels.h: wf_carry_kernel; the call's last slice runs all its rounds).  A path does not depend on
+    its slice and the pool kernels' film is summed in fixed point: six slices with the hand-over after one, two or three rounds, with none at all
+    (every slice drains: the round 3-5 behaviour), eight tiles at a time, and as three shards must be THE SAME film, every sample counted."""
+    scene = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16, target_triangles=60_000))
+    films = {}
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(scene)
+        for name, kw in (("never", dict(carry_rounds=65535)), ("default", {}), ("two", dict(carry_rounds=2)), ("three", dict(carry_rounds=3)),
+                         ("default, eight tiles at a time", dict(tiny_tile_groups=True)), ("one slice", None)):
+            if kw is None:
+                renderer.set_wavefront(True)
+            else:
+                renderer.set_wavefront(True, slice_paths=256 * 144 * 3, **kw)  # 3 spp per slice: six slices, the last one short
+            renderer.clear()
+            renderer.render(0, 16, sync=True)
+            films[name] = renderer.download(False)
+            assert renderer.last_variant() == (POOL | WF | 16 | 32 | 64), name
+        renderer.set_wavefront(True, slice_paths=256 * 144 * 3)
+        total = np.zeros_like(films["never"])
+        for rank in range(3):
+            renderer.clear()
+            renderer.render(0, 16, rank=rank, world=3, sync=True)
+            total += renderer.download(False)
+        films["default, three shards"] = total
+    finally:
+        renderer.set_wavefront(True)
+        renderer.set_scheduler(None)
+    ref = films["never"]
+    assert np.isfinite(ref).all() and (ref[..., 3] == 16).all() and ref[..., :3].sum() > 0
+    for name, f in films.items():
+        assert np.array_equal(f, ref), (name, _rel_l1(f, ref))
+
+
 def test_frames_that_do_not_fit_fixed_point_take_the_float_kernels(renderer, tmp_path):
     """A film clamp used to switch clamping off (1e20) leaves no fractional bits in 64-bit fixed point: the pool kernels -- and wavefront
     mode, whose parked paths add in fixed point -- step aside for the float-accumulating kernels instead of quantising the frame
