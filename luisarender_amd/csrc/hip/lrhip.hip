@@ -114,7 +114,7 @@ struct DeviceBuffer {
 constexpr double kNominalWaves = 4096.0;// 256 CUs x 4 SIMDs x 4 waves
 constexpr uint32_t kMaxChunks = 64u;     // partial planes: chunk_count x 16 B per pixel
 constexpr uint32_t kWfCarryRounds = 1u;// wavefront mode: rounds of a slice before its parked paths wait for the next slice (film_kernels.h: wf_carry_kernel)
-constexpr uint64_t kWfQueueBudget = 96ull << 30u;// bytes the queues of wavefront mode may take (of 288 GB)
+constexpr uint64_t kWfQueueBudget = 104ull << 30u;// bytes the queues of wavefront mode may take (of 288 GB; round 6: 104 GB -- the default slice with its hand-over margin takes 86 - 100)
 #ifndef LR_MAX_BLOCKS_PER_CU
 #define LR_MAX_BLOCKS_PER_CU 8
 #endif
@@ -1147,7 +1147,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     size_t free_bytes = 0u, total_bytes = 0u;
     LR_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
     const auto have = free_bytes + ctx->wf_heavy.bytes + ctx->wf_cont.bytes;// (the queues of an earlier call count as free)
-    // at most half of what is free, and at most kWfQueueBudget: the 2^28-path default slice needs 76-89 GB, more buys nothing
+    // at most half of what is free, and at most kWfQueueBudget: the 2^28-path default slice needs 86-100 GB with its hand-over margin, more buys nothing
     auto fit_paths = std::min<uint64_t>(1ull << 30u,// (dev_wavefront.h: a slot's byte offset inside a queue column is 32 bits)
                                          std::max<uint64_t>(1ull << 16u, std::min<uint64_t>(have / 2u, kWfQueueBudget) / per_path));
     if (ctx->wf_mode == 2u) { fit_paths = 8ull * 64u * slice_spp; }// (tests: eight tiles at a time)
