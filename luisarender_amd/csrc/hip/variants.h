@@ -33,7 +33,8 @@
     X(8208) X(8209) X(8210) X(8211) X(8212) X(8213) X(8214) X(8215) X(12304) X(12305) X(12306) X(12307) X(12308) X(12309) X(12310) X(12311)
 
 // round 6: the lean pool kernels once more with the generic sampler's kind fixed to PaddedSobol (kFeatPadded = 16384 | kFeatGeneric): plain,
-// Disney, environment + Disney, and the 8-bit-texel Disney sets, each with its counting twin (measured, profiles/r06y_padded_sobol_kernels.txt: C2 949 -> 973
-// Msamples/s, the camera class under PaddedSobol 1007 -> 1068; the plain environment set <20486> gained nothing on the bedroom class, 971 -> 966, and is not built).  Not part of the
-// kSceneVariants x {Count} x {Generic} grid: lrhip_render looks them up by mask (kPaddedVariants).
-#define LR_PADDED_LIST(X) X(20482) X(20483) X(20498) X(20499) X(20502) X(20503) X(28690) X(28691) X(28694) X(28695)
+// environment, alpha, environment + alpha, Disney, environment + Disney, and the 8-bit-texel Disney sets, each with its counting twin.  Not part of
+// the kSceneVariants x {Count} x {Generic} grid: lrhip_render looks them up by mask (kPaddedVariants).  Measured (profiles/r06y_padded_sobol_kernels.txt,
+// r06za_padded_draws_out_of_line.txt, r06zf_padded_environment_set.txt): C2 949 -> 1004 Msamples/s at 256 spp, the camera class under PaddedSobol 1007 -> 1111,
+// the bedroom class 974 -> 1011.
+#define LR_PADDED_LIST(X) X(20482) X(20483) X(20486) X(20487) X(20490) X(20491) X(20494) X(20495) X(20498) X(20499) X(20502) X(20503) X(28690) X(28691) X(28694) X(28695)

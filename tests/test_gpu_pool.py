@@ -54,7 +54,8 @@ ALPHA = ('Texture holes : Checkerboard { on : Constant { v { 1 } } off : Constan
 PADDED = 16384  # LRHIP_FEAT_PADDED_SOBOL: a pool kernel compiled for the PaddedSobol sampler (round 6)
 
 
-@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "padded_sobol", "padded_sobol_lens_rr", "pcg", "mitchell", "rr", "alpha", "environment"])
+@pytest.mark.parametrize("case", ["lean", "glass", "disney", "sobol", "padded_sobol", "padded_sobol_lens_rr", "padded_sobol_alpha", "padded_sobol_environment", "pcg", "mitchell", "rr",
+                                  "alpha", "environment"])
 def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(renderer, case):
     """(padded_sobol*: the pool side is a kernel compiled for that sampler, which keeps only (sample index, pixel) of the stream and derives the
     dimension from the depth -- two for the pixel, two for a thin lens, six per vertex, one more from the roulette depth on -- against the
@@ -76,10 +77,12 @@ def test_pool_kernels_render_the_frames_of_the_one_path_per_lane_kernels(rendere
         kw.update(filter_impl="Mitchell", filter_radius=2.0)  # negative lobes: negative samples (signed fixed-point adds)
     elif case == "rr":
         kw.update(rr_depth=2, depth=12)
-    elif case == "alpha":  # the alpha-tested traversal: candidates parked for the test outside the loop, beside lanes that wait for a turnover
+    elif case in ("alpha", "padded_sobol_alpha"):  # the alpha-tested traversal: candidates parked for the test outside the loop, beside lanes that wait for a turnover
         kw.update(extra_surfaces=ALPHA, short_box_surface="cutout")
+    if case in ("padded_sobol_alpha", "padded_sobol_environment"):
+        kw.update(sampler="PaddedSobol")
     text = cornell_box(**kw)
-    if case == "environment":  # the <environment> variants: rays that leave through the open front are lit
+    if case in ("environment", "padded_sobol_environment"):  # the <environment> variants: rays that leave through the open front are lit
         text = text.replace("render {", "render {\n  environment : Spherical { emission : Constant { v { 0.3, 0.4, 0.6 } } }")
     if case == "padded_sobol_lens_rr":
         text = text.replace("Camera cam : Pinhole {\n  fov { 39.3 }", "Camera cam : ThinLens {\n  fov { 39.3 } aperture { 2 } focal_length { 50 } focus_distance { 1000 }")
