@@ -1258,6 +1258,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         LR_HIP_CHECK(hipMemsetAsync(ctx->work_counter.ptr, 0, 1024u, ctx->stream));
         LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 1u);// (the paths the slice before handed over)
+        LR_HIP_CHECK(hipGetLastError());
         LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
         if (chunk_count > 1u && !pool_film) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
@@ -1278,6 +1279,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, 2u * sizeof(uint32_t), ctx->stream));// (+ its work counter, next to it)
             if (!last_slice && round + 1u >= carry_rounds && carry_rounds < 0xffffu) {
                 hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 0u);
+                LR_HIP_CHECK(hipGetLastError());
             }
         }
     }
