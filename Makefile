@@ -61,7 +61,8 @@ VARIANT_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 6
                  5120 5121 5122 5123 5124 5125 5126 5127 5128 5129 5130 5131 5132 5133 5134 5135 \
                  7168 7169 7170 7171 7172 7173 7174 7175 7176 7177 7178 7179 7180 7181 7182 7183 \
                  8208 8209 8210 8211 8212 8213 8214 8215 12304 12305 12306 12307 12308 12309 12310 12311 \
-                 20482 20483 20486 20487 20490 20491 20494 20495 20498 20499 20502 20503 28690 28691 28694 28695
+                 20482 20483 20486 20487 20490 20491 20494 20495 20498 20499 20502 20503 28690 28691 28694 28695 \
+                 21506 21507 21514 21515 23554 23555 23562 23563
 # the heavy-closure kernels of wavefront mode (csrc/hip/heavy_kernel.h; mask: 1 counters, 2 generic sampler, 4 Mix / 8 Layered instead of
 # Disney, 512 nested Mix / Layered)
 HEAVY_MASKS ?= 0 1 2 3 4 5 6 7 8 9 10 11 516 517 518 519 520 521 522 523

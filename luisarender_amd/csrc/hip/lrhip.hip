@@ -150,7 +150,7 @@ struct lrhip_ctx {
     uint32_t features{0u};// lrd::kFeat* bits the uploaded scene needs (environment, alpha test, Disney / Mix / Layered)
     bool env_tree{false};// Combined environments nested in each other: only the call-making variants walk them (dev_shade.h)
     int variant_blocks[lrd::kSceneVariantCount * 4u];// resident blocks per CU of each precompiled variant (-1: not asked yet)
-    int padded_blocks[16];// ... and of the kFeatPadded kernels (kPaddedVariants)
+    int padded_blocks[32];// ... and of the kFeatPadded kernels (kPaddedVariants)
     uint32_t diag_force_features{0u};// lrhip_set_diagnostics (tests / tools)
     double diag_item_scale{0.};
     // wavefront mode (dev_scene.h: WfArgs): queues, counters and the fixed-point radiance sums; sized on first use
@@ -1196,6 +1196,16 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     if (vi_camera < 0 || vi_cont < 0 || !heavy_ok || kVariants[vi_camera].launch == nullptr || kVariants[vi_cont].launch == nullptr) {
         return fail(LRHIP_ERROR_UNSUPPORTED, "lrhip_render: the wavefront kernels for feature mask " + std::to_string(ctx->features) + " were not compiled into this library");
     }
+    // round 6: the two lean passes compiled for the PaddedSobol sampler, where the scene's sampler is that and both exist for the mask (variants.h: LR_PADDED_LIST)
+    auto e_camera = &kVariants[vi_camera], e_cont = &kVariants[vi_cont];
+    auto eb_camera = &ctx->variant_blocks[vi_camera], eb_cont = &ctx->variant_blocks[vi_cont];
+    if (pool && generic && ctx->scene.sampler_kind == LR_SAMPLER_PADDED_SOBOL) {
+        const auto pa = find_variant(kPaddedVariants, kPaddedVariantCount, kVariants[vi_camera].mask | lrd::kFeatPadded);
+        const auto pb = find_variant(kPaddedVariants, kPaddedVariantCount, kVariants[vi_cont].mask | lrd::kFeatPadded);
+        if (pa >= 0 && pb >= 0 && kPaddedVariants[pa].launch != nullptr && kPaddedVariants[pb].launch != nullptr) {
+            e_camera = &kPaddedVariants[pa], e_cont = &kPaddedVariants[pb], eb_camera = &ctx->padded_blocks[pa], eb_cont = &ctx->padded_blocks[pb];
+        }
+    }
     auto blocks_of = [&](int &cache, const VariantEntry &v, int &out) -> int {
         if (cache < 0) {
             int per_cu = 0;
@@ -1206,8 +1216,8 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         return LRHIP_OK;
     };
     int b_camera = 0, b_cont = 0, b_heavy[lrd::kWfKinds] = {0, 0, 0};
-    if (auto r = blocks_of(ctx->variant_blocks[vi_camera], kVariants[vi_camera], b_camera); r != LRHIP_OK) { return r; }
-    if (auto r = blocks_of(ctx->variant_blocks[vi_cont], kVariants[vi_cont], b_cont); r != LRHIP_OK) { return r; }
+    if (auto r = blocks_of(*eb_camera, *e_camera, b_camera); r != LRHIP_OK) { return r; }
+    if (auto r = blocks_of(*eb_cont, *e_cont, b_cont); r != LRHIP_OK) { return r; }
     for (auto k = 0u; k < lrd::kWfKinds; k++) {
         if (auto r = blocks_of(ctx->heavy_blocks[hi[k]], kHeavyVariants[hi[k]], b_heavy[k]); r != LRHIP_OK) { return r; }
     }
@@ -1259,7 +1269,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
         LR_HIP_CHECK(hipMemsetAsync(counts, 0, lrd::kWfCounterWords * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 1u);// (the paths the slice before handed over)
         LR_HIP_CHECK(hipGetLastError());
-        LR_HIP_CHECK(kVariants[vi_camera].launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
+        LR_HIP_CHECK(e_camera->launch(std::min(ctx->cu_count * static_cast<uint32_t>(b_camera), (args.item_count + 3u) / 4u), ctx->stream, device_scene, &args));
         if (chunk_count > 1u && !pool_film) {
             hipLaunchKernelGGL(lrd::resolve_partial_kernel, dim3((pixel_count + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->film,
                                args.partial, pixel_count, chunk_count, ctx->width, tiles_x, args.tile_begin, args.tile_end, p->tile_stride);
@@ -1275,7 +1285,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountHeavy, 0, 3u * sizeof(uint32_t), ctx->stream));
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfWorkHeavy, 0, 3u * sizeof(uint32_t), ctx->stream));
             args.total_threads = ctx->cu_count * static_cast<uint32_t>(b_cont) * lrd::kBlockThreads;
-            LR_HIP_CHECK(kVariants[vi_cont].launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
+            LR_HIP_CHECK(e_cont->launch(ctx->cu_count * static_cast<uint32_t>(b_cont), ctx->stream, device_scene, &args));
             LR_HIP_CHECK(hipMemsetAsync(counts + lrd::kWfCountCont, 0, 2u * sizeof(uint32_t), ctx->stream));// (+ its work counter, next to it)
             if (!last_slice && round + 1u >= carry_rounds && carry_rounds < 0xffffu) {
                 hipLaunchKernelGGL(lrd::wf_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, counts, carry_margin, 0u);
@@ -1290,7 +1300,7 @@ static int render_wavefront(lrhip_ctx *ctx, const lrhip_render_params *p, uint32
     LR_HIP_CHECK(hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->timed = true;
     // what rendered: the lean camera-pass kernel's mask + the closure bits the heavy kernel served
-    ctx->last_variant = kVariants[vi_camera].mask | (ctx->features & (lrd::kFeatDisney | lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatNest));
+    ctx->last_variant = e_camera->mask | (ctx->features & (lrd::kFeatDisney | lrd::kFeatMix | lrd::kFeatLayered | lrd::kFeatNest));
     return LRHIP_OK;
 }
 

@@ -304,13 +304,15 @@ __global__ __launch_bounds__(kBlockThreads, LR_MIN_WAVES) void megapool_kernel(D
     // PADDED (round 6): the generic sampler's kind known at compile time to be PaddedSobol (LR_ONLY_SAMPLER).  Its stream position is (sample
     // index, pixel, dimension): the first two never change along a path -- written with quad 3 when the path starts -- and the dimension is a
     // function of the depth (two for the pixel, two for a thin lens, six per vertex, one more from the Russian-roulette depth on): nothing
-    // is written back where a vertex's numbers are drawn, and the record is four quads like the Independent sampler's.
+    // is written back where a vertex's numbers are drawn, and the record is four quads like the Independent sampler's.  In wavefront mode a parked
+    // path takes the position along in the generic sampler's four words (sample index, 0, dimension, pixel): the heavy kernels draw a vertex's numbers
+    // in the same pattern, so the dimension a continuation record comes back with IS the derived one and only (sample index, pixel) return to the record.
 #ifdef LR_ONLY_SAMPLER
-    constexpr bool PADDED = PCG && !WF && (LR_ONLY_SAMPLER) == LR_SAMPLER_PADDED_SOBOL;
+    constexpr bool PADDED = PCG && (LR_ONLY_SAMPLER) == LR_SAMPLER_PADDED_SOBOL;
 #else
     constexpr bool PADDED = false;
 #endif
-    static_assert(PADDED == ((F & kFeatPadded) != 0u) || (F & kFeatPadded) == 0u, "a kFeatPadded kernel: generic sampler, no wavefront role, LR_ONLY_SAMPLER = PaddedSobol");
+    static_assert(PADDED == ((F & kFeatPadded) != 0u) || (F & kFeatPadded) == 0u, "a kFeatPadded kernel: generic sampler, LR_ONLY_SAMPLER = PaddedSobol");
     constexpr uint32_t QUADS = PADDED ? 4u : pool_quads<PCG>();
     __shared__ uint32_t s_stack[kStackLds * kBlockThreads];
     __shared__ float4 s_stage[kWavesPerBlock * kStageWave];// 4 KiB of node packets per wave

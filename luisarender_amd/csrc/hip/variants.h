@@ -37,4 +37,6 @@
 // the kSceneVariants x {Count} x {Generic} grid: lrhip_render looks them up by mask (kPaddedVariants).  Measured (profiles/r06y_padded_sobol_kernels.txt,
 // r06za_padded_draws_out_of_line.txt, r06zf_padded_environment_set.txt): C2 949 -> 1004 Msamples/s at 256 spp, the camera class under PaddedSobol 1007 -> 1111,
 // the bedroom class 974 -> 1011.
-#define LR_PADDED_LIST(X) X(20482) X(20483) X(20486) X(20487) X(20490) X(20491) X(20494) X(20495) X(20498) X(20499) X(20502) X(20503) X(28690) X(28691) X(28694) X(28695)
+#define LR_PADDED_LIST(X) X(20482) X(20483) X(20486) X(20487) X(20490) X(20491) X(20494) X(20495) X(20498) X(20499) X(20502) X(20503) X(28690) X(28691) X(28694) X(28695) \
+    /* ... and the lean passes of wavefront mode, camera pass and continuation pass, plain and with the alpha-tested traversal (the kitchen class under PaddedSobol) */ \
+    X(21506) X(21507) X(21514) X(21515) X(23554) X(23555) X(23562) X(23563)

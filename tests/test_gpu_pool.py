@@ -133,7 +133,7 @@ def test_shipped_pool_kernels_equal_their_counting_twins(renderer, tmp_path, cas
         # wavefront mode: the lean camera pass <5128> + the continuation pass <7176> around the heavy-closure kernel
         "wf_mix_alpha": (cornell_box(resolution=64, spp=8, short_box_surface="mix_nested", tall_box_surface="cutout", extra_surfaces=mat("mix_nested") + ALPHA), POOL | WF | 8 | 32),
         "wf_layered_sobol": (cornell_box(resolution=64, spp=8, short_box_surface="layered", tall_box_surface="cutout", extra_surfaces=mat("layered") + ALPHA, sampler="PaddedSobol"),
-                             POOL | WF | 8 | 16 | 64 | 2),
+                             POOL | WF | 8 | 16 | 64 | 2 | PADDED),
     }[case]
     sc = Scene.from_string(text)
     films = []
@@ -236,6 +236,25 @@ def test_pool_kernels_in_wavefront_mode(renderer, tmp_path):
         assert np.array_equal(total, pool)
     finally:
         renderer.set_scheduler(None)
+
+
+def test_padded_sobol_kernels_in_wavefront_mode(renderer, tmp_path):
+    """Round 6: the lean passes of wavefront mode compiled for the PaddedSobol sampler (kFeatPadded).  A parked path takes its stream position along in
+    the generic sampler's four words, the heavy kernels (run-time sampler) draw a vertex's numbers, and what comes back to the pool's record is
+    (sample index, pixel) only -- the dimension is derived from the depth again.  Against the one-path-per-lane passes, which count their draws:
+    the same film (Layered walks included: same hit bits, same seeds), several slices with the hand-over between them."""
+    scene = Scene.load(generate_kitchen_scene(str(tmp_path), resolution=(256, 144), spp=16, target_triangles=60_000, sampler="PaddedSobol"))
+    try:
+        renderer.set_wavefront(True, slice_paths=256 * 144 * 5)  # four slices, the last one short
+        out = _both(renderer, scene, 16)
+    finally:
+        renderer.set_wavefront(True)
+    (lane, v_lane, _), (pool, v_pool, _) = out["lane"], out["pool"]
+    assert v_lane == (WF | 16 | 32 | 64 | 2) and v_pool == (v_lane | POOL | PADDED), (v_lane, v_pool)
+    err = _rel_l1(pool, lane)
+    print(f"wavefront mode under PaddedSobol, padded pool passes vs one-path-per-lane passes: rel-L1 {err:.2e}")
+    assert np.array_equal(pool[..., 3], lane[..., 3]) and (pool[..., 3] == 16).all() and np.isfinite(pool).all()
+    assert err < 1e-6
 
 
 def test_a_slice_hands_its_parked_paths_over_to_the_next_one(renderer, tmp_path):
