@@ -291,6 +291,28 @@ def test_a_slice_hands_its_parked_paths_over_to_the_next_one(renderer, tmp_path)
     assert np.isfinite(ref).all() and (ref[..., 3] == 16).all() and ref[..., :3].sum() > 0
     for name, f in films.items():
         assert np.array_equal(f, ref), (name, _rel_l1(f, ref))
+    # A scene whose paths mostly STAY parked: every wall of the box is a Mix surface, so after a slice's first round far more paths wait than the
+    # queues' margin holds (an eighth of a slice) -- the hand-over must not happen until a later round has thinned them out, and nothing may be lost
+    text = cornell_box(resolution=64, spp=16, depth=6)
+    white = "Surface white : Matte { Kd : Constant { v { 0.725, 0.71, 0.68 } } }\n"
+    assert white in text
+    text = text.replace(white, "Surface wa : Matte { Kd : Constant { v { 0.8, 0.75, 0.7 } } }\nSurface wb : Matte { Kd : Constant { v { 0.65, 0.67, 0.66 } } sigma : Constant { v { 0.4 } } }\n"
+                               "Surface white : Mix { a { @wa } b { @wb } ratio : Constant { v { 0.5 } } }\n")
+    heavy = Scene.from_string(text)
+    out = {}
+    try:
+        renderer.set_scheduler(True)
+        renderer.upload(heavy)
+        for name, kw in (("never", dict(carry_rounds=65535)), ("default", {})):
+            renderer.set_wavefront(True, slice_paths=64 * 64 * 4, **kw)  # four slices
+            renderer.clear()
+            renderer.render(0, 16, sync=True)
+            out[name] = renderer.download(False)
+            assert renderer.last_variant() & (POOL | WF) == (POOL | WF), name
+    finally:
+        renderer.set_wavefront(True)
+        renderer.set_scheduler(None)
+    assert (out["never"][..., 3] == 16).all() and out["never"][..., :3].sum() > 0 and np.array_equal(out["default"], out["never"])
 
 
 def test_frames_that_do_not_fit_fixed_point_take_the_float_kernels(renderer, tmp_path):
