@@ -504,19 +504,42 @@ LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, T
 #endif
     auto flags = __float_as_uint(c.w);
     f3 p0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+#ifdef LR_EXACT_LEAF
+    // (`make ieee` and the volumetric kernels: the oracle's arithmetic -- no contraction, exact division)
     auto pvec = cross(tr.d, e2);
     auto det = dot(e1, pvec);
-#ifdef LR_EXACT_LEAF
-    auto inv_det = 1.f / det;// (`make ieee`: the experiment build with the oracle's arithmetic)
-#else
-    auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
-#endif
+    auto inv_det = 1.f / det;
     auto tvec = tr.o - p0;
     auto u = dot(tvec, pvec) * inv_det;
     auto qvec = cross(tvec, e1);
     auto v = dot(tr.d, qvec) * inv_det;
     auto t = dot(e2, qvec) * inv_det;
-    auto ok = det != 0.f && u >= 0.f && v >= 0.f && u + v <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
+    auto uv_sum = u + v;
+#else
+    // THE FUSED MULTIPLY-ADDS ARE WRITTEN OUT (round 6).  Left to -ffp-contract=fast the compiler chose which product of a sum to fuse per
+    // INSTANTIATION of this function -- the serial and the fused flow, a counting twin, a build with one register initialised differently --
+    // and a hit point that differs in its last bit sends the path elsewhere within a few bounces: films of such builds differed by 1e-3
+    // (profiles/r06zn_triangle_test_written_out.txt).  One evaluation order now, whatever the context: cross products as fma(a, b, -(c * d)),
+    // dot products x first, then y, then z.
+    const auto crossf = [](f3 p, f3 q) {
+        return mk3(__builtin_fmaf(p.y, q.z, -(p.z * q.y)), __builtin_fmaf(p.z, q.x, -(p.x * q.z)), __builtin_fmaf(p.x, q.y, -(p.y * q.x)));
+    };
+    const auto dotf = [](f3 p, f3 q) { return __builtin_fmaf(p.z, q.z, __builtin_fmaf(p.y, q.y, p.x * q.x)); };
+    float u, v, t, uv_sum, det;
+    {
+#pragma clang fp contract(off)
+        const auto pvec = crossf(tr.d, e2);
+        det = dotf(e1, pvec);
+        const auto inv_det = __builtin_amdgcn_rcpf(det);// (a denormal det is a degenerate triangle either way)
+        const auto tvec = mk3(tr.o.x - p0.x, tr.o.y - p0.y, tr.o.z - p0.z);
+        u = dotf(tvec, pvec) * inv_det;
+        const auto qvec = crossf(tvec, e1);
+        v = dotf(tr.d, qvec) * inv_det;
+        t = dotf(e2, qvec) * inv_det;
+        uv_sum = u + v;
+    }
+#endif
+    auto ok = det != 0.f && u >= 0.f && v >= 0.f && uv_sum <= 1.f && t > tr.t_min && t < tr.t_max && (flags & 1u);
     if (ALPHA && ok && (flags & 2u) == 0u) {// park the candidate: the alpha test runs outside this loop
         tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
         tr.phase |= kPhasePendingAlpha;
@@ -575,7 +598,12 @@ LR_D void trav_iteration(const TraversalStack &stack, const TravLane &tl, TravSt
         const auto any_inner = lr_any(is_inner);
         prio_chain();
         if (any_inner) { trav_node_fetch(stack, tl, tr, is_inner); }
-        LeafTriangle tri{};
+        // (the lanes that fetch no triangle never read one: their registers need a DEFINED value, not a particular one -- an empty asm "writes" them
+        // instead of the ten v_mov_b32 per iteration of `LeafTriangle tri{}`: 259 -> 250 VALU instructions in the pool loop, C2 1091 -> 1101, C3 1087 ->
+        // 1100, C4 1224 -> 1235 Msamples/s, films bit-identical now that trav_leaf_test's arithmetic is written out: profiles/r06zn_triangle_test_written_out.txt)
+        LeafTriangle tri;
+        asm volatile("" : "=v"(tri.a.x), "=v"(tri.a.y), "=v"(tri.a.z), "=v"(tri.a.w), "=v"(tri.b.x), "=v"(tri.b.y), "=v"(tri.b.z), "=v"(tri.b.w),
+                          "=v"(tri.c.x), "=v"(tri.c.y), "=v"(tri.c.z), "=v"(tri.c.w));
         if (is_leaf) { tri = trav_leaf_fetch(tl, tr.cur); }
         LR_MARK(kProbeIssue);
         prio_tests();
