@@ -2,7 +2,7 @@
 """Section-level stall attribution of the pool megakernels (GPU box; the round-6 instrument: the box offers neither PC sampling nor a
 thread-trace decoder, profiles/r06a_pc_sampling_unavailable.txt).
 
-    make hip-variant NAME=probe DEFS=-DLR_STALL_PROBE VARIANT_MASKS="4097 4099 4117 5129 7177" HEAVY_MASKS="1 5 9"      (here)
+    make hip-variant NAME=probe DEFS=-DLR_STALL_PROBE VARIANT_MASKS="1 4097 1033 3081 5129 7177 8213 12309 21 4117 3 4099 20483" HEAVY_MASKS="1 5 9"      (here: the counting twins of both schedulers for C2 - C5 and the PaddedSobol kernels)
     python tools/stall_probe.py <workload> <spp> [out.json]            (on the box; SAMPLER=PaddedSobol, LIB=probe by default)
 
 The probe build of the COUNTING kernels reads s_memtime at every section boundary of the traversal loop's iteration (dev_trace.h: THE
