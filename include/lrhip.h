@@ -186,7 +186,7 @@ int lrhip_work_items(uint32_t width, uint32_t height, uint32_t spp, uint32_t bal
  *                independent of their slice and add to the frame's order-independent fixed-point sums; the call's last slice runs all its
  *                rounds) -- its remaining rounds moved a few thousand paths each at one batch's latency, 6 % of a kitchen-class frame.
  *                mode | rounds << 8 overrides the one (tests, A/B); mode | 65535 << 8: never, every slice runs all its rounds.
- *   slice_paths  paths per slice (0 = default 2^28: 76 .. 89 GB of queues when a whole slice is in flight)
+ *   slice_paths  paths per slice (0 = default 2^28: 86 .. 100 GB of queues when a whole slice is in flight, the hand-over margin included)
  * lrhip_last_variant reports LRHIP_FEAT_WAVEFRONT | the lean kernel's bits | the closure bits the heavy kernel served.          */
 #define LRHIP_FEAT_WAVEFRONT 1024u
 int lrhip_set_wavefront(lrhip_ctx *ctx, uint32_t mode, uint32_t slice_paths);
