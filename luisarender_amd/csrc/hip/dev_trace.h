@@ -481,6 +481,16 @@ LR_D void trav_node_step(const TraversalStack &stack, const TravLane &tl, TravSt
 //   * fused fetch -- the node packets and the leaf triangles of an iteration requested together and waited for once: +-1 %.
 // The leaf step's price is its triangle fetch's latency, which the SIMD's other three waves cover; the instructions such schemes save
 // are fewer than the votes, extra pops and longer live ranges they add to EVERY iteration.
+// LR_LEAF_TAIL_ONE_COMPARE: what the leaf test does with a hit, written around ONE compare of the phase (pool kernels without the alpha test: three
+// VALU instructions per iteration, C2 1102 -> 1115, C3 1100 -> 1110, C4 1229 -> 1235 Msamples/s, films bit-identical; the one-path kernels gain
+// nothing and keep the round 1-5 form; the ALPHA kernels' allocation takes it badly -- <5128> 32 -> 65 spilled VGPRs: profiles/r06zq_leaf_tail.txt)
+#ifndef LR_LEAF_TAIL_ONE_COMPARE
+#if defined(LR_VARIANT) && ((LR_VARIANT) & 4096)
+#define LR_LEAF_TAIL_ONE_COMPARE 1
+#else
+#define LR_LEAF_TAIL_ONE_COMPARE 0
+#endif
+#endif
 struct LeafTriangle { float4 a, b, c; };
 LR_D LeafTriangle trav_leaf_fetch(const TravLane &tl, uint32_t ref) {
     // (a 32-bit byte offset from the scalar table base: 48 B x 2^27 triangles does not fit 32 bits, 48 B x the 89 M a 4 GB table holds does -- lrhip_upload_scene refuses more)
@@ -544,6 +554,22 @@ LR_D bool trav_leaf_test(TravState &tr, uint32_t ref, const LeafTriangle &tri, T
         tr.pend_t = t, tr.pend_u = u, tr.pend_v = v;
         tr.phase |= kPhasePendingAlpha;
         ok = false;
+    }
+    if constexpr (!ALPHA && LR_LEAF_TAIL_ONE_COMPARE != 0) {
+        // (a lane at a leaf traces a shadow ray or a closest-hit ray -- kPhaseShadow / kPhaseClosest, nothing else where no alpha test parks candidates:
+        // ONE compare serves both uses of the phase)
+        const auto shadow = tr.phase == kPhaseShadow;
+        if (ok) {
+            tr.t_max = t;
+            if (!shadow) {
+                tr.hit.inst = __float_as_uint(a.w), tr.hit.prim = __float_as_uint(b.w);
+                tr.hit.u = u, tr.hit.v = v;
+                tr.hit.tri = ref & kLeafIndexMask;
+            }
+        }
+        found = ok && shadow;
+        if (found) { tr.occluded = true; }
+        return found;
     }
     if (ok) {
         tr.t_max = t;
